@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: fingerprint generation, 1-s segments per second.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one pass of  audio -> log-mel -> encoder -> L2-normalised fingerprint
+over one batch of 640 synthetic 1-s segments that are already resident in HBM
+(BASELINE.json configs[1]: "Fingerprint generate, d=128 encoder, BSZ=640, 1xMI355X").
+With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank owns its
+own batches: generation shards by segment with no data-path collective, so scaling
+is weak and `value` is the whole-job segments/s.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     the dominant kernel (the fp32-MFMA implicit-GEMM convs): algorithmic
+               FLOPs per launch / mean launch duration from HIP events recorded on the
+               launch stream inside the timed region, vs the 157.3 TFLOP/s fp32 matrix peak
+  cpu_baseline the oracle's torch-CPU restatement of the same graph timed on the host
+               cores of this box on a bounded sample (kind "port": TensorFlow is absent)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BSZ = 640                      # BASELINE.json configs[1]
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def conv_effective_macs(input_shape=(256, 32, 1)):
+    """Per-conv multiply-accumulates per segment, zero-padding taps excluded
+    (SURVEY.md appendix A).  Host arithmetic on the geometry only."""
+    hidden = [128, 128, 256, 256, 512, 512, 1024, 1024]
+    stride_t = [2, 2, 2, 2, 1, 2, 1, 2]
+    F, T, C = input_shape
+    out = []
+
+    def same(n, k, s):
+        n_out = -(-n // s)
+        tot = max((n_out - 1) * s + k - n, 0)
+        return n_out, tot // 2
+
+    def live(n_in, n_out, s, pad):
+        return sum(1 for o in range(n_out) for t in range(3) if 0 <= o * s - pad + t < n_in)
+
+    for i in range(8):
+        To, pb = same(T, 3, stride_t[i])
+        out.append(F * live(T, To, stride_t[i], pb) * C * hidden[i])
+        T, C = To, hidden[i]
+        Fo, pb = same(F, 3, 2)
+        out.append(T * live(F, Fo, 2, pb) * C * hidden[i])
+        F = Fo
+    return out
+
+
+def make_audio(n, seed, torch):
+    """white noise sigma=0.1 + a 440 Hz tone."""
+    g = torch.Generator().manual_seed(seed)
+    t = torch.arange(8000, dtype=torch.float32) / 8000.0
+    x = 0.1 * torch.randn((n, 1, 8000), generator=g) + 0.2 * torch.sin(2 * torch.pi * 440.0 * t)
+    return x.float()
+
+
+def cpu_baseline(target_s=12.0, max_batches=40):
+    import numpy as np
+    import torch
+    from oracle import nnfp as o_nnfp, torch_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    w = o_nnfp.init_weights(seed=0)
+    tf = torch_ref.TorchFingerprinter(w)
+    x = make_audio(125, 7, torch)                       # TS_BATCH_SZ of config/default.yaml
+    with torch.no_grad():
+        tf(torch_ref.melspec_layer(x))                  # warm-up (oneDNN primitive caches)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            tf(torch_ref.melspec_layer(x))
+            n += 125
+            el = time.perf_counter() - t0
+            if el >= target_s or n >= 125 * max_batches:
+                break
+    return {'value': round(n / el, 2), 'unit': 'segments/s', 'cores': torch.get_num_threads(),
+            'kind': 'port',
+            'sample': f'{n} segments in batches of 125 (TS_BATCH_SZ), torch-CPU fp32 restatement '
+                      f'of melspec+encoder (oracle/torch_ref.py), {el:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import yaml
+    import __graft_entry__
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if rank == 0:
+        __graft_entry__.build()
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        dist.barrier()
+    else:
+        torch.cuda.set_device(0)
+    import neural_audio_fp_amd as nafp
+    dev = torch.device('cuda', local_rank if world > 1 else 0)
+
+    with open(os.path.join(ROOT, 'config', 'default.yaml')) as f:
+        cfg = yaml.safe_load(f)
+    m_pre = nafp.get_melspec_layer(cfg)
+    m_fp = nafp.FingerPrinter(emb_sz=cfg['MODEL']['EMB_SZ'], norm=cfg['MODEL']['BN'], seed=0, device=dev)
+    n_pool = 4
+    pool = [make_audio(BSZ, 1000 * rank + i, torch).to(dev) for i in range(n_pool)]
+
+    def step(i):
+        return m_fp(m_pre(pool[i % n_pool], group_size=BSZ))
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    m_fp.profile_enable(args.steps)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * args.steps)]
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        x = pool[i % n_pool]
+        ev[2 * i].record()
+        feat = m_pre(x, group_size=BSZ)
+        ev[2 * i + 1].record()
+        emb = m_fp(feat)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t[0])
+    assert emb.shape == (BSZ, 128) and bool(torch.isfinite(emb).all())
+
+    prof = m_fp.profile_read()
+    mel_ms = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(args.steps)) / args.steps
+    if rank == 0:
+        macs = conv_effective_macs()
+        gemm_flops_per_step = 2.0 * sum(macs[1:]) * BSZ            # the 15 implicit-GEMM launches
+        gemm_ms = sum(sum(p[1:16]) for p in prof) / len(prof)      # per step, all 15 launches
+        ach = gemm_flops_per_step / (gemm_ms * 1e-3) / 1e12
+        conv0_ms = sum(p[0] for p in prof) / len(prof)
+        tail_ms = sum(p[16] for p in prof) / len(prof)
+        value = world * BSZ * args.steps / el
+        out = {
+            'metric': 'fingerprint generation throughput (1-s segments/s)',
+            'value': round(value, 1), 'unit': 'segments/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(el / args.steps * 1e3, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': 'generate: f32 audio (640,1,8000) resident in HBM -> log-mel -> '
+                                   '16-conv encoder -> div-enc -> L2, d=128, BSZ=640 per GPU per step '
+                                   '(BASELINE.json configs[1]); seeded glorot weights',
+                       'segments_per_step_per_gpu': BSZ, 'parallelism': f'segment-sharded x{world}, no collective'},
+            'roofline': {
+                'bound': 'mfma', 'kernel': 'conv_gemm_kernel (15 launches/step, fp32 v_mfma_f32_32x32x2_f32)',
+                'achieved': round(ach, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                'flops_per_launch_avg': gemm_flops_per_step / 15, 'ms_per_launch_avg': round(gemm_ms / 15, 5)},
+            'stage_ms_per_step': {'melspec(3 kernels)': round(mel_ms, 4), 'conv0': round(conv0_ms, 4),
+                                  'conv_gemm x15': round(gemm_ms, 4), 'tail': round(tail_ms, 4),
+                                  'per_conv': [round(sum(p[k] for p in prof) / len(prof), 4) for k in range(17)]},
+            'frontend_hbm': {'algorithmic_bytes_per_segment': 32000 + 32768,
+                             'GB/s': round(BSZ * (32000 + 32768) / (mel_ms * 1e-3) / 1e9, 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,168 @@
+/*
+ * nafp.h -- C ABI of libnafp.so: the MI355X (gfx950) hot path of neural audio
+ * fingerprinting (1-s segment -> log-mel -> conv encoder -> 128-d fingerprint,
+ * and the NT-Xent loss).
+ *
+ * The reference (mimbres/neural-audio-fp) is pure Python on TensorFlow; it has no
+ * FFI of its own.  Each entry point below replaces the device work behind one
+ * Python-level operator of the reference, cited as file:line of the reference
+ * checkout.  INTEGRATION.md shows the ctypes stub a maintainer of the reference
+ * would add to route those operators here.
+ *
+ * Conventions
+ *   - every function returns an int status (NAFP_OK == 0); no C++ exception
+ *     crosses this boundary;
+ *   - all data pointers are CALLER-OWNED DEVICE pointers unless the name ends in
+ *     `_host`; the library allocates only what hangs off an opaque handle
+ *     (tables, packed weights) and frees it in the matching *_destroy;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *     all work is enqueued asynchronously on it;
+ *   - a handle is re-entrant across handles, not thread-safe per handle (the
+ *     reference drives the device from one host thread: generate.py:176-181).
+ */
+#ifndef NAFP_H
+#define NAFP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NAFP_ABI_VERSION 1
+
+enum {
+    NAFP_OK = 0,
+    NAFP_ERR_INVALID_ARG = 1,
+    NAFP_ERR_UNSUPPORTED = 2,   /* geometry the kernels are not built for */
+    NAFP_ERR_HIP = 3,           /* a HIP runtime call failed; see nafp_last_hip_error */
+    NAFP_ERR_WORKSPACE = 4,     /* caller workspace too small */
+    NAFP_ERR_NO_WEIGHTS = 5     /* encoder forward before set_weights */
+};
+
+typedef struct nafp_melspec nafp_melspec;
+typedef struct nafp_encoder nafp_encoder;
+
+int nafp_abi_version(void);
+const char* nafp_status_string(int status);
+/* hipError_t (as int) of the most recent failing HIP call on this thread. */
+int nafp_last_hip_error(void);
+
+/* ------------------------------------------------------------------------
+ * Front end: Melspec_layer (model/fp/melspec/melspectrogram.py:10-112)
+ * ---------------------------------------------------------------------- */
+
+/* Host-side Slaney mel filter bank, float32, row-major (n_mels, n_fft/2+1).
+ * Replaces librosa.filters.mel reached via kapre ApplyFilterbank
+ * (melspectrogram.py:93-98).  No GPU needed. */
+int nafp_mel_filterbank_host(int fs, int n_fft, int n_mels, float f_min, float f_max,
+                             float* out_host);
+
+/* Plan for get_melspec_layer(cfg) (melspectrogram.py:115-141).  seg_len = FS*DUR.
+ * Supported: n_fft == 1024, hop == 256, n_mels % 64 == 0 && n_mels <= 256,
+ * every mel filter <= 8 taps wide, seg_len <= 16384. */
+int nafp_melspec_create(nafp_melspec** plan, int fs, int seg_len, int n_fft, int hop,
+                        int n_mels, float f_min, float f_max);
+int nafp_melspec_destroy(nafp_melspec* plan);
+int nafp_melspec_n_frames(const nafp_melspec* plan);   /* 1 + seg_len/hop   (32)  */
+int nafp_melspec_n_mels(const nafp_melspec* plan);
+
+/* Melspec_layer.call (melspectrogram.py:102-112).
+ *   audio      (n_seg, seg_len) float32 or int16 PCM (int16 is scaled by 2^-15 as
+ *              load_audio does, model/utils/audio_utils.py:245-246)
+ *   group_size the reference subtracts the max over the WHOLE device batch
+ *              (melspectrogram.py:108); consecutive runs of group_size segments
+ *              (last ragged) form one such batch.  <= 0 means one group.
+ *   segment_norm  FEAT == 'melspec_maxnorm' (melspectrogram.py:110-111)
+ *   feat       out, (n_seg, n_mels, n_frames) float32 == the reference's
+ *              (B, n_mels, n_frames, 1)
+ *   group_stat scratch, 2*ceil(n_seg/group_size) floats (raw max / min per group)
+ */
+int nafp_melspec_forward_f32(nafp_melspec* plan, const float* audio, int64_t n_seg,
+                             int group_size, int segment_norm, float* feat,
+                             float* group_stat, void* stream);
+int nafp_melspec_forward_i16(nafp_melspec* plan, const int16_t* audio, int64_t n_seg,
+                             int group_size, int segment_norm, float* feat,
+                             float* group_stat, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Encoder: FingerPrinter (model/fp/nnfp.py:159-231)
+ * ---------------------------------------------------------------------- */
+
+/* get_fingerprinter(cfg) (nnfp.py:234-258): 8 ConvLayer blocks with the channel
+ * and stride tables of nnfp.py:193-197 on an (in_f, in_t, 1) input, DivEncLayer
+ * with q = emb_sz slices, unit_dim [32,1].  (256,32,1) is the deployed shape. */
+int nafp_encoder_create(nafp_encoder** enc, int in_f, int in_t, int emb_sz);
+int nafp_encoder_destroy(nafp_encoder* enc);
+
+/* Parameter tensors, in this fixed order (n = nafp_encoder_n_tensors):
+ *   for j in 0..15 (even = conv 1x3, odd = conv 3x1; nnfp.py:48-79):
+ *     4j+0 kernel (kh,kw,Cin,Cout)   4j+1 bias (Cout)
+ *     4j+2 LN gamma (F,T,C)          4j+3 LN beta (F,T,C)
+ *   64 div.w1 (Q,S,32)   65 div.b1 (Q,32)   66 div.w2 (Q,32,1)   67 div.b2 (Q,1)
+ * i.e. the keras variable shapes, C-order float32. */
+int nafp_encoder_n_tensors(const nafp_encoder* enc);
+int64_t nafp_encoder_tensor_numel(const nafp_encoder* enc, int index);
+/* writes up to 4 dims, returns rank (or -1) */
+int nafp_encoder_tensor_shape(const nafp_encoder* enc, int index, int64_t dims_out[4]);
+int64_t nafp_encoder_flat_dim(const nafp_encoder* enc);    /* F'*T'*C of front_conv (1024) */
+
+/* Copy/pack weights from caller device tensors (array of n device pointers, the
+ * array itself in host memory).  May be called again after every optimizer step. */
+int nafp_encoder_set_weights(nafp_encoder* enc, const float* const* tensors_host_array,
+                             void* stream);
+
+int64_t nafp_encoder_workspace_bytes(const nafp_encoder* enc, int64_t n_seg);
+
+/* m_fp(feat) (nnfp.py:223-231).  feat (n_seg, in_f, in_t) float32.
+ *   out_flat  optional (n_seg, flat_dim): front_conv output (nnfp.py:225), may be NULL
+ *   out_emb   optional (n_seg, emb_sz): l2_normalize(div_enc(.)) if l2norm != 0,
+ *             else div_enc(.) (use_L2layer, nnfp.py:228-231), may be NULL   */
+int nafp_encoder_forward(nafp_encoder* enc, const float* feat, int64_t n_seg,
+                         void* workspace, int64_t workspace_bytes,
+                         float* out_flat, float* out_emb, int l2norm, void* stream);
+
+/* Per-kernel timing of nafp_encoder_forward with HIP events recorded on the
+ * caller's stream (bench.py's roofline leg).  enable(max_forwards > 0) allocates a
+ * ring of event sets, one per forward call; enable(0) turns it off.  read() waits
+ * for slot `slot` (0 = the first forward after enable) and writes 17 durations in
+ * milliseconds: [0] conv0, [1..15] the implicit-GEMM convs, [16] the tail. */
+#define NAFP_ENCODER_PROFILE_KERNELS 17
+int nafp_encoder_profile_enable(nafp_encoder* enc, int max_forwards);
+int nafp_encoder_profile_count(const nafp_encoder* enc);   /* forwards recorded so far */
+int nafp_encoder_profile_read(nafp_encoder* enc, int slot, float* ms_out_host);
+
+/* m_fp.div_enc(x) alone (nnfp.py:141-156; called separately at trainer.py:73-76). */
+int nafp_encoder_div_enc(nafp_encoder* enc, const float* flat, int64_t n_seg,
+                         float* out_emb, int l2norm, void* stream);
+
+/* ------------------------------------------------------------------------
+ * NT-Xent loss (model/fp/NTxent_loss_single_gpu.py:52-82; sharded form
+ * model/fp/NTxent_loss_tpu.py:90-137)
+ * ---------------------------------------------------------------------- */
+
+int64_t nafp_ntxent_workspace_bytes(int64_t n_local, int64_t n_global);
+
+/* Rows of this rank: emb_org_local/emb_rep_local (n_local, d); columns: the
+ * (all-gathered) emb_org_all/emb_rep_all (n_global, d); this rank's rows sit at
+ * [rank_offset, rank_offset+n_local) of the global arrays.  Single device:
+ * local == all, rank_offset = 0.
+ *   loss_sum  out, 1 float: sum over local rows of (CE_a + CE_b); the caller
+ *             divides by n_global for the reference's mean (and all-reduces)
+ *   sim_mtx   optional (n_local, 2*n_global-1): [ab | aa without its diagonal]
+ *             as compute_loss returns it; NULL to skip
+ *   d_org_all/d_rep_all optional (n_global, d): gradient of (loss_sum/n_global)
+ *             w.r.t. the global arrays contributed by this rank's rows AND
+ *             columns restricted to local rows (sum over ranks = full gradient);
+ *             NULL to skip.  d must be 128. */
+int nafp_ntxent_forward(const float* emb_org_local, const float* emb_rep_local,
+                        const float* emb_org_all, const float* emb_rep_all,
+                        int64_t n_local, int64_t n_global, int64_t rank_offset, int d,
+                        float tau, float* loss_sum, float* sim_mtx,
+                        float* d_org_all, float* d_rep_all,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NAFP_H */

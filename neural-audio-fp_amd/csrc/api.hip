@@ -1,0 +1,269 @@
+// C-ABI glue of libnafp: status strings and the encoder handle (geometry, packed
+// weights, the 16-conv + tail launch sequence).  See include/nafp.h.
+#include "nafp_common.h"
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+namespace nafp {
+
+thread_local int g_last_hip_error = 0;
+
+// Channel and stride tables of FingerPrinter (model/fp/nnfp.py:193-197).
+static const int kHiddenCh[8] = {128, 128, 256, 256, 512, 512, 1024, 1024};
+// stride of the 1x3 conv along T; the 3x1 conv always has stride 2 along F.
+static const int kStrideT[8] = {2, 2, 2, 2, 1, 2, 1, 2};
+
+std::vector<ConvGeom> encoder_geometry(int in_f, int in_t) {
+    std::vector<ConvGeom> g;
+    int F = in_f, T = in_t, C = 1;
+    for (int i = 0; i < 8; ++i) {
+        SamePad pt = same_pad(T, 3, kStrideT[i]);
+        g.push_back(ConvGeom{0, F, T, C, F, pt.n_out, kHiddenCh[i], kStrideT[i], pt.before});
+        T = pt.n_out; C = kHiddenCh[i];
+        SamePad pf = same_pad(F, 3, 2);
+        g.push_back(ConvGeom{1, F, T, C, pf.n_out, T, kHiddenCh[i], 2, pf.before});
+        F = pf.n_out;
+    }
+    return g;
+}
+
+}  // namespace nafp
+
+using namespace nafp;
+
+struct nafp_encoder {
+    int in_f, in_t, emb_sz;
+    std::vector<ConvGeom> geom;           // 16
+    int64_t flat_dim; int S;
+    // tensor table (keras shapes)
+    std::vector<std::vector<int64_t>> shapes;
+    // device storage (one allocation)
+    float* d_blob = nullptr;
+    int64_t blob_floats = 0;
+    std::vector<float*> d_w;              // per conv: conv0 -> raw (3,Cout); others packed (Cout,3Cin)
+    std::vector<float*> d_bias, d_gamma, d_beta;
+    float *d_w1p = nullptr, *d_b1p = nullptr, *d_w2p = nullptr, *d_b2 = nullptr;
+    bool has_weights = false;
+    // per-segment workspace layout (floats)
+    int64_t bufA_per_seg = 0, bufB_per_seg = 0;
+    // optional per-kernel event timing (nafp_encoder_profile_*)
+    std::vector<hipEvent_t> prof_events;  // (max_forwards, 18)
+    int prof_max = 0, prof_count = 0;
+};
+
+static void profile_free(nafp_encoder* e) {
+    for (auto ev : e->prof_events) (void)hipEventDestroy(ev);
+    e->prof_events.clear();
+    e->prof_max = 0; e->prof_count = 0;
+}
+
+static int64_t numel(const std::vector<int64_t>& s) {
+    int64_t n = 1;
+    for (auto d : s) n *= d;
+    return n;
+}
+
+extern "C" int nafp_abi_version(void) { return NAFP_ABI_VERSION; }
+
+extern "C" const char* nafp_status_string(int status) {
+    switch (status) {
+        case NAFP_OK: return "ok";
+        case NAFP_ERR_INVALID_ARG: return "invalid argument";
+        case NAFP_ERR_UNSUPPORTED: return "unsupported geometry or option";
+        case NAFP_ERR_HIP: return "HIP runtime error";
+        case NAFP_ERR_WORKSPACE: return "workspace too small";
+        case NAFP_ERR_NO_WEIGHTS: return "encoder weights not set";
+        default: return "unknown status";
+    }
+}
+
+extern "C" int nafp_last_hip_error(void) { return g_last_hip_error; }
+
+extern "C" int nafp_encoder_create(nafp_encoder** out, int in_f, int in_t, int emb_sz) {
+    if (!out || in_f <= 0 || in_t <= 0 || emb_sz <= 0) return NAFP_ERR_INVALID_ARG;
+    nafp_encoder* e = new nafp_encoder();
+    e->in_f = in_f; e->in_t = in_t; e->emb_sz = emb_sz;
+    e->geom = encoder_geometry(in_f, in_t);
+    const ConvGeom& last = e->geom.back();
+    e->flat_dim = (int64_t)last.Fout * last.Tout * last.Cout;
+    if (e->flat_dim % emb_sz != 0 || emb_sz % 64 != 0 || emb_sz > 1024 || e->flat_dim / emb_sz > 16) {
+        delete e; return NAFP_ERR_UNSUPPORTED;
+    }
+    e->S = (int)(e->flat_dim / emb_sz);
+    for (int j = 0; j < 16; ++j) {
+        const ConvGeom& g = e->geom[j];
+        if (g.axis == 0) e->shapes.push_back({1, 3, g.Cin, g.Cout});
+        else             e->shapes.push_back({3, 1, g.Cin, g.Cout});
+        e->shapes.push_back({g.Cout});
+        e->shapes.push_back({g.Fout, g.Tout, g.Cout});
+        e->shapes.push_back({g.Fout, g.Tout, g.Cout});
+    }
+    e->shapes.push_back({emb_sz, e->S, 32});
+    e->shapes.push_back({emb_sz, 32});
+    e->shapes.push_back({emb_sz, 32, 1});
+    e->shapes.push_back({emb_sz, 1});
+    int64_t total = 0;
+    for (auto& s : e->shapes) total += (numel(s) + 63) / 64 * 64;      // 256-B aligned slots
+    e->blob_floats = total;
+    hipError_t err = hipMalloc(&e->d_blob, sizeof(float) * total);
+    if (err != hipSuccess) { g_last_hip_error = (int)err; delete e; return NAFP_ERR_HIP; }
+    float* p = e->d_blob;
+    auto take = [&](int idx) { float* r = p; p += (numel(e->shapes[idx]) + 63) / 64 * 64; return r; };
+    for (int j = 0; j < 16; ++j) {
+        e->d_w.push_back(take(4 * j));
+        e->d_bias.push_back(take(4 * j + 1));
+        e->d_gamma.push_back(take(4 * j + 2));
+        e->d_beta.push_back(take(4 * j + 3));
+    }
+    e->d_w1p = take(64); e->d_b1p = take(65); e->d_w2p = take(66); e->d_b2 = take(67);
+    for (int j = 0; j < 16; ++j) {
+        const ConvGeom& g = e->geom[j];
+        const int64_t n = (int64_t)g.Fout * g.Tout * g.Cout;
+        if (j % 2 == 0) e->bufA_per_seg = std::max(e->bufA_per_seg, n);
+        else            e->bufB_per_seg = std::max(e->bufB_per_seg, n);
+    }
+    *out = e;
+    return NAFP_OK;
+}
+
+extern "C" int nafp_encoder_destroy(nafp_encoder* e) {
+    if (!e) return NAFP_OK;
+    if (e->d_blob) (void)hipFree(e->d_blob);
+    profile_free(e);
+    delete e;
+    return NAFP_OK;
+}
+
+extern "C" int nafp_encoder_n_tensors(const nafp_encoder* e) { return e ? (int)e->shapes.size() : -1; }
+
+extern "C" int64_t nafp_encoder_tensor_numel(const nafp_encoder* e, int index) {
+    if (!e || index < 0 || index >= (int)e->shapes.size()) return -1;
+    return numel(e->shapes[index]);
+}
+
+extern "C" int nafp_encoder_tensor_shape(const nafp_encoder* e, int index, int64_t dims_out[4]) {
+    if (!e || !dims_out || index < 0 || index >= (int)e->shapes.size()) return -1;
+    const auto& s = e->shapes[index];
+    for (size_t i = 0; i < s.size(); ++i) dims_out[i] = s[i];
+    return (int)s.size();
+}
+
+extern "C" int64_t nafp_encoder_flat_dim(const nafp_encoder* e) { return e ? e->flat_dim : -1; }
+
+extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, void* stream) {
+    if (!e || !t) return NAFP_ERR_INVALID_ARG;
+    for (size_t i = 0; i < e->shapes.size(); ++i)
+        if (!t[i]) return NAFP_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    for (int j = 0; j < 16; ++j) {
+        const ConvGeom& g = e->geom[j];
+        if (j == 0) {
+            NAFP_HIP_CHECK(hipMemcpyAsync(e->d_w[0], t[0], sizeof(float) * 3 * g.Cout, hipMemcpyDeviceToDevice, st));
+        } else {
+            int rc = launch_pack_conv_weight(t[4 * j], e->d_w[j], g.Cin, g.Cout, st);
+            if (rc != NAFP_OK) return rc;
+        }
+        const int64_t nln = (int64_t)g.Fout * g.Tout * g.Cout;
+        NAFP_HIP_CHECK(hipMemcpyAsync(e->d_bias[j], t[4 * j + 1], sizeof(float) * g.Cout, hipMemcpyDeviceToDevice, st));
+        NAFP_HIP_CHECK(hipMemcpyAsync(e->d_gamma[j], t[4 * j + 2], sizeof(float) * nln, hipMemcpyDeviceToDevice, st));
+        NAFP_HIP_CHECK(hipMemcpyAsync(e->d_beta[j], t[4 * j + 3], sizeof(float) * nln, hipMemcpyDeviceToDevice, st));
+    }
+    int rc = launch_pack_div(t[64], t[65], t[66], e->d_w1p, e->d_b1p, e->d_w2p, e->emb_sz, e->S, st);
+    if (rc != NAFP_OK) return rc;
+    NAFP_HIP_CHECK(hipMemcpyAsync(e->d_b2, t[67], sizeof(float) * e->emb_sz, hipMemcpyDeviceToDevice, st));
+    e->has_weights = true;
+    return NAFP_OK;
+}
+
+static int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+extern "C" int64_t nafp_encoder_workspace_bytes(const nafp_encoder* e, int64_t n_seg) {
+    if (!e || n_seg < 0) return -1;
+    const int64_t stats = align_up((int64_t)sizeof(double) * 2 * 16 * n_seg, 256);
+    const int64_t a = align_up((int64_t)sizeof(float) * e->bufA_per_seg * n_seg, 256);
+    const int64_t b = align_up((int64_t)sizeof(float) * e->bufB_per_seg * n_seg, 256);
+    return stats + a + b + 256;
+}
+
+extern "C" int nafp_encoder_forward(nafp_encoder* e, const float* feat, int64_t n_seg,
+                                    void* workspace, int64_t workspace_bytes,
+                                    float* out_flat, float* out_emb, int l2norm, void* stream) {
+    if (!e || !feat || !workspace || n_seg < 0) return NAFP_ERR_INVALID_ARG;
+    if (!e->has_weights) return NAFP_ERR_NO_WEIGHTS;
+    if (n_seg == 0) return NAFP_OK;
+    if (workspace_bytes < nafp_encoder_workspace_bytes(e, n_seg)) return NAFP_ERR_WORKSPACE;
+    if (n_seg * e->bufA_per_seg >= ((int64_t)1 << 40)) return NAFP_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)align_up((int64_t)(uintptr_t)workspace, 256);
+    const int64_t stats_bytes = align_up((int64_t)sizeof(double) * 2 * 16 * n_seg, 256);
+    double* stats = (double*)ws;
+    float* bufA = (float*)(ws + stats_bytes);
+    float* bufB = (float*)(ws + stats_bytes + align_up((int64_t)sizeof(float) * e->bufA_per_seg * n_seg, 256));
+    NAFP_HIP_CHECK(hipMemsetAsync(stats, 0, sizeof(double) * 2 * 16 * n_seg, st));
+    hipEvent_t* ev = nullptr;
+    if (e->prof_max > 0 && e->prof_count < e->prof_max) ev = e->prof_events.data() + (size_t)18 * e->prof_count++;
+    if (ev) NAFP_HIP_CHECK(hipEventRecord(ev[0], st));
+
+    int rc = launch_conv0(feat, e->d_w[0], e->d_bias[0], bufA, stats, n_seg, e->geom[0], st);
+    if (rc != NAFP_OK) return rc;
+    if (ev) NAFP_HIP_CHECK(hipEventRecord(ev[1], st));
+    float* cur = bufA;
+    for (int j = 1; j < 16; ++j) {
+        float* nxt = (j % 2 == 0) ? bufA : bufB;
+        ConvGemmArgs a;
+        a.x = cur; a.stats_in = stats + 2 * n_seg * (j - 1);
+        a.gamma_in = e->d_gamma[j - 1]; a.beta_in = e->d_beta[j - 1];
+        a.wp = e->d_w[j]; a.bias = e->d_bias[j];
+        a.y = nxt; a.stats_out = stats + 2 * n_seg * j;
+        rc = launch_conv_gemm(a, n_seg, e->geom[j], st);
+        if (rc != NAFP_OK) return rc;
+        if (ev) NAFP_HIP_CHECK(hipEventRecord(ev[j + 1], st));
+        cur = nxt;
+    }
+    TailArgs t;
+    t.x = cur; t.stats = stats + 2 * n_seg * 15; t.gamma = e->d_gamma[15]; t.beta = e->d_beta[15];
+    t.w1p = e->d_w1p; t.b1p = e->d_b1p; t.w2p = e->d_w2p; t.b2 = e->d_b2;
+    t.out_flat = out_flat; t.out_emb = out_emb;
+    t.D = (int)e->flat_dim; t.Q = e->emb_sz; t.S = e->S; t.l2norm = l2norm;
+    rc = launch_tail(t, n_seg, st);
+    if (rc != NAFP_OK) return rc;
+    if (ev) NAFP_HIP_CHECK(hipEventRecord(ev[17], st));
+    return NAFP_OK;
+}
+
+extern "C" int nafp_encoder_profile_enable(nafp_encoder* e, int max_forwards) {
+    if (!e || max_forwards < 0 || max_forwards > 4096) return NAFP_ERR_INVALID_ARG;
+    profile_free(e);
+    for (int i = 0; i < max_forwards * 18; ++i) {
+        hipEvent_t ev;
+        hipError_t err = hipEventCreate(&ev);
+        if (err != hipSuccess) { g_last_hip_error = (int)err; profile_free(e); return NAFP_ERR_HIP; }
+        e->prof_events.push_back(ev);
+    }
+    e->prof_max = max_forwards;
+    return NAFP_OK;
+}
+
+extern "C" int nafp_encoder_profile_count(const nafp_encoder* e) { return e ? e->prof_count : -1; }
+
+extern "C" int nafp_encoder_profile_read(nafp_encoder* e, int slot, float* ms_out_host) {
+    if (!e || !ms_out_host || slot < 0 || slot >= e->prof_count) return NAFP_ERR_INVALID_ARG;
+    hipEvent_t* ev = e->prof_events.data() + (size_t)18 * slot;
+    NAFP_HIP_CHECK(hipEventSynchronize(ev[17]));
+    for (int k = 0; k < 17; ++k) NAFP_HIP_CHECK(hipEventElapsedTime(ms_out_host + k, ev[k], ev[k + 1]));
+    return NAFP_OK;
+}
+
+extern "C" int nafp_encoder_div_enc(nafp_encoder* e, const float* flat, int64_t n_seg,
+                                    float* out_emb, int l2norm, void* stream) {
+    if (!e || !flat || !out_emb || n_seg < 0) return NAFP_ERR_INVALID_ARG;
+    if (!e->has_weights) return NAFP_ERR_NO_WEIGHTS;
+    TailArgs t;
+    t.x = flat; t.stats = nullptr; t.gamma = nullptr; t.beta = nullptr;
+    t.w1p = e->d_w1p; t.b1p = e->d_b1p; t.w2p = e->d_w2p; t.b2 = e->d_b2;
+    t.out_flat = nullptr; t.out_emb = out_emb;
+    t.D = (int)e->flat_dim; t.Q = e->emb_sz; t.S = e->S; t.l2norm = l2norm;
+    return launch_tail(t, n_seg, (hipStream_t)stream);
+}

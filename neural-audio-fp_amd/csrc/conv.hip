@@ -1,0 +1,377 @@
+// Encoder convolutions for gfx950 (MI355X).
+//
+// Replaces the 16 keras Conv2D -> ELU -> LayerNormalization groups of the reference
+// (model/fp/nnfp.py:48-79, eight ConvLayer blocks at nnfp.py:210-216).
+//
+// Every conv is a dense channel-mixing 3-tap conv along ONE axis, i.e. an implicit
+// GEMM  Y[m, n] = sum_{tap, c} Xhat[row(m, tap), c] * W[tap, c, n]  with
+// m = (sample, f_out, t_out), K = 3*Cin, N = Cout, computed in exact fp32 on the
+// matrix cores (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak).  The LayerNorm of the
+// PREVIOUS conv (per-sample statistics over (F,T,C), per-element gamma/beta) is
+// applied while the A operand is staged into LDS; the epilogue adds bias, applies
+// ELU, stores the activation once, and accumulates the per-sample sum / sum of
+// squares that the NEXT conv's A-load needs.  Activations therefore cross HBM
+// exactly once in each direction.
+#include "nafp_common.h"
+
+namespace nafp {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// ============================================================================
+// conv0: b0.conv1x3, Cin = 1 (nnfp.py:48-53 on the (F,T,1) log-mel input).
+// Pure store-bandwidth: 3 FMAs per output element, 2 MB written per segment.
+// One workgroup = one sample x `ROWS0` frequency rows; 32 threads x float4 cover
+// the Cout = 128 channels of one (f, t_out) position, a wave stores 1 KiB
+// contiguous.
+// ============================================================================
+constexpr int ROWS0 = 4;
+
+__global__ __launch_bounds__(256) void conv0_kernel(
+        const float* __restrict__ feat, const float* __restrict__ w3, const float* __restrict__ bias,
+        float* __restrict__ y, double* __restrict__ stats,
+        int F, int Tin, int Tout, int Cout, int stride, int pad) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int blocks_per_sample = (F + ROWS0 - 1) / ROWS0;
+    const int64_t b = blockIdx.x / blocks_per_sample;
+    const int f0 = (blockIdx.x % blocks_per_sample) * ROWS0;
+    const int cgroups = Cout / 4;                   // float4 groups per position
+    const int pos_per_iter = 256 / cgroups;         // positions covered per iteration (8 for Cout=128)
+    const int cg = tid % cgroups, pslot = tid / cgroups;
+    const float4 w0 = *(const float4*)(w3 + 0 * Cout + 4 * cg);
+    const float4 w1 = *(const float4*)(w3 + 1 * Cout + 4 * cg);
+    const float4 w2 = *(const float4*)(w3 + 2 * Cout + 4 * cg);
+    const float4 bb = *(const float4*)(bias + 4 * cg);
+    const int rows = min(ROWS0, F - f0);
+    const int npos = rows * Tout;
+    const float* xin = feat + (b * F + f0) * (int64_t)Tin;
+    float* yout = y + ((b * F + f0) * (int64_t)Tout) * Cout;
+    float s = 0.f, q = 0.f;
+    for (int p = pslot; p < npos; p += pos_per_iter) {
+        const int r = p / Tout, to = p % Tout;
+        const int t0 = to * stride - pad;
+        const float* xr = xin + r * Tin;
+        const float x0 = (t0 >= 0 && t0 < Tin) ? xr[t0] : 0.f;
+        const float x1 = (t0 + 1 >= 0 && t0 + 1 < Tin) ? xr[t0 + 1] : 0.f;
+        const float x2 = (t0 + 2 >= 0 && t0 + 2 < Tin) ? xr[t0 + 2] : 0.f;
+        float4 v;
+        v.x = elu1(fmaf(x2, w2.x, fmaf(x1, w1.x, fmaf(x0, w0.x, bb.x))));
+        v.y = elu1(fmaf(x2, w2.y, fmaf(x1, w1.y, fmaf(x0, w0.y, bb.y))));
+        v.z = elu1(fmaf(x2, w2.z, fmaf(x1, w1.z, fmaf(x0, w0.z, bb.z))));
+        v.w = elu1(fmaf(x2, w2.w, fmaf(x1, w1.w, fmaf(x0, w0.w, bb.w))));
+        *(float4*)(yout + (int64_t)p * Cout + 4 * cg) = v;
+        s += (v.x + v.y) + (v.z + v.w);
+        q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    double ds = wave_sum((double)s), dq = wave_sum((double)q);
+    __shared__ double red[8];
+    if (lane == 0) { red[wave] = ds; red[4 + wave] = dq; }
+    __syncthreads();
+    if (tid == 0) {
+        atomicAdd(stats + 2 * b, red[0] + red[1] + red[2] + red[3]);
+        atomicAdd(stats + 2 * b + 1, red[4] + red[5] + red[6] + red[7]);
+    }
+}
+
+int launch_conv0(const float* feat, const float* w3, const float* bias, float* y, double* stats,
+                 int64_t B, const ConvGeom& g, hipStream_t st) {
+    if (g.Cin != 1 || g.axis != 0 || (g.Cout % 4) != 0 || 256 % (g.Cout / 4) != 0) return NAFP_ERR_UNSUPPORTED;
+    const int64_t blocks = B * ((g.Fin + ROWS0 - 1) / ROWS0);
+    conv0_kernel<<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, y, stats, g.Fin, g.Tin, g.Tout,
+                                                         g.Cout, g.stride, g.pad);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}
+
+// ============================================================================
+// Implicit-GEMM conv, fp32 MFMA.
+//   tile BM x BN x BK = 128 x 128 x 32, 256 threads = 4 waves as 2(M) x 2(N),
+//   each wave 64 x 64 = 2 x 2 tiles of v_mfma_f32_32x32x2_f32 (64 accumulators).
+//   LDS tiles are [row][k] with leading dimension 36 floats: a lane's operand
+//   fetch is one ds_read_b128 = 4 consecutive k of its row; with LD = 36 any 16
+//   consecutive rows hit 64 distinct banks, so the four 16-lane groups of a b128
+//   read are conflict-free.  The k permutation this implies (lane half h of MFMA
+//   step j multiplies k = 8*kk + 4*h + j) is the same for A and B, so the sum is
+//   unchanged.
+//   Register-staged double buffering: global loads of K-step s+1 are issued
+//   before the MFMAs of step s and written to the other LDS buffer afterwards
+//   (one barrier per K-step).
+// ============================================================================
+constexpr int BM = 128, BN = 128, BK = 32, LD = 36;
+constexpr int TILE_FLOATS = BM * LD;      // A or B tile in LDS (BM == BN)
+
+struct ConvKernelParams {
+    const float* x; const double* stats_in; const float* gamma_in; const float* beta_in;
+    const float* wp; const float* bias; float* y; double* stats_out;
+    int Fin, Tin, Cin, Fout, Tout, Cout;
+    int axis, stride, pad;
+    int64_t M;             // B * Fout * Tout
+    int rps;               // rows per sample = Fout * Tout
+    int64_t sample_in;     // Fin * Tin * Cin
+    int64_t tap_stride;    // elements between consecutive taps of one output row
+    double inv_n_in;       // 1 / sample_in
+    int stats_mode;        // 0: whole tile in one sample, 1: pow2 rps <= 64, 2: generic per-row
+};
+
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKernelParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // [A0 | B0 | A1 | B1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t tile_m0 = (int64_t)blockIdx.x * BM;
+    const int tile_n0 = blockIdx.y * BN;
+    const int K = 3 * p.Cin;
+
+    // ---- loader geometry: thread loads rows (tid>>3) + 32*i, float4 column (tid&7) ----
+    const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+    int64_t off0[4];          // element offset of tap 0 (channel 0) for each of my rows
+    int64_t gb0[4];           // same offset inside one sample (for gamma/beta)
+    float lnA[4], lnC[4];     // xhat = (x*lnA + lnC)*gamma + beta
+    unsigned tapmask[4];
+    unsigned my_live = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = tile_m0 + lrow + 32 * i;
+        tapmask[i] = 0; off0[i] = 0; gb0[i] = 0; lnA[i] = 0.f; lnC[i] = 0.f;
+        if (m < p.M) {
+            const int64_t b = m / p.rps;
+            const int rem = (int)(m - b * p.rps);
+            const int fo = rem / p.Tout, to = rem - fo * p.Tout;
+            int64_t inner;
+            int pos0, lim;
+            if (p.axis == 0) { pos0 = to * p.stride - p.pad; lim = p.Tin; inner = ((int64_t)fo * p.Tin + pos0) * p.Cin; }
+            else             { pos0 = fo * p.stride - p.pad; lim = p.Fin; inner = ((int64_t)pos0 * p.Tin + to) * p.Cin; }
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                if (pos0 + t >= 0 && pos0 + t < lim) tapmask[i] |= 1u << t;
+            gb0[i] = inner;
+            off0[i] = b * p.sample_in + inner;
+            const double su = p.stats_in[2 * b], sq = p.stats_in[2 * b + 1];
+            const double mean = su * p.inv_n_in;
+            double var = sq * p.inv_n_in - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
+            lnA[i] = (float)rstd;
+            lnC[i] = (float)(-mean * rstd);
+            my_live |= tapmask[i];
+        }
+    }
+    // taps that read only zero padding for EVERY row of this tile are skipped
+    int* s_live = (int*)smem;
+    if (tid == 0) *s_live = 0;
+    __syncthreads();
+    if (my_live) atomicOr(s_live, (int)my_live);
+    __syncthreads();
+    const unsigned live = (unsigned)*s_live;
+    __syncthreads();
+    int live_tap[3]; int n_live = 0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) if (live & (1u << t)) live_tap[n_live++] = t;
+    const int cpt = p.Cin / BK;                 // K-steps per tap
+    const int n_steps = n_live * cpt;
+
+    const float* wrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wrow[i] = p.wp + (int64_t)(tile_n0 + lrow + 32 * i) * K + lcol;
+
+    float4 ra[4], rg[4], rb[4], rw[4];
+    auto load_step = [&](int s) {
+        const int tsel = s / cpt;
+        const int tap = tsel == 0 ? live_tap[0] : (tsel == 1 ? live_tap[1] : live_tap[2]);
+        const int c0 = (s - tsel * cpt) * BK;
+        const int64_t toff = tap * p.tap_stride + c0 + lcol;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (tapmask[i] & (1u << tap)) {
+                ra[i] = *(const float4*)(p.x + off0[i] + toff);
+                rg[i] = *(const float4*)(p.gamma_in + gb0[i] + toff);
+                rb[i] = *(const float4*)(p.beta_in + gb0[i] + toff);
+            } else {
+                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                rg[i] = ra[i]; rb[i] = ra[i];
+            }
+            rw[i] = *(const float4*)(wrow[i] + tap * p.Cin + c0);
+        }
+    };
+    auto store_step = [&](int buf, int s) {
+        const int tsel = s / cpt;
+        const int tap = tsel == 0 ? live_tap[0] : (tsel == 1 ? live_tap[1] : live_tap[2]);
+        float* As = smem + buf * 2 * TILE_FLOATS;
+        float* Bs = As + TILE_FLOATS;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v;
+            if (tapmask[i] & (1u << tap)) {
+                v.x = fmaf(fmaf(ra[i].x, lnA[i], lnC[i]), rg[i].x, rb[i].x);
+                v.y = fmaf(fmaf(ra[i].y, lnA[i], lnC[i]), rg[i].y, rb[i].y);
+                v.z = fmaf(fmaf(ra[i].z, lnA[i], lnC[i]), rg[i].z, rb[i].z);
+                v.w = fmaf(fmaf(ra[i].w, lnA[i], lnC[i]), rg[i].w, rb[i].w);
+            } else {
+                v = make_float4(0.f, 0.f, 0.f, 0.f);      // zero padding is applied AFTER LayerNorm
+            }
+            *(float4*)(As + (lrow + 32 * i) * LD + lcol) = v;
+            *(float4*)(Bs + (lrow + 32 * i) * LD + lcol) = rw[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    if (n_steps > 0) {
+        load_step(0);
+        store_step(0, 0);
+    }
+    __syncthreads();
+
+    const int arow = wm * 64 + (lane & 31), brow = wn * 64 + (lane & 31);
+    const int kq = (lane >> 5) * 4;
+    for (int s = 0; s < n_steps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < n_steps) load_step(s + 1);
+        const float* As = smem + buf * 2 * TILE_FLOATS;
+        const float* Bs = As + TILE_FLOATS;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            float4 a[2], b[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) a[mi] = *(const float4*)(As + (arow + 32 * mi) * LD + kk * 8 + kq);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) b[ni] = *(const float4*)(Bs + (brow + 32 * ni) * LD + kk * 8 + kq);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].x, b[ni].x, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].y, b[ni].y, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].z, b[ni].z, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, b[ni].w, acc[mi][ni], 0, 0, 0);
+                }
+        }
+        if (s + 1 < n_steps) store_step(buf ^ 1, s + 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias + ELU, store, per-sample statistics ----
+    // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
+    const int ncol = lane & 31;
+    float bias_v[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) bias_v[ni] = p.bias[tile_n0 + wn * 64 + ni * 32 + ncol];
+    float tot_s = 0.f, tot_q = 0.f;
+    float* rowS = smem;                 // [BM] (LDS is free again: last loop barrier passed)
+    float* rowQ = smem + BM;
+    if (p.stats_mode != 0) {
+        if (tid < BM) { rowS[tid] = 0.f; rowQ[tid] = 0.f; }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int64_t m = tile_m0 + lr;
+            float rs = 0.f, rq = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const float v = elu1(acc[mi][ni][r] + bias_v[ni]);
+                if (m < p.M) p.y[m * p.Cout + tile_n0 + wn * 64 + ni * 32 + ncol] = v;
+                rs += v; rq += v * v;
+            }
+            if (p.stats_mode == 0) { tot_s += rs; tot_q += rq; }
+            else {
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) { rs += __shfl_xor(rs, o, 64); rq += __shfl_xor(rq, o, 64); }
+                if (ncol == 0 && m < p.M) { atomicAdd(rowS + lr, rs); atomicAdd(rowQ + lr, rq); }
+            }
+        }
+    }
+    if (p.stats_mode == 0) {
+        // every row of this tile belongs to sample tile_m0 / rps and is valid
+        double ds = wave_sum((double)tot_s), dq = wave_sum((double)tot_q);
+        double* red = (double*)smem;
+        __syncthreads();
+        if (lane == 0) { red[wave] = ds; red[4 + wave] = dq; }
+        __syncthreads();
+        if (tid == 0) {
+            const int64_t b = tile_m0 / p.rps;
+            atomicAdd(p.stats_out + 2 * b, red[0] + red[1] + red[2] + red[3]);
+            atomicAdd(p.stats_out + 2 * b + 1, red[4] + red[5] + red[6] + red[7]);
+        }
+    } else {
+        __syncthreads();
+        if (tid < BM) {
+            const int64_t m = tile_m0 + tid;
+            const bool valid = m < p.M;
+            double ds = valid ? (double)rowS[tid] : 0.0, dq = valid ? (double)rowQ[tid] : 0.0;
+            if (p.stats_mode == 1) {
+                // rps is a power of two <= 64: xor-reduce inside aligned groups of rps lanes
+                for (int o = 1; o < p.rps; o <<= 1) { ds += __shfl_xor(ds, o, 64); dq += __shfl_xor(dq, o, 64); }
+                if (valid && (tid & (p.rps - 1)) == 0) {
+                    const int64_t b = m / p.rps;
+                    atomicAdd(p.stats_out + 2 * b, ds);
+                    atomicAdd(p.stats_out + 2 * b + 1, dq);
+                }
+            } else if (valid) {
+                const int64_t b = m / p.rps;
+                atomicAdd(p.stats_out + 2 * b, ds);
+                atomicAdd(p.stats_out + 2 * b + 1, dq);
+            }
+        }
+    }
+}
+
+int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStream_t st) {
+    if (g.Cin % BK != 0 || g.Cout % BN != 0) return NAFP_ERR_UNSUPPORTED;
+    ConvKernelParams p;
+    p.x = a.x; p.stats_in = a.stats_in; p.gamma_in = a.gamma_in; p.beta_in = a.beta_in;
+    p.wp = a.wp; p.bias = a.bias; p.y = a.y; p.stats_out = a.stats_out;
+    p.Fin = g.Fin; p.Tin = g.Tin; p.Cin = g.Cin; p.Fout = g.Fout; p.Tout = g.Tout; p.Cout = g.Cout;
+    p.axis = g.axis; p.stride = g.stride; p.pad = g.pad;
+    p.rps = g.Fout * g.Tout;
+    p.M = B * p.rps;
+    p.sample_in = (int64_t)g.Fin * g.Tin * g.Cin;
+    p.tap_stride = g.axis == 0 ? g.Cin : (int64_t)g.Tin * g.Cin;
+    p.inv_n_in = 1.0 / (double)p.sample_in;
+    const bool pow2 = (p.rps & (p.rps - 1)) == 0;
+    p.stats_mode = (p.rps % BM == 0) ? 0 : ((pow2 && p.rps <= 64) ? 1 : 2);
+    const int64_t mt = (p.M + BM - 1) / BM;
+    static bool attr_set = false;
+    const int lds = 4 * TILE_FLOATS * (int)sizeof(float);      // 73,728 B
+    if (!attr_set) {
+        NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)conv_gemm_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    conv_gemm_kernel<<<dim3((unsigned)mt, (unsigned)(g.Cout / BN)), 256, lds, st>>>(p);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}
+
+// ============================================================================
+// weight packing: keras kernel (3, Cin, Cout) -> Wp (Cout, 3*Cin), k contiguous,
+// so that B-operand tiles load exactly like A-operand tiles.
+// ============================================================================
+__global__ void pack_conv_weight_kernel(const float* __restrict__ k3, float* __restrict__ wp, int K, int Cout) {
+    __shared__ float t[32][33];
+    const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 256 threads: ty 0..7
+    for (int r = ty; r < 32; r += 8)
+        if (k0 + r < K && n0 + tx < Cout) t[r][tx] = k3[(int64_t)(k0 + r) * Cout + n0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (n0 + r < Cout && k0 + tx < K) wp[(int64_t)(n0 + r) * K + k0 + tx] = t[tx][r];
+}
+
+int launch_pack_conv_weight(const float* k3, float* wp, int Cin, int Cout, hipStream_t st) {
+    const int K = 3 * Cin;
+    pack_conv_weight_kernel<<<dim3((K + 31) / 32, (Cout + 31) / 32), 256, 0, st>>>(k3, wp, K, Cout);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}
+
+}  // namespace nafp

@@ -1,0 +1,417 @@
+// Front end: 1-s PCM segment -> padded STFT (Hann, 1024/256) -> |.| -> sparse mel
+// -> log10(.+0.06) -> (minus group max, clamp) .  gfx950.
+//
+// Replaces Melspec_layer.call of the reference (model/fp/melspec/melspectrogram.py:
+// 59-65 pad, 82-98 kapre STFT/Magnitude/ApplyFilterbank, 102-112 log/max/clamp).
+//
+// One 256-thread workgroup per segment.  The zero-padded segment sits in LDS once
+// (every sample is reused by four overlapping frames).  Two real frames are packed
+// into one complex 1024-point FFT (frame t -> re, frame t+1 -> im); each of the
+// 4 waves runs one such FFT per round as a radix-4 Stockham autosort in LDS
+// (5 passes), un-packs the two spectra, and the 256 threads then apply the mel
+// bank as a <=8-tap gather from the LDS-resident magnitudes (941 non-zeros in
+// total: never a dense 513x256 GEMM).  The (n_mels, 32) tile is staged in LDS and
+// leaves with 16-byte coalesced stores.
+#include "nafp_common.h"
+
+#include <cmath>
+#include <vector>
+
+namespace nafp {
+
+constexpr int NFFT = 1024;
+constexpr int HOP = 256;
+constexpr int NBIN = NFFT / 2 + 1;          // 513
+constexpr int MAX_TAPS = 8;
+constexpr int MAX_SEG = 16384;
+constexpr int TILE_LD = 36;                 // LDS leading dimension of the (n_mels, <=32) tile chunk
+
+}  // namespace nafp
+
+struct nafp_melspec {
+    int fs, seg_len, n_fft, hop, n_mels, n_frames;
+    float f_min, f_max;
+    float2* d_twiddle;     // 1024: exp(-2 pi i n / 1024)
+    float* d_window;       // 1024 periodic Hann
+    int* d_mel_start;      // n_mels
+    float* d_mel_w;        // n_mels * 8
+};
+
+namespace nafp {
+
+// ---- host: librosa-0.8.1 Slaney mel bank (restated from the published formula) --
+static double hz_to_mel(double f) {
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp;
+    const double logstep = std::log(6.4) / 27.0;
+    return f >= min_log_hz ? min_log_mel + std::log(f / min_log_hz) / logstep : f / f_sp;
+}
+static double mel_to_hz(double m) {
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp;
+    const double logstep = std::log(6.4) / 27.0;
+    return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m;
+}
+
+static void mel_bank_host(int fs, int n_fft, int n_mels, double fmin, double fmax,
+                          std::vector<float>& out) {
+    const int n_freq = n_fft / 2 + 1;
+    out.assign((size_t)n_mels * n_freq, 0.f);
+    std::vector<double> mel_f(n_mels + 2);
+    const double m0 = hz_to_mel(fmin), m1 = hz_to_mel(fmax);
+    for (int i = 0; i < n_mels + 2; ++i) {
+        // numpy.linspace: start + i*step, last point forced to stop
+        double m = (i == n_mels + 1) ? m1 : m0 + i * ((m1 - m0) / (n_mels + 1));
+        mel_f[i] = mel_to_hz(m);
+    }
+    for (int i = 0; i < n_mels; ++i) {
+        const double fd0 = mel_f[i + 1] - mel_f[i], fd1 = mel_f[i + 2] - mel_f[i + 1];
+        const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+        for (int k = 0; k < n_freq; ++k) {
+            double fk = (k == n_freq - 1) ? fs / 2.0 : k * ((fs / 2.0) / (n_freq - 1));
+            double lower = -(mel_f[i] - fk) / fd0;
+            double upper = (mel_f[i + 2] - fk) / fd1;
+            // librosa keeps `weights` in float32: round the triangle, then scale in f64, round again
+            const float tri = (float)std::fmax(0.0, std::fmin(lower, upper));
+            out[(size_t)i * n_freq + k] = (float)((double)tri * enorm);
+        }
+    }
+}
+
+// ---- device ------------------------------------------------------------------
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// One radix-4 Stockham pass over a 1024-point complex sequence held in LDS
+// (src -> dst), executed by one wave: 256 butterflies, 4 per lane.
+template <int P>
+__device__ __forceinline__ void stockham_pass(const float2* __restrict__ src, float2* __restrict__ dst,
+                                              const float2* __restrict__ tw, int lane) {
+    constexpr int T = NFFT / 4;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = it * 64 + lane;
+        const int k = i & (P - 1);
+        const int j = ((i - k) << 2) + k;
+        float2 u0 = src[i], u1 = src[i + T], u2 = src[i + 2 * T], u3 = src[i + 3 * T];
+        if (P > 1) {
+            const int m = k * (256 / P);
+            u1 = cmul(u1, tw[m]);
+            u2 = cmul(u2, tw[2 * m]);
+            u3 = cmul(u3, tw[3 * m]);
+        }
+        const float2 v0 = make_float2(u0.x + u2.x, u0.y + u2.y);
+        const float2 v1 = make_float2(u0.x - u2.x, u0.y - u2.y);
+        const float2 v2 = make_float2(u1.x + u3.x, u1.y + u3.y);
+        const float2 v3 = make_float2(u1.y - u3.y, -(u1.x - u3.x));   // (u1-u3) * (-i)
+        dst[j] = make_float2(v0.x + v2.x, v0.y + v2.y);
+        dst[j + P] = make_float2(v1.x + v3.x, v1.y + v3.y);
+        dst[j + 2 * P] = make_float2(v0.x - v2.x, v0.y - v2.y);
+        dst[j + 3 * P] = make_float2(v1.x - v3.x, v1.y - v3.y);
+    }
+}
+
+template <typename T> __device__ __forceinline__ float pcm_to_float(T v);
+template <> __device__ __forceinline__ float pcm_to_float<float>(float v) { return v; }
+template <> __device__ __forceinline__ float pcm_to_float<int16_t>(int16_t v) {
+    return (float)v * (1.0f / 32768.0f);     // audio_utils.py:245-246 (exact in f32)
+}
+
+__global__ void melspec_init_stats(float* group_stat, int n_groups) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_groups) {
+        group_stat[2 * i] = -INFINITY;
+        group_stat[2 * i + 1] = INFINITY;
+    }
+}
+
+// LDS carve (floats):
+//   sig  [padded_len]                 zero-padded segment
+//   fftX [4][2048]  fftY [4][2048]    per-wave ping-pong complex buffers
+//   tile [n_mels][TILE_LD]            log-mel tile (<=32 frames per chunk)
+template <typename TIn>
+__global__ __launch_bounds__(256) void melspec_kernel(
+        const TIn* __restrict__ audio, float* __restrict__ feat, float* __restrict__ group_stat,
+        const float2* __restrict__ tw, const float* __restrict__ window,
+        const int* __restrict__ mel_start, const float* __restrict__ mel_w,
+        int seg_len, int n_frames, int n_mels, int group_size) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t seg = blockIdx.x;
+    const int padded_len = seg_len + NFFT;                 // 512 + seg_len + 512
+    const int sig_alloc = (padded_len + 3) & ~3;
+    float* sig = smem;
+    float2* fftX = (float2*)(smem + sig_alloc) + wave * NFFT;
+    float2* fftY = (float2*)(smem + sig_alloc + 4 * 2 * NFFT) + wave * NFFT;
+    float* tile = smem + sig_alloc + 8 * 2 * NFFT;
+
+    // ---- padded segment into LDS (melspectrogram.py:59-65) ----
+    const TIn* a = audio + seg * seg_len;
+    for (int i = tid; i < padded_len; i += 256) {
+        const int s = i - NFFT / 2;
+        sig[i] = (s >= 0 && s < seg_len) ? pcm_to_float<TIn>(a[s]) : 0.f;
+    }
+    // per-thread mel filter (thread m <-> mel bin m)
+    const bool has_mel = tid < n_mels;
+    int mstart = 0;
+    float mw[MAX_TAPS];
+#pragma unroll
+    for (int j = 0; j < MAX_TAPS; ++j) mw[j] = 0.f;
+    if (has_mel) {
+        mstart = mel_start[tid];
+#pragma unroll
+        for (int j = 0; j < MAX_TAPS; ++j) mw[j] = mel_w[tid * MAX_TAPS + j];
+    }
+    __syncthreads();
+
+    float lmax = -INFINITY, lmin = INFINITY;
+    const int n_pairs = (n_frames + 1) / 2;
+    float* out_seg = feat + seg * (int64_t)n_mels * n_frames;
+
+    for (int chunk0 = 0; chunk0 < n_frames; chunk0 += 32) {          // 32-frame tile chunks
+        const int chunk_frames = min(32, n_frames - chunk0);
+        for (int round = 0; round < 4; ++round) {                      // 4 waves x 2 frames
+            const int pair = chunk0 / 2 + round * 4 + wave;
+            const int f0 = 2 * pair, f1 = 2 * pair + 1;
+            const bool live = pair < n_pairs && f0 < chunk0 + chunk_frames;
+            if (live) {
+                // pass 1 reads the windowed frames straight from `sig`: z = w*(x_f0 + i x_f1)
+                const float* s0 = sig + f0 * HOP;
+                const bool has1 = f1 < n_frames;
+                const float* s1 = sig + (has1 ? f1 : f0) * HOP;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int i = it * 64 + lane;
+                    float2 u[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = i + q * 256;
+                        const float w = window[n];
+                        u[q] = make_float2(w * s0[n], has1 ? w * s1[n] : 0.f);
+                    }
+                    const float2 v0 = make_float2(u[0].x + u[2].x, u[0].y + u[2].y);
+                    const float2 v1 = make_float2(u[0].x - u[2].x, u[0].y - u[2].y);
+                    const float2 v2 = make_float2(u[1].x + u[3].x, u[1].y + u[3].y);
+                    const float2 v3 = make_float2(u[1].y - u[3].y, -(u[1].x - u[3].x));
+                    const int j = i << 2;
+                    fftX[j] = make_float2(v0.x + v2.x, v0.y + v2.y);
+                    fftX[j + 1] = make_float2(v1.x + v3.x, v1.y + v3.y);
+                    fftX[j + 2] = make_float2(v0.x - v2.x, v0.y - v2.y);
+                    fftX[j + 3] = make_float2(v1.x - v3.x, v1.y - v3.y);
+                }
+            }
+            __syncthreads();
+            if (live) stockham_pass<4>(fftX, fftY, tw, lane);
+            __syncthreads();
+            if (live) stockham_pass<16>(fftY, fftX, tw, lane);
+            __syncthreads();
+            if (live) stockham_pass<64>(fftX, fftY, tw, lane);
+            __syncthreads();
+            if (live) stockham_pass<256>(fftY, fftX, tw, lane);
+            __syncthreads();
+            if (live) {
+                // un-pack: X0[k] = (Z[k]+conj Z[N-k])/2, X1[k] = (Z[k]-conj Z[N-k])/(2i); keep |.|
+                float* mag0 = (float*)fftY;            // [0..512]
+                float* mag1 = mag0 + 520;              // [0..512]
+                for (int k = lane; k < NBIN; k += 64) {
+                    const float2 z = fftX[k];
+                    const float2 zc = fftX[(NFFT - k) & (NFFT - 1)];
+                    const float ar = 0.5f * (z.x + zc.x), ai = 0.5f * (z.y - zc.y);
+                    const float br = 0.5f * (z.y + zc.y), bi = -0.5f * (z.x - zc.x);
+                    mag0[k] = sqrtf(ar * ar + ai * ai);            // kapre Magnitude = tf.abs
+                    mag1[k] = sqrtf(br * br + bi * bi);
+                }
+            }
+            __syncthreads();
+            // mel gather for the 8 frames of this round (thread <-> mel bin)
+            if (has_mel) {
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) {
+                    const int p = chunk0 / 2 + round * 4 + wv;
+                    const float* mg = (const float*)((float2*)(smem + sig_alloc + 4 * 2 * NFFT) + wv * NFFT);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int f = 2 * p + h;
+                        if (f < chunk0 + chunk_frames && f < n_frames) {
+                            const float* mm = mg + h * 520 + mstart;
+                            float acc = 0.f;
+#pragma unroll
+                            for (int j = 0; j < MAX_TAPS; ++j) acc += mw[j] * mm[j];
+                            // melspectrogram.py:104,107
+                            const float v = logf(fmaxf(acc + 0.06f, 1e-10f)) / 2.302585092994046f;
+                            tile[tid * TILE_LD + (f - chunk0)] = v;
+                            lmax = fmaxf(lmax, v);
+                            lmin = fminf(lmin, v);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // ---- tile chunk out: (n_mels, chunk_frames) -> feat[seg][m][chunk0 + t] ----
+        if (chunk_frames == 32 && (n_frames & 3) == 0) {
+            for (int idx = tid; idx < n_mels * 8; idx += 256) {
+                const int m = idx >> 3, q = idx & 7;
+                const float4 v = *(const float4*)(tile + m * TILE_LD + 4 * q);
+                *(float4*)(out_seg + (int64_t)m * n_frames + chunk0 + 4 * q) = v;
+            }
+        } else {
+            for (int idx = tid; idx < n_mels * chunk_frames; idx += 256) {
+                const int m = idx / chunk_frames, t = idx % chunk_frames;
+                out_seg[(int64_t)m * n_frames + chunk0 + t] = tile[m * TILE_LD + t];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- group max / min (melspectrogram.py:108, 110) ----
+    lmax = wave_max(lmax);
+    lmin = wave_min(lmin);
+    float* red = tile;                     // tile is dead after the last chunk's barrier
+    if (lane == 0) { red[wave] = lmax; red[4 + wave] = lmin; }
+    __syncthreads();
+    if (tid == 0) {
+        const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const float mn = fminf(fminf(red[4], red[5]), fminf(red[6], red[7]));
+        const int64_t g = group_size > 0 ? seg / group_size : 0;
+        atomic_max_float(group_stat + 2 * g, mx);
+        atomic_min_float(group_stat + 2 * g + 1, mn);
+    }
+}
+
+// feat <- max(raw - group_max, -80) [; segment_norm]   (melspectrogram.py:108-111)
+__global__ __launch_bounds__(256) void melspec_finalize_kernel(
+        float* __restrict__ feat, const float* __restrict__ group_stat, int64_t n_vec4,
+        int vec4_per_seg, int group_size, int segment_norm) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_vec4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t seg = i / vec4_per_seg;
+        const int64_t g = group_size > 0 ? seg / group_size : 0;
+        const float gmax = group_stat[2 * g];
+        float4 v = ((float4*)feat)[i];
+        v.x = fmaxf(v.x - gmax, -80.f);
+        v.y = fmaxf(v.y - gmax, -80.f);
+        v.z = fmaxf(v.z - gmax, -80.f);
+        v.w = fmaxf(v.w - gmax, -80.f);
+        if (segment_norm) {
+            const float mn = fmaxf(group_stat[2 * g + 1] - gmax, -80.f);
+            const float h = mn / 2.f, d = fabsf(h + 1e-10f);
+            v.x = (v.x - h) / d; v.y = (v.y - h) / d; v.z = (v.z - h) / d; v.w = (v.w - h) / d;
+        }
+        ((float4*)feat)[i] = v;
+    }
+}
+
+template <typename TIn>
+static int melspec_forward(nafp_melspec* p, const TIn* audio, int64_t n_seg, int group_size,
+                           int segment_norm, float* feat, float* group_stat, void* stream) {
+    if (!p || !audio || !feat || !group_stat || n_seg < 0) return NAFP_ERR_INVALID_ARG;
+    if (n_seg == 0) return NAFP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (group_size <= 0 || group_size > n_seg) group_size = (int)std::min<int64_t>(n_seg, INT32_MAX);
+    const int n_groups = (int)((n_seg + group_size - 1) / group_size);
+    melspec_init_stats<<<(n_groups + 255) / 256, 256, 0, st>>>(group_stat, n_groups);
+    NAFP_LAUNCH_CHECK();
+    const int padded_len = p->seg_len + NFFT;
+    const int sig_alloc = (padded_len + 3) & ~3;
+    const size_t lds = (size_t)(sig_alloc + 8 * 2 * NFFT + p->n_mels * TILE_LD) * sizeof(float);
+    melspec_kernel<TIn><<<dim3((unsigned)n_seg), 256, lds, st>>>(
+        audio, feat, group_stat, p->d_twiddle, p->d_window, p->d_mel_start, p->d_mel_w,
+        p->seg_len, p->n_frames, p->n_mels, group_size);
+    NAFP_LAUNCH_CHECK();
+    const int per_seg = p->n_mels * p->n_frames;     // multiple of 4 (n_mels % 64 == 0)
+    const int64_t n_vec4 = n_seg * per_seg / 4;
+    const int blocks = (int)std::min<int64_t>((n_vec4 + 255) / 256, 2048);
+    melspec_finalize_kernel<<<blocks, 256, 0, st>>>(feat, group_stat, n_vec4, per_seg / 4,
+                                                    group_size, segment_norm);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}
+
+}  // namespace nafp
+
+using namespace nafp;
+
+extern "C" int nafp_mel_filterbank_host(int fs, int n_fft, int n_mels, float f_min, float f_max,
+                                        float* out_host) {
+    if (!out_host || fs <= 0 || n_fft <= 0 || n_mels <= 0 || !(f_max > f_min)) return NAFP_ERR_INVALID_ARG;
+    std::vector<float> fb;
+    mel_bank_host(fs, n_fft, n_mels, f_min, f_max, fb);
+    std::copy(fb.begin(), fb.end(), out_host);
+    return NAFP_OK;
+}
+
+extern "C" int nafp_melspec_create(nafp_melspec** plan, int fs, int seg_len, int n_fft, int hop,
+                                   int n_mels, float f_min, float f_max) {
+    if (!plan || fs <= 0 || seg_len <= 0 || !(f_max > f_min)) return NAFP_ERR_INVALID_ARG;
+    if (n_fft != NFFT || hop != HOP || n_mels <= 0 || n_mels > 256 || (n_mels % 64) != 0 ||
+        seg_len > MAX_SEG)
+        return NAFP_ERR_UNSUPPORTED;
+    std::vector<float> fb;
+    mel_bank_host(fs, n_fft, n_mels, f_min, f_max, fb);
+    std::vector<int> start(n_mels, 0);
+    std::vector<float> w((size_t)n_mels * MAX_TAPS, 0.f);
+    for (int m = 0; m < n_mels; ++m) {
+        int lo = -1, hi = -1;
+        for (int k = 0; k < NBIN; ++k)
+            if (fb[(size_t)m * NBIN + k] != 0.f) { if (lo < 0) lo = k; hi = k; }
+        if (lo < 0) { start[m] = 0; continue; }
+        if (hi - lo + 1 > MAX_TAPS) return NAFP_ERR_UNSUPPORTED;
+        if (lo + MAX_TAPS > NBIN) lo = NBIN - MAX_TAPS;       // keep the 8-wide window in range
+        start[m] = lo;
+        for (int j = 0; j < MAX_TAPS; ++j) w[(size_t)m * MAX_TAPS + j] = fb[(size_t)m * NBIN + lo + j];
+    }
+    std::vector<float2> tw(NFFT);
+    std::vector<float> win(NFFT);
+    for (int n = 0; n < NFFT; ++n) {
+        const double a = -2.0 * M_PI * n / NFFT;
+        tw[n] = make_float2((float)std::cos(a), (float)std::sin(a));
+        win[n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * n / NFFT));   // tf.signal.hann_window, periodic
+    }
+    nafp_melspec* p = new nafp_melspec();
+    p->fs = fs; p->seg_len = seg_len; p->n_fft = n_fft; p->hop = hop; p->n_mels = n_mels;
+    p->f_min = f_min; p->f_max = f_max;
+    p->n_frames = 1 + seg_len / hop;          // 1 + ((seg_len + n_fft) - n_fft) // hop
+    p->d_twiddle = nullptr; p->d_window = nullptr; p->d_mel_start = nullptr; p->d_mel_w = nullptr;
+    auto fail = [&](hipError_t e) { g_last_hip_error = (int)e; nafp_melspec_destroy(p); return NAFP_ERR_HIP; };
+    hipError_t e;
+    if ((e = hipMalloc(&p->d_twiddle, sizeof(float2) * NFFT)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&p->d_window, sizeof(float) * NFFT)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&p->d_mel_start, sizeof(int) * n_mels)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&p->d_mel_w, sizeof(float) * n_mels * MAX_TAPS)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpy(p->d_twiddle, tw.data(), sizeof(float2) * NFFT, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpy(p->d_window, win.data(), sizeof(float) * NFFT, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpy(p->d_mel_start, start.data(), sizeof(int) * n_mels, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpy(p->d_mel_w, w.data(), sizeof(float) * n_mels * MAX_TAPS, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    // the kernel needs > 64 KiB of dynamic LDS
+    const int sig_alloc = (seg_len + NFFT + 3) & ~3;
+    const int lds = (sig_alloc + 8 * 2 * NFFT + n_mels * TILE_LD) * (int)sizeof(float);
+    if ((e = hipFuncSetAttribute((const void*)melspec_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return fail(e);
+    if ((e = hipFuncSetAttribute((const void*)melspec_kernel<int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return fail(e);
+    *plan = p;
+    return NAFP_OK;
+}
+
+extern "C" int nafp_melspec_destroy(nafp_melspec* p) {
+    if (!p) return NAFP_OK;
+    if (p->d_twiddle) (void)hipFree(p->d_twiddle);
+    if (p->d_window) (void)hipFree(p->d_window);
+    if (p->d_mel_start) (void)hipFree(p->d_mel_start);
+    if (p->d_mel_w) (void)hipFree(p->d_mel_w);
+    delete p;
+    return NAFP_OK;
+}
+
+extern "C" int nafp_melspec_n_frames(const nafp_melspec* p) { return p ? p->n_frames : -1; }
+extern "C" int nafp_melspec_n_mels(const nafp_melspec* p) { return p ? p->n_mels : -1; }
+
+extern "C" int nafp_melspec_forward_f32(nafp_melspec* plan, const float* audio, int64_t n_seg,
+                                        int group_size, int segment_norm, float* feat,
+                                        float* group_stat, void* stream) {
+    return melspec_forward<float>(plan, audio, n_seg, group_size, segment_norm, feat, group_stat, stream);
+}
+extern "C" int nafp_melspec_forward_i16(nafp_melspec* plan, const int16_t* audio, int64_t n_seg,
+                                        int group_size, int segment_norm, float* feat,
+                                        float* group_stat, void* stream) {
+    return melspec_forward<int16_t>(plan, audio, n_seg, group_size, segment_norm, feat, group_stat, stream);
+}

@@ -1,0 +1,122 @@
+// Shared declarations for libnafp (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+
+#include "../../include/nafp.h"
+
+namespace nafp {
+
+extern thread_local int g_last_hip_error;
+
+#define NAFP_HIP_CHECK(expr)                                   \
+    do {                                                       \
+        hipError_t _e = (expr);                                \
+        if (_e != hipSuccess) {                                \
+            nafp::g_last_hip_error = (int)_e;                  \
+            return NAFP_ERR_HIP;                               \
+        }                                                      \
+    } while (0)
+
+#define NAFP_LAUNCH_CHECK() NAFP_HIP_CHECK(hipGetLastError())
+
+constexpr float LN_EPS = 1e-3f;   // keras LayerNormalization default (nnfp.py:66-67)
+
+// TF 'SAME' geometry along one axis.
+struct SamePad { int n_out, before, after; };
+inline SamePad same_pad(int n_in, int k, int s) {
+    int n_out = (n_in + s - 1) / s;
+    int total = (n_out - 1) * s + k - n_in;
+    if (total < 0) total = 0;
+    return {n_out, total / 2, total - total / 2};
+}
+
+// One conv of the 16 in front_conv (nnfp.py:48-59): 3 taps along T (axis 0, "1x3")
+// or along F (axis 1, "3x1"), dense over channels, TF SAME padding.
+struct ConvGeom {
+    int axis;            // 0: taps along T, 1: taps along F
+    int Fin, Tin, Cin;
+    int Fout, Tout, Cout;
+    int stride;          // along the tap axis (the other axis has stride 1)
+    int pad;             // pad before, along the tap axis
+};
+
+std::vector<ConvGeom> encoder_geometry(int in_f, int in_t);
+
+__device__ __forceinline__ float elu1(float v) {   // keras ELU(alpha=1) (nnfp.py:74,77)
+    return v > 0.f ? v : expm1f(v);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// atomic max / min on a float stored in global memory (any sign).
+__device__ __forceinline__ void atomic_max_float(float* addr, float v) {
+    if (v >= 0.f) atomicMax((int*)addr, __float_as_int(v));
+    else          atomicMin((unsigned int*)addr, __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_min_float(float* addr, float v) {
+    if (v >= 0.f) atomicMin((int*)addr, __float_as_int(v));
+    else          atomicMax((unsigned int*)addr, __float_as_uint(v));
+}
+
+// ---- kernels' host launchers (defined in the .hip files) -------------------
+
+// conv0: (B,F,T) x kernel(3,Cout) -> (B,F,Tout,Cout) + per-sample sum/sumsq.
+int launch_conv0(const float* feat, const float* w3, const float* bias, float* y, double* stats,
+                 int64_t B, const ConvGeom& g, hipStream_t st);
+
+// implicit-GEMM conv with LayerNorm of the input fused into the A-operand load.
+struct ConvGemmArgs {
+    const float* x;          // (B,Fin,Tin,Cin), post-ELU pre-LN output of the previous conv
+    const double* stats_in;  // (B,2): sum, sumsq of x per sample
+    const float* gamma_in;   // (Fin,Tin,Cin)
+    const float* beta_in;    // (Fin,Tin,Cin)
+    const float* wp;         // packed (Cout, 3*Cin), k = tap*Cin + cin
+    const float* bias;       // (Cout)
+    float* y;                // (B,Fout,Tout,Cout) post-ELU, pre-LN
+    double* stats_out;       // (B,2), must be zero on entry
+};
+int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStream_t st);
+
+// tail: LN of the last conv + flatten + divide-and-encode + optional L2 norm.
+struct TailArgs {
+    const float* x;          // (B, D) last conv output (pre-LN), or already-normalised flat
+    const double* stats;     // (B,2) or nullptr when x is already the LN output
+    const float* gamma;      // (D) or nullptr
+    const float* beta;       // (D) or nullptr
+    const float* w1p;        // (S,32,Q)
+    const float* b1p;        // (32,Q)
+    const float* w2p;        // (32,Q)
+    const float* b2;         // (Q)
+    float* out_flat;         // (B,D) or nullptr
+    float* out_emb;          // (B,Q) or nullptr
+    int D, Q, S, l2norm;
+};
+int launch_tail(const TailArgs& a, int64_t B, hipStream_t st);
+
+// weight packing
+int launch_pack_conv_weight(const float* k3, float* wp, int Cin, int Cout, hipStream_t st);
+int launch_pack_div(const float* w1, const float* b1, const float* w2, float* w1p, float* b1p,
+                    float* w2p, int Q, int S, hipStream_t st);
+
+}  // namespace nafp

@@ -1,0 +1,175 @@
+// NT-Xent in-batch contrastive loss for gfx950, fused similarity + log-sum-exp.
+//
+// Replaces NTxentLoss.compute_loss (model/fp/NTxent_loss_single_gpu.py:52-82) and,
+// with n_local < n_global, one replica of NTxentLoss.loss_fn
+// (model/fp/NTxent_loss_tpu.py:90-137).
+//
+// Rows R = [emb_org_local ; emb_rep_local] (2*n_local), columns
+// C = [emb_org_all ; emb_rep_all] (2*n_global).  For row (a, i) the reference's
+// logits are [ab | aa without diagonal]: every column except (a, gi); the label is
+// column (b, gi).  For row (b, i): every column except (b, gi); label (a, gi).
+// So per row:   CE = LSE_{c != self(r)} S[r,c] - S[r, pos(r)],   S = R C^T / tau.
+// The (2N)^2 logits are never materialised (105 MB at BSZ 5120) unless the caller
+// asks for the (n, 2n-1) sim_mtx the reference's trainer logs once per epoch.
+//
+// One workgroup = 32 rows of R; its 4 waves stride over 32-column tiles of C.
+// The product is computed TRANSPOSED (S^T tile = C_tile . R_blk^T) so that in the
+// 32x32 MFMA C/D layout a lane owns ONE row of R (col = lane & 31) and its 16
+// accumulators are 16 different columns: the running max / sum-exp are lane-local.
+// K = d = 128: lane half h multiplies k in [64h, 64h+64) (same split for both
+// operands), the row fragment of R stays in 64 registers for the whole kernel.
+#include "nafp_common.h"
+
+namespace nafp {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int ND = 128;
+
+__global__ __launch_bounds__(256) void ntxent_fwd_kernel(
+        const float* __restrict__ org_l, const float* __restrict__ rep_l,
+        const float* __restrict__ org_all, const float* __restrict__ rep_all,
+        int n_local, int n_global, int rank_offset, float tau,
+        float* __restrict__ row_loss, float* __restrict__ row_lse, float* __restrict__ sim_mtx) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, rl = lane & 31;
+    const int n_rows = 2 * n_local, n_cols = 2 * n_global;
+    const int r = blockIdx.x * 32 + rl;                    // my row of R
+    const bool rvalid = r < n_rows;
+    const bool r_is_b = r >= n_local;
+    const int ri = r_is_b ? r - n_local : r;               // index inside the local half
+    const int gi = rank_offset + ri;
+    const int self_col = r_is_b ? n_global + gi : gi;
+    const int pos_col = r_is_b ? gi : n_global + gi;
+
+    float rf[64];                                           // R[r][64h .. 64h+63]
+    {
+        const float* src = rvalid ? ((r_is_b ? rep_l : org_l) + (int64_t)ri * ND + 64 * h) : nullptr;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            float4 t = rvalid ? *(const float4*)(src + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rf[4 * v] = t.x; rf[4 * v + 1] = t.y; rf[4 * v + 2] = t.z; rf[4 * v + 3] = t.w;
+        }
+    }
+    float run_m = -INFINITY, run_s = 0.f, pos_v = 0.f;
+    const int n_tiles = (n_cols + 31) / 32;
+    for (int t = wave; t < n_tiles; t += 4) {
+        const int c = t * 32 + rl;                          // column this lane feeds into the A operand
+        const bool cvalid = c < n_cols;
+        const float* csrc = nullptr;
+        if (cvalid) csrc = (c >= n_global ? rep_all + (int64_t)(c - n_global) * ND : org_all + (int64_t)c * ND) + 64 * h;
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const float4 cv = cvalid ? *(const float4*)(csrc + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cv.x, rf[4 * v], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cv.y, rf[4 * v + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cv.z, rf[4 * v + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cv.w, rf[4 * v + 3], acc, 0, 0, 0);
+        }
+        // D[i = column-in-tile][j = row]: lane holds j = lane & 31, i = (q&3) + 8*(q>>2) + 4*h
+        float tmax = -INFINITY;
+        float sv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int cc = t * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            const float s = acc[q] / tau;            // `/ self.tau` (NTxent_loss_single_gpu.py:72-77)
+            const bool use = cc < n_cols && cc != self_col;
+            if (cc == pos_col) pos_v = s;
+            sv[q] = use ? s : -INFINITY;
+            tmax = fmaxf(tmax, sv[q]);
+            if (sim_mtx && rvalid && !r_is_b && cc < n_cols && cc != self_col) {
+                // [ab | aa without diagonal] (NTxent_loss_single_gpu.py:78-82)
+                const int j = cc >= n_global ? cc - n_global : n_global + (cc < gi ? cc : cc - 1);
+                sim_mtx[(int64_t)ri * (n_cols - 1) + j] = s;
+            }
+        }
+        if (tmax > -INFINITY) {
+            const float nm = fmaxf(run_m, tmax);
+            float add = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) add += __expf(sv[q] - nm);     // exp(-inf) = 0
+            run_s = run_s * __expf(run_m - nm) + add;
+            run_m = nm;
+        }
+    }
+    // combine lane halves, then the 4 waves
+    {
+        const float om = __shfl_xor(run_m, 32, 64), os = __shfl_xor(run_s, 32, 64);
+        const float op = __shfl_xor(pos_v, 32, 64);
+        const float nm = fmaxf(run_m, om);
+        const float a = run_m > -INFINITY ? run_s * __expf(run_m - nm) : 0.f;
+        const float b = om > -INFINITY ? os * __expf(om - nm) : 0.f;
+        run_s = a + b; run_m = nm; pos_v += op;               // pos_v is non-zero in exactly one place
+    }
+    __shared__ float sm[4][32], ss[4][32], sp[4][32];
+    if (h == 0) { sm[wave][rl] = run_m; ss[wave][rl] = run_s; sp[wave][rl] = pos_v; }
+    __syncthreads();
+    if (tid < 32) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) m = fmaxf(m, sm[w][tid]);
+        float s = 0.f, pv = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (sm[w][tid] > -INFINITY) s += ss[w][tid] * __expf(sm[w][tid] - m);
+            pv += sp[w][tid];
+        }
+        const int rr = blockIdx.x * 32 + tid;
+        if (rr < n_rows) {
+            const float lse = m + __logf(s);
+            row_lse[rr] = lse;
+            row_loss[rr] = lse - pv;
+        }
+    }
+}
+
+__global__ void ntxent_sum_kernel(const float* __restrict__ row_loss, int n, float* __restrict__ out) {
+    // single workgroup, fixed order: deterministic
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += (double)row_loss[i];
+    acc = wave_sum(acc);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+
+}  // namespace nafp
+
+using namespace nafp;
+
+extern "C" int64_t nafp_ntxent_workspace_bytes(int64_t n_local, int64_t n_global) {
+    (void)n_global;
+    if (n_local < 0) return -1;
+    return (int64_t)sizeof(float) * 2 * (2 * n_local) + 256;     // row_loss + row_lse
+}
+
+extern "C" int nafp_ntxent_forward(const float* emb_org_local, const float* emb_rep_local,
+                                   const float* emb_org_all, const float* emb_rep_all,
+                                   int64_t n_local, int64_t n_global, int64_t rank_offset, int d,
+                                   float tau, float* loss_sum, float* sim_mtx,
+                                   float* d_org_all, float* d_rep_all,
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!emb_org_local || !emb_rep_local || !emb_org_all || !emb_rep_all || !loss_sum || !workspace)
+        return NAFP_ERR_INVALID_ARG;
+    if (n_local <= 0 || n_global < n_local || rank_offset < 0 || rank_offset + n_local > n_global ||
+        !(tau > 0.f) || n_global > (1 << 29))
+        return NAFP_ERR_INVALID_ARG;
+    if (d != ND) return NAFP_ERR_UNSUPPORTED;
+    if (d_org_all || d_rep_all) return NAFP_ERR_UNSUPPORTED;     // backward: not built yet
+    if (workspace_bytes < nafp_ntxent_workspace_bytes(n_local, n_global)) return NAFP_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* row_loss = (float*)workspace;
+    float* row_lse = row_loss + 2 * n_local;
+    const int n_rows = (int)(2 * n_local);
+    ntxent_fwd_kernel<<<(n_rows + 31) / 32, 256, 0, st>>>(
+        emb_org_local, emb_rep_local, emb_org_all, emb_rep_all, (int)n_local, (int)n_global,
+        (int)rank_offset, tau, row_loss, row_lse, sim_mtx);
+    NAFP_LAUNCH_CHECK();
+    ntxent_sum_kernel<<<1, 256, 0, st>>>(row_loss, n_rows, loss_sum);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}

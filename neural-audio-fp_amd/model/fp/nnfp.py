@@ -1,0 +1,208 @@
+"""Host mirror of the reference's fingerprinter, backed by libnafp's HIP encoder.
+
+Mirrors `FingerPrinter` / `get_fingerprinter` of the reference
+(model/fp/nnfp.py:159-258): `m_fp(feat) -> (B, emb_sz)`, `.front_conv(feat) ->
+(B, 1024)`, `.div_enc(x) -> (B, emb_sz)`, attributes `front_hidden_ch`,
+`front_strides`, `emb_sz`, `norm`, `use_L2layer`, `trainable`,
+`trainable_variables` (used at trainer.py:42,47-48,73-75,87-88).
+
+Parameters are torch CUDA tensors in the keras variable shapes and order
+(include/nafp.h, "Parameter tensors"); they are pushed to the library (which
+re-packs them for its kernels) lazily, whenever they were replaced or marked
+dirty.  No CPU path.
+"""
+import ctypes
+import math
+
+import torch
+
+from ... import _lib
+
+FRONT_HIDDEN_CH = [128, 128, 256, 256, 512, 512, 1024, 1024]            # nnfp.py:193
+FRONT_STRIDES = [[(1, 2), (2, 1)], [(1, 2), (2, 1)], [(1, 2), (2, 1)], [(1, 2), (2, 1)],
+                 [(1, 1), (2, 1)], [(1, 2), (2, 1)], [(1, 1), (2, 1)], [(1, 2), (2, 1)]]  # nnfp.py:194-197
+
+
+def tensor_names():
+    """Checkpoint key of each parameter tensor, in library order."""
+    names = []
+    for j in range(16):
+        blk, kind = j // 2, ('conv2d_1x3' if j % 2 == 0 else 'conv2d_3x1')
+        bn = 'BN_1x3' if j % 2 == 0 else 'BN_3x1'
+        names += [f'front_conv.{blk}.{kind}.kernel', f'front_conv.{blk}.{kind}.bias',
+                  f'front_conv.{blk}.{bn}.gamma', f'front_conv.{blk}.{bn}.beta']
+    names += ['div_enc.fc1.kernel', 'div_enc.fc1.bias', 'div_enc.fc2.kernel', 'div_enc.fc2.bias']
+    return names
+
+
+class FingerPrinter:
+    def __init__(self, input_shape=(256, 32, 1), front_hidden_ch=None, front_strides=None,
+                 emb_sz=128, fc_unit_dim=(32, 1), norm='layer_norm2d', use_L2layer=True,
+                 device=None, seed=None):
+        front_hidden_ch = list(front_hidden_ch or FRONT_HIDDEN_CH)
+        front_strides = [list(map(tuple, s)) for s in (front_strides or FRONT_STRIDES)]
+        if front_hidden_ch != FRONT_HIDDEN_CH or front_strides != FRONT_STRIDES or \
+                list(fc_unit_dim) != [32, 1] or input_shape[2] != 1:
+            raise NotImplementedError('only the channel/stride tables of nnfp.py:193-197 are built')
+        if norm != 'layer_norm2d':
+            raise NotImplementedError(f"norm='{norm}' (config MODEL.BN); only 'layer_norm2d' is built")
+        self.front_hidden_ch, self.front_strides = front_hidden_ch, front_strides
+        self.emb_sz, self.norm, self.use_L2layer = emb_sz, norm, use_L2layer
+        self.n_clayers = len(front_strides)
+        self.input_shape = tuple(input_shape)
+        self.trainable = False
+        self.device = torch.device(device if device is not None else 'cuda')
+        lib = _lib.load()
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.nafp_encoder_create(ctypes.byref(h), int(input_shape[0]), int(input_shape[1]),
+                                               int(emb_sz)), 'encoder_create')
+        self._h, self._lib = h, lib
+        self.flat_dim = int(lib.nafp_encoder_flat_dim(h))
+        self._shapes = []
+        dims = (ctypes.c_int64 * 4)()
+        for i in range(lib.nafp_encoder_n_tensors(h)):
+            r = lib.nafp_encoder_tensor_shape(h, i, dims)
+            self._shapes.append(tuple(int(dims[k]) for k in range(r)))
+        self._names = tensor_names()
+        self._vars = self._init_variables(seed)
+        self._dirty = True
+        self._ws = None
+
+    # ---- parameters -------------------------------------------------------
+    def _init_variables(self, seed):
+        """keras defaults: glorot-uniform kernels, zero biases, LN gamma=1 / beta=0
+        (nnfp.py:48-59, 66-67, 135-137)."""
+        g = torch.Generator().manual_seed(int(seed) if seed is not None else torch.seed() % (2 ** 31))
+        out = []
+        for i, shp in enumerate(self._shapes):
+            if i < 64:
+                kind = i % 4
+                if kind == 0:
+                    kh, kw, cin, cout = shp
+                    lim = math.sqrt(6.0 / (kh * kw * cin + kh * kw * cout))
+                    t = (torch.rand(shp, generator=g) * 2 - 1) * lim
+                elif kind == 2:
+                    t = torch.ones(shp)
+                else:
+                    t = torch.zeros(shp)
+            elif i in (64, 66):
+                fan_in, fan_out = shp[1], shp[2]
+                lim = math.sqrt(6.0 / (fan_in + fan_out))
+                t = (torch.rand(shp, generator=g) * 2 - 1) * lim
+            else:
+                t = torch.zeros(shp)
+            out.append(t.to(self.device, torch.float32).contiguous())
+        return out
+
+    @property
+    def trainable_variables(self):
+        return list(self._vars)
+
+    def mark_dirty(self):
+        """Call after modifying a variable in place (e.g. an optimizer step)."""
+        self._dirty = True
+
+    def state_dict(self):
+        return {n: v.detach().cpu().clone() for n, v in zip(self._names, self._vars)}
+
+    def load_state_dict(self, sd):
+        missing = [n for n in self._names if n not in sd]
+        if missing:
+            raise KeyError(f'missing checkpoint keys: {missing[:4]}...')
+        for i, n in enumerate(self._names):
+            t = torch.as_tensor(sd[n], dtype=torch.float32)
+            if tuple(t.shape) != self._shapes[i]:
+                raise ValueError(f'{n}: shape {tuple(t.shape)} != {self._shapes[i]}')
+            self._vars[i] = t.to(self.device).contiguous()
+        self._dirty = True
+
+    def set_weights(self, arrays):
+        """arrays: sequence of 68 array-likes in library order (keras shapes)."""
+        self.load_state_dict({n: a for n, a in zip(self._names, arrays)})
+
+    def _sync(self):
+        if not self._dirty:
+            return
+        arr = (ctypes.c_void_p * len(self._vars))(*[v.data_ptr() for v in self._vars])
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.nafp_encoder_set_weights(self._h, arr, _lib.current_stream()),
+                       'encoder_set_weights')
+        self._dirty = False
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h:
+            self._lib.nafp_encoder_destroy(h)
+            self._h = None
+
+    # ---- forward ------------------------------------------------------------
+    def _prep(self, x, shape_tail):
+        x = torch.as_tensor(x)
+        if not x.is_cuda:
+            x = x.to(self.device)
+        if tuple(x.shape[1:]) != tuple(shape_tail):
+            raise ValueError(f'expected (B,{",".join(map(str, shape_tail))}), got {tuple(x.shape)}')
+        return x.float().contiguous()
+
+    def _workspace(self, n):
+        need = int(self._lib.nafp_encoder_workspace_bytes(self._h, n))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
+        return self._ws, need
+
+    def _forward(self, feat, want_flat, want_emb):
+        feat = self._prep(feat, self.input_shape)
+        self._sync()
+        B = feat.shape[0]
+        flat = torch.empty((B, self.flat_dim), dtype=torch.float32, device=feat.device) if want_flat else None
+        emb = torch.empty((B, self.emb_sz), dtype=torch.float32, device=feat.device) if want_emb else None
+        ws, need = self._workspace(B)
+        with torch.cuda.device(feat.device):
+            _lib.check(self._lib.nafp_encoder_forward(self._h, _lib.ptr(feat), B, _lib.ptr(ws), need,
+                                                      _lib.ptr(flat), _lib.ptr(emb),
+                                                      int(bool(self.use_L2layer)), _lib.current_stream()),
+                       'encoder_forward')
+        return flat, emb
+
+    # ---- per-kernel HIP-event timing (bench.py roofline leg) ----------------
+    def profile_enable(self, max_forwards):
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.nafp_encoder_profile_enable(self._h, int(max_forwards)), 'profile_enable')
+
+    def profile_read(self):
+        """-> list of 17-float lists (ms): conv0, 15 implicit-GEMM convs, tail; one per forward."""
+        out = []
+        buf = (ctypes.c_float * 17)()
+        for s in range(self._lib.nafp_encoder_profile_count(self._h)):
+            _lib.check(self._lib.nafp_encoder_profile_read(self._h, s, buf), 'profile_read')
+            out.append([float(v) for v in buf])
+        return out
+
+    def front_conv(self, feat):
+        """(B,F,T,1) -> (B, F'*T'*C) (nnfp.py:210-218)."""
+        return self._forward(feat, True, False)[0]
+
+    def div_enc(self, x):
+        """(B, D) -> (B, Q), no L2 (nnfp.py:141-156)."""
+        x = self._prep(x, (self.flat_dim,))
+        self._sync()
+        out = torch.empty((x.shape[0], self.emb_sz), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(self._lib.nafp_encoder_div_enc(self._h, _lib.ptr(x), x.shape[0], _lib.ptr(out), 0,
+                                                      _lib.current_stream()), 'encoder_div_enc')
+        return out
+
+    def __call__(self, inputs):
+        """nnfp.py:223-231."""
+        return self._forward(inputs, False, True)[1]
+
+    call = __call__
+
+
+def get_fingerprinter(cfg, trainable=False):
+    """nnfp.py:234-258 (input shape is hard-coded to (256,32,1) there, :248)."""
+    m = FingerPrinter(input_shape=(256, 32, 1), emb_sz=cfg['MODEL']['EMB_SZ'], fc_unit_dim=[32, 1],
+                      norm=cfg['MODEL']['BN'])
+    m.trainable = trainable
+    return m

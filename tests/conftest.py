@@ -1,0 +1,38 @@
+"""pytest configuration: `gpu` marker, repo root on sys.path, shared fixtures."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU tests fail loudly on a box without a GPU only if explicitly selected
+    with -m gpu; otherwise they are skipped."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason='no GPU in this container')
+    for item in items:
+        if 'gpu' in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope='session')
+def nafp():
+    import neural_audio_fp_amd
+    return neural_audio_fp_amd
+
+
+@pytest.fixture(scope='session')
+def cfg():
+    import yaml
+    with open(os.path.join(ROOT, 'config', 'default.yaml')) as f:
+        return yaml.safe_load(f)

@@ -1,0 +1,98 @@
+"""GPU parity: the HIP path (through the C ABI) vs the CPU oracle on the same seeded
+inputs.  Floating point; tolerances are written next to each check.  The contract
+(BASELINE.json north_star) is cosine(embedding, oracle) >= 1 - 1e-3 per segment."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import melspec as o_mel, nnfp as o_nnfp
+
+pytestmark = pytest.mark.gpu
+
+
+def _audio(B, seed=0, T=8000):
+    rng = np.random.default_rng(seed)
+    t = np.arange(T) / 8000.0
+    x = 0.1 * rng.normal(size=(B, 1, T))
+    for b in range(B):
+        f = rng.uniform(300, 3900, size=3)
+        x[b, 0] += sum(0.2 * np.sin(2 * np.pi * fi * t + rng.uniform(0, 6.28)) for fi in f)
+    return x.astype(np.float32)
+
+
+def test_melspec_matches_oracle(nafp, cfg):
+    x = _audio(7, seed=1)
+    m_pre = nafp.get_melspec_layer(cfg)
+    got = m_pre(torch.from_numpy(x).cuda()).cpu().numpy()
+    want = o_mel.melspec_layer(x, dtype=np.float64)
+    assert got.shape == want.shape == (7, 256, 32, 1)
+    # log10 of fp32 FFT magnitudes: abs tolerance 2e-5 (values span [-1.3, 0])
+    assert np.abs(got - want).max() < 2e-5
+    assert got.max() == 0.0          # the group max is subtracted exactly
+
+
+def test_melspec_groups_and_int16(nafp, cfg):
+    x = _audio(10, seed=2)
+    xi = np.clip(np.round(x * 32768), -32768, 32767).astype(np.int16)
+    xf = (xi / 2 ** 15).astype(np.float32)          # audio_utils.py:245-246
+    m_pre = nafp.get_melspec_layer(cfg)
+    got_i = m_pre(torch.from_numpy(xi).cuda(), group_size=4).cpu().numpy()
+    got_f = m_pre(torch.from_numpy(xf).cuda(), group_size=4).cpu().numpy()
+    want = o_mel.melspec_layer(xf, group_size=4, dtype=np.float64)
+    assert np.array_equal(got_i, got_f)              # int16 path == float path, bit for bit
+    assert np.abs(got_f - want).max() < 2e-5
+    # each group (4,4,2 segments) has its own zero maximum
+    assert got_f[:4].max() == 0.0 and got_f[4:8].max() == 0.0 and got_f[8:].max() == 0.0
+
+
+def test_melspec_maxnorm(nafp, cfg):
+    import copy
+    c = copy.deepcopy(cfg)
+    c['MODEL']['FEAT'] = 'melspec_maxnorm'
+    x = _audio(3, seed=3)
+    got = nafp.get_melspec_layer(c)(torch.from_numpy(x).cuda()).cpu().numpy()
+    want = o_mel.melspec_layer(x, segment_norm=True, dtype=np.float64)
+    assert np.abs(got - want).max() < 1e-4
+
+
+def _load_oracle_weights(m_fp, w):
+    arrays = []
+    for j in range(16):
+        arrays += [w[f'conv{j}.kernel'], w[f'conv{j}.bias'], w[f'ln{j}.gamma'], w[f'ln{j}.beta']]
+    arrays += [w['div.w1'], w['div.b1'], w['div.w2'], w['div.b2']]
+    m_fp.set_weights(arrays)
+
+
+@pytest.mark.parametrize('B', [1, 5])
+def test_encoder_matches_oracle(nafp, cfg, B):
+    rng = np.random.default_rng(10 + B)
+    feat = (-rng.uniform(0, 1.2, size=(B, 256, 32, 1))).astype(np.float32)
+    w = o_nnfp.init_weights(seed=3, randomize_affine=True)
+    m_fp = nafp.get_fingerprinter(cfg)
+    _load_oracle_weights(m_fp, w)
+    f_t = torch.from_numpy(feat).cuda()
+    flat = m_fp.front_conv(f_t).cpu().numpy()
+    emb = m_fp(f_t).cpu().numpy()
+    want_flat = o_nnfp.front_conv(feat, w, dtype=np.float64)
+    want_emb = o_nnfp.fingerprinter(feat, w, dtype=np.float64)
+    assert flat.shape == (B, 1024) and emb.shape == (B, 128)
+    # fp32 through 16 conv+LN layers vs float64 oracle: abs 2e-4 on O(1) activations
+    assert np.abs(flat - want_flat).max() < 2e-4
+    assert np.abs(emb - want_emb).max() < 2e-5
+    cos = (emb * want_emb).sum(1) / np.linalg.norm(emb, axis=1) / np.linalg.norm(want_emb, axis=1)
+    assert (1 - cos).max() < 1e-6                  # contract: 1e-3
+    # div_enc alone (trainer.py:73-76 calls the halves separately), no L2
+    de = m_fp.div_enc(torch.from_numpy(want_flat.astype(np.float32)).cuda()).cpu().numpy()
+    assert np.abs(de - o_nnfp.div_enc(want_flat, w)).max() < 1e-5
+
+
+def test_end_to_end_audio_to_fingerprint(nafp, cfg):
+    x = _audio(6, seed=5)
+    w = o_nnfp.init_weights(seed=4, randomize_affine=True)
+    m_pre, m_fp = nafp.get_melspec_layer(cfg), nafp.get_fingerprinter(cfg)
+    _load_oracle_weights(m_fp, w)
+    emb = m_fp(m_pre(torch.from_numpy(x).cuda())).cpu().numpy()       # generate.py:83-88
+    want = o_nnfp.fingerprinter(o_mel.melspec_layer(x), w)
+    cos = (emb * want).sum(1)
+    assert (1 - cos).max() < 1e-5
+    assert np.abs(np.linalg.norm(emb, axis=1) - 1).max() < 1e-5
