@@ -175,6 +175,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKernelParam
     for (int i = 0; i < 4; ++i) wrow[i] = p.wp + (int64_t)(tile_n0 + lrow + 32 * i) * K + lcol;
 
     float4 ra[4], rg[4], rb[4], rw[4];
+    // Branch-free: rows whose tap falls into the zero padding (or beyond M) read a
+    // harmless in-range address (offset 0) and are zeroed by a select afterwards, so
+    // all 16 loads of a K-step are in flight together.
     auto load_step = [&](int s) {
         const int tsel = s / cpt;
         const int tap = tsel == 0 ? live_tap[0] : (tsel == 1 ? live_tap[1] : live_tap[2]);
@@ -182,14 +185,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKernelParam
         const int64_t toff = tap * p.tap_stride + c0 + lcol;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (tapmask[i] & (1u << tap)) {
-                ra[i] = *(const float4*)(p.x + off0[i] + toff);
-                rg[i] = *(const float4*)(p.gamma_in + gb0[i] + toff);
-                rb[i] = *(const float4*)(p.beta_in + gb0[i] + toff);
-            } else {
-                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                rg[i] = ra[i]; rb[i] = ra[i];
-            }
+            const bool ok = (tapmask[i] >> tap) & 1u;
+            const int64_t ox = ok ? off0[i] + toff : 0;
+            const int64_t og = ok ? gb0[i] + toff : 0;
+            ra[i] = *(const float4*)(p.x + ox);
+            rg[i] = *(const float4*)(p.gamma_in + og);
+            rb[i] = *(const float4*)(p.beta_in + og);
             rw[i] = *(const float4*)(wrow[i] + tap * p.Cin + c0);
         }
     };
@@ -200,15 +201,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKernelParam
         float* Bs = As + TILE_FLOATS;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            const bool ok = (tapmask[i] >> tap) & 1u;
             float4 v;
-            if (tapmask[i] & (1u << tap)) {
-                v.x = fmaf(fmaf(ra[i].x, lnA[i], lnC[i]), rg[i].x, rb[i].x);
-                v.y = fmaf(fmaf(ra[i].y, lnA[i], lnC[i]), rg[i].y, rb[i].y);
-                v.z = fmaf(fmaf(ra[i].z, lnA[i], lnC[i]), rg[i].z, rb[i].z);
-                v.w = fmaf(fmaf(ra[i].w, lnA[i], lnC[i]), rg[i].w, rb[i].w);
-            } else {
-                v = make_float4(0.f, 0.f, 0.f, 0.f);      // zero padding is applied AFTER LayerNorm
-            }
+            v.x = fmaf(fmaf(ra[i].x, lnA[i], lnC[i]), rg[i].x, rb[i].x);
+            v.y = fmaf(fmaf(ra[i].y, lnA[i], lnC[i]), rg[i].y, rb[i].y);
+            v.z = fmaf(fmaf(ra[i].z, lnA[i], lnC[i]), rg[i].z, rb[i].z);
+            v.w = fmaf(fmaf(ra[i].w, lnA[i], lnC[i]), rg[i].w, rb[i].w);
+            // zero padding is applied AFTER LayerNorm
+            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
             *(float4*)(As + (lrow + 32 * i) * LD + lcol) = v;
             *(float4*)(Bs + (lrow + 32 * i) * LD + lcol) = rw[i];
         }

@@ -44,8 +44,11 @@ struct ConvGeom {
 
 std::vector<ConvGeom> encoder_geometry(int in_f, int in_t);
 
-__device__ __forceinline__ float elu1(float v) {   // keras ELU(alpha=1) (nnfp.py:74,77)
-    return v > 0.f ? v : expm1f(v);
+// keras ELU(alpha=1) (nnfp.py:74,77).  TF computes exp(x) - 1 for x < 0; branch-free here
+// (v_exp_f32 + select) because it sits in every conv epilogue.
+__device__ __forceinline__ float elu1(float v) {
+    const float e = __expf(fminf(v, 0.f)) - 1.f;
+    return v > 0.f ? v : e;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
