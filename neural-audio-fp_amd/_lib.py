@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401  (must be loaded before libnafp; see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libnafp.so')
+# NAFP_LIB: load another build of the same ABI (kernel ablation experiments, tools/ablate.sh)
+LIB_PATH = os.environ.get('NAFP_LIB') or os.path.join(_HERE, 'libnafp.so')
 
 c_i64 = ctypes.c_int64
 c_int = ctypes.c_int

@@ -164,55 +164,62 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKernelParam
     __syncthreads();
     const unsigned live = (unsigned)*s_live;
     __syncthreads();
-    int live_tap[3]; int n_live = 0;
+    // live taps packed 2 bits each (no runtime-indexed array: that would live in scratch)
+    unsigned tap_pack = 0; int n_live = 0;
 #pragma unroll
-    for (int t = 0; t < 3; ++t) if (live & (1u << t)) live_tap[n_live++] = t;
+    for (int t = 0; t < 3; ++t)
+        if (live & (1u << t)) { tap_pack |= (unsigned)t << (2 * n_live); ++n_live; }
     const int cpt = p.Cin / BK;                 // K-steps per tap
     const int n_steps = n_live * cpt;
 
-    const float* wrow[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wrow[i] = p.wp + (int64_t)(tile_n0 + lrow + 32 * i) * K + lcol;
+    const float* wrow0 = p.wp + (int64_t)(tile_n0 + lrow) * K + lcol;
+    const int64_t wrow_stride = (int64_t)32 * K;
 
-    float4 ra[4], rg[4], rb[4], rw[4];
+    float4 ra0, ra1, ra2, ra3, rg0, rg1, rg2, rg3, rb0, rb1, rb2, rb3, rw0, rw1, rw2, rw3;
     // Branch-free: rows whose tap falls into the zero padding (or beyond M) read a
     // harmless in-range address (offset 0) and are zeroed by a select afterwards, so
-    // all 16 loads of a K-step are in flight together.
-    auto load_step = [&](int s) {
-        const int tsel = s / cpt;
-        const int tap = tsel == 0 ? live_tap[0] : (tsel == 1 ? live_tap[1] : live_tap[2]);
-        const int c0 = (s - tsel * cpt) * BK;
-        const int64_t toff = tap * p.tap_stride + c0 + lcol;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool ok = (tapmask[i] >> tap) & 1u;
-            const int64_t ox = ok ? off0[i] + toff : 0;
-            const int64_t og = ok ? gb0[i] + toff : 0;
-            ra[i] = *(const float4*)(p.x + ox);
-            rg[i] = *(const float4*)(p.gamma_in + og);
-            rb[i] = *(const float4*)(p.beta_in + og);
-            rw[i] = *(const float4*)(wrow[i] + tap * p.Cin + c0);
-        }
-    };
-    auto store_step = [&](int buf, int s) {
-        const int tsel = s / cpt;
-        const int tap = tsel == 0 ? live_tap[0] : (tsel == 1 ? live_tap[1] : live_tap[2]);
-        float* As = smem + buf * 2 * TILE_FLOATS;
-        float* Bs = As + TILE_FLOATS;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool ok = (tapmask[i] >> tap) & 1u;
-            float4 v;
-            v.x = fmaf(fmaf(ra[i].x, lnA[i], lnC[i]), rg[i].x, rb[i].x);
-            v.y = fmaf(fmaf(ra[i].y, lnA[i], lnC[i]), rg[i].y, rb[i].y);
-            v.z = fmaf(fmaf(ra[i].z, lnA[i], lnC[i]), rg[i].z, rb[i].z);
-            v.w = fmaf(fmaf(ra[i].w, lnA[i], lnC[i]), rg[i].w, rb[i].w);
-            // zero padding is applied AFTER LayerNorm
-            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-            *(float4*)(As + (lrow + 32 * i) * LD + lcol) = v;
-            *(float4*)(Bs + (lrow + 32 * i) * LD + lcol) = rw[i];
-        }
-    };
+    // all 16 loads of a K-step are in flight together.  (Macros, not lambdas: captured
+    // arrays ended up in scratch memory.)
+#define NAFP_TAP_OF(s_) ((int)((tap_pack >> (2 * ((s_) / cpt))) & 3u))
+#define NAFP_LOAD_ROW(i_, RA, RG, RB, RW)                                              \
+    {                                                                                    \
+        const bool ok = (tapmask[i_] >> tap_l) & 1u;                                     \
+        const int64_t ox = ok ? off0[i_] + toff_l : 0;                                   \
+        const int64_t og = ok ? gb0[i_] + toff_l : 0;                                    \
+        RA = *(const float4*)(p.x + ox);                                                 \
+        RG = *(const float4*)(p.gamma_in + og);                                          \
+        RB = *(const float4*)(p.beta_in + og);                                           \
+        RW = *(const float4*)(wrow0 + (i_) * wrow_stride + woff_l);                      \
+    }
+#define NAFP_LOAD_STEP(s_)                                                              \
+    {                                                                                    \
+        const int tap_l = NAFP_TAP_OF(s_);                                               \
+        const int c0_l = ((s_) % cpt) * BK;                                              \
+        const int64_t toff_l = tap_l * p.tap_stride + c0_l + lcol;                       \
+        const int woff_l = tap_l * p.Cin + c0_l;                                         \
+        NAFP_LOAD_ROW(0, ra0, rg0, rb0, rw0) NAFP_LOAD_ROW(1, ra1, rg1, rb1, rw1)         \
+        NAFP_LOAD_ROW(2, ra2, rg2, rb2, rw2) NAFP_LOAD_ROW(3, ra3, rg3, rb3, rw3)         \
+    }
+#define NAFP_STORE_ROW(i_, RA, RG, RB, RW)                                              \
+    {                                                                                    \
+        const bool ok = (tapmask[i_] >> tap_l) & 1u;                                     \
+        float4 v;                                                                        \
+        v.x = fmaf(fmaf(RA.x, lnA[i_], lnC[i_]), RG.x, RB.x);                            \
+        v.y = fmaf(fmaf(RA.y, lnA[i_], lnC[i_]), RG.y, RB.y);                            \
+        v.z = fmaf(fmaf(RA.z, lnA[i_], lnC[i_]), RG.z, RB.z);                            \
+        v.w = fmaf(fmaf(RA.w, lnA[i_], lnC[i_]), RG.w, RB.w);                            \
+        /* zero padding is applied AFTER LayerNorm */                                    \
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f; \
+        *(float4*)(As_l + (lrow + 32 * (i_)) * LD + lcol) = v;                           \
+        *(float4*)(As_l + TILE_FLOATS + (lrow + 32 * (i_)) * LD + lcol) = RW;            \
+    }
+#define NAFP_STORE_STEP(buf_, s_)                                                       \
+    {                                                                                    \
+        const int tap_l = NAFP_TAP_OF(s_);                                               \
+        float* As_l = smem + (buf_) * 2 * TILE_FLOATS;                                   \
+        NAFP_STORE_ROW(0, ra0, rg0, rb0, rw0) NAFP_STORE_ROW(1, ra1, rg1, rb1, rw1)       \
+        NAFP_STORE_ROW(2, ra2, rg2, rb2, rw2) NAFP_STORE_ROW(3, ra3, rg3, rb3, rw3)       \
+    }
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -223,8 +230,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKernelParam
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     if (n_steps > 0) {
-        load_step(0);
-        store_step(0, 0);
+        NAFP_LOAD_STEP(0)
+        NAFP_STORE_STEP(0, 0)
     }
     __syncthreads();
 
@@ -232,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKernelParam
     const int kq = (lane >> 5) * 4;
     for (int s = 0; s < n_steps; ++s) {
         const int buf = s & 1;
-        if (s + 1 < n_steps) load_step(s + 1);
+        if (s + 1 < n_steps) NAFP_LOAD_STEP(s + 1)
         const float* As = smem + buf * 2 * TILE_FLOATS;
         const float* Bs = As + TILE_FLOATS;
 #pragma unroll
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKernelParam
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, b[ni].w, acc[mi][ni], 0, 0, 0);
                 }
         }
-        if (s + 1 < n_steps) store_step(buf ^ 1, s + 1);
+        if (s + 1 < n_steps) NAFP_STORE_STEP(buf ^ 1, s + 1)
         __syncthreads();
     }
 
