@@ -44,6 +44,7 @@ struct nafp_encoder {
     int64_t blob_floats = 0;
     std::vector<float*> d_w;              // per conv: conv0 -> raw (3,Cout); others packed (Cout,3Cin)
     std::vector<float*> d_bias, d_gamma, d_beta;
+    std::vector<float*> d_G, d_Hb;        // per conv j >= 1: conv_j(gamma_{j-1}), conv_j(beta_{j-1}) + bias_j
     float *d_w1p = nullptr, *d_b1p = nullptr, *d_w2p = nullptr, *d_b2 = nullptr;
     bool has_weights = false;
     // per-segment workspace layout (floats)
@@ -106,6 +107,7 @@ extern "C" int nafp_encoder_create(nafp_encoder** out, int in_f, int in_t, int e
     e->shapes.push_back({emb_sz, 1});
     int64_t total = 0;
     for (auto& s : e->shapes) total += (numel(s) + 63) / 64 * 64;      // 256-B aligned slots
+    for (int j = 1; j < 16; ++j) total += 2 * ((numel(e->shapes[4 * j + 2]) + 63) / 64 * 64);   // G, Hb
     e->blob_floats = total;
     hipError_t err = hipMalloc(&e->d_blob, sizeof(float) * total);
     if (err != hipSuccess) { g_last_hip_error = (int)err; delete e; return NAFP_ERR_HIP; }
@@ -118,6 +120,8 @@ extern "C" int nafp_encoder_create(nafp_encoder** out, int in_f, int in_t, int e
         e->d_beta.push_back(take(4 * j + 3));
     }
     e->d_w1p = take(64); e->d_b1p = take(65); e->d_w2p = take(66); e->d_b2 = take(67);
+    e->d_G.push_back(nullptr); e->d_Hb.push_back(nullptr);
+    for (int j = 1; j < 16; ++j) { e->d_G.push_back(take(4 * j + 2)); e->d_Hb.push_back(take(4 * j + 2)); }
     for (int j = 0; j < 16; ++j) {
         const ConvGeom& g = e->geom[j];
         const int64_t n = (int64_t)g.Fout * g.Tout * g.Cout;
@@ -170,6 +174,17 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
         NAFP_HIP_CHECK(hipMemcpyAsync(e->d_gamma[j], t[4 * j + 2], sizeof(float) * nln, hipMemcpyDeviceToDevice, st));
         NAFP_HIP_CHECK(hipMemcpyAsync(e->d_beta[j], t[4 * j + 3], sizeof(float) * nln, hipMemcpyDeviceToDevice, st));
     }
+    // positional epilogue terms of conv j: G = conv_j(gamma_{j-1}), Hb = conv_j(beta_{j-1}) + bias_j
+    for (int j = 1; j < 16; ++j) {
+        ConvGemmArgs a{};
+        a.wp = e->d_w[j]; a.plain = true;
+        a.x = e->d_gamma[j - 1]; a.bias = nullptr; a.y = e->d_G[j];
+        int rc = launch_conv_gemm(a, 1, e->geom[j], st);
+        if (rc != NAFP_OK) return rc;
+        a.x = e->d_beta[j - 1]; a.bias = e->d_bias[j]; a.y = e->d_Hb[j];
+        rc = launch_conv_gemm(a, 1, e->geom[j], st);
+        if (rc != NAFP_OK) return rc;
+    }
     int rc = launch_pack_div(t[64], t[65], t[66], e->d_w1p, e->d_b1p, e->d_w2p, e->emb_sz, e->S, st);
     if (rc != NAFP_OK) return rc;
     NAFP_HIP_CHECK(hipMemcpyAsync(e->d_b2, t[67], sizeof(float) * e->emb_sz, hipMemcpyDeviceToDevice, st));
@@ -206,17 +221,16 @@ extern "C" int nafp_encoder_forward(nafp_encoder* e, const float* feat, int64_t 
     if (e->prof_max > 0 && e->prof_count < e->prof_max) ev = e->prof_events.data() + (size_t)18 * e->prof_count++;
     if (ev) NAFP_HIP_CHECK(hipEventRecord(ev[0], st));
 
-    int rc = launch_conv0(feat, e->d_w[0], e->d_bias[0], bufA, stats, n_seg, e->geom[0], st);
+    int rc = launch_conv0(feat, e->d_w[0], e->d_bias[0], e->d_gamma[0], bufA, stats, n_seg, e->geom[0], st);
     if (rc != NAFP_OK) return rc;
     if (ev) NAFP_HIP_CHECK(hipEventRecord(ev[1], st));
     float* cur = bufA;
     for (int j = 1; j < 16; ++j) {
         float* nxt = (j % 2 == 0) ? bufA : bufB;
-        ConvGemmArgs a;
+        ConvGemmArgs a{};
         a.x = cur; a.stats_in = stats + 2 * n_seg * (j - 1);
-        a.gamma_in = e->d_gamma[j - 1]; a.beta_in = e->d_beta[j - 1];
-        a.wp = e->d_w[j]; a.bias = e->d_bias[j];
-        a.y = nxt; a.stats_out = stats + 2 * n_seg * j;
+        a.wp = e->d_w[j]; a.G = e->d_G[j]; a.Hb = e->d_Hb[j]; a.gamma_out = e->d_gamma[j];
+        a.y = nxt; a.stats_out = stats + 2 * n_seg * j; a.plain = false;
         rc = launch_conv_gemm(a, n_seg, e->geom[j], st);
         if (rc != NAFP_OK) return rc;
         if (ev) NAFP_HIP_CHECK(hipEventRecord(ev[j + 1], st));

@@ -4,14 +4,24 @@
 // (model/fp/nnfp.py:48-79, eight ConvLayer blocks at nnfp.py:210-216).
 //
 // Every conv is a dense channel-mixing 3-tap conv along ONE axis, i.e. an implicit
-// GEMM  Y[m, n] = sum_{tap, c} Xhat[row(m, tap), c] * W[tap, c, n]  with
-// m = (sample, f_out, t_out), K = 3*Cin, N = Cout, computed in exact fp32 on the
-// matrix cores (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak).  The LayerNorm of the
-// PREVIOUS conv (per-sample statistics over (F,T,C), per-element gamma/beta) is
-// applied while the A operand is staged into LDS; the epilogue adds bias, applies
-// ELU, stores the activation once, and accumulates the per-sample sum / sum of
-// squares that the NEXT conv's A-load needs.  Activations therefore cross HBM
-// exactly once in each direction.
+// GEMM with m = (sample, f_out, t_out), K = 3*Cin, N = Cout, computed in exact fp32
+// on the matrix cores (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak).
+//
+// LayerNorm is folded OUT of the operand path.  With v = ELU(conv + bias) the
+// activation of conv j-1, (mu_b, r_b) its per-sample mean / rstd over (F,T,C) and
+// (gamma, beta) its per-element affine, the next conv needs
+//     conv_j( (v - mu_b) r_b gamma + beta )
+//   = r_b * conv_j(gamma . v)  -  mu_b r_b * conv_j(gamma)  +  conv_j(beta)
+// (zero padding applies to every term alike).  So each conv STORES z = gamma . v
+// (its own LN scale applied in the epilogue, where the data is in registers anyway)
+// and the consumer multiplies raw z tiles on the MFMAs, then finishes in ITS epilogue
+//     out = r_b * acc + (-mu_b r_b) * G[pos, n] + Hb[pos, n]
+// with G = conv_j(gamma), Hb = conv_j(beta) + bias_j: two (positions, Cout) tensors
+// that depend only on the weights and are rebuilt at set_weights time by this same
+// kernel in PLAIN mode.  The K-loop therefore moves raw tiles only (no gamma/beta
+// loads, no per-element math), activations cross HBM exactly once in each direction,
+// and the per-sample sum / sum-of-squares of v for the NEXT conv come out of the
+// epilogue as before.
 #include "nafp_common.h"
 
 namespace nafp {
@@ -23,13 +33,13 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // Pure store-bandwidth: 3 FMAs per output element, 2 MB written per segment.
 // One workgroup = one sample x `ROWS0` frequency rows; 32 threads x float4 cover
 // the Cout = 128 channels of one (f, t_out) position, a wave stores 1 KiB
-// contiguous.
+// contiguous.  Stores z = gamma0 . v; statistics are those of v.
 // ============================================================================
 constexpr int ROWS0 = 4;
 
 __global__ __launch_bounds__(256) void conv0_kernel(
         const float* __restrict__ feat, const float* __restrict__ w3, const float* __restrict__ bias,
-        float* __restrict__ y, double* __restrict__ stats,
+        const float* __restrict__ gamma, float* __restrict__ y, double* __restrict__ stats,
         int F, int Tin, int Tout, int Cout, int stride, int pad) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int blocks_per_sample = (F + ROWS0 - 1) / ROWS0;
@@ -46,6 +56,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(
     const int npos = rows * Tout;
     const float* xin = feat + (b * F + f0) * (int64_t)Tin;
     float* yout = y + ((b * F + f0) * (int64_t)Tout) * Cout;
+    const float* gin = gamma + ((int64_t)f0 * Tout) * Cout;
     float s = 0.f, q = 0.f;
     for (int p = pslot; p < npos; p += pos_per_iter) {
         const int r = p / Tout, to = p % Tout;
@@ -54,14 +65,15 @@ __global__ __launch_bounds__(256) void conv0_kernel(
         const float x0 = (t0 >= 0 && t0 < Tin) ? xr[t0] : 0.f;
         const float x1 = (t0 + 1 >= 0 && t0 + 1 < Tin) ? xr[t0 + 1] : 0.f;
         const float x2 = (t0 + 2 >= 0 && t0 + 2 < Tin) ? xr[t0 + 2] : 0.f;
+        const float4 g = *(const float4*)(gin + (int64_t)p * Cout + 4 * cg);
         float4 v;
         v.x = elu1(fmaf(x2, w2.x, fmaf(x1, w1.x, fmaf(x0, w0.x, bb.x))));
         v.y = elu1(fmaf(x2, w2.y, fmaf(x1, w1.y, fmaf(x0, w0.y, bb.y))));
         v.z = elu1(fmaf(x2, w2.z, fmaf(x1, w1.z, fmaf(x0, w0.z, bb.z))));
         v.w = elu1(fmaf(x2, w2.w, fmaf(x1, w1.w, fmaf(x0, w0.w, bb.w))));
-        *(float4*)(yout + (int64_t)p * Cout + 4 * cg) = v;
         s += (v.x + v.y) + (v.z + v.w);
         q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        *(float4*)(yout + (int64_t)p * Cout + 4 * cg) = make_float4(v.x * g.x, v.y * g.y, v.z * g.z, v.w * g.w);
     }
     double ds = wave_sum((double)s), dq = wave_sum((double)q);
     __shared__ double red[8];
@@ -73,12 +85,12 @@ __global__ __launch_bounds__(256) void conv0_kernel(
     }
 }
 
-int launch_conv0(const float* feat, const float* w3, const float* bias, float* y, double* stats,
-                 int64_t B, const ConvGeom& g, hipStream_t st) {
+int launch_conv0(const float* feat, const float* w3, const float* bias, const float* gamma, float* y,
+                 double* stats, int64_t B, const ConvGeom& g, hipStream_t st) {
     if (g.Cin != 1 || g.axis != 0 || (g.Cout % 4) != 0 || 256 % (g.Cout / 4) != 0) return NAFP_ERR_UNSUPPORTED;
     const int64_t blocks = B * ((g.Fin + ROWS0 - 1) / ROWS0);
-    conv0_kernel<<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, y, stats, g.Fin, g.Tin, g.Tout,
-                                                         g.Cout, g.stride, g.pad);
+    conv0_kernel<<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, gamma, y, stats, g.Fin, g.Tin,
+                                                         g.Tout, g.Cout, g.stride, g.pad);
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }
@@ -87,56 +99,86 @@ int launch_conv0(const float* feat, const float* w3, const float* bias, float* y
 // Implicit-GEMM conv, fp32 MFMA.
 //   tile BM x BN x BK = 128 x 128 x 32, 256 threads = 4 waves as 2(M) x 2(N),
 //   each wave 64 x 64 = 2 x 2 tiles of v_mfma_f32_32x32x2_f32 (64 accumulators).
+//
+//   Tile rows are PT output positions x ST samples (PT*ST = 128, sample index
+//   minor, ST >= 4).  In the 32x32 C/D layout a lane's 4 consecutive registers are
+//   4 consecutive rows = 4 samples at ONE position, so the position-indexed
+//   epilogue operands (G, Hb, gamma_out) are fetched once per 4 outputs.
+//
 //   LDS tiles are [row][k] with leading dimension 36 floats: a lane's operand
 //   fetch is one ds_read_b128 = 4 consecutive k of its row; with LD = 36 any 16
 //   consecutive rows hit 64 distinct banks, so the four 16-lane groups of a b128
-//   read are conflict-free.  The k permutation this implies (lane half h of MFMA
-//   step j multiplies k = 8*kk + 4*h + j) is the same for A and B, so the sum is
-//   unchanged.
+//   read are conflict-free (SQ_LDS_BANK_CONFLICT = 0 measured).  The k permutation
+//   this implies (lane half h of MFMA step j multiplies k = 8*kk + 4*h + j) is the
+//   same for A and B, so the sum is unchanged.
 //   Register-staged double buffering: global loads of K-step s+1 are issued
 //   before the MFMAs of step s and written to the other LDS buffer afterwards
-//   (one barrier per K-step).
+//   (one barrier per K-step).  Taps that hit only zero padding for every row of
+//   the tile are skipped.
 // ============================================================================
 constexpr int BM = 128, BN = 128, BK = 32, LD = 36;
 constexpr int TILE_FLOATS = BM * LD;      // A or B tile in LDS (BM == BN)
 
 struct ConvKernelParams {
-    const float* x; const double* stats_in; const float* gamma_in; const float* beta_in;
-    const float* wp; const float* bias; float* y; double* stats_out;
-    int Fin, Tin, Cin, Fout, Tout, Cout;
+    const float* x;           // (B, Fin, Tin, Cin)
+    const float* wp;          // (Cout, 3*Cin)
+    const float* G;           // (P, Cout)      FULL
+    const float* Hb;          // (P, Cout)      FULL
+    const float* gamma_out;   // (P, Cout)      FULL
+    const float* bias;        // (Cout) or null PLAIN
+    const double* stats_in;   // (B, 2)         FULL
+    double* stats_out;        // (B, 2)         FULL
+    float* y;                 // (B, P, Cout)
+    int Fin, Tin, Cin, Tout, Cout;
     int axis, stride, pad;
-    int64_t M;             // B * Fout * Tout
-    int rps;               // rows per sample = Fout * Tout
-    int64_t sample_in;     // Fin * Tin * Cin
-    int64_t tap_stride;    // elements between consecutive taps of one output row
-    double inv_n_in;       // 1 / sample_in
-    int stats_mode;        // 0: whole tile in one sample, 1: pow2 rps <= 64, 2: generic per-row
+    int B, P;                 // samples; output positions per sample (Fout*Tout)
+    int PT, ST, log2ST;       // tile = PT positions x ST samples
+    int n_sg;                 // sample groups = ceil(B / ST)
+    int64_t sample_in;        // Fin*Tin*Cin
+    int64_t tap_stride;       // elements between consecutive taps of one output row
+    double inv_n_in;          // 1 / sample_in
+    int mode;                 // 0 FULL, 1 PLAIN
 };
 
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKernelParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // [A0 | B0 | A1 | B1]
+    // [A0 | B0 | A1 | B1 | sRB[128] | sCB[128]]
+    float* sRB = smem + 4 * TILE_FLOATS;
+    float* sCB = sRB + BM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int64_t tile_m0 = (int64_t)blockIdx.x * BM;
+    const int sg = blockIdx.x % p.n_sg, pb = blockIdx.x / p.n_sg;
     const int tile_n0 = blockIdx.y * BN;
     const int K = 3 * p.Cin;
+    const int ST1 = p.ST - 1;
+
+    // ---- per-sample LayerNorm scalars of the INPUT (FULL): r_b and -mu_b r_b ----
+    if (tid < p.ST) {
+        const int b = sg * p.ST + tid;
+        float r = 0.f, c = 0.f;
+        if (p.mode == 0 && b < p.B) {
+            const double mean = p.stats_in[2 * (int64_t)b] * p.inv_n_in;
+            double var = p.stats_in[2 * (int64_t)b + 1] * p.inv_n_in - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
+            r = (float)rstd; c = (float)(-mean * rstd);
+        }
+        sRB[tid] = r; sCB[tid] = c;
+    }
 
     // ---- loader geometry: thread loads rows (tid>>3) + 32*i, float4 column (tid&7) ----
     const int lrow = tid >> 3, lcol = (tid & 7) * 4;
     int64_t off0[4];          // element offset of tap 0 (channel 0) for each of my rows
-    int64_t gb0[4];           // same offset inside one sample (for gamma/beta)
-    float lnA[4], lnC[4];     // xhat = (x*lnA + lnC)*gamma + beta
     unsigned tapmask[4];
     unsigned my_live = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int64_t m = tile_m0 + lrow + 32 * i;
-        tapmask[i] = 0; off0[i] = 0; gb0[i] = 0; lnA[i] = 0.f; lnC[i] = 0.f;
-        if (m < p.M) {
-            const int64_t b = m / p.rps;
-            const int rem = (int)(m - b * p.rps);
-            const int fo = rem / p.Tout, to = rem - fo * p.Tout;
+        const int lr = lrow + 32 * i;
+        const int pos = pb * p.PT + (lr >> p.log2ST);
+        const int b = sg * p.ST + (lr & ST1);
+        tapmask[i] = 0; off0[i] = 0;
+        if (pos < p.P && b < p.B) {
+            const int fo = pos / p.Tout, to = pos - fo * p.Tout;
             int64_t inner;
             int pos0, lim;
             if (p.axis == 0) { pos0 = to * p.stride - p.pad; lim = p.Tin; inner = ((int64_t)fo * p.Tin + pos0) * p.Cin; }
@@ -144,15 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKernelParam
 #pragma unroll
             for (int t = 0; t < 3; ++t)
                 if (pos0 + t >= 0 && pos0 + t < lim) tapmask[i] |= 1u << t;
-            gb0[i] = inner;
-            off0[i] = b * p.sample_in + inner;
-            const double su = p.stats_in[2 * b], sq = p.stats_in[2 * b + 1];
-            const double mean = su * p.inv_n_in;
-            double var = sq * p.inv_n_in - mean * mean;
-            var = var > 0.0 ? var : 0.0;
-            const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
-            lnA[i] = (float)rstd;
-            lnC[i] = (float)(-mean * rstd);
+            off0[i] = (int64_t)b * p.sample_in + inner;
             my_live |= tapmask[i];
         }
     }
@@ -175,20 +209,17 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKernelParam
     const float* wrow0 = p.wp + (int64_t)(tile_n0 + lrow) * K + lcol;
     const int64_t wrow_stride = (int64_t)32 * K;
 
-    float4 ra0, ra1, ra2, ra3, rg0, rg1, rg2, rg3, rb0, rb1, rb2, rb3, rw0, rw1, rw2, rw3;
-    // Branch-free: rows whose tap falls into the zero padding (or beyond M) read a
-    // harmless in-range address (offset 0) and are zeroed by a select afterwards, so
-    // all 16 loads of a K-step are in flight together.  (Macros, not lambdas: captured
-    // arrays ended up in scratch memory.)
+    float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
+    // Branch-free: rows whose tap falls into the zero padding (or outside the batch)
+    // read a harmless in-range address (offset 0) and are zeroed by a select, so all 8
+    // loads of a K-step are in flight together.  (Macros, not lambdas: captured arrays
+    // ended up in scratch memory.)
 #define NAFP_TAP_OF(s_) ((int)((tap_pack >> (2 * ((s_) / cpt))) & 3u))
-#define NAFP_LOAD_ROW(i_, RA, RG, RB, RW)                                              \
+#define NAFP_LOAD_ROW(i_, RA, RW)                                                       \
     {                                                                                    \
         const bool ok = (tapmask[i_] >> tap_l) & 1u;                                     \
         const int64_t ox = ok ? off0[i_] + toff_l : 0;                                   \
-        const int64_t og = ok ? gb0[i_] + toff_l : 0;                                    \
         RA = *(const float4*)(p.x + ox);                                                 \
-        RG = *(const float4*)(p.gamma_in + og);                                          \
-        RB = *(const float4*)(p.beta_in + og);                                           \
         RW = *(const float4*)(wrow0 + (i_) * wrow_stride + woff_l);                      \
     }
 #define NAFP_LOAD_STEP(s_)                                                              \
@@ -197,18 +228,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKernelParam
         const int c0_l = ((s_) % cpt) * BK;                                              \
         const int64_t toff_l = tap_l * p.tap_stride + c0_l + lcol;                       \
         const int woff_l = tap_l * p.Cin + c0_l;                                         \
-        NAFP_LOAD_ROW(0, ra0, rg0, rb0, rw0) NAFP_LOAD_ROW(1, ra1, rg1, rb1, rw1)         \
-        NAFP_LOAD_ROW(2, ra2, rg2, rb2, rw2) NAFP_LOAD_ROW(3, ra3, rg3, rb3, rw3)         \
+        NAFP_LOAD_ROW(0, ra0, rw0) NAFP_LOAD_ROW(1, ra1, rw1)                             \
+        NAFP_LOAD_ROW(2, ra2, rw2) NAFP_LOAD_ROW(3, ra3, rw3)                             \
     }
-#define NAFP_STORE_ROW(i_, RA, RG, RB, RW)                                              \
+#define NAFP_STORE_ROW(i_, RA, RW)                                                      \
     {                                                                                    \
         const bool ok = (tapmask[i_] >> tap_l) & 1u;                                     \
-        float4 v;                                                                        \
-        v.x = fmaf(fmaf(RA.x, lnA[i_], lnC[i_]), RG.x, RB.x);                            \
-        v.y = fmaf(fmaf(RA.y, lnA[i_], lnC[i_]), RG.y, RB.y);                            \
-        v.z = fmaf(fmaf(RA.z, lnA[i_], lnC[i_]), RG.z, RB.z);                            \
-        v.w = fmaf(fmaf(RA.w, lnA[i_], lnC[i_]), RG.w, RB.w);                            \
-        /* zero padding is applied AFTER LayerNorm */                                    \
+        float4 v = RA;                                                                   \
         v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f; \
         *(float4*)(As_l + (lrow + 32 * (i_)) * LD + lcol) = v;                           \
         *(float4*)(As_l + TILE_FLOATS + (lrow + 32 * (i_)) * LD + lcol) = RW;            \
@@ -217,8 +243,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKernelParam
     {                                                                                    \
         const int tap_l = NAFP_TAP_OF(s_);                                               \
         float* As_l = smem + (buf_) * 2 * TILE_FLOATS;                                   \
-        NAFP_STORE_ROW(0, ra0, rg0, rb0, rw0) NAFP_STORE_ROW(1, ra1, rg1, rb1, rw1)       \
-        NAFP_STORE_ROW(2, ra2, rg2, rb2, rw2) NAFP_STORE_ROW(3, ra3, rg3, rb3, rw3)       \
+        NAFP_STORE_ROW(0, ra0, rw0) NAFP_STORE_ROW(1, ra1, rw1)                           \
+        NAFP_STORE_ROW(2, ra2, rw2) NAFP_STORE_ROW(3, ra3, rw3)                           \
     }
 
     f32x16 acc[2][2];
@@ -263,92 +289,136 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKernelParam
         __syncthreads();
     }
 
-    // ---- epilogue: bias + ELU, store, per-sample statistics ----
-    // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
+    // ---- epilogue ----
+    // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).
+    // Row groups of 4 (r & 3) = 4 consecutive samples at one position.
     const int ncol = lane & 31;
-    float bias_v[2];
+    const int n_base = tile_n0 + wn * 64 + ncol;
+    const int g4 = p.ST >> 2;                         // sample quads per position
+    if (p.mode == 1) {
+        // PLAIN: y = acc (+ bias)
+        float bv[2];
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) bias_v[ni] = p.bias[tile_n0 + wn * 64 + ni * 32 + ncol];
-    float tot_s = 0.f, tot_q = 0.f;
-    float* rowS = smem;                 // [BM] (LDS is free again: last loop barrier passed)
+        for (int ni = 0; ni < 2; ++ni) bv[ni] = p.bias ? p.bias[n_base + ni * 32] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int pos = pb * p.PT + (lr >> p.log2ST);
+                const int b = sg * p.ST + (lr & ST1);
+                if (pos < p.P && b < p.B) {
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        p.y[((int64_t)b * p.P + pos) * p.Cout + n_base + ni * 32] = acc[mi][ni][r] + bv[ni];
+                }
+            }
+        return;
+    }
+
+    // FULL: v = ELU(r_b*acc + c_b*G + Hb); stats of v; store z = gamma_out * v
+    float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+    float* rowS = smem;                 // [BM] (LDS tiles are free again: last loop barrier passed)
     float* rowQ = smem + BM;
-    if (p.stats_mode != 0) {
+    const bool fast_stats = p.ST == 4;
+    if (!fast_stats) {
         if (tid < BM) { rowS[tid] = 0.f; rowQ[tid] = 0.f; }
         __syncthreads();
     }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int lr = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int64_t m = tile_m0 + lr;
-            float rs = 0.f, rq = 0.f;
+        for (int rg = 0; rg < 4; ++rg) {
+            const int grp = wm * 16 + mi * 8 + 2 * rg + (lane >> 5);      // = lr >> 2
+            const int pos = pb * p.PT + (grp >> (p.log2ST - 2));
+            const int sl0 = (grp & (g4 - 1)) << 2;                         // first of the 4 samples
+            const bool pvalid = pos < p.P;
+            const int64_t pofs = (int64_t)(pvalid ? pos : 0) * p.Cout + n_base;
+            float Gv[2], Hv[2], gv[2];
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
-                const float v = elu1(acc[mi][ni][r] + bias_v[ni]);
-                if (m < p.M) p.y[m * p.Cout + tile_n0 + wn * 64 + ni * 32 + ncol] = v;
-                rs += v; rq += v * v;
+                Gv[ni] = p.G[pofs + ni * 32];
+                Hv[ni] = p.Hb[pofs + ni * 32];
+                gv[ni] = p.gamma_out[pofs + ni * 32];
             }
-            if (p.stats_mode == 0) { tot_s += rs; tot_q += rq; }
-            else {
 #pragma unroll
-                for (int o = 16; o > 0; o >>= 1) { rs += __shfl_xor(rs, o, 64); rq += __shfl_xor(rq, o, 64); }
-                if (ncol == 0 && m < p.M) { atomicAdd(rowS + lr, rs); atomicAdd(rowQ + lr, rq); }
+            for (int q = 0; q < 4; ++q) {
+                const int r = rg * 4 + q;
+                const int sl = sl0 + q;
+                const int b = sg * p.ST + sl;
+                const bool valid = pvalid && b < p.B;
+                const float rb = sRB[sl], cb = sCB[sl];
+                float rs = 0.f, rq = 0.f;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    float v = elu1(fmaf(rb, acc[mi][ni][r], fmaf(cb, Gv[ni], Hv[ni])));
+                    v = valid ? v : 0.f;
+                    if (valid) p.y[((int64_t)b * p.P + pos) * p.Cout + n_base + ni * 32] = v * gv[ni];
+                    rs += v; rq += v * v;
+                }
+                if (fast_stats) { s4[q] += rs; q4[q] += rq; }
+                else {
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) { rs += __shfl_xor(rs, o, 64); rq += __shfl_xor(rq, o, 64); }
+                    if (ncol == 0) { atomicAdd(rowS + (grp << 2) + q, rs); atomicAdd(rowQ + (grp << 2) + q, rq); }
+                }
             }
         }
     }
-    if (p.stats_mode == 0) {
-        // every row of this tile belongs to sample tile_m0 / rps and is valid
-        double ds = wave_sum((double)tot_s), dq = wave_sum((double)tot_q);
-        double* red = (double*)smem;
+    if (fast_stats) {
+        // ST == 4: the tile's 4 samples are the 4 register slots (r & 3)
+        double* red = (double*)smem;        // [4 waves][8]
         __syncthreads();
-        if (lane == 0) { red[wave] = ds; red[4 + wave] = dq; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double ds = wave_sum((double)s4[q]), dq = wave_sum((double)q4[q]);
+            if (lane == 0) { red[wave * 8 + q] = ds; red[wave * 8 + 4 + q] = dq; }
+        }
         __syncthreads();
-        if (tid == 0) {
-            const int64_t b = tile_m0 / p.rps;
-            atomicAdd(p.stats_out + 2 * b, red[0] + red[1] + red[2] + red[3]);
-            atomicAdd(p.stats_out + 2 * b + 1, red[4] + red[5] + red[6] + red[7]);
+        if (tid < 8) {
+            const int q = tid & 3, which = tid >> 2;
+            const int b = sg * 4 + q;
+            if (b < p.B) {
+                const double t = red[tid] + red[8 + tid] + red[16 + tid] + red[24 + tid];
+                atomicAdd(p.stats_out + 2 * (int64_t)b + which, t);
+            }
         }
     } else {
         __syncthreads();
-        if (tid < BM) {
-            const int64_t m = tile_m0 + tid;
-            const bool valid = m < p.M;
-            double ds = valid ? (double)rowS[tid] : 0.0, dq = valid ? (double)rowQ[tid] : 0.0;
-            if (p.stats_mode == 1) {
-                // rps is a power of two <= 64: xor-reduce inside aligned groups of rps lanes
-                for (int o = 1; o < p.rps; o <<= 1) { ds += __shfl_xor(ds, o, 64); dq += __shfl_xor(dq, o, 64); }
-                if (valid && (tid & (p.rps - 1)) == 0) {
-                    const int64_t b = m / p.rps;
-                    atomicAdd(p.stats_out + 2 * b, ds);
-                    atomicAdd(p.stats_out + 2 * b + 1, dq);
-                }
-            } else if (valid) {
-                const int64_t b = m / p.rps;
-                atomicAdd(p.stats_out + 2 * b, ds);
-                atomicAdd(p.stats_out + 2 * b + 1, dq);
+        if (tid < p.ST) {
+            const int b = sg * p.ST + tid;
+            if (b < p.B) {
+                double ds = 0.0, dq = 0.0;
+                for (int pl = 0; pl < p.PT; ++pl) { ds += (double)rowS[pl * p.ST + tid]; dq += (double)rowQ[pl * p.ST + tid]; }
+                atomicAdd(p.stats_out + 2 * (int64_t)b, ds);
+                atomicAdd(p.stats_out + 2 * (int64_t)b + 1, dq);
             }
         }
     }
 }
 
 int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStream_t st) {
-    if (g.Cin % BK != 0 || g.Cout % BN != 0) return NAFP_ERR_UNSUPPORTED;
+    if (g.Cin % BK != 0 || g.Cout % BN != 0 || B > (1 << 24)) return NAFP_ERR_UNSUPPORTED;
     ConvKernelParams p;
-    p.x = a.x; p.stats_in = a.stats_in; p.gamma_in = a.gamma_in; p.beta_in = a.beta_in;
-    p.wp = a.wp; p.bias = a.bias; p.y = a.y; p.stats_out = a.stats_out;
-    p.Fin = g.Fin; p.Tin = g.Tin; p.Cin = g.Cin; p.Fout = g.Fout; p.Tout = g.Tout; p.Cout = g.Cout;
+    p.x = a.x; p.wp = a.wp; p.G = a.G; p.Hb = a.Hb; p.gamma_out = a.gamma_out; p.bias = a.bias;
+    p.stats_in = a.stats_in; p.stats_out = a.stats_out; p.y = a.y;
+    p.Fin = g.Fin; p.Tin = g.Tin; p.Cin = g.Cin; p.Tout = g.Tout; p.Cout = g.Cout;
     p.axis = g.axis; p.stride = g.stride; p.pad = g.pad;
-    p.rps = g.Fout * g.Tout;
-    p.M = B * p.rps;
+    p.B = (int)B; p.P = g.Fout * g.Tout;
+    int pt = 1;
+    while (pt * 2 <= p.P && pt * 2 <= 32) pt *= 2;          // largest power of two <= min(P, 32)
+    p.PT = pt; p.ST = BM / pt;
+    p.log2ST = 0;
+    while ((1 << p.log2ST) < p.ST) ++p.log2ST;
+    p.n_sg = (int)((B + p.ST - 1) / p.ST);
     p.sample_in = (int64_t)g.Fin * g.Tin * g.Cin;
     p.tap_stride = g.axis == 0 ? g.Cin : (int64_t)g.Tin * g.Cin;
     p.inv_n_in = 1.0 / (double)p.sample_in;
-    const bool pow2 = (p.rps & (p.rps - 1)) == 0;
-    p.stats_mode = (p.rps % BM == 0) ? 0 : ((pow2 && p.rps <= 64) ? 1 : 2);
-    const int64_t mt = (p.M + BM - 1) / BM;
+    p.mode = a.plain ? 1 : 0;
+    const int n_pb = (p.P + p.PT - 1) / p.PT;
+    const int64_t mt = (int64_t)p.n_sg * n_pb;
     static bool attr_set = false;
-    const int lds = 4 * TILE_FLOATS * (int)sizeof(float);      // 73,728 B
+    const int lds = (4 * TILE_FLOATS + 2 * BM) * (int)sizeof(float);      // 74,752 B
     if (!attr_set) {
         NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)conv_gemm_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));

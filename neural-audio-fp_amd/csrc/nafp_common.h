@@ -84,26 +84,29 @@ __device__ __forceinline__ void atomic_min_float(float* addr, float v) {
 
 // ---- kernels' host launchers (defined in the .hip files) -------------------
 
-// conv0: (B,F,T) x kernel(3,Cout) -> (B,F,Tout,Cout) + per-sample sum/sumsq.
-int launch_conv0(const float* feat, const float* w3, const float* bias, float* y, double* stats,
-                 int64_t B, const ConvGeom& g, hipStream_t st);
+// conv0: (B,F,T) x kernel(3,Cout) -> z0 = gamma0 . ELU(conv + bias), (B,F,Tout,Cout),
+// + per-sample sum/sumsq of the ELU output.
+int launch_conv0(const float* feat, const float* w3, const float* bias, const float* gamma, float* y,
+                 double* stats, int64_t B, const ConvGeom& g, hipStream_t st);
 
-// implicit-GEMM conv with LayerNorm of the input fused into the A-operand load.
+// implicit-GEMM conv (see conv.hip for the LayerNorm folding).
 struct ConvGemmArgs {
-    const float* x;          // (B,Fin,Tin,Cin), post-ELU pre-LN output of the previous conv
-    const double* stats_in;  // (B,2): sum, sumsq of x per sample
-    const float* gamma_in;   // (Fin,Tin,Cin)
-    const float* beta_in;    // (Fin,Tin,Cin)
+    const float* x;          // (B,Fin,Tin,Cin): z of the previous conv (FULL) or a raw image (PLAIN)
     const float* wp;         // packed (Cout, 3*Cin), k = tap*Cin + cin
-    const float* bias;       // (Cout)
-    float* y;                // (B,Fout,Tout,Cout) post-ELU, pre-LN
-    double* stats_out;       // (B,2), must be zero on entry
+    const float* G;          // (P,Cout) conv(gamma_in)            FULL
+    const float* Hb;         // (P,Cout) conv(beta_in) + bias      FULL
+    const float* gamma_out;  // (P,Cout) LN scale of THIS conv     FULL
+    const float* bias;       // (Cout) or nullptr                  PLAIN
+    const double* stats_in;  // (B,2): sum, sumsq of the previous conv's ELU output   FULL
+    double* stats_out;       // (B,2), must be zero on entry                          FULL
+    float* y;                // (B,Fout,Tout,Cout): z = gamma_out . v (FULL) or acc + bias (PLAIN)
+    bool plain;
 };
 int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStream_t st);
 
 // tail: LN of the last conv + flatten + divide-and-encode + optional L2 norm.
 struct TailArgs {
-    const float* x;          // (B, D) last conv output (pre-LN), or already-normalised flat
+    const float* x;          // (B, D): z = gamma . v of the last conv, or already-normalised flat
     const double* stats;     // (B,2) or nullptr when x is already the LN output
     const float* gamma;      // (D) or nullptr
     const float* beta;       // (D) or nullptr

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(1024) void tail_kernel(const TailArgs a) {
         if (i < S) {
             const int d = q * S + i;                      // tf.reshape (B,D)->(B,Q,S): nnfp.py:155
             float v = a.x[b * a.D + d];
-            if (a.stats) v = fmaf(fmaf(v, lnA, lnC), a.gamma[d], a.beta[d]);
+            if (a.stats) v = fmaf(lnA, v, fmaf(lnC, a.gamma[d], a.beta[d]));   // v holds gamma . ELU(.)
             x[i] = v;
             if (a.out_flat) a.out_flat[b * a.D + d] = v;
         } else {
