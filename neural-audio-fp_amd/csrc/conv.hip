@@ -24,6 +24,8 @@
 // epilogue as before.
 #include "nafp_common.h"
 
+#include <cstdlib>
+
 namespace nafp {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -96,28 +98,34 @@ int launch_conv0(const float* feat, const float* w3, const float* bias, const fl
 }
 
 // ============================================================================
-// Implicit-GEMM conv, fp32 MFMA.
-//   tile BM x BN x BK = 128 x 128 x 32, 256 threads = 4 waves as 2(M) x 2(N),
-//   each wave 64 x 64 = 2 x 2 tiles of v_mfma_f32_32x32x2_f32 (64 accumulators).
+// Implicit-GEMM conv, fp32 MFMA, operands staged by direct-to-LDS DMA.
+//   tile BM x BN = 128 x 128, K-step BK (template), 256 threads = 4 waves as
+//   2(M) x 2(N), each wave 64 x 64 = 2 x 2 tiles of v_mfma_f32_32x32x2_f32
+//   (64 accumulators).
 //
 //   Tile rows are PT output positions x ST samples (PT*ST = 128, sample index
 //   minor, ST >= 4).  In the 32x32 C/D layout a lane's 4 consecutive registers are
 //   4 consecutive rows = 4 samples at ONE position, so the position-indexed
 //   epilogue operands (G, Hb, gamma_out) are fetched once per 4 outputs.
 //
-//   LDS tiles are [row][k] with leading dimension 36 floats: a lane's operand
-//   fetch is one ds_read_b128 = 4 consecutive k of its row; with LD = 36 any 16
-//   consecutive rows hit 64 distinct banks, so the four 16-lane groups of a b128
-//   read are conflict-free (SQ_LDS_BANK_CONFLICT = 0 measured).  The k permutation
-//   this implies (lane half h of MFMA step j multiplies k = 8*kk + 4*h + j) is the
-//   same for A and B, so the sum is unchanged.
-//   Register-staged double buffering: global loads of K-step s+1 are issued
-//   before the MFMAs of step s and written to the other LDS buffer afterwards
-//   (one barrier per K-step).  Taps that hit only zero padding for every row of
-//   the tile are skipped.
+//   Staging: `buffer_load_dwordx4 ... lds` (LDS-DMA).  No VGPR round trip, no
+//   ds_write, no per-element VALU in the K-loop.  The buffer descriptor of the A
+//   operand is re-based per tile on the tile's first sample and sized to the valid
+//   samples only, so rows outside the batch AND taps that fall into the conv's zero
+//   padding are simply out-of-range lanes: the DMA writes zeros for them
+//   (tools/probes/lds_dma_probe.hip verifies that on gfx950).
+//   The LDS image of a DMA is lane-linear (16 B per lane, rows of BK floats
+//   unpadded), so bank conflicts are avoided by XOR-swizzling the 16-B chunk index
+//   with the row on the SOURCE side and applying the same involution when reading:
+//   physical chunk = logical chunk ^ swz(row).  A lane's operand fetch is one
+//   ds_read_b128 = 4 consecutive k of its row; the k permutation this implies (lane
+//   half h of MFMA step j multiplies k = 8*kk + 4*h + j) is the same for A and B.
+//   NSTAGE-deep LDS ring, one barrier per K-step: wait own DMA of step s ->
+//   barrier -> issue DMA of step s+NSTAGE-1 into the buffer everybody just left ->
+//   MFMAs of step s.  Taps that hit only zero padding for every row of the tile
+//   are skipped.
 // ============================================================================
-constexpr int BM = 128, BN = 128, BK = 32, LD = 36;
-constexpr int TILE_FLOATS = BM * LD;      // A or B tile in LDS (BM == BN)
+constexpr int BM = 128, BN = 128;
 
 struct ConvKernelParams {
     const float* x;           // (B, Fin, Tin, Cin)
@@ -135,26 +143,63 @@ struct ConvKernelParams {
     int PT, ST, log2ST;       // tile = PT positions x ST samples
     int n_sg;                 // sample groups = ceil(B / ST)
     int64_t sample_in;        // Fin*Tin*Cin
-    int64_t tap_stride;       // elements between consecutive taps of one output row
+    int tap_stride;           // elements between consecutive taps of one output row
     double inv_n_in;          // 1 / sample_in
     int mode;                 // 0 FULL, 1 PLAIN
+    unsigned wp_bytes;
+    int abl;                  // ablation flags for kernel-time breakdown (NAFP_ABL env; 0 in production)
 };
 
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKernelParams p) {
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Raw buffer descriptor in SGPRs (base, num_records bytes; stride 0, no swizzle).
+__device__ __forceinline__ u32x4 make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    u32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+    r.z = __builtin_amdgcn_readfirstlane(bytes);
+    r.w = 0x00020000u;
+    return r;
+}
+
+// One LDS-DMA wave-instruction: lane l copies 16 B from (rsrc base + voff_l + soff) to LDS
+// byte address lds_addr + 16*l; out-of-range lanes write zeros.  Inline asm on purpose:
+// hipcc treats the builtin form as a pending LDS store and drains it (s_waitcnt vmcnt(0))
+// before the next ds_read, which would expose the whole DMA latency on every K-step.
+// The kernel counts these itself with s_waitcnt vmcnt(N).
+__device__ __forceinline__ void lds_dma16(unsigned lds_addr, unsigned voff, u32x4 rsrc, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 4\n\t"
+                 "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+template <int BK, int NSTAGE>
+__device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
+    constexpr int CH = BK / 4;                     // 16-B chunks per row
+    constexpr int RPI = 64 / CH;                   // rows covered by one DMA wave-instruction
+    constexpr int NI = 32 / RPI;                   // DMA instructions per wave per operand per step
+    constexpr int TILE = BM * BK;                  // floats per operand tile
+    constexpr int STAGE = 2 * TILE;                // A | B
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // [A0 | B0 | A1 | B1 | sRB[128] | sCB[128]]
-    float* sRB = smem + 4 * TILE_FLOATS;
+    // [stage 0: A | B] ... [stage NSTAGE-1] [sRB[128]] [sCB[128]]
+    float* sRB = smem + NSTAGE * STAGE;
     float* sCB = sRB + BM;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int sg = blockIdx.x % p.n_sg, pb = blockIdx.x / p.n_sg;
     const int tile_n0 = blockIdx.y * BN;
     const int K = 3 * p.Cin;
     const int ST1 = p.ST - 1;
+    const int b0 = sg * p.ST;                       // first sample of this tile
+    const int nb = min(p.ST, p.B - b0);             // valid samples in this tile
 
     // ---- per-sample LayerNorm scalars of the INPUT (FULL): r_b and -mu_b r_b ----
     if (tid < p.ST) {
-        const int b = sg * p.ST + tid;
+        const int b = b0 + tid;
         float r = 0.f, c = 0.f;
         if (p.mode == 0 && b < p.B) {
             const double mean = p.stats_in[2 * (int64_t)b] * p.inv_n_in;
@@ -166,29 +211,35 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKernelParam
         sRB[tid] = r; sCB[tid] = c;
     }
 
-    // ---- loader geometry: thread loads rows (tid>>3) + 32*i, float4 column (tid&7) ----
-    const int lrow = tid >> 3, lcol = (tid & 7) * 4;
-    int64_t off0[4];          // element offset of tap 0 (channel 0) for each of my rows
-    unsigned tapmask[4];
+    // ---- DMA geometry.  Wave w stages rows [32w, 32w+32) of A and of B; instruction q
+    // covers rows 32w + q*RPI + lane/CH, physical chunk pc = lane % CH, which must hold
+    // the logical chunk pc ^ swz(row).
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned voffA[NI];           // byte offset of tap 0 from the tile's first sample
+    unsigned vmaskA[NI];          // bit t: tap t reads real data (else zero padding -> OOB lane)
+    unsigned voffB[NI];
     unsigned my_live = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int lr = lrow + 32 * i;
+    for (int q = 0; q < NI; ++q) {
+        const int lr = wave * 32 + q * RPI + lane / CH;
+        const int pc = lane % CH;
+        const int swz = BK == 32 ? ((lr >> 1) & 7) : ((lr >> 2) & 3);
+        const int lc = pc ^ swz;
         const int pos = pb * p.PT + (lr >> p.log2ST);
-        const int b = sg * p.ST + (lr & ST1);
-        tapmask[i] = 0; off0[i] = 0;
-        if (pos < p.P && b < p.B) {
+        const int sl = lr & ST1;
+        voffA[q] = 0; vmaskA[q] = 0;
+        if (pos < p.P && sl < nb) {
             const int fo = pos / p.Tout, to = pos - fo * p.Tout;
-            int64_t inner;
-            int pos0, lim;
-            if (p.axis == 0) { pos0 = to * p.stride - p.pad; lim = p.Tin; inner = ((int64_t)fo * p.Tin + pos0) * p.Cin; }
-            else             { pos0 = fo * p.stride - p.pad; lim = p.Fin; inner = ((int64_t)pos0 * p.Tin + to) * p.Cin; }
+            int inner, pos0, lim;
+            if (p.axis == 0) { pos0 = to * p.stride - p.pad; lim = p.Tin; inner = (fo * p.Tin + pos0) * p.Cin; }
+            else             { pos0 = fo * p.stride - p.pad; lim = p.Fin; inner = (pos0 * p.Tin + to) * p.Cin; }
+            voffA[q] = (unsigned)(sl * (int)p.sample_in + inner + lc * 4) * 4u;   // may wrap for tap 0 in the padding: masked
 #pragma unroll
             for (int t = 0; t < 3; ++t)
-                if (pos0 + t >= 0 && pos0 + t < lim) tapmask[i] |= 1u << t;
-            off0[i] = (int64_t)b * p.sample_in + inner;
-            my_live |= tapmask[i];
+                if (pos0 + t >= 0 && pos0 + t < lim) vmaskA[q] |= 1u << t;
+            my_live |= vmaskA[q];
         }
+        voffB[q] = (unsigned)((tile_n0 + lr) * K + lc * 4) * 4u;
     }
     // taps that read only zero padding for EVERY row of this tile are skipped
     int* s_live = (int*)smem;
@@ -206,45 +257,24 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKernelParam
     const int cpt = p.Cin / BK;                 // K-steps per tap
     const int n_steps = n_live * cpt;
 
-    const float* wrow0 = p.wp + (int64_t)(tile_n0 + lrow) * K + lcol;
-    const int64_t wrow_stride = (int64_t)32 * K;
+    const u32x4 rsA = make_rsrc(p.x + (int64_t)b0 * p.sample_in, (unsigned)nb * (unsigned)p.sample_in * 4u);
+    const u32x4 rsB = make_rsrc(p.wp, p.wp_bytes);
+    const unsigned lds0 = (unsigned)(unsigned long long)(lds_ptr_t)smem + (unsigned)(wave * 32 * BK * 4);
 
-    float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
-    // Branch-free: rows whose tap falls into the zero padding (or outside the batch)
-    // read a harmless in-range address (offset 0) and are zeroed by a select, so all 8
-    // loads of a K-step are in flight together.  (Macros, not lambdas: captured arrays
-    // ended up in scratch memory.)
-#define NAFP_TAP_OF(s_) ((int)((tap_pack >> (2 * ((s_) / cpt))) & 3u))
-#define NAFP_LOAD_ROW(i_, RA, RW)                                                       \
-    {                                                                                    \
-        const bool ok = (tapmask[i_] >> tap_l) & 1u;                                     \
-        const int64_t ox = ok ? off0[i_] + toff_l : 0;                                   \
-        RA = *(const float4*)(p.x + ox);                                                 \
-        RW = *(const float4*)(wrow0 + (i_) * wrow_stride + woff_l);                      \
-    }
-#define NAFP_LOAD_STEP(s_)                                                              \
-    {                                                                                    \
-        const int tap_l = NAFP_TAP_OF(s_);                                               \
-        const int c0_l = ((s_) % cpt) * BK;                                              \
-        const int64_t toff_l = tap_l * p.tap_stride + c0_l + lcol;                       \
-        const int woff_l = tap_l * p.Cin + c0_l;                                         \
-        NAFP_LOAD_ROW(0, ra0, rw0) NAFP_LOAD_ROW(1, ra1, rw1)                             \
-        NAFP_LOAD_ROW(2, ra2, rw2) NAFP_LOAD_ROW(3, ra3, rw3)                             \
-    }
-#define NAFP_STORE_ROW(i_, RA, RW)                                                      \
-    {                                                                                    \
-        const bool ok = (tapmask[i_] >> tap_l) & 1u;                                     \
-        float4 v = RA;                                                                   \
-        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f; \
-        *(float4*)(As_l + (lrow + 32 * (i_)) * LD + lcol) = v;                           \
-        *(float4*)(As_l + TILE_FLOATS + (lrow + 32 * (i_)) * LD + lcol) = RW;            \
-    }
-#define NAFP_STORE_STEP(buf_, s_)                                                       \
-    {                                                                                    \
-        const int tap_l = NAFP_TAP_OF(s_);                                               \
-        float* As_l = smem + (buf_) * 2 * TILE_FLOATS;                                   \
-        NAFP_STORE_ROW(0, ra0, rw0) NAFP_STORE_ROW(1, ra1, rw1)                           \
-        NAFP_STORE_ROW(2, ra2, rw2) NAFP_STORE_ROW(3, ra3, rw3)                           \
+    // Issue the DMA of K-step s_ into ring slot slot_ (wave-uniform LDS bases).
+#define NAFP_DMA_STEP(s_, slot_)                                                              \
+    {                                                                                          \
+        const int tsel_l = (s_) / cpt;                                                         \
+        const int tap_l = (int)((tap_pack >> (2 * tsel_l)) & 3u);                              \
+        const int c0_l = ((s_) - tsel_l * cpt) * BK;                                           \
+        const unsigned la_l = lds0 + (unsigned)((slot_) * STAGE * 4);                          \
+        const unsigned tapb_l = (unsigned)(tap_l * p.tap_stride) * 4u;                         \
+        _Pragma("unroll") for (int q = 0; q < NI; ++q) {                                       \
+            const unsigned va = ((vmaskA[q] >> tap_l) & 1u) ? voffA[q] + tapb_l : OOB;         \
+            lds_dma16(la_l + q * RPI * BK * 4, va, rsA, (unsigned)(c0_l * 4));                 \
+            lds_dma16(la_l + (TILE + q * RPI * BK) * 4, voffB[q], rsB,                          \
+                      (unsigned)((tap_l * p.Cin + c0_l) * 4));                                 \
+        }                                                                                      \
     }
 
     f32x16 acc[2][2];
@@ -255,26 +285,35 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKernelParam
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    if (n_steps > 0) {
-        NAFP_LOAD_STEP(0)
-        NAFP_STORE_STEP(0, 0)
-    }
-    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < n_steps) NAFP_DMA_STEP(s, s)
 
-    const int arow = wm * 64 + (lane & 31), brow = wn * 64 + (lane & 31);
-    const int kq = (lane >> 5) * 4;
+    // operand read addresses (floats): row*BK + ((lc ^ swz(row)) * 4), lc = 2*kk + (lane>>5)
+    const int rl = lane & 31, hh = lane >> 5;
+    const int rswz = BK == 32 ? ((rl >> 1) & 7) : ((rl >> 2) & 3);     // wm*64, 32*mi do not change swz
+    const int aoff = (wm * 64 + rl) * BK, boff = TILE + (wn * 64 + rl) * BK;
+    int slot = 0;
     for (int s = 0; s < n_steps; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < n_steps) NAFP_LOAD_STEP(s + 1)
-        const float* As = smem + buf * 2 * TILE_FLOATS;
-        const float* Bs = As + TILE_FLOATS;
+        // my DMA of step s has landed; after the barrier everybody's has, and everybody has
+        // finished reading slot (s-1) % NSTAGE, which the next DMA overwrites.
+        if (NSTAGE == 2 || s + NSTAGE - 2 >= n_steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "i"((NSTAGE - 2) * 2 * NI) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + NSTAGE - 1 < n_steps && !(p.abl & 1)) {
+            int nslot = slot + NSTAGE - 1; if (nslot >= NSTAGE) nslot -= NSTAGE;
+            NAFP_DMA_STEP(s + NSTAGE - 1, nslot)
+        }
+        const float* St = smem + slot * STAGE;
+        if (p.abl & 4) { if (++slot == NSTAGE) slot = 0; continue; }
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
+            const int pc4 = ((2 * kk + hh) ^ rswz) * 4;
             float4 a[2], b[2];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) a[mi] = *(const float4*)(As + (arow + 32 * mi) * LD + kk * 8 + kq);
+            for (int mi = 0; mi < 2; ++mi) a[mi] = *(const float4*)(St + aoff + mi * 32 * BK + pc4);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) b[ni] = *(const float4*)(Bs + (brow + 32 * ni) * LD + kk * 8 + kq);
+            for (int ni = 0; ni < 2; ++ni) b[ni] = *(const float4*)(St + boff + ni * 32 * BK + pc4);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -285,10 +324,21 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKernelParam
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, b[ni].w, acc[mi][ni], 0, 0, 0);
                 }
         }
-        if (s + 1 < n_steps) NAFP_STORE_STEP(buf ^ 1, s + 1)
-        __syncthreads();
+        if (++slot == NSTAGE) slot = 0;
     }
+    __syncthreads();          // all waves are done with the operand tiles: LDS is reused below
 
+    if (p.abl & 2) {          // ablation: no epilogue (keep the accumulators alive)
+        float t = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[mi][ni][r];
+        if (t == 12345.678f) p.y[tid] = t;
+        return;
+    }
     // ---- epilogue ----
     // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).
     // Row groups of 4 (r & 3) = 4 consecutive samples at one position.
@@ -325,6 +375,23 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKernelParam
         if (tid < BM) { rowS[tid] = 0.f; rowQ[tid] = 0.f; }
         __syncthreads();
     }
+    // All position-indexed operands first (48 independent loads in flight together),
+    // then the arithmetic: issuing them group by group exposed one L2 round trip per group.
+    float Gv[2][4][2], Hv[2][4][2], gv[2][4][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int grp = wm * 16 + mi * 8 + 2 * rg + (lane >> 5);      // = lr >> 2
+            const int pos = pb * p.PT + (grp >> (p.log2ST - 2));
+            const int pofs = (pos < p.P ? pos : 0) * p.Cout + n_base;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                Gv[mi][rg][ni] = p.G[pofs + ni * 32];
+                Hv[mi][rg][ni] = p.Hb[pofs + ni * 32];
+                gv[mi][rg][ni] = p.gamma_out[pofs + ni * 32];
+            }
+        }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -333,27 +400,20 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKernelParam
             const int pos = pb * p.PT + (grp >> (p.log2ST - 2));
             const int sl0 = (grp & (g4 - 1)) << 2;                         // first of the 4 samples
             const bool pvalid = pos < p.P;
-            const int64_t pofs = (int64_t)(pvalid ? pos : 0) * p.Cout + n_base;
-            float Gv[2], Hv[2], gv[2];
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                Gv[ni] = p.G[pofs + ni * 32];
-                Hv[ni] = p.Hb[pofs + ni * 32];
-                gv[ni] = p.gamma_out[pofs + ni * 32];
-            }
+            float* yrow = p.y + ((int64_t)(sg * p.ST + sl0) * p.P + pos) * p.Cout + n_base;
+            const int64_t ystep = (int64_t)p.P * p.Cout;                   // next sample, same position
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = rg * 4 + q;
                 const int sl = sl0 + q;
-                const int b = sg * p.ST + sl;
-                const bool valid = pvalid && b < p.B;
+                const bool valid = pvalid && (sg * p.ST + sl) < p.B;
                 const float rb = sRB[sl], cb = sCB[sl];
                 float rs = 0.f, rq = 0.f;
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
-                    float v = elu1(fmaf(rb, acc[mi][ni][r], fmaf(cb, Gv[ni], Hv[ni])));
+                    float v = elu1(fmaf(rb, acc[mi][ni][r], fmaf(cb, Gv[mi][rg][ni], Hv[mi][rg][ni])));
                     v = valid ? v : 0.f;
-                    if (valid) p.y[((int64_t)b * p.P + pos) * p.Cout + n_base + ni * 32] = v * gv[ni];
+                    if (valid) yrow[q * ystep + ni * 32] = v * gv[mi][rg][ni];
                     rs += v; rq += v * v;
                 }
                 if (fast_stats) { s4[q] += rs; q4[q] += rq; }
@@ -397,8 +457,28 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvKernelParam
     }
 }
 
+// One __global__ per staging variant (launch bounds are not template-dependent).
+#define NAFP_GEMM_KERNEL(name_, BK_, NSTAGE_, MINW_)                                        \
+    __global__ __launch_bounds__(256, MINW_) void name_(const ConvKernelParams p) {          \
+        conv_gemm_body<BK_, NSTAGE_>(p);                                                     \
+    }
+NAFP_GEMM_KERNEL(conv_gemm_k32s2, 32, 2, 2)
+NAFP_GEMM_KERNEL(conv_gemm_k16s2, 16, 2, 4)
+NAFP_GEMM_KERNEL(conv_gemm_k16s3, 16, 3, 3)
+NAFP_GEMM_KERNEL(conv_gemm_k16s4, 16, 4, 2)
+NAFP_GEMM_KERNEL(conv_gemm_k32s3, 32, 3, 1)
+
+template <typename KernelT>
+static int launch_variant(KernelT kernel, int BK, int NSTAGE, const ConvKernelParams& p, dim3 grid, hipStream_t st) {
+    const int lds = (NSTAGE * 2 * BM * BK + 2 * BM) * (int)sizeof(float);
+    NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    kernel<<<grid, 256, lds, st>>>(p);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}
+
 int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStream_t st) {
-    if (g.Cin % BK != 0 || g.Cout % BN != 0 || B > (1 << 24)) return NAFP_ERR_UNSUPPORTED;
+    if (g.Cin % 32 != 0 || g.Cout % BN != 0 || B > (1 << 24)) return NAFP_ERR_UNSUPPORTED;
     ConvKernelParams p;
     p.x = a.x; p.wp = a.wp; p.G = a.G; p.Hb = a.Hb; p.gamma_out = a.gamma_out; p.bias = a.bias;
     p.stats_in = a.stats_in; p.stats_out = a.stats_out; p.y = a.y;
@@ -412,21 +492,27 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     while ((1 << p.log2ST) < p.ST) ++p.log2ST;
     p.n_sg = (int)((B + p.ST - 1) / p.ST);
     p.sample_in = (int64_t)g.Fin * g.Tin * g.Cin;
-    p.tap_stride = g.axis == 0 ? g.Cin : (int64_t)g.Tin * g.Cin;
+    p.tap_stride = g.axis == 0 ? g.Cin : g.Tin * g.Cin;
     p.inv_n_in = 1.0 / (double)p.sample_in;
     p.mode = a.plain ? 1 : 0;
+    // per-tile A descriptor covers ST samples: must stay below the 2 GiB OOB marker
+    if ((int64_t)p.ST * p.sample_in * 4 >= ((int64_t)1 << 31)) return NAFP_ERR_UNSUPPORTED;
+    const int64_t wbytes = (int64_t)g.Cout * 3 * g.Cin * 4;
+    if (wbytes >= ((int64_t)1 << 31)) return NAFP_ERR_UNSUPPORTED;
+    p.wp_bytes = (unsigned)wbytes;
+    static const int abl = []() { const char* e = getenv("NAFP_ABL"); return e ? atoi(e) : 0; }();
+    p.abl = a.plain ? 0 : abl;
     const int n_pb = (p.P + p.PT - 1) / p.PT;
-    const int64_t mt = (int64_t)p.n_sg * n_pb;
-    static bool attr_set = false;
-    const int lds = (4 * TILE_FLOATS + 2 * BM) * (int)sizeof(float);      // 74,752 B
-    if (!attr_set) {
-        NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)conv_gemm_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
+    const dim3 grid((unsigned)((int64_t)p.n_sg * n_pb), (unsigned)(g.Cout / BN));
+    static const int variant = []() { const char* e = getenv("NAFP_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
+    switch (variant) {
+        case 1: return launch_variant(conv_gemm_k32s2, 32, 2, p, grid, st);
+        case 2: return launch_variant(conv_gemm_k16s2, 16, 2, p, grid, st);
+        case 3: return launch_variant(conv_gemm_k16s3, 16, 3, p, grid, st);
+        case 4: return launch_variant(conv_gemm_k16s4, 16, 4, p, grid, st);
+        case 5: return launch_variant(conv_gemm_k32s3, 32, 3, p, grid, st);
+        default: return launch_variant(conv_gemm_k16s3, 16, 3, p, grid, st);   // best measured (profiles/)
     }
-    conv_gemm_kernel<<<dim3((unsigned)mt, (unsigned)(g.Cout / BN)), 256, lds, st>>>(p);
-    NAFP_LAUNCH_CHECK();
-    return NAFP_OK;
 }
 
 // ============================================================================
