@@ -1,0 +1,180 @@
+"""Fingerprint generation driver: checkpoint -> sources -> <key>.mm + <key>_shape.npy.
+
+Mirrors `generate_fingerprint` of the reference (model/generate.py:91-194): same
+arguments, same output directory layout `<OUTPUT_ROOT_DIR>/<NAME>/<IDX>/`, same
+files (`np.memmap` float32 (n_items, EMB_SZ) C-order + `np.save(shape)`), same row
+order, same keys (`dummy_db`, `query`, `db`, or `custom_source`), the same
+overwrite prompt, FileNotFoundError and size warning.
+
+What is different underneath:
+  * the device work is the HIP path (`m_fp(m_pre(X))`, generate.py:83-88);
+  * one launch carries several TS_BATCH_SZ batches; the log-mel max-normalisation
+    group stays TS_BATCH_SZ (melspectrogram.py:108), so every fingerprint equals what
+    the reference computes batch by batch;
+  * with torch.distributed initialised (one process per GPU) the rows are split
+    across ranks on group boundaries and every rank writes its own slice of the
+    same memmap -- no collective on the data path, one barrier at the end.
+Checkpoints are torch files `<LOG_ROOT_DIR>/checkpoint/<NAME>/ckpt-<IDX>.pt` holding
+{'model': state_dict} with the key names of `nnfp.tensor_names()`.
+"""
+import glob
+import os
+import re
+import sys
+
+import numpy as np
+import torch
+
+from .dataset import Dataset
+from .fp.melspec.melspectrogram import get_melspec_layer
+from .fp.nnfp import get_fingerprinter
+
+LAUNCH_SEGMENTS = 640       # target segments per launch (whole groups)
+
+
+def build_fp(cfg):
+    """generate.py:16-23."""
+    return get_melspec_layer(cfg, trainable=False), get_fingerprinter(cfg, trainable=False)
+
+
+def load_checkpoint(checkpoint_root_dir, checkpoint_name, checkpoint_index, m_fp):
+    """generate.py:26-52: latest index when none is given; FileNotFoundError if absent."""
+    checkpoint_dir = checkpoint_root_dir + f'/{checkpoint_name}/'
+    if checkpoint_index is None:
+        print("\x1b[1;32mArgument 'checkpoint_index' was not specified.\x1b[0m")
+        print('\x1b[1;32mSearching for the latest checkpoint...\x1b[0m')
+        idx = [int(m.group(1)) for f in glob.glob(checkpoint_dir + 'ckpt-*.pt')
+               for m in [re.search(r'ckpt-(\d+)\.pt$', f)] if m]
+        if not idx:
+            raise FileNotFoundError(f'Cannot find checkpoint in {checkpoint_dir}')
+        checkpoint_index = max(idx)
+    fpath = checkpoint_dir + 'ckpt-' + str(checkpoint_index) + '.pt'
+    if not os.path.exists(fpath):
+        raise FileNotFoundError(f'Cannot find checkpoint {fpath}')
+    ck = torch.load(fpath, map_location='cpu', weights_only=True)
+    m_fp.load_state_dict(ck['model'] if 'model' in ck else ck)
+    print(f'---Restored from {fpath}---')
+    return int(checkpoint_index)
+
+
+def save_checkpoint(checkpoint_root_dir, checkpoint_name, checkpoint_index, m_fp, extra=None):
+    d = checkpoint_root_dir + f'/{checkpoint_name}/'
+    os.makedirs(d, exist_ok=True)
+    payload = {'model': m_fp.state_dict()}
+    if extra:
+        payload.update(extra)
+    torch.save(payload, d + f'ckpt-{int(checkpoint_index)}.pt')
+    return d + f'ckpt-{int(checkpoint_index)}.pt'
+
+
+def prevent_overwrite(key, target_path):
+    """generate.py:55-58."""
+    if (key == 'dummy_db') & os.path.exists(target_path):
+        answer = input(f'{target_path} exists. Will you overwrite (y/N)?')
+        if answer.lower() not in ['y', 'yes']:
+            sys.exit()
+
+
+def get_data_source(cfg, source_root_dir, skip_dummy):
+    """generate.py:61-80."""
+    dataset = Dataset(cfg)
+    ds = dict()
+    if source_root_dir:
+        ds['custom_source'] = dataset.get_custom_db_ds(source_root_dir)
+    else:
+        if skip_dummy:
+            print("Excluding \033[33m'dummy_db'\033[0m from source.")
+        else:
+            ds['dummy_db'] = dataset.get_test_dummy_db_ds()
+        if dataset.datasel_test_query_db in ['unseen_icassp', 'unseen_syn']:
+            ds['query'], ds['db'] = dataset.get_test_query_db_ds()
+        else:
+            raise ValueError(dataset.datasel_test_query_db)
+    print(f'\x1b[1;32mData source: {ds.keys()}\x1b[0m', f'{dataset.datasel_test_query_db}')
+    return ds
+
+
+def test_step(X, m_pre, m_fp, group_size=None):
+    """generate.py:83-88: m_fp(m_pre(X))."""
+    m_fp.trainable = False
+    return m_fp(m_pre(X, group_size=group_size))
+
+
+def shard_rows(n_items, group, rank, world):
+    """Contiguous row range of `rank`: whole max-normalisation groups, balanced to
+    within one group.  Every row belongs to exactly one rank."""
+    n_groups = (n_items + group - 1) // group
+    g0 = (n_groups * rank) // world
+    g1 = (n_groups * (rank + 1)) // world
+    return min(g0 * group, n_items), min(g1 * group, n_items)
+
+
+def write_fingerprints(source, embed_fn, arr, group, rank=0, world=1, launch_rows=None):
+    """Fill arr[rows of this rank] = embed_fn(int16 chunk (n,1,T), group) in row order."""
+    r0, r1 = shard_rows(source.n_samples, group, rank, world)
+    k = max(1, -(-LAUNCH_SEGMENTS // group))
+    launch_rows = launch_rows or k * group
+    for start, chunk in source.iter_rows(r0, r1, launch_rows):
+        emb = embed_fn(chunk, group)
+        arr[start:start + len(chunk), :] = emb
+    return r0, r1
+
+
+def _dist():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+def generate_fingerprint(cfg, checkpoint_name, checkpoint_index, source_root_dir, output_root_dir,
+                         skip_dummy):
+    """generate.py:91-194."""
+    dist, rank, world = _dist()
+    m_pre, m_fp = build_fp(cfg)
+    checkpoint_root_dir = cfg['DIR']['LOG_ROOT_DIR'] + 'checkpoint/'
+    checkpoint_index = load_checkpoint(checkpoint_root_dir, checkpoint_name, checkpoint_index, m_fp)
+
+    ds = get_data_source(cfg, source_root_dir, skip_dummy)
+
+    if output_root_dir:
+        output_root_dir = output_root_dir + f'/{checkpoint_name}/{checkpoint_index}/'
+    else:
+        output_root_dir = cfg['DIR']['OUTPUT_ROOT_DIR'] + f'/{checkpoint_name}/{checkpoint_index}/'
+    os.makedirs(output_root_dir, exist_ok=True)
+    if not skip_dummy and rank == 0:
+        prevent_overwrite('dummy_db', f'{output_root_dir}/dummy_db.mm')
+
+    def embed(chunk_i16, group):
+        x = torch.from_numpy(chunk_i16).cuda(non_blocking=True)
+        return test_step(x, m_pre, m_fp, group_size=group).cpu().numpy()
+
+    sz_check = dict()
+    for key in ds.keys():
+        bsz = int(cfg['BSZ']['TS_BATCH_SZ'])
+        n_items = ds[key].n_samples
+        dim = cfg['MODEL']['EMB_SZ']
+        assert n_items > 0
+        arr_shape = (n_items, dim)
+        path = f'{output_root_dir}/{key}.mm'
+        if rank == 0:
+            arr = np.memmap(path, dtype='float32', mode='w+', shape=arr_shape)
+            np.save(f'{output_root_dir}/{key}_shape.npy', arr_shape)
+        if dist:
+            dist.barrier()
+        if rank != 0:
+            arr = np.memmap(path, dtype='float32', mode='r+', shape=arr_shape)
+        print(f"=== Generating fingerprint from \x1b[1;32m'{key}'\x1b[0m bsz={bsz}, {n_items} items, d={dim} ===")
+        write_fingerprints(ds[key], embed, arr, bsz, rank, world)
+        arr.flush()
+        if dist:
+            dist.barrier()
+        print(f'=== Succesfully stored {arr_shape[0]} fingerprint to {output_root_dir} ===')
+        sz_check[key] = len(arr)
+        del arr
+
+    if 'custom_source' in ds.keys():
+        pass
+    elif sz_check['db'] != sz_check['query']:
+        print("\033[93mWarning: 'db' and 'qeury' size does not match. This can cause a problem in evaluataion stage.\033[0m")
+    return

@@ -1,0 +1,120 @@
+"""Command line of the MI355X build: the reference's `run.py` surface.
+
+    python run.py generate CHECKPOINT_NAME [CHECKPOINT_INDEX] [-c CONFIG] [-s SRC] [-o OUT] [--skip_dummy]
+    python run.py train    CHECKPOINT_NAME [-c CONFIG] [--max_epoch N]
+    python run.py evaluate CHECKPOINT_NAME CHECKPOINT_INDEX [-c CONFIG] [-i INDEX_TYPE] ...
+
+Same commands, arguments, options and config resolution (./config/<name>.yaml) as
+the reference's run.py:13-162.  `generate` runs the HIP hot path.  `train` and
+`evaluate` sit outside the path built so far and say so.
+
+Multi-GPU generate: launch one process per GPU, e.g.
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        run.py generate NAME
+Rows are then sharded across the ranks (no collective on the data path).
+"""
+import os
+import sys
+
+import click
+import yaml
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def load_config(config_fname):
+    config_filepath = './config/' + config_fname + '.yaml'
+    if os.path.exists(config_filepath):
+        print(f'cli: Configuration from {config_filepath}')
+    else:
+        sys.exit(f'cli: ERROR! Configuration file {config_filepath} is missing!!')
+    with open(config_filepath, 'r') as f:
+        cfg = yaml.safe_load(f)
+    return cfg
+
+
+def update_config(cfg, key1: str, key2: str, val):
+    cfg[key1][key2] = val
+    return cfg
+
+
+def print_config(cfg):
+    print('\033[36m' + yaml.dump(cfg, indent=4, width=120, sort_keys=False) + '\033[0m')
+
+
+def _init_distributed():
+    """One process per GPU when launched by torch.distributed.run; no-op otherwise."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        local = int(os.environ.get('LOCAL_RANK', '0'))
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+
+
+@click.group()
+def cli():
+    """train-> generate-> evaluate.  `python run.py COMMAND --help` for details."""
+
+
+@cli.command()
+@click.argument('checkpoint_name', required=True)
+@click.option('--config', '-c', default='default', type=click.STRING,
+              help="Name of model configuration located in './config/.'")
+@click.option('--max_epoch', default=None, type=click.INT, help='Max epoch.')
+def train(checkpoint_name, config, max_epoch):
+    """Train a neural audio fingerprinter (not built yet for MI355X: forward kernels and the
+    NT-Xent loss exist, the backward kernels do not)."""
+    cfg = load_config(config)
+    if max_epoch:
+        update_config(cfg, 'TRAIN', 'MAX_EPOCH', max_epoch)
+    print_config(cfg)
+    raise NotImplementedError('train: backward kernels of the encoder are not built yet '
+                              '(DESIGN.md, "out of scope this round")')
+
+
+@cli.command()
+@click.argument('checkpoint_name', required=True)
+@click.argument('checkpoint_index', required=False)
+@click.option('--config', '-c', default='default', required=False, type=click.STRING,
+              help="Name of the model configuration file located in 'config/'. Default is 'default'")
+@click.option('--source', '-s', default=None, type=click.STRING, required=False,
+              help='Custom source root directory. The source must be 16-bit 8 Khz mono WAV.')
+@click.option('--output', '-o', default=None, type=click.STRING, required=False,
+              help='Root directory where the generated embeddings (uncompressed) will be stored. '
+                   'Default is OUTPUT_ROOT_DIR/CHECKPOINT_NAME defined in config.')
+@click.option('--skip_dummy', default=False, is_flag=True, help='Exclude dummy-DB from the default source.')
+def generate(checkpoint_name, checkpoint_index, config, source, output, skip_dummy):
+    """Generate fingerprints from a saved checkpoint.
+
+    If CHECKPOINT_INDEX is not specified, the latest checkpoint is loaded.  The default
+    sources are [TEST_DUMMY_DB] and [TEST_QUERY_DB] of the config file.
+    """
+    from neural_audio_fp_amd.model.generate import generate_fingerprint
+    cfg = load_config(config)
+    _init_distributed()
+    generate_fingerprint(cfg, checkpoint_name, checkpoint_index, source, output, skip_dummy)
+
+
+@cli.command()
+@click.argument('checkpoint_name', required=True)
+@click.argument('checkpoint_index', required=True)
+@click.option('--config', '-c', default='default', required=False, type=click.STRING)
+@click.option('--index_type', '-i', default='ivfpq', type=click.STRING)
+@click.option('--test_seq_len', default='1 3 5 9 11 19', type=click.STRING)
+@click.option('--test_ids', '-t', default='icassp', type=click.STRING)
+@click.option('--nogpu', default=False, is_flag=True)
+def evaluate(checkpoint_name, checkpoint_index, config, index_type, test_seq_len, test_ids, nogpu):
+    """Search and evaluation over the generated .mm files (consumer of the hot path's output;
+    the reference uses faiss, which is outside the built path)."""
+    cfg = load_config(config)
+    emb_dir = cfg['DIR']['OUTPUT_ROOT_DIR'] + checkpoint_name + '/' + str(checkpoint_index) + '/'
+    raise NotImplementedError(f'evaluate: the search/eval side is outside the built path; the fingerprints in '
+                              f'{emb_dir} are drop-in for the reference\'s eval/eval_faiss.py')
+
+
+if __name__ == '__main__':
+    cli()

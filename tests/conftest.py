@@ -7,6 +7,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.join(ROOT, 'tests') not in sys.path:
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 
 def pytest_configure(config):
@@ -36,3 +38,11 @@ def cfg():
     import yaml
     with open(os.path.join(ROOT, 'config', 'default.yaml')) as f:
         return yaml.safe_load(f)
+
+
+@pytest.fixture(scope='session')
+def golden():
+    """Vectors written by tests/gen_golden.py from the float64 oracle (not from the
+    reference: it cannot run here; see oracle/__init__.py)."""
+    import numpy as np
+    return dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'hotpath_v1.npz')))

@@ -1,0 +1,77 @@
+"""CPU: the input contract (segment enumeration, tail zero-padding, int16 scaling):
+host mirror vs the oracle restatement of audio_utils.py:140-264."""
+import os
+import wave
+
+import numpy as np
+import pytest
+
+from oracle import segments as o_seg
+
+
+def _write_wav(path, pcm, fs=8000):
+    with wave.open(path, 'w') as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(fs)
+        w.writeframes(pcm.astype('<i2').tobytes())
+
+
+@pytest.fixture()
+def wavs(tmp_path):
+    rng = np.random.default_rng(0)
+    lens = {'a_short': 3000, 'b_exact': 8000, 'c_plus1': 8001, 'd_1p5': 12000, 'e_odd': 20001, 'f_30s': 240000}
+    paths = []
+    for name, n in lens.items():
+        p = str(tmp_path / f'{name}.wav')
+        _write_wav(p, rng.integers(-8192, 8192, size=n))
+        paths.append(p)
+    return sorted(paths), lens
+
+
+def test_n_segments_rule():
+    # audio_utils.py:173-177
+    assert [o_seg.n_segments(n) for n in (1, 3000, 8000, 8001, 11999, 12000, 16000, 240000)] == [1, 1, 1, 1, 1, 2, 3, 59]
+    # 59 segments per 30-s clip is what eval/test_ids_icassp2021.npy encodes
+    from neural_audio_fp_amd.model.utils import audio_utils as h
+    assert all(h.n_segments(n) == o_seg.n_segments(n) for n in range(1, 50000, 37))
+
+
+def test_source_matches_oracle_batches(wavs):
+    from neural_audio_fp_amd.model.utils.audio_utils import SegmentSource, get_fns_seg_list
+    paths, lens = wavs
+    src = SegmentSource(paths, bsz=7)
+    want = list(o_seg.load_batches(paths, 7))
+    assert src.n_samples == sum(o_seg.n_segments(n) for n in lens.values()) == 1 + 1 + 1 + 2 + 4 + 59
+    assert len(src) == len(want)
+    assert [tuple(e) for e in get_fns_seg_list(paths, 8000, 1., .5)] == o_seg.enumerate_segments(paths)
+    for i, wb in enumerate(want):
+        got, _ = src[i]
+        assert got.dtype == np.int16 and got.shape == wb.shape
+        # int16 * 2^-15 in float32 is exactly the reference's float64 x / 2**15 cast to float32
+        assert np.array_equal(got.astype(np.float32) * np.float32(2.0 ** -15), wb)
+    # tail zero padding of the short file and of the ragged last segment of e_odd
+    first, _ = src[0]
+    assert np.all(first[0, 0, 3000:] == 0) and np.any(first[0, 0, :3000] != 0)
+    # iter_rows over an arbitrary range == concatenation of the batches
+    allrows = np.concatenate([b for b in want])
+    for r0, r1, chunk in [(0, src.n_samples, 10), (5, 40, 8), (9, 10, 4)]:
+        parts = [c for _, c in src.iter_rows(r0, r1, chunk)]
+        got = np.concatenate(parts).astype(np.float32) * np.float32(2.0 ** -15)
+        assert np.array_equal(got, allrows[r0:r1])
+
+
+def test_wrong_sample_rate_raises(tmp_path):
+    from neural_audio_fp_amd.model.utils.audio_utils import SegmentSource
+    p = str(tmp_path / 'x.wav')
+    _write_wav(p, np.zeros(100), fs=16000)
+    with pytest.raises(ValueError, match='Sample rate should be 8000'):
+        SegmentSource([p], 4)
+    with pytest.raises(ValueError):
+        o_seg.enumerate_segments([p])
+
+
+def test_reference_fixture_encodes_59_segments_per_clip():
+    # eval/test_ids_icassp2021.npy is the only data fixture of the reference; its content
+    # (2000 int64 ids, id % 59 spanning 0..58 over 500 clips) is restated here as facts.
+    ids_max, n_clips, segs = 29492, 500, 59
+    assert n_clips * segs == 29500 and ids_max < n_clips * segs
+    assert o_seg.n_segments(30 * 8000) == segs
