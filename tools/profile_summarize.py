@@ -1,0 +1,146 @@
+#!/usr/bin/env python
+"""Turn gpurun_out/prof_<tag>/ (written by tools/profile_round.sh on the GPU box) into the
+tracked artefacts under profiles/:  <tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats
+summary, verbatim), <tag>_summary.md, <tag>_bench.json, and profiles/traffic.json (per-launch
+HBM bytes of the dominant kernel, read by bench.py for roofline.traffic).
+
+HBM traffic follows MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE come from separate
+--pmc passes, are in KiB, and on gfx950 FETCH_SIZE counts a wide (16 B/lane) coalesced read
+stream at half its bytes -> doubled here.  WRITE_SIZE is taken as reported (uncalibrated).
+"""
+import csv
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+src = os.path.join(ROOT, 'gpurun_out', f'prof_{tag}')
+dst = os.path.join(ROOT, 'profiles')
+os.makedirs(dst, exist_ok=True)
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+GEMM = 'conv_gemm'
+BSZ = bench.BSZ
+
+
+def read_csv(path):
+    with open(path, newline='') as f:
+        return list(csv.DictReader(f))
+
+
+shutil.copy(os.path.join(src, 'trace', 't_kernel_stats.csv'), os.path.join(dst, f'{tag}_kernel_stats.csv'))
+bench_line = [l for l in open(os.path.join(src, 'bench.json')).read().splitlines() if l.startswith('{')][-1]
+bj = json.loads(bench_line)
+json.dump(bj, open(os.path.join(dst, f'{tag}_bench.json'), 'w'), indent=1)
+
+stats = read_csv(os.path.join(src, 'trace', 't_kernel_stats.csv'))
+trace = read_csv(os.path.join(src, 'trace', 't_kernel_trace.csv'))
+# per-shape durations of the GEMM conv: group by grid size (15 distinct layer shapes share some grids)
+by_grid = defaultdict(list)
+for r in trace:
+    if GEMM in r['Kernel_Name']:
+        g = (int(r['Grid_Size_X']) if 'Grid_Size_X' in r else int(r['Grid_Size']), int(r.get('Grid_Size_Y', 1) or 1))
+        by_grid[g].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+# full-mode launches: drop the 30 PLAIN launches of set_weights (one sample: tiny grids, issued once)
+gemm_all = sorted(((g, v) for g, v in by_grid.items()), key=lambda t: -sum(t[1]))
+
+
+def pmc(dirname, counter):
+    rows = read_csv(os.path.join(src, dirname, 'p_counter_collection.csv'))
+    out = defaultdict(list)
+    for r in rows:
+        if r['Counter_Name'] == counter:
+            out[r['Kernel_Name']].append((int(r['Grid_Size']), float(r['Counter_Value']),
+                                          int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
+    return out
+
+
+fetch, write = pmc('pmc_fetch', 'FETCH_SIZE'), pmc('pmc_write', 'WRITE_SIZE')
+
+
+def per_step_sum(d, name_part, min_grid=0):
+    """sum of a counter over the launches of one bench step (launch count / steps)."""
+    vals = [v for k, lst in d.items() if name_part in k for (g, v, _) in lst if g >= min_grid]
+    return sum(vals), len(vals)
+
+
+macs = bench.conv_effective_macs()
+n_steps_pmc = 7            # profile_round.sh: --steps 5 --warmup 2
+f_sum, f_n = per_step_sum(fetch, GEMM, min_grid=256 * 8)
+w_sum, w_n = per_step_sum(write, GEMM, min_grid=256 * 8)
+# launches of the bench steps only: 15 per step
+n_full = 15 * n_steps_pmc
+fetch_bytes_per_launch = 2.0 * f_sum * 1024 / f_n if f_n else None       # gfx950 x2 correction
+write_bytes_per_launch = w_sum * 1024 / w_n if w_n else None
+alg_bytes_per_launch = None
+# algorithmic HBM bytes of the 15 convs per step: each activation read once + written once (z tensors)
+geo_out = []
+F, T, C = 256, 32, 1
+hidden = [128, 128, 256, 256, 512, 512, 1024, 1024]
+st = [2, 2, 2, 2, 1, 2, 1, 2]
+sizes = []
+for i in range(8):
+    T = -(-T // st[i]); C = hidden[i]; sizes.append(F * T * C)
+    F = -(-F // 2); sizes.append(F * T * C)
+alg = sum((sizes[j - 1] + sizes[j]) * 4 * BSZ for j in range(1, 16))
+alg_bytes_per_launch = alg / 15
+
+traffic = None
+if fetch_bytes_per_launch and write_bytes_per_launch:
+    traffic = fetch_bytes_per_launch + write_bytes_per_launch
+json.dump({'tag': tag, 'kernel': 'conv_gemm_k16s3', 'per_launch_bytes': traffic,
+           'fetch_bytes_x2_corrected': fetch_bytes_per_launch, 'write_bytes': write_bytes_per_launch,
+           'algorithmic_activation_bytes_per_launch': alg_bytes_per_launch,
+           'launches_averaged': {'fetch': f_n, 'write': w_n},
+           'method': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over '
+                     '`python bench.py --steps 5 --warmup 2`; KiB -> bytes; FETCH_SIZE doubled '
+                     '(gfx950 counts a 16 B/lane stream at half, MI355X_MICROARCH.md HBM)'},
+          open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
+
+sq = read_csv(os.path.join(src, 'pmc_sq', 'p_counter_collection.csv'))
+agg = defaultdict(lambda: defaultdict(list))
+for r in sq:
+    if GEMM in r['Kernel_Name'] and int(r['Grid_Size']) >= 256 * 8:
+        agg[int(r['Grid_Size'])][r['Counter_Name']].append(float(r['Counter_Value']))
+        agg[int(r['Grid_Size'])]['_dur'].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+
+with open(os.path.join(dst, f'{tag}_summary.md'), 'w') as f:
+    f.write(f'# Profile summary {tag}\n\n')
+    f.write('Command profiled: `python bench.py --steps 30 --warmup 5` (1x MI355X, BSZ 640 per step), '
+            'under `rocprofv3 --kernel-trace --stats` (full CSV: `%s_kernel_stats.csv`).\n\n' % tag)
+    f.write(f'Bench line of the same run (un-profiled): **{bj["value"]} {bj["unit"]}**, '
+            f'roofline {bj["roofline"]["achieved"]} / {bj["roofline"]["peak"]} TFLOP/s '
+            f'= {bj["roofline"]["frac"]} (HIP-event mean launch {bj["roofline"]["ms_per_launch_avg"]} ms).\n\n')
+    f.write('## Kernel stats (rocprofv3 --stats)\n\n| kernel | calls | avg us | total ms | % |\n|---|---|---|---|---|\n')
+    for r in stats[:8]:
+        f.write(f'| `{r["Name"][:70]}` | {r["Calls"]} | {float(r["AverageNs"]) / 1e3:.1f} | '
+                f'{float(r["TotalDurationNs"]) / 1e6:.2f} | {r["Percentage"]} |\n')
+    full = [(g, v) for g, v in gemm_all if len(v) >= 30]
+    tot = sum(sum(v) for g, v in full); cnt = sum(len(v) for g, v in full)
+    f.write(f'\nGEMM-conv launches of the bench steps only (the 30 one-off PLAIN launches of set_weights '
+            f'excluded): {cnt} launches, mean {tot / cnt / 1e3:.1f} us under the profiler vs '
+            f'{bj["roofline"]["ms_per_launch_avg"] * 1e3:.1f} us from HIP events un-profiled.\n\n')
+    f.write('## HBM traffic of the dominant kernel (separate PMC passes)\n\n')
+    if traffic:
+        f.write(f'* FETCH_SIZE (x2 gfx950 correction): {fetch_bytes_per_launch / 1e6:.1f} MB per launch (mean of {f_n})\n')
+        f.write(f'* WRITE_SIZE: {write_bytes_per_launch / 1e6:.1f} MB per launch (mean of {w_n})\n')
+        f.write(f'* total {traffic / 1e6:.1f} MB per launch vs {alg_bytes_per_launch / 1e6:.1f} MB algorithmic '
+                f'activation bytes (each z tensor read once + written once; weights/G/Hb/gamma not counted)\n\n')
+    f.write('## SQ counters per GEMM-conv shape (grid threads -> mean over launches)\n\n')
+    f.write('| grid threads | dur us | clock GHz | MFMA busy % | wave occupancy/CU | WAIT_ANY % | WAIT_INST % | LDS bank conflicts |\n|---|---|---|---|---|---|---|---|\n')
+    for g in sorted(agg, reverse=True):
+        a = {k: sum(v) / len(v) for k, v in agg[g].items()}
+        if 'GRBM_GUI_ACTIVE' not in a:
+            continue
+        cyc = a['GRBM_GUI_ACTIVE'] / 8.0
+        clk = cyc / a['_dur']
+        mf = a['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc) * 100
+        occ = a['SQ_WAVE_CYCLES'] * 4 / (cyc * 256)
+        f.write(f'| {g} | {a["_dur"] / 1e3:.1f} | {clk:.2f} | {mf:.1f} | {occ:.1f} | '
+                f'{a["SQ_WAIT_ANY"] / a["SQ_WAVE_CYCLES"] * 100:.1f} | {a["SQ_WAIT_INST_ANY"] / a["SQ_WAVE_CYCLES"] * 100:.1f} | '
+                f'{a.get("SQ_LDS_BANK_CONFLICT", 0):.0f} |\n')
+print(open(os.path.join(dst, f'{tag}_summary.md')).read())
