@@ -199,7 +199,9 @@ extern "C" int64_t nafp_encoder_workspace_bytes(const nafp_encoder* e, int64_t n
     const int64_t stats = align_up((int64_t)sizeof(double) * 2 * 16 * n_seg, 256);
     const int64_t a = align_up((int64_t)sizeof(float) * e->bufA_per_seg * n_seg, 256);
     const int64_t b = align_up((int64_t)sizeof(float) * e->bufB_per_seg * n_seg, 256);
-    return stats + a + b + 256;
+    int64_t slab = 0;
+    for (int j = 1; j < 16; ++j) slab = std::max(slab, conv_gemm_slab_floats(n_seg, e->geom[j]));
+    return stats + a + b + align_up(slab * (int64_t)sizeof(float), 256) + 256;
 }
 
 extern "C" int nafp_encoder_forward(nafp_encoder* e, const float* feat, int64_t n_seg,
@@ -216,6 +218,9 @@ extern "C" int nafp_encoder_forward(nafp_encoder* e, const float* feat, int64_t 
     double* stats = (double*)ws;
     float* bufA = (float*)(ws + stats_bytes);
     float* bufB = (float*)(ws + stats_bytes + align_up((int64_t)sizeof(float) * e->bufA_per_seg * n_seg, 256));
+    float* slab = (float*)((char*)bufB + align_up((int64_t)sizeof(float) * e->bufB_per_seg * n_seg, 256));
+    int64_t slab_floats = 0;
+    for (int j = 1; j < 16; ++j) slab_floats = std::max(slab_floats, conv_gemm_slab_floats(n_seg, e->geom[j]));
     NAFP_HIP_CHECK(hipMemsetAsync(stats, 0, sizeof(double) * 2 * 16 * n_seg, st));
     hipEvent_t* ev = nullptr;
     if (e->prof_max > 0 && e->prof_count < e->prof_max) ev = e->prof_events.data() + (size_t)18 * e->prof_count++;
@@ -231,6 +236,7 @@ extern "C" int nafp_encoder_forward(nafp_encoder* e, const float* feat, int64_t 
         a.x = cur; a.stats_in = stats + 2 * n_seg * (j - 1);
         a.wp = e->d_w[j]; a.G = e->d_G[j]; a.Hb = e->d_Hb[j]; a.gamma_out = e->d_gamma[j];
         a.y = nxt; a.stats_out = stats + 2 * n_seg * j; a.plain = false;
+        a.slab = slab_floats ? slab : nullptr; a.slab_floats = slab_floats;
         rc = launch_conv_gemm(a, n_seg, e->geom[j], st);
         if (rc != NAFP_OK) return rc;
         if (ev) NAFP_HIP_CHECK(hipEventRecord(ev[j + 1], st));

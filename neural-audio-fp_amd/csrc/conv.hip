@@ -147,6 +147,7 @@ struct ConvKernelParams {
     double inv_n_in;          // 1 / sample_in
     int mode;                 // 0 FULL, 1 PLAIN
     unsigned wp_bytes;
+    int n_split;              // split-K factor (blockIdx.z); > 1 writes raw partial sums to `y` = slab
     int abl;                  // ablation flags for kernel-time breakdown (NAFP_ABL env; 0 in production)
 };
 
@@ -255,7 +256,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     for (int t = 0; t < 3; ++t)
         if (live & (1u << t)) { tap_pack |= (unsigned)t << (2 * n_live); ++n_live; }
     const int cpt = p.Cin / BK;                 // K-steps per tap
-    const int n_steps = n_live * cpt;
+    const int n_steps_all = n_live * cpt;
+    // split-K: this workgroup owns K-steps [s_begin, n_steps) of the tile's live steps
+    const int s_begin = (int)(((int64_t)n_steps_all * blockIdx.z) / p.n_split);
+    const int n_steps = (int)(((int64_t)n_steps_all * (blockIdx.z + 1)) / p.n_split);
 
     const u32x4 rsA = make_rsrc(p.x + (int64_t)b0 * p.sample_in, (unsigned)nb * (unsigned)p.sample_in * 4u);
     const u32x4 rsB = make_rsrc(p.wp, p.wp_bytes);
@@ -287,14 +291,14 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
 
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
-        if (s < n_steps) NAFP_DMA_STEP(s, s)
+        if (s_begin + s < n_steps) NAFP_DMA_STEP(s_begin + s, s)
 
     // operand read addresses (floats): row*BK + ((lc ^ swz(row)) * 4), lc = 2*kk + (lane>>5)
     const int rl = lane & 31, hh = lane >> 5;
     const int rswz = BK == 32 ? ((rl >> 1) & 7) : ((rl >> 2) & 3);     // wm*64, 32*mi do not change swz
     const int aoff = (wm * 64 + rl) * BK, boff = TILE + (wn * 64 + rl) * BK;
     int slot = 0;
-    for (int s = 0; s < n_steps; ++s) {
+    for (int s = s_begin; s < n_steps; ++s) {
         // my DMA of step s has landed; after the barrier everybody's has, and everybody has
         // finished reading slot (s-1) % NSTAGE, which the next DMA overwrites.
         if (NSTAGE == 2 || s + NSTAGE - 2 >= n_steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -345,7 +349,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     const int ncol = lane & 31;
     const int n_base = tile_n0 + wn * 64 + ncol;
     const int g4 = p.ST >> 2;                         // sample quads per position
-    if (p.mode == 1) {
+    if (p.mode != 0) {
         // PLAIN: y = acc (+ bias)
         float bv[2];
 #pragma unroll
@@ -360,7 +364,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
                 if (pos < p.P && b < p.B) {
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
-                        p.y[((int64_t)b * p.P + pos) * p.Cout + n_base + ni * 32] = acc[mi][ni][r] + bv[ni];
+                        p.y[(((int64_t)blockIdx.z * p.B + b) * p.P + pos) * p.Cout + n_base + ni * 32] = acc[mi][ni][r] + bv[ni];
                 }
             }
         return;
@@ -477,6 +481,89 @@ static int launch_variant(KernelT kernel, int BK, int NSTAGE, const ConvKernelPa
     return NAFP_OK;
 }
 
+// Split-K finish: sums the S partial slabs in a fixed order (deterministic), then the same
+// epilogue as the fused path: v = ELU(r_b*A + c_b*G + Hb), statistics of v, z = gamma_out . v.
+// One workgroup per output row (sample, position).
+__global__ __launch_bounds__(256) void splitk_finish_kernel(
+        const float* __restrict__ slab, int S, const float* __restrict__ G, const float* __restrict__ Hb,
+        const float* __restrict__ gamma_out, const double* __restrict__ stats_in,
+        double* __restrict__ stats_out, float* __restrict__ y, int B, int P, int Cout, double inv_n_in) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row = blockIdx.x;
+    const int b = (int)(row / P), pos = (int)(row - (int64_t)b * P);
+    const double mean = stats_in[2 * (int64_t)b] * inv_n_in;
+    double var = stats_in[2 * (int64_t)b + 1] * inv_n_in - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
+    const float rb = (float)rstd, cb = (float)(-mean * rstd);
+    const int64_t slab_stride = (int64_t)B * P * Cout;
+    float s = 0.f, q = 0.f;
+    for (int n = tid * 4; n < Cout; n += 1024) {
+        const float* src = slab + row * Cout + n;
+        float4 acc = *(const float4*)src;
+        for (int sp = 1; sp < S; ++sp) {
+            const float4 t = *(const float4*)(src + sp * slab_stride);
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+        const float4 g4 = *(const float4*)(G + (int64_t)pos * Cout + n);
+        const float4 h4 = *(const float4*)(Hb + (int64_t)pos * Cout + n);
+        const float4 go = *(const float4*)(gamma_out + (int64_t)pos * Cout + n);
+        float4 v;
+        v.x = elu1(fmaf(rb, acc.x, fmaf(cb, g4.x, h4.x)));
+        v.y = elu1(fmaf(rb, acc.y, fmaf(cb, g4.y, h4.y)));
+        v.z = elu1(fmaf(rb, acc.z, fmaf(cb, g4.z, h4.z)));
+        v.w = elu1(fmaf(rb, acc.w, fmaf(cb, g4.w, h4.w)));
+        s += (v.x + v.y) + (v.z + v.w);
+        q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        *(float4*)(y + row * Cout + n) = make_float4(v.x * go.x, v.y * go.y, v.z * go.z, v.w * go.w);
+    }
+    const double ds = wave_sum((double)s), dq = wave_sum((double)q);
+    __shared__ double red[8];
+    if (lane == 0) { red[wave] = ds; red[4 + wave] = dq; }
+    __syncthreads();
+    if (tid == 0) {
+        atomicAdd(stats_out + 2 * (int64_t)b, red[0] + red[1] + red[2] + red[3]);
+        atomicAdd(stats_out + 2 * (int64_t)b + 1, red[4] + red[5] + red[6] + red[7]);
+    }
+}
+
+// Split-K policy: layers whose M x N tiling yields too few workgroups to fill 256 CUs
+// (the late convs: M = 640...20480 rows at B = 640) split their K-steps across blockIdx.z.
+static int live_k_steps(const ConvGeom& g) {
+    // K-steps (BK = 16) of the taps that read real data for at least one output position
+    const int n_in = g.axis == 0 ? g.Tin : g.Fin, n_out = g.axis == 0 ? g.Tout : g.Fout;
+    int n_live = 0;
+    for (int t = 0; t < 3; ++t) {
+        bool live = false;
+        for (int o = 0; o < n_out && !live; ++o) { const int i = o * g.stride - g.pad + t; live = i >= 0 && i < n_in; }
+        n_live += live;
+    }
+    return n_live * g.Cin / 16;
+}
+
+static int choose_split(int64_t n_tiles, int k_steps, int64_t out_floats) {
+    static const int force = []() { const char* e = getenv("NAFP_SPLITK"); return e ? atoi(e) : -1; }();
+    if (force == 0) return 1;
+    if (n_tiles > 512) return 1;
+    int s = (int)((768 + n_tiles - 1) / n_tiles);
+    if (force > 0) s = force;
+    const int max_by_steps = k_steps / 16 > 1 ? k_steps / 16 : 1;      // >= 16 K-steps per split
+    if (s > max_by_steps) s = max_by_steps;
+    if (s > 16) s = 16;
+    while (s > 1 && (int64_t)s * out_floats * 4 > ((int64_t)64 << 20)) --s;   // slab round trip <= 64 MB
+    return s < 1 ? 1 : s;
+}
+
+int64_t conv_gemm_slab_floats(int64_t B, const ConvGeom& g) {
+    const int P = g.Fout * g.Tout;
+    int pt = 1;
+    while (pt * 2 <= P && pt * 2 <= 32) pt *= 2;
+    const int ST = BM / pt;
+    const int64_t n_tiles = ((B + ST - 1) / ST) * ((P + pt - 1) / pt) * (g.Cout / BN);
+    const int S = choose_split(n_tiles, live_k_steps(g), B * P * g.Cout);
+    return S > 1 ? (int64_t)S * B * P * g.Cout : 0;
+}
+
 int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStream_t st) {
     if (g.Cin % 32 != 0 || g.Cout % BN != 0 || B > (1 << 24)) return NAFP_ERR_UNSUPPORTED;
     ConvKernelParams p;
@@ -495,6 +582,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     p.tap_stride = g.axis == 0 ? g.Cin : g.Tin * g.Cin;
     p.inv_n_in = 1.0 / (double)p.sample_in;
     p.mode = a.plain ? 1 : 0;
+    p.n_split = 1;
     // per-tile A descriptor covers ST samples: must stay below the 2 GiB OOB marker
     if ((int64_t)p.ST * p.sample_in * 4 >= ((int64_t)1 << 31)) return NAFP_ERR_UNSUPPORTED;
     const int64_t wbytes = (int64_t)g.Cout * 3 * g.Cin * 4;
@@ -503,16 +591,29 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     static const int abl = []() { const char* e = getenv("NAFP_ABL"); return e ? atoi(e) : 0; }();
     p.abl = a.plain ? 0 : abl;
     const int n_pb = (p.P + p.PT - 1) / p.PT;
-    const dim3 grid((unsigned)((int64_t)p.n_sg * n_pb), (unsigned)(g.Cout / BN));
-    static const int variant = []() { const char* e = getenv("NAFP_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
-    switch (variant) {
-        case 1: return launch_variant(conv_gemm_k32s2, 32, 2, p, grid, st);
-        case 2: return launch_variant(conv_gemm_k16s2, 16, 2, p, grid, st);
-        case 3: return launch_variant(conv_gemm_k16s3, 16, 3, p, grid, st);
-        case 4: return launch_variant(conv_gemm_k16s4, 16, 4, p, grid, st);
-        case 5: return launch_variant(conv_gemm_k32s3, 32, 3, p, grid, st);
-        default: return launch_variant(conv_gemm_k16s3, 16, 3, p, grid, st);   // best measured (profiles/)
+    const int64_t n_tiles = (int64_t)p.n_sg * n_pb * (g.Cout / BN);
+    int S = 1;
+    if (!a.plain && a.slab) {
+        S = choose_split(n_tiles, live_k_steps(g), B * p.P * g.Cout);
+        if ((int64_t)S * B * p.P * g.Cout > a.slab_floats) S = 1;
     }
+    if (S > 1) { p.mode = 2; p.n_split = S; p.y = a.slab; p.bias = nullptr; }
+    const dim3 grid((unsigned)((int64_t)p.n_sg * n_pb), (unsigned)(g.Cout / BN), (unsigned)S);
+    static const int variant = []() { const char* e = getenv("NAFP_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
+    int rc;
+    switch (variant) {
+        case 1: rc = launch_variant(conv_gemm_k32s2, 32, 2, p, grid, st); break;
+        case 2: rc = launch_variant(conv_gemm_k16s2, 16, 2, p, grid, st); break;
+        case 3: rc = launch_variant(conv_gemm_k16s3, 16, 3, p, grid, st); break;
+        case 4: rc = launch_variant(conv_gemm_k16s4, 16, 4, p, grid, st); break;
+        case 5: rc = launch_variant(conv_gemm_k32s3, 32, 3, p, grid, st); break;
+        default: rc = launch_variant(conv_gemm_k16s3, 16, 3, p, grid, st); break;   // best measured (profiles/)
+    }
+    if (rc != NAFP_OK || S == 1) return rc;
+    splitk_finish_kernel<<<dim3((unsigned)(B * p.P)), 256, 0, st>>>(a.slab, S, a.G, a.Hb, a.gamma_out, a.stats_in,
+                                                                   a.stats_out, a.y, p.B, p.P, g.Cout, p.inv_n_in);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
 }
 
 // ============================================================================

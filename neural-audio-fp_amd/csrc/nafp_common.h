@@ -101,7 +101,10 @@ struct ConvGemmArgs {
     double* stats_out;       // (B,2), must be zero on entry                          FULL
     float* y;                // (B,Fout,Tout,Cout): z = gamma_out . v (FULL) or acc + bias (PLAIN)
     bool plain;
+    float* slab;             // split-K partial sums workspace (or nullptr: never split)
+    int64_t slab_floats;
 };
+int64_t conv_gemm_slab_floats(int64_t B, const ConvGeom& g);   // workspace the split-K policy wants
 int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStream_t st);
 
 // tail: LN of the last conv + flatten + divide-and-encode + optional L2 norm.
