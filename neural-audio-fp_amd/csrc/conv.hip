@@ -219,7 +219,6 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     unsigned voffA[NI];           // byte offset of tap 0 from the tile's first sample
     unsigned vmaskA[NI];          // bit t: tap t reads real data (else zero padding -> OOB lane)
     unsigned voffB[NI];
-    unsigned my_live = 0;
 #pragma unroll
     for (int q = 0; q < NI; ++q) {
         const int lr = wave * 32 + q * RPI + lane / CH;
@@ -238,18 +237,32 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
 #pragma unroll
             for (int t = 0; t < 3; ++t)
                 if (pos0 + t >= 0 && pos0 + t < lim) vmaskA[q] |= 1u << t;
-            my_live |= vmaskA[q];
         }
         voffB[q] = (unsigned)((tile_n0 + lr) * K + lc * 4) * 4u;
     }
-    // taps that read only zero padding for EVERY row of this tile are skipped
-    int* s_live = (int*)smem;
-    if (tid == 0) *s_live = 0;
-    __syncthreads();
-    if (my_live) atomicOr(s_live, (int)my_live);
-    __syncthreads();
-    const unsigned live = (unsigned)*s_live;
-    __syncthreads();
+    // Taps that read only zero padding for EVERY row of this tile are skipped.  Each wave
+    // derives the tile-wide mask on its own (lane l inspects rows l and l+64, then a
+    // wave-wide OR), so no LDS traffic and no barrier is needed in the prologue.
+    unsigned live = 0;
+    {
+        unsigned m = 0;
+#pragma unroll
+        for (int hrow = 0; hrow < 2; ++hrow) {
+            const int lr = lane + 64 * hrow;
+            const int pos = pb * p.PT + (lr >> p.log2ST);
+            if (pos < p.P && (lr & ST1) < nb) {
+                const int fo = pos / p.Tout, to = pos - fo * p.Tout;
+                const int pos0 = (p.axis == 0 ? to : fo) * p.stride - p.pad;
+                const int lim = p.axis == 0 ? p.Tin : p.Fin;
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    if (pos0 + t >= 0 && pos0 + t < lim) m |= 1u << t;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            if (__ballot((m >> t) & 1u) != 0ull) live |= 1u << t;
+    }
     // live taps packed 2 bits each (no runtime-indexed array: that would live in scratch)
     unsigned tap_pack = 0; int n_live = 0;
 #pragma unroll
