@@ -126,6 +126,147 @@ __global__ __launch_bounds__(256) void ntxent_fwd_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Backward.  dS[r,c] = (softmax_r[c] - [c == pos(r)]) / n_global for c != self(r); then
+//   dR_r = sum_c dS[r,c] C_c / tau     (rows: this rank's embeddings)
+//   dC_c = sum_r dS[r,c] R_r / tau     (columns: the gathered embeddings)
+// One kernel, two roles.  The OWNER set (32 per workgroup, one per lane) is the rows (ROW
+// mode, other set = columns) or the columns (COL mode, other set = rows).  Per 32-wide
+// tile of the other set T the S^T tile is recomputed exactly as in the forward kernel
+// (D[i = tile index][j = owner]); p = exp(s - lse_row) uses the row LSE saved by the
+// forward pass.  The second product  out[owner][feature] += dS[i][owner] * T[i][feature]
+// reuses the accumulator registers of the first as its B operand: MFMA step t needs
+// k = i_h(t) = (t&3) + 8(t>>2) + 4h, which is exactly register t of lane half h.
+// Every output row is produced by one workgroup in a fixed order: deterministic, no atomics.
+// ---------------------------------------------------------------------------------------
+template <bool COL>
+__global__ __launch_bounds__(256) void ntxent_bwd_kernel(
+        const float* __restrict__ org_l, const float* __restrict__ rep_l,
+        const float* __restrict__ org_all, const float* __restrict__ rep_all,
+        const float* __restrict__ row_lse, int n_local, int n_global, int rank_offset,
+        float tau, float scale,                 // scale = 1 / (tau * n_global)
+        float* __restrict__ part,               // [4 waves][n_owner][128] partial sums over this wave's tiles
+        int n_owner_pad) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, jl = lane & 31;
+    const int n_rows = 2 * n_local, n_cols = 2 * n_global;
+    const int n_owner = COL ? n_cols : n_rows, n_other = COL ? n_rows : n_cols;
+    const int o = blockIdx.x * 32 + jl;                     // my owner index
+    const bool ovalid = o < n_owner;
+    // owner vector fragment (64 values: features 64h .. 64h+63), like `rf` in the forward kernel
+    auto row_ptr = [&](int r) { return r >= n_local ? rep_l + (int64_t)(r - n_local) * ND : org_l + (int64_t)r * ND; };
+    auto col_ptr = [&](int c) { return c >= n_global ? rep_all + (int64_t)(c - n_global) * ND : org_all + (int64_t)c * ND; };
+    float of[64];
+    {
+        const float* src = ovalid ? (COL ? col_ptr(o) : row_ptr(o)) + 64 * h : nullptr;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const float4 t = ovalid ? *(const float4*)(src + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+            of[4 * v] = t.x; of[4 * v + 1] = t.y; of[4 * v + 2] = t.z; of[4 * v + 3] = t.w;
+        }
+    }
+    // row/column bookkeeping of the owner
+    int o_self = -1, o_pos = -1;       // ROW: column indices self(r), pos(r);  COL: unused
+    float o_lse = 0.f;
+    if (!COL && ovalid) {
+        const bool is_b = o >= n_local; const int gi = rank_offset + (is_b ? o - n_local : o);
+        o_self = is_b ? n_global + gi : gi; o_pos = is_b ? gi : n_global + gi;
+        o_lse = row_lse[o];
+    }
+    f32x16 out[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) out[nb][q] = 0.f;
+
+    const int n_tiles = (n_other + 31) / 32;
+    for (int t = wave; t < n_tiles; t += 4) {
+        const int ti = t * 32 + jl;                          // tile member this lane feeds (A operand)
+        const bool tvalid = ti < n_other;
+        const float* tsrc = tvalid ? (COL ? row_ptr(ti) : col_ptr(ti)) + 64 * h : nullptr;
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const float4 cv = tvalid ? *(const float4*)(tsrc + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cv.x, of[4 * v], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cv.y, of[4 * v + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cv.z, of[4 * v + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cv.w, of[4 * v + 3], acc, 0, 0, 0);
+        }
+        // acc[q] = S^T[i][owner] * tau with i = t*32 + (q&3) + 8(q>>2) + 4h  -> dS in place
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int i = t * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            const float sv = acc[q] / tau;
+            float d = 0.f;
+            if (ovalid && i < n_other) {
+                int r, c; float lse;
+                if (COL) {
+                    r = i; c = o;
+                    const bool is_b = r >= n_local; const int gi = rank_offset + (is_b ? r - n_local : r);
+                    const int self_c = is_b ? n_global + gi : gi, pos_c = is_b ? gi : n_global + gi;
+                    lse = row_lse[r];
+                    if (c != self_c) d = (__expf(sv - lse) - (c == pos_c ? 1.f : 0.f)) * scale;
+                } else {
+                    c = i;
+                    if (c != o_self) d = (__expf(sv - o_lse) - (c == o_pos ? 1.f : 0.f)) * scale;
+                }
+            }
+            acc[q] = d;
+        }
+        // out[owner][feature] += sum_i dS[i][owner] * T[i][feature]
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int i = t * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            const bool iv = i < n_other;
+            const float* trow = iv ? (COL ? row_ptr(i) : col_ptr(i)) : nullptr;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const float tv = iv ? trow[nb * 32 + jl] : 0.f;
+                out[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(tv, acc[q], out[nb], 0, 0, 0);
+            }
+        }
+    }
+    // D2[i' = feature (regs)][j' = owner (lane)]: feature = nb*32 + (q&3) + 8(q>>2) + 4h
+    if (ovalid) {
+        float* dst = part + ((int64_t)wave * n_owner_pad + o) * ND;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(float4*)(dst + nb * 32 + 8 * g + 4 * h) =
+                    make_float4(out[nb][4 * g], out[nb][4 * g + 1], out[nb][4 * g + 2], out[nb][4 * g + 3]);
+    }
+}
+
+// d_all[c] = sum_w partC[w][c] (+ sum_w partR[w][local row of c]); fixed order.
+__global__ void ntxent_bwd_combine_kernel(const float* __restrict__ partC, const float* __restrict__ partR,
+                                          int n_local, int n_global, int rank_offset, int padC, int padR,
+                                          float* __restrict__ d_org_all, float* __restrict__ d_rep_all) {
+    const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;     // float4 index over (2*n_global, 32)
+    const int64_t total = (int64_t)2 * n_global * (ND / 4);
+    if (idx >= total) return;
+    const int c = (int)(idx / (ND / 4)), f4 = (int)(idx % (ND / 4));
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int w = 0; w < 4; ++w) {
+        const float4 t = *(const float4*)(partC + ((int64_t)w * padC + c) * ND + 4 * f4);
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    const bool is_b = c >= n_global; const int gi = is_b ? c - n_global : c;
+    const int li = gi - rank_offset;
+    if (li >= 0 && li < n_local) {
+        const int r = is_b ? n_local + li : li;
+        for (int w = 0; w < 4; ++w) {
+            const float4 t = *(const float4*)(partR + ((int64_t)w * padR + r) * ND + 4 * f4);
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+    }
+    float* dst = (is_b ? d_rep_all : d_org_all) + (int64_t)gi * ND + 4 * f4;
+    *(float4*)dst = s;
+}
+
 __global__ void ntxent_sum_kernel(const float* __restrict__ row_loss, int n, float* __restrict__ out) {
     // single workgroup, fixed order: deterministic
     double acc = 0.0;
@@ -142,9 +283,10 @@ __global__ void ntxent_sum_kernel(const float* __restrict__ row_loss, int n, flo
 using namespace nafp;
 
 extern "C" int64_t nafp_ntxent_workspace_bytes(int64_t n_local, int64_t n_global) {
-    (void)n_global;
-    if (n_local < 0) return -1;
-    return (int64_t)sizeof(float) * 2 * (2 * n_local) + 256;     // row_loss + row_lse
+    if (n_local < 0 || n_global < n_local) return -1;
+    // row_loss + row_lse, then the backward partials: [4][2*n_local padded][128] + [4][2*n_global padded][128]
+    const int64_t padR = (2 * n_local + 31) / 32 * 32, padC = (2 * n_global + 31) / 32 * 32;
+    return (int64_t)sizeof(float) * (2 * (2 * n_local) + 64 + 4 * (padR + padC) * ND) + 256;
 }
 
 extern "C" int nafp_ntxent_forward(const float* emb_org_local, const float* emb_rep_local,
@@ -159,7 +301,7 @@ extern "C" int nafp_ntxent_forward(const float* emb_org_local, const float* emb_
         !(tau > 0.f) || n_global > (1 << 29))
         return NAFP_ERR_INVALID_ARG;
     if (d != ND) return NAFP_ERR_UNSUPPORTED;
-    if (d_org_all || d_rep_all) return NAFP_ERR_UNSUPPORTED;     // backward: not built yet
+    if ((d_org_all == nullptr) != (d_rep_all == nullptr)) return NAFP_ERR_INVALID_ARG;
     if (workspace_bytes < nafp_ntxent_workspace_bytes(n_local, n_global)) return NAFP_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float* row_loss = (float*)workspace;
@@ -171,5 +313,24 @@ extern "C" int nafp_ntxent_forward(const float* emb_org_local, const float* emb_
     NAFP_LAUNCH_CHECK();
     ntxent_sum_kernel<<<1, 256, 0, st>>>(row_loss, n_rows, loss_sum);
     NAFP_LAUNCH_CHECK();
+    if (d_org_all) {
+        const int padR = (n_rows + 31) / 32 * 32, padC = (int)((2 * n_global + 31) / 32 * 32);
+        float* partR = row_lse + 2 * n_local + 64 - ((2 * n_local) % 4 ? 0 : 0);
+        partR = (float*)(((uintptr_t)partR + 15) & ~(uintptr_t)15);
+        float* partC = partR + (int64_t)4 * padR * ND;
+        const float scale = 1.0f / (tau * (float)n_global);
+        ntxent_bwd_kernel<false><<<padR / 32, 256, 0, st>>>(emb_org_local, emb_rep_local, emb_org_all, emb_rep_all,
+                                                           row_lse, (int)n_local, (int)n_global, (int)rank_offset,
+                                                           tau, scale, partR, padR);
+        NAFP_LAUNCH_CHECK();
+        ntxent_bwd_kernel<true><<<padC / 32, 256, 0, st>>>(emb_org_local, emb_rep_local, emb_org_all, emb_rep_all,
+                                                          row_lse, (int)n_local, (int)n_global, (int)rank_offset,
+                                                          tau, scale, partC, padC);
+        NAFP_LAUNCH_CHECK();
+        const int64_t total = (int64_t)2 * n_global * (ND / 4);
+        ntxent_bwd_combine_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
+            partC, partR, (int)n_local, (int)n_global, (int)rank_offset, padC, padR, d_org_all, d_rep_all);
+        NAFP_LAUNCH_CHECK();
+    }
     return NAFP_OK;
 }

@@ -42,9 +42,11 @@ def main():
         out[f'ntxent_loss_n{n}'] = np.array([loss])
         if n == 5:
             out['ntxent_sim_n5'] = sim.astype(np.float32)
-            ga, gb = o_nt.grad_embeddings(a, b, tau=0.05)
-            out['ntxent_grad_a_n5'] = ga
-            out['ntxent_grad_b_n5'] = gb
+    # hard pairs (replica far from its anchor) so that the gradient is not saturated to ~1e-7
+    a, b = _inputs.unit_pairs(5, seed=105, noise=1.5)
+    ga, gb = o_nt.grad_embeddings(a, b, tau=0.05)
+    out['ntxent_grad_a_n5'] = ga
+    out['ntxent_grad_b_n5'] = gb
     path = os.path.join(ROOT, 'tests', 'golden', 'hotpath_v1.npz')
     np.savez_compressed(path, **out)
     print('wrote', path, os.path.getsize(path), 'bytes')

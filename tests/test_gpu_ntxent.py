@@ -60,3 +60,45 @@ def test_ntxent_argument_errors(nafp):
         obj.compute_loss(a, torch.zeros(5, 128, device='cuda'))
     with pytest.raises(nafp._lib.NafpError):
         obj.compute_loss(torch.zeros(4, 128), torch.zeros(4, 128))          # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize('n', [5, 60, 97])
+def test_ntxent_gradient_vs_oracle(nafp, n, golden):
+    # hard pairs (noise 1.5): with the easy pairs of the loss tests the softmax saturates and the
+    # gradient is ~1e-7, i.e. rounding noise
+    a, b = __import__('_inputs').unit_pairs(n, seed=100 + n, noise=1.5)
+    obj = nafp.NTxentLoss(n_org=n, n_rep=n, tau=0.05)
+    loss, da, db = obj.loss_and_grad(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+    wa, wb = o_nt.grad_embeddings(a, b, tau=0.05)
+    scale = max(np.abs(wa).max(), np.abs(wb).max())
+    # fp32 softmax: (p - 1) near saturation carries ~1e-7 absolute error, times 1/tau = 20 -> 1e-6 floor,
+    # plus 2e-4 relative to the largest entry
+    assert np.abs(da.cpu().numpy() - wa).max() < 2e-4 * scale + 1e-6
+    assert np.abs(db.cpu().numpy() - wb).max() < 2e-4 * scale + 1e-6
+    assert abs(float(loss) - o_nt.compute_loss(a, b, 0.05)[0]) < 1e-4
+    if n == 5:
+        assert np.abs(da.cpu().numpy() - golden['ntxent_grad_a_n5']).max() < 2e-4 * scale + 1e-6
+    # the autograd route gives the same numbers
+    ta = torch.from_numpy(a).cuda().requires_grad_(True)
+    tb = torch.from_numpy(b).cuda().requires_grad_(True)
+    l2, _, _ = obj.compute_loss(ta, tb, return_sim=False)
+    l2.backward()
+    assert torch.equal(ta.grad, da) and torch.equal(tb.grad, db)
+
+
+def test_ntxent_sharded_gradients_sum_to_full(nafp):
+    from neural_audio_fp_amd import _lib
+    from neural_audio_fp_amd.model.fp.NTxent_loss_single_gpu import _ntxent_call
+    lib = _lib.load()
+    R, n_a = 3, 24
+    a, b = __import__('_inputs').unit_pairs(R * n_a, seed=5, noise=1.5)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    tot_a, tot_b = torch.zeros_like(ta), torch.zeros_like(tb)
+    for r in range(R):
+        sl = slice(r * n_a, (r + 1) * n_a)
+        _, _, da, db = _ntxent_call(lib, ta[sl].contiguous(), tb[sl].contiguous(), ta, tb, r * n_a, 0.05, False, True)
+        tot_a += da; tot_b += db
+    wa, wb = o_nt.grad_embeddings(a, b, 0.05)
+    scale = max(np.abs(wa).max(), np.abs(wb).max())
+    assert np.abs(tot_a.cpu().numpy() - wa).max() < 2e-4 * scale + 1e-6
+    assert np.abs(tot_b.cpu().numpy() - wb).max() < 2e-4 * scale + 1e-6
