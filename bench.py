@@ -107,6 +107,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--streams', type=int, default=1,
+                    help='streams of the timed region (1: every kernel runs alone, so HIP-event launch '
+                         'durations are the kernels own).  With 1, a second region with 4 streams is '
+                         'timed afterwards and reported as "pipelined".')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -139,8 +143,24 @@ def main():
     def step(i):
         return m_fp(m_pre(pool[i % n_pool], group_size=BSZ))
 
-    for i in range(args.warmup):
-        step(i)
+    # Every step is one complete pass over its own batch.  Consecutive steps are issued
+    # round-robin on `--streams` HIP streams so that the low-occupancy late convs of one batch
+    # overlap the large convs of the next (same pipelining the generate driver uses).
+    n_str = max(1, args.streams)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_str)]
+
+    def step_on(i, ev=None):
+        with torch.cuda.stream(streams[i % n_str]):
+            x = pool[i % n_pool]
+            if ev:
+                ev[2 * i].record()
+            feat = m_pre(x, group_size=BSZ)
+            if ev:
+                ev[2 * i + 1].record()
+            return m_fp(feat)
+
+    for i in range(max(args.warmup, n_str)):
+        step_on(i)
     torch.cuda.synchronize()
     m_fp.profile_enable(args.steps)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * args.steps)]
@@ -149,11 +169,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        x = pool[i % n_pool]
-        ev[2 * i].record()
-        feat = m_pre(x, group_size=BSZ)
-        ev[2 * i + 1].record()
-        emb = m_fp(feat)
+        emb = step_on(i, ev)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -166,6 +182,46 @@ def main():
 
     prof = m_fp.profile_read()
     mel_ms = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(args.steps)) / args.steps
+    # Outside the timed region: the same steps on ONE stream, so that each kernel's duration is
+    # its own (in the pipelined region kernels of different batches share the chip and the
+    # per-launch durations include that sharing).
+    # Same K steps again, pipelined over 4 streams (what the generate driver does): the low-
+    # occupancy late convs of one batch overlap the large convs of the next.  Reported
+    # separately; `value` stays the single-stream figure that `roofline` is consistent with.
+    pipelined = None
+    if n_str == 1:
+        m_fp.profile_enable(0)
+        ps = [torch.cuda.Stream(device=dev) for _ in range(4)]
+
+        def pstep(i):
+            with torch.cuda.stream(ps[i % 4]):
+                return m_fp(m_pre(pool[i % n_pool], group_size=BSZ))
+        for i in range(4):
+            pstep(i)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        tp0 = time.perf_counter()
+        for i in range(args.steps):
+            pstep(i)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        pel = time.perf_counter() - tp0
+        if dist:
+            t = torch.tensor([pel], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            pel = float(t[0])
+        pipelined = {'streams': 4, 'value': round(world * BSZ * args.steps / pel, 1), 'unit': 'segments/s',
+                     'ms_per_step': round(pel / args.steps * 1e3, 4)}
+    iso = None
+    if n_str > 1:
+        m_fp.profile_enable(6)
+        for i in range(6):
+            with torch.cuda.stream(streams[0]):
+                m_fp(m_pre(pool[i % n_pool], group_size=BSZ))
+        torch.cuda.synchronize()
+        iso = m_fp.profile_read()
     if rank == 0:
         macs = conv_effective_macs()
         gemm_flops_per_step = 2.0 * sum(macs[1:]) * BSZ            # the 15 implicit-GEMM launches
@@ -195,13 +251,27 @@ def main():
                 'achieved': round(ach, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_unit': 'bytes/launch',
                 'traffic_source': traffic_src,
-                'flops_per_launch_avg': gemm_flops_per_step / 15, 'ms_per_launch_avg': round(gemm_ms / 15, 5)},
+                'flops_per_launch_avg': gemm_flops_per_step / 15, 'ms_per_launch_avg': round(gemm_ms / 15, 5),
+                'note': 'durations from HIP events recorded by the library on the launch stream inside the '
+                        'timed region' + ('' if n_str == 1 else f'; {n_str} batches are in flight on separate '
+                        'streams there, so launches of different batches share the chip; "isolated" = the same '
+                        'launches alone on one stream (un-timed pass after the region)')},
             'stage_ms_per_step': {'melspec(3 kernels)': round(mel_ms, 4), 'conv0': round(conv0_ms, 4),
                                   'conv_gemm x15': round(gemm_ms, 4), 'tail': round(tail_ms, 4),
                                   'per_conv': [round(sum(p[k] for p in prof) / len(prof), 4) for k in range(17)]},
             'frontend_hbm': {'algorithmic_bytes_per_segment': 32000 + 32768,
                              'GB/s': round(BSZ * (32000 + 32768) / (mel_ms * 1e-3) / 1e9, 2)},
         }
+        out['config']['streams'] = n_str
+        if pipelined:
+            out['pipelined'] = pipelined
+        if iso:
+            iso_ms = sum(sum(p[1:16]) for p in iso) / len(iso)
+            iso_ach = gemm_flops_per_step / (iso_ms * 1e-3) / 1e12
+            out['roofline']['isolated'] = {
+                'achieved': round(iso_ach, 2), 'frac': round(iso_ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                'ms_per_launch_avg': round(iso_ms / 15, 5),
+                'per_conv_ms': [round(sum(p[k] for p in iso) / len(iso), 4) for k in range(17)]}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -67,7 +67,7 @@ class FingerPrinter:
         self._names = tensor_names()
         self._vars = self._init_variables(seed)
         self._dirty = True
-        self._ws = None
+        self._ws = {}          # one workspace per HIP stream: batches may be pipelined across streams
 
     # ---- parameters -------------------------------------------------------
     def _init_variables(self, seed):
@@ -147,9 +147,12 @@ class FingerPrinter:
 
     def _workspace(self, n):
         need = int(self._lib.nafp_encoder_workspace_bytes(self._h, n))
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
-        return self._ws, need
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws, need
 
     def _forward(self, feat, want_flat, want_emb):
         feat = self._prep(feat, self.input_shape)

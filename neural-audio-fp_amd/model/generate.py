@@ -30,6 +30,7 @@ from .fp.melspec.melspectrogram import get_melspec_layer
 from .fp.nnfp import get_fingerprinter
 
 LAUNCH_SEGMENTS = 640       # target segments per launch (whole groups)
+N_STREAMS = 4               # consecutive launches are pipelined round-robin over this many HIP streams
 
 
 def build_fp(cfg):
@@ -114,10 +115,61 @@ def write_fingerprints(source, embed_fn, arr, group, rank=0, world=1, launch_row
     r0, r1 = shard_rows(source.n_samples, group, rank, world)
     k = max(1, -(-LAUNCH_SEGMENTS // group))
     launch_rows = launch_rows or k * group
+    # embed_fn may return the array itself or a handle with .result() (device work still in
+    # flight); up to `depth` launches are kept pending so that host I/O, copies and the kernels
+    # of consecutive launches overlap.
+    pending, depth = [], getattr(embed_fn, 'depth', 1)
+
+    def drain(limit):
+        while len(pending) > limit:
+            st, n, fut = pending.pop(0)
+            arr[st:st + n, :] = fut.result() if hasattr(fut, 'result') else fut
+
     for start, chunk in source.iter_rows(r0, r1, launch_rows):
-        emb = embed_fn(chunk, group)
-        arr[start:start + len(chunk), :] = emb
+        pending.append((start, len(chunk), embed_fn(chunk, group)))
+        drain(depth - 1)
+    drain(0)
     return r0, r1
+
+
+class _Pending:
+    def __init__(self, host, event):
+        self.host, self.event = host, event
+
+    def result(self):
+        self.event.synchronize()
+        return self.host.numpy()
+
+
+class StreamedEmbedder:
+    """m_fp(m_pre(X)) for consecutive launches, round-robin over HIP streams, with pinned
+    staging buffers for the int16 upload and the float32 download (the reference does a
+    synchronous `emb.numpy()` per batch, generate.py:180)."""
+
+    def __init__(self, m_pre, m_fp, n_streams=N_STREAMS):
+        self.m_pre, self.m_fp = m_pre, m_fp
+        self.streams = [torch.cuda.Stream() for _ in range(n_streams)]
+        self.depth = n_streams
+        self.i = 0
+        self.h_in = [None] * n_streams
+        self.h_out = [None] * n_streams
+
+    def __call__(self, chunk_i16, group):
+        k = self.i % len(self.streams)
+        self.i += 1
+        n = chunk_i16.shape[0]
+        if self.h_in[k] is None or self.h_in[k].shape[0] < n:
+            self.h_in[k] = torch.empty((n,) + chunk_i16.shape[1:], dtype=torch.int16).pin_memory()
+            self.h_out[k] = torch.empty((n, self.m_fp.emb_sz), dtype=torch.float32).pin_memory()
+        self.h_in[k][:n].copy_(torch.from_numpy(chunk_i16))
+        with torch.cuda.stream(self.streams[k]):
+            x = self.h_in[k][:n].cuda(non_blocking=True)
+            emb = test_step(x, self.m_pre, self.m_fp, group_size=group)
+            out = self.h_out[k][:n]
+            out.copy_(emb, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        return _Pending(out, ev)
 
 
 def _dist():
@@ -145,9 +197,7 @@ def generate_fingerprint(cfg, checkpoint_name, checkpoint_index, source_root_dir
     if not skip_dummy and rank == 0:
         prevent_overwrite('dummy_db', f'{output_root_dir}/dummy_db.mm')
 
-    def embed(chunk_i16, group):
-        x = torch.from_numpy(chunk_i16).cuda(non_blocking=True)
-        return test_step(x, m_pre, m_fp, group_size=group).cpu().numpy()
+    embed = StreamedEmbedder(m_pre, m_fp)
 
     sz_check = dict()
     for key in ds.keys():
