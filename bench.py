@@ -125,8 +125,16 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        # NAFP_BENCH_BACKEND=gloo + NAFP_BENCH_ONE_GPU=1: exercise this code path with several
+        # ranks on ONE device (RCCL refuses two ranks per GPU); never used by the driver.
+        backend = os.environ.get('NAFP_BENCH_BACKEND', 'nccl')
+        if os.environ.get('NAFP_BENCH_ONE_GPU'):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
         dist.barrier()
     else:
         torch.cuda.set_device(0)
@@ -175,7 +183,7 @@ def main():
         dist.barrier()
     el = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        t = torch.tensor([el], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t[0])
     assert emb.shape == (BSZ, 128) and bool(torch.isfinite(emb).all())
@@ -209,7 +217,7 @@ def main():
             dist.barrier()
         pel = time.perf_counter() - tp0
         if dist:
-            t = torch.tensor([pel], dtype=torch.float64, device=dev)
+            t = torch.tensor([pel], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             pel = float(t[0])
         pipelined = {'streams': 4, 'value': round(world * BSZ * args.steps / pel, 1), 'unit': 'segments/s',

@@ -555,16 +555,25 @@ static int live_k_steps(const ConvGeom& g) {
 }
 
 static int choose_split(int64_t n_tiles, int k_steps, int64_t out_floats) {
+    // Score each split factor S by (how full the last round of workgroups is) x (share of a
+    // workgroup's time spent in its K-loop rather than prologue/epilogue); 768 = 256 CUs x 3
+    // resident workgroups.  Splitting costs a slab round trip, so it must win by a margin.
     static const int force = []() { const char* e = getenv("NAFP_SPLITK"); return e ? atoi(e) : -1; }();
     if (force == 0) return 1;
-    if (n_tiles > 512) return 1;
-    int s = (int)((768 + n_tiles - 1) / n_tiles);
-    if (force > 0) s = force;
-    const int max_by_steps = k_steps / 16 > 1 ? k_steps / 16 : 1;      // >= 16 K-steps per split
-    if (s > max_by_steps) s = max_by_steps;
-    if (s > 16) s = 16;
-    while (s > 1 && (int64_t)s * out_floats * 4 > ((int64_t)64 << 20)) --s;   // slab round trip <= 64 MB
-    return s < 1 ? 1 : s;
+    if (force > 0) return force;
+    if (n_tiles >= 3072) return 1;
+    const double slots = 768.0, overhead_steps = 6.0;
+    int best = 1; double best_score = 0.0;
+    for (int S = 1; S <= 16; ++S) {
+        const double k = (double)k_steps / S;
+        if (S > 1 && (k < 8.0 || (int64_t)S * out_floats * 4 > ((int64_t)64 << 20))) break;
+        const double w = (double)n_tiles * S;
+        const double rounds = (double)((int64_t)((w + slots - 1) / slots));
+        double score = (w / (rounds * slots)) * (k / (k + overhead_steps));
+        if (S > 1) score *= 0.93;                      // slab write + read + finish launch
+        if (score > best_score + 1e-9) { best_score = score; best = S; }
+    }
+    return best;
 }
 
 int64_t conv_gemm_slab_floats(int64_t B, const ConvGeom& g) {
