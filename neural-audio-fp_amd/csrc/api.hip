@@ -89,7 +89,7 @@ extern "C" int nafp_encoder_create(nafp_encoder** out, int in_f, int in_t, int e
     e->geom = encoder_geometry(in_f, in_t);
     const ConvGeom& last = e->geom.back();
     e->flat_dim = (int64_t)last.Fout * last.Tout * last.Cout;
-    if (e->flat_dim % emb_sz != 0 || emb_sz % 64 != 0 || emb_sz > 1024 || e->flat_dim / emb_sz > 16) {
+    if (e->flat_dim % emb_sz != 0 || emb_sz % 64 != 0 || emb_sz > 256 || e->flat_dim / emb_sz > 16) {
         delete e; return NAFP_ERR_UNSUPPORTED;
     }
     e->S = (int)(e->flat_dim / emb_sz);

@@ -4,64 +4,113 @@
 // Replaces, in the reference: the last LayerNormalization + Flatten of front_conv
 // (model/fp/nnfp.py:66-67, 218), DivEncLayer (nnfp.py:131-156; the BN list built at
 // :119-122 is never applied, :136 is commented out) and tf.math.l2_normalize
-// (nnfp.py:229).  In TF this is 256 tiny matmuls + a concat; here one workgroup of
-// Q threads handles one segment, thread q owning slice q.  Slice weights are
-// re-laid out (S,32,Q)/(32,Q) at set_weights time so that thread q's reads coalesce.
+// (nnfp.py:229).  In TF this is 256 tiny matmuls + a concat.
+//
+// A workgroup is 2*Q threads: thread (q, half) owns 16 of the 32 hidden units of slice q
+// and keeps their weights in registers (S*16 + 32 floats), then loops over segments
+// (grid-stride).  Slice weights are re-laid out (S,32,Q)/(32,Q) at set_weights time so
+// that the one-time register fill coalesces.  Per segment: S inputs per thread (LayerNorm
+// folded: the last conv stored z = gamma . v, so xhat = r*z + c*gamma + beta), 16 hidden
+// units, the halves meet in LDS, then the L2 norm over the Q outputs.
 #include "nafp_common.h"
+
+#include <algorithm>
 
 namespace nafp {
 
 constexpr int MAX_S = 16;
+constexpr int HALF_H = 16;
 
-__global__ __launch_bounds__(1024) void tail_kernel(const TailArgs a) {
-    const int q = threadIdx.x, Q = a.Q, S = a.S;
-    const int64_t b = blockIdx.x;
-    float lnA = 1.f, lnC = 0.f;
-    if (a.stats) {
-        const double mean = a.stats[2 * b] / (double)a.D;
-        double var = a.stats[2 * b + 1] / (double)a.D - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
-        lnA = (float)rstd; lnC = (float)(-mean * rstd);
-    }
-    float x[MAX_S];
+template <int S>
+__global__ __launch_bounds__(512) void tail_kernel(const TailArgs a, int64_t B) {   // 2*Q <= 512 threads: 256 VGPRs each
+    const int Q = a.Q;
+    const int tid = threadIdx.x;
+    const int q = tid % Q, half = tid / Q;            // blockDim.x == 2*Q
+    extern __shared__ float sm[];                       // [Q] half-1 partials, then [16] reduction scratch
+    float* s_part = sm;
+    float* s_red = sm + Q;
+
+    float w1[S][HALF_H], b1[HALF_H], w2[HALF_H];
 #pragma unroll
-    for (int i = 0; i < MAX_S; ++i) {
-        if (i < S) {
-            const int d = q * S + i;                      // tf.reshape (B,D)->(B,Q,S): nnfp.py:155
-            float v = a.x[b * a.D + d];
-            if (a.stats) v = fmaf(lnA, v, fmaf(lnC, a.gamma[d], a.beta[d]));   // v holds gamma . ELU(.)
-            x[i] = v;
-            if (a.out_flat) a.out_flat[b * a.D + d] = v;
-        } else {
-            x[i] = 0.f;
+    for (int j = 0; j < HALF_H; ++j) {
+        const int jj = half * HALF_H + j;
+        b1[j] = a.b1p[jj * Q + q];
+        w2[j] = a.w2p[jj * Q + q];
+#pragma unroll
+        for (int i = 0; i < S; ++i) w1[i][j] = a.w1p[(i * 32 + jj) * Q + q];
+    }
+    const float b2 = a.b2[q];
+    float gam[S], bet[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        gam[i] = a.stats ? a.gamma[q * S + i] : 0.f;
+        bet[i] = a.stats ? a.beta[q * S + i] : 0.f;
+    }
+
+    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+        float lnA = 1.f, lnC = 0.f;
+        if (a.stats) {
+            const double mean = a.stats[2 * b] / (double)a.D;
+            double var = a.stats[2 * b + 1] / (double)a.D - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
+            lnA = (float)rstd; lnC = (float)(-mean * rstd);
         }
-    }
-    if (!a.out_emb) return;
-    float y = a.b2[q];
-    for (int j = 0; j < 32; ++j) {
-        float h = a.b1p[j * Q + q];
+        float x[S];
 #pragma unroll
-        for (int i = 0; i < MAX_S; ++i)
-            if (i < S) h = fmaf(x[i], a.w1p[(i * 32 + j) * Q + q], h);
-        y = fmaf(elu1(h), a.w2p[j * Q + q], y);           // Dense(32, elu) -> Dense(1): nnfp.py:135-137
-    }
-    if (a.l2norm) {
-        __shared__ float red[16];
-        const float ss = wave_sum(y * y);
-        if ((q & 63) == 0) red[q >> 6] = ss;
+        for (int i = 0; i < S; ++i) {
+            const int d = q * S + i;                    // tf.reshape (B,D)->(B,Q,S): nnfp.py:155
+            float v = a.x[b * a.D + d];
+            if (a.stats) v = fmaf(lnA, v, fmaf(lnC, gam[i], bet[i]));   // v held gamma . ELU(.)
+            x[i] = v;
+            if (a.out_flat && half == 0) a.out_flat[b * a.D + d] = v;
+        }
+        if (!a.out_emb) continue;
+        float y = 0.f;
+#pragma unroll
+        for (int j = 0; j < HALF_H; ++j) {
+            float h = b1[j];
+#pragma unroll
+            for (int i = 0; i < S; ++i) h = fmaf(x[i], w1[i][j], h);
+            y = fmaf(elu1(h), w2[j], y);                // Dense(32, elu) -> Dense(1): nnfp.py:135-137
+        }
+        __syncthreads();                                // previous segment's readers are done with s_part/s_red
+        if (half == 1) s_part[q] = y;
         __syncthreads();
-        float tot = 0.f;
-        for (int w = 0; w < (Q + 63) / 64; ++w) tot += red[w];
-        y = y * rsqrtf(fmaxf(tot, 1e-12f));               // tf.math.l2_normalize: nnfp.py:229
+        if (half == 0) {
+            y = y + s_part[q] + b2;
+            if (a.l2norm) {
+                const float ss = wave_sum(y * y);
+                if ((q & 63) == 0) s_red[q >> 6] = ss;
+            }
+        }
+        if (a.l2norm) {
+            __syncthreads();
+            if (half == 0) {
+                float tot = 0.f;
+                for (int w = 0; w < (Q + 63) / 64; ++w) tot += s_red[w];
+                y = y * rsqrtf(fmaxf(tot, 1e-12f));     // tf.math.l2_normalize: nnfp.py:229
+            }
+        }
+        if (half == 0) a.out_emb[b * Q + q] = y;
     }
-    a.out_emb[b * Q + q] = y;
 }
 
 int launch_tail(const TailArgs& a, int64_t B, hipStream_t st) {
-    if (a.Q % 64 != 0 || a.Q > 1024 || a.S > MAX_S || a.S * a.Q != a.D) return NAFP_ERR_UNSUPPORTED;
+    if (a.Q % 64 != 0 || a.Q > 256 || a.S > MAX_S || a.S * a.Q != a.D) return NAFP_ERR_UNSUPPORTED;
     if (B == 0) return NAFP_OK;
-    tail_kernel<<<dim3((unsigned)B), a.Q, 0, st>>>(a);
+    // enough workgroups to cover the CUs, few enough that the register fill (S*16+32 floats
+    // per thread, from L2) is amortised over several segments
+    const int grid = (int)std::min<int64_t>(B, 128);
+    const size_t lds = (size_t)(a.Q + 16) * sizeof(float);
+    switch (a.S) {
+        case 8: tail_kernel<8><<<grid, 2 * a.Q, lds, st>>>(a, B); break;
+        case 16: tail_kernel<16><<<grid, 2 * a.Q, lds, st>>>(a, B); break;
+        case 4: tail_kernel<4><<<grid, 2 * a.Q, lds, st>>>(a, B); break;
+        case 2: tail_kernel<2><<<grid, 2 * a.Q, lds, st>>>(a, B); break;
+        case 1: tail_kernel<1><<<grid, 2 * a.Q, lds, st>>>(a, B); break;
+        default: return NAFP_ERR_UNSUPPORTED;
+    }
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }
