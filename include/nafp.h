@@ -132,6 +132,13 @@ int nafp_encoder_profile_enable(nafp_encoder* enc, int max_forwards);
 int nafp_encoder_profile_count(const nafp_encoder* enc);   /* forwards recorded so far */
 int nafp_encoder_profile_read(nafp_encoder* enc, int slot, float* ms_out_host);
 
+/* Execution options of an encoder handle (results are identical either way).
+ *   NAFP_OPT_FUSE_CONV0  0 (default): b0.conv1x3 writes its activation, b0.conv3x1 reads it back.
+ *                        1: only conv0's LayerNorm statistics are computed up front and conv1
+ *                           re-generates its input tiles in-kernel from the log-mel features. */
+#define NAFP_OPT_FUSE_CONV0 1
+int nafp_encoder_set_option(nafp_encoder* enc, int option, int value);
+
 /* m_fp.div_enc(x) alone (nnfp.py:141-156; called separately at trainer.py:73-76). */
 int nafp_encoder_div_enc(nafp_encoder* enc, const float* flat, int64_t n_seg,
                          float* out_emb, int l2norm, void* stream);

@@ -39,6 +39,8 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // ============================================================================
 constexpr int ROWS0 = 4;
 
+// STORE = false: statistics only (the activation is re-generated inside conv1, see FUSE0).
+template <bool STORE, int ROWS0>
 __global__ __launch_bounds__(256) void conv0_kernel(
         const float* __restrict__ feat, const float* __restrict__ w3, const float* __restrict__ bias,
         const float* __restrict__ gamma, float* __restrict__ y, double* __restrict__ stats,
@@ -57,8 +59,8 @@ __global__ __launch_bounds__(256) void conv0_kernel(
     const int rows = min(ROWS0, F - f0);
     const int npos = rows * Tout;
     const float* xin = feat + (b * F + f0) * (int64_t)Tin;
-    float* yout = y + ((b * F + f0) * (int64_t)Tout) * Cout;
-    const float* gin = gamma + ((int64_t)f0 * Tout) * Cout;
+    float* yout = STORE ? y + ((b * F + f0) * (int64_t)Tout) * Cout : nullptr;
+    const float* gin = STORE ? gamma + ((int64_t)f0 * Tout) * Cout : nullptr;
     float s = 0.f, q = 0.f;
     for (int p = pslot; p < npos; p += pos_per_iter) {
         const int r = p / Tout, to = p % Tout;
@@ -67,7 +69,8 @@ __global__ __launch_bounds__(256) void conv0_kernel(
         const float x0 = (t0 >= 0 && t0 < Tin) ? xr[t0] : 0.f;
         const float x1 = (t0 + 1 >= 0 && t0 + 1 < Tin) ? xr[t0 + 1] : 0.f;
         const float x2 = (t0 + 2 >= 0 && t0 + 2 < Tin) ? xr[t0 + 2] : 0.f;
-        const float4 g = *(const float4*)(gin + (int64_t)p * Cout + 4 * cg);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (STORE) g = *(const float4*)(gin + (int64_t)p * Cout + 4 * cg);
         float4 v;
         v.x = elu1(fmaf(x2, w2.x, fmaf(x1, w1.x, fmaf(x0, w0.x, bb.x))));
         v.y = elu1(fmaf(x2, w2.y, fmaf(x1, w1.y, fmaf(x0, w0.y, bb.y))));
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(
         v.w = elu1(fmaf(x2, w2.w, fmaf(x1, w1.w, fmaf(x0, w0.w, bb.w))));
         s += (v.x + v.y) + (v.z + v.w);
         q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-        *(float4*)(yout + (int64_t)p * Cout + 4 * cg) = make_float4(v.x * g.x, v.y * g.y, v.z * g.z, v.w * g.w);
+        if (STORE) *(float4*)(yout + (int64_t)p * Cout + 4 * cg) = make_float4(v.x * g.x, v.y * g.y, v.z * g.z, v.w * g.w);
     }
     double ds = wave_sum((double)s), dq = wave_sum((double)q);
     __shared__ double red[8];
@@ -91,8 +94,19 @@ int launch_conv0(const float* feat, const float* w3, const float* bias, const fl
                  double* stats, int64_t B, const ConvGeom& g, hipStream_t st) {
     if (g.Cin != 1 || g.axis != 0 || (g.Cout % 4) != 0 || 256 % (g.Cout / 4) != 0) return NAFP_ERR_UNSUPPORTED;
     const int64_t blocks = B * ((g.Fin + ROWS0 - 1) / ROWS0);
-    conv0_kernel<<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, gamma, y, stats, g.Fin, g.Tin,
-                                                         g.Tout, g.Cout, g.stride, g.pad);
+    conv0_kernel<true, ROWS0><<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, gamma, y, stats, g.Fin, g.Tin,
+                                                                      g.Tout, g.Cout, g.stride, g.pad);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}
+
+int launch_conv0_stats(const float* feat, const float* w3, const float* bias, double* stats, int64_t B,
+                       const ConvGeom& g, hipStream_t st) {
+    if (g.Cin != 1 || g.axis != 0 || (g.Cout % 4) != 0 || 256 % (g.Cout / 4) != 0) return NAFP_ERR_UNSUPPORTED;
+    constexpr int R = 32;
+    const int64_t blocks = B * ((g.Fin + R - 1) / R);
+    conv0_kernel<false, R><<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, nullptr, nullptr, stats, g.Fin,
+                                                                   g.Tin, g.Tout, g.Cout, g.stride, g.pad);
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }
@@ -149,6 +163,13 @@ struct ConvKernelParams {
     unsigned wp_bytes;
     int n_split;              // split-K factor (blockIdx.z); > 1 writes raw partial sums to `y` = slab
     int abl;                  // ablation flags for kernel-time breakdown (NAFP_ABL env; 0 in production)
+    // FUSE0 (conv1 only): the A operand z0 = gamma0 . ELU(conv0(feat)) is generated in-kernel
+    // from the log-mel features instead of being read from memory (`x` unused).
+    const float* f0_feat;     // (B, F0, T0)
+    const float* f0_w;        // (3, Cin)   conv0 kernel (Cin of this conv = Cout of conv0)
+    const float* f0_bias;     // (Cin)
+    const float* f0_gamma;    // (F0, Tin, Cin) = LN scale of conv0 = layout of z0
+    int f0_T, f0_stride, f0_pad;   // conv0: input frames, stride and pad-before along T
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -177,17 +198,19 @@ __device__ __forceinline__ void lds_dma16(unsigned lds_addr, unsigned voff, u32x
                  : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 
-template <int BK, int NSTAGE>
+template <int BK, int NSTAGE, bool FUSE0>
 __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
+    static_assert(!FUSE0 || BK == 16, "the in-kernel conv0 generator is written for BK = 16");
     constexpr int CH = BK / 4;                     // 16-B chunks per row
     constexpr int RPI = 64 / CH;                   // rows covered by one DMA wave-instruction
     constexpr int NI = 32 / RPI;                   // DMA instructions per wave per operand per step
     constexpr int TILE = BM * BK;                  // floats per operand tile
     constexpr int STAGE = 2 * TILE;                // A | B
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // [stage 0: A | B] ... [stage NSTAGE-1] [sRB[128]] [sCB[128]]
+    // [stage 0: A | B] ... [stage NSTAGE-1] [sRB[128]] [sCB[128]] [FUSE0: conv0 w (3,Cin) | bias (Cin)]
     float* sRB = smem + NSTAGE * STAGE;
     float* sCB = sRB + BM;
+    float* sW0 = sCB + BM;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -240,6 +263,40 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         }
         voffB[q] = (unsigned)((tile_n0 + lr) * K + lc * 4) * 4u;
     }
+    // ---- FUSE0 generator geometry: thread t builds row t>>1, channels 8*(t&1)..+8 of every
+    // K-step of the A tile: z0[b, f, t, c] = gamma0[f,t,c] * ELU(bias0[c] + sum_k w0[k,c] feat[b, f, t*s0 - p0 + k])
+    float x0[3][3];            // [conv1 tap (along F)][conv0 tap (along T)] log-mel inputs of my row
+    unsigned g_valid = 0;      // bit t: the z0 row of conv1 tap t exists (else conv1 zero padding)
+    int g_off = 0;             // offset of conv1 tap 0, channel 0 inside z0 / gamma0
+    const int g_row = tid >> 1, g_ch = (tid & 1) * 8;
+    const int g_swz = (g_row >> 2) & 3;
+    if (FUSE0) {
+        for (int i = tid; i < 4 * p.Cin; i += 256) sW0[i] = i < 3 * p.Cin ? p.f0_w[i] : p.f0_bias[i - 3 * p.Cin];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { x0[t][0] = 0.f; x0[t][1] = 0.f; x0[t][2] = 0.f; }
+        const int pos = pb * p.PT + (g_row >> p.log2ST);
+        const int sl = g_row & ST1;
+        if (pos < p.P && sl < nb) {
+            const int fo = pos / p.Tout, to = pos - fo * p.Tout;
+            const int f00 = fo * p.stride - p.pad;           // this conv's taps run along F (axis 1)
+            g_off = (f00 * p.Tin + to) * p.Cin;
+            const int t00 = to * p.f0_stride - p.f0_pad;      // conv0's taps run along T
+            const float* fb = p.f0_feat + ((int64_t)(b0 + sl) * p.Fin) * p.f0_T;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int f = f00 + t;
+                if (f >= 0 && f < p.Fin) {
+                    g_valid |= 1u << t;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int tt = t00 + k;
+                        x0[t][k] = (tt >= 0 && tt < p.f0_T) ? fb[(int64_t)f * p.f0_T + tt] : 0.f;
+                    }
+                }
+            }
+        }
+        __syncthreads();       // sW0 is read by the generator below
+    }
     // Taps that read only zero padding for EVERY row of this tile are skipped.  Each wave
     // derives the tile-wide mask on its own (lane l inspects rows l and l+64, then a
     // wave-wide OR), so no LDS traffic and no barrier is needed in the prologue.
@@ -288,10 +345,39 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         const unsigned tapb_l = (unsigned)(tap_l * p.tap_stride) * 4u;                         \
         _Pragma("unroll") for (int q = 0; q < NI; ++q) {                                       \
             const unsigned va = ((vmaskA[q] >> tap_l) & 1u) ? voffA[q] + tapb_l : OOB;         \
-            lds_dma16(la_l + q * RPI * BK * 4, va, rsA, (unsigned)(c0_l * 4));                 \
+            if (!FUSE0) lds_dma16(la_l + q * RPI * BK * 4, va, rsA, (unsigned)(c0_l * 4));     \
             lds_dma16(la_l + (TILE + q * RPI * BK) * 4, voffB[q], rsB,                          \
                       (unsigned)((tap_l * p.Cin + c0_l) * 4));                                 \
         }                                                                                      \
+    }
+    // FUSE0: gamma0 of my 8 channels of K-step s_ (issued early), then build + store the A rows.
+    float4 gg0 = make_float4(0.f, 0.f, 0.f, 0.f), gg1 = gg0;
+#define NAFP_GEN_LOAD(s_)                                                                     \
+    {                                                                                          \
+        const int tsel_l = (s_) / cpt;                                                         \
+        const int tap_l = (int)((tap_pack >> (2 * tsel_l)) & 3u);                              \
+        const int c0_l = ((s_) - tsel_l * cpt) * BK;                                           \
+        const int go_l = ((g_valid >> tap_l) & 1u) ? g_off + tap_l * p.tap_stride + c0_l + g_ch : 0; \
+        gg0 = *(const float4*)(p.f0_gamma + go_l);                                             \
+        gg1 = *(const float4*)(p.f0_gamma + go_l + 4);                                         \
+    }
+#define NAFP_GEN_ONE(j_, G_) \
+    ((ok_l ? elu1(fmaf(xc_l, wt_l[2 * p.Cin + (j_)], fmaf(xb_l, wt_l[p.Cin + (j_)], fmaf(xa_l, wt_l[(j_)], wt_l[3 * p.Cin + (j_)])))) : 0.f) * (G_))
+#define NAFP_GEN_STORE(s_, slot_)                                                             \
+    {                                                                                          \
+        const int tsel_l = (s_) / cpt;                                                         \
+        const int tap_l = (int)((tap_pack >> (2 * tsel_l)) & 3u);                              \
+        const int c0_l = ((s_) - tsel_l * cpt) * BK;                                           \
+        const bool ok_l = (g_valid >> tap_l) & 1u;                                             \
+        const float xa_l = tap_l == 0 ? x0[0][0] : (tap_l == 1 ? x0[1][0] : x0[2][0]);         \
+        const float xb_l = tap_l == 0 ? x0[0][1] : (tap_l == 1 ? x0[1][1] : x0[2][1]);         \
+        const float xc_l = tap_l == 0 ? x0[0][2] : (tap_l == 1 ? x0[1][2] : x0[2][2]);         \
+        const float* wt_l = sW0 + c0_l + g_ch;                                                 \
+        float* dst_l = smem + (slot_) * STAGE + g_row * BK;                                    \
+        *(float4*)(dst_l + (((2 * (tid & 1)) ^ g_swz) * 4)) = make_float4(                      \
+            NAFP_GEN_ONE(0, gg0.x), NAFP_GEN_ONE(1, gg0.y), NAFP_GEN_ONE(2, gg0.z), NAFP_GEN_ONE(3, gg0.w)); \
+        *(float4*)(dst_l + (((2 * (tid & 1) + 1) ^ g_swz) * 4)) = make_float4(                  \
+            NAFP_GEN_ONE(4, gg1.x), NAFP_GEN_ONE(5, gg1.y), NAFP_GEN_ONE(6, gg1.z), NAFP_GEN_ONE(7, gg1.w)); \
     }
 
     f32x16 acc[2][2];
@@ -304,7 +390,13 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
 
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
-        if (s_begin + s < n_steps) NAFP_DMA_STEP(s_begin + s, s)
+        if (s_begin + s < n_steps) {
+            NAFP_DMA_STEP(s_begin + s, s)
+            if (FUSE0) {
+                NAFP_GEN_LOAD(s_begin + s)
+                NAFP_GEN_STORE(s_begin + s, s)
+            }
+        }
 
     // operand read addresses (floats): row*BK + ((lc ^ swz(row)) * 4), lc = 2*kk + (lane>>5)
     const int rl = lane & 31, hh = lane >> 5;
@@ -314,12 +406,17 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     for (int s = s_begin; s < n_steps; ++s) {
         // my DMA of step s has landed; after the barrier everybody's has, and everybody has
         // finished reading slot (s-1) % NSTAGE, which the next DMA overwrites.
-        if (NSTAGE == 2 || s + NSTAGE - 2 >= n_steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (FUSE0: the A rows are ds_writes of this wave -> also drain lgkmcnt; the compiler's own
+        // wait for the gamma0 loads has already retired every older DMA.)
+        if (FUSE0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if (NSTAGE == 2 || s + NSTAGE - 2 >= n_steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" :: "i"((NSTAGE - 2) * 2 * NI) : "memory");
         __builtin_amdgcn_s_barrier();
-        if (s + NSTAGE - 1 < n_steps && !(p.abl & 1)) {
-            int nslot = slot + NSTAGE - 1; if (nslot >= NSTAGE) nslot -= NSTAGE;
+        const bool has_next = s + NSTAGE - 1 < n_steps && !(p.abl & 1);
+        int nslot = slot + NSTAGE - 1; if (nslot >= NSTAGE) nslot -= NSTAGE;
+        if (has_next) {
             NAFP_DMA_STEP(s + NSTAGE - 1, nslot)
+            if (FUSE0) NAFP_GEN_LOAD(s + NSTAGE - 1)
         }
         const float* St = smem + slot * STAGE;
         if (p.abl & 4) { if (++slot == NSTAGE) slot = 0; continue; }
@@ -341,6 +438,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, b[ni].w, acc[mi][ni], 0, 0, 0);
                 }
         }
+        if (FUSE0 && has_next) NAFP_GEN_STORE(s + NSTAGE - 1, nslot)
         if (++slot == NSTAGE) slot = 0;
     }
     __syncthreads();          // all waves are done with the operand tiles: LDS is reused below
@@ -475,19 +573,20 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
 }
 
 // One __global__ per staging variant (launch bounds are not template-dependent).
-#define NAFP_GEMM_KERNEL(name_, BK_, NSTAGE_, MINW_)                                        \
+#define NAFP_GEMM_KERNEL(name_, BK_, NSTAGE_, MINW_, FUSE0_)                                \
     __global__ __launch_bounds__(256, MINW_) void name_(const ConvKernelParams p) {          \
-        conv_gemm_body<BK_, NSTAGE_>(p);                                                     \
+        conv_gemm_body<BK_, NSTAGE_, FUSE0_>(p);                                             \
     }
-NAFP_GEMM_KERNEL(conv_gemm_k32s2, 32, 2, 2)
-NAFP_GEMM_KERNEL(conv_gemm_k16s2, 16, 2, 4)
-NAFP_GEMM_KERNEL(conv_gemm_k16s3, 16, 3, 3)
-NAFP_GEMM_KERNEL(conv_gemm_k16s4, 16, 4, 2)
-NAFP_GEMM_KERNEL(conv_gemm_k32s3, 32, 3, 1)
+NAFP_GEMM_KERNEL(conv_gemm_k32s2, 32, 2, 2, false)
+NAFP_GEMM_KERNEL(conv_gemm_k16s2, 16, 2, 4, false)
+NAFP_GEMM_KERNEL(conv_gemm_k16s3, 16, 3, 3, false)
+NAFP_GEMM_KERNEL(conv_gemm_k16s4, 16, 4, 2, false)
+NAFP_GEMM_KERNEL(conv_gemm_k32s3, 32, 3, 1, false)
+NAFP_GEMM_KERNEL(conv_gemm_k16s3_fuse0, 16, 3, 3, true)    // conv1 with conv0 generated in-kernel
 
 template <typename KernelT>
 static int launch_variant(KernelT kernel, int BK, int NSTAGE, const ConvKernelParams& p, dim3 grid, hipStream_t st) {
-    const int lds = (NSTAGE * 2 * BM * BK + 2 * BM) * (int)sizeof(float);
+    const int lds = (NSTAGE * 2 * BM * BK + 2 * BM + (p.f0_feat ? 4 * p.Cin : 0)) * (int)sizeof(float);
     NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     kernel<<<grid, 256, lds, st>>>(p);
     NAFP_LAUNCH_CHECK();
@@ -615,7 +714,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     const int n_pb = (p.P + p.PT - 1) / p.PT;
     const int64_t n_tiles = (int64_t)p.n_sg * n_pb * (g.Cout / BN);
     int S = 1;
-    if (!a.plain && a.slab) {
+    if (!a.plain && a.slab && !a.f0_feat) {
         S = choose_split(n_tiles, live_k_steps(g), B * p.P * g.Cout);
         if ((int64_t)S * B * p.P * g.Cout > a.slab_floats) S = 1;
     }
@@ -623,6 +722,17 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     const dim3 grid((unsigned)((int64_t)p.n_sg * n_pb), (unsigned)(g.Cout / BN), (unsigned)S);
     static const int variant = []() { const char* e = getenv("NAFP_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
     int rc;
+    p.f0_feat = nullptr; p.f0_w = nullptr; p.f0_bias = nullptr; p.f0_gamma = nullptr;
+    p.f0_T = 0; p.f0_stride = 1; p.f0_pad = 0;
+    if (a.f0_feat) {
+        // conv0 generated in-kernel: this conv must be the 3x1 conv that consumes conv0's output
+        if (a.plain || S != 1 || !a.f0_geom || g.axis != 1 || a.f0_geom->Cout != g.Cin || a.f0_geom->Tout != g.Tin ||
+            a.f0_geom->Fin != g.Fin || g.Cin % 16 != 0)
+            return NAFP_ERR_UNSUPPORTED;
+        p.f0_feat = a.f0_feat; p.f0_w = a.f0_w; p.f0_bias = a.f0_bias; p.f0_gamma = a.f0_gamma;
+        p.f0_T = a.f0_geom->Tin; p.f0_stride = a.f0_geom->stride; p.f0_pad = a.f0_geom->pad;
+        return launch_variant(conv_gemm_k16s3_fuse0, 16, 3, p, grid, st);
+    }
     switch (variant) {
         case 1: rc = launch_variant(conv_gemm_k32s2, 32, 2, p, grid, st); break;
         case 2: rc = launch_variant(conv_gemm_k16s2, 16, 2, p, grid, st); break;

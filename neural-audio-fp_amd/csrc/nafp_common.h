@@ -103,7 +103,14 @@ struct ConvGemmArgs {
     bool plain;
     float* slab;             // split-K partial sums workspace (or nullptr: never split)
     int64_t slab_floats;
+    // optional: generate the A operand from the log-mel features (conv0 fused into conv1);
+    // `x` is then unused.  f0_geom = geometry of conv0.
+    const float* f0_feat; const float* f0_w; const float* f0_bias; const float* f0_gamma;
+    const ConvGeom* f0_geom;
 };
+// statistics (sum, sum of squares of ELU(conv0 + bias) per sample) without storing the activation
+int launch_conv0_stats(const float* feat, const float* w3, const float* bias, double* stats, int64_t B,
+                       const ConvGeom& g, hipStream_t st);
 int64_t conv_gemm_slab_floats(int64_t B, const ConvGeom& g);   // workspace the split-K policy wants
 int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStream_t st);
 

@@ -168,6 +168,10 @@ class FingerPrinter:
                        'encoder_forward')
         return flat, emb
 
+    def set_option(self, option, value):
+        """Execution options of the library handle (include/nafp.h NAFP_OPT_*); results do not change."""
+        _lib.check(self._lib.nafp_encoder_set_option(self._h, int(option), int(value)), 'encoder_set_option')
+
     # ---- per-kernel HIP-event timing (bench.py roofline leg) ----------------
     def profile_enable(self, max_forwards):
         with torch.cuda.device(self.device):

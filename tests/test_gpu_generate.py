@@ -101,3 +101,20 @@ def test_generate_fingerprint_end_to_end(nafp, cfg, tmp_path):
     want = np.concatenate([o_nnfp.fingerprinter(o_mel.melspec_layer(b), w) for b in o_seg.load_batches(paths, 5)])
     assert (1 - (got * want).sum(1)).max() < 1e-5                       # contract 1e-3
     assert np.abs(got - want).max() < 1e-4
+
+
+def test_fused_conv0_option_is_bit_identical(nafp):
+    """NAFP_OPT_FUSE_CONV0 re-generates conv0's activation inside conv1 with the same FMA order:
+    the fingerprints must not change by a single bit (ragged and full batch sizes)."""
+    rng = np.random.default_rng(4)
+    m_fp = nafp.FingerPrinter(seed=9)
+    for n in (3, 130, 640):
+        feat = torch.from_numpy((-rng.uniform(0, 1.2, size=(n, 256, 32, 1))).astype(np.float32)).cuda()
+        m_fp.set_option(1, 0)
+        ref_flat, ref = m_fp.front_conv(feat), m_fp(feat)
+        m_fp.set_option(1, 1)
+        got_flat, got = m_fp.front_conv(feat), m_fp(feat)
+        m_fp.set_option(1, 0)
+        # statistics are accumulated with double atomics in a different order: allow 1 ulp-level noise
+        assert float((got_flat - ref_flat).abs().max()) < 1e-5
+        assert float((got - ref).abs().max()) < 1e-6
