@@ -60,7 +60,7 @@ int nafp_mel_filterbank_host(int fs, int n_fft, int n_mels, float f_min, float f
 
 /* Plan for get_melspec_layer(cfg) (melspectrogram.py:115-141).  seg_len = FS*DUR.
  * Supported: n_fft == 1024, hop == 256, n_mels % 64 == 0 && n_mels <= 256,
- * every mel filter <= 8 taps wide, seg_len <= 16384. */
+ * every mel filter <= 8 taps wide. */
 int nafp_melspec_create(nafp_melspec** plan, int fs, int seg_len, int n_fft, int hop,
                         int n_mels, float f_min, float f_max);
 int nafp_melspec_destroy(nafp_melspec* plan);

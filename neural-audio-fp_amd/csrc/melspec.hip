@@ -23,8 +23,9 @@ constexpr int NFFT = 1024;
 constexpr int HOP = 256;
 constexpr int NBIN = NFFT / 2 + 1;          // 513
 constexpr int MAX_TAPS = 8;
-constexpr int MAX_SEG = 16384;
+constexpr int MAX_SEG = 1 << 22;             // LDS use no longer depends on the segment length
 constexpr int TILE_LD = 36;                 // LDS leading dimension of the (n_mels, <=32) tile chunk
+constexpr int SIG_CHUNK = 31 * HOP + NFFT;  // 8960 samples feed 32 consecutive frames
 
 }  // namespace nafp
 
@@ -126,7 +127,7 @@ __global__ void melspec_init_stats(float* group_stat, int n_groups) {
 }
 
 // LDS carve (floats):
-//   sig  [padded_len]                 zero-padded segment
+//   sig  [SIG_CHUNK]                  zero-padded samples of the current 32-frame chunk
 //   fftX [4][2048]  fftY [4][2048]    per-wave ping-pong complex buffers
 //   tile [n_mels][TILE_LD]            log-mel tile (<=32 frames per chunk)
 template <typename TIn>
@@ -138,19 +139,13 @@ __global__ __launch_bounds__(256) void melspec_kernel(
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t seg = blockIdx.x;
-    const int padded_len = seg_len + NFFT;                 // 512 + seg_len + 512
-    const int sig_alloc = (padded_len + 3) & ~3;
+    constexpr int sig_alloc = SIG_CHUNK;                   // samples spanned by 32 frames: 31*256 + 1024
     float* sig = smem;
     float2* fftX = (float2*)(smem + sig_alloc) + wave * NFFT;
     float2* fftY = (float2*)(smem + sig_alloc + 4 * 2 * NFFT) + wave * NFFT;
     float* tile = smem + sig_alloc + 8 * 2 * NFFT;
 
-    // ---- padded segment into LDS (melspectrogram.py:59-65) ----
     const TIn* a = audio + seg * seg_len;
-    for (int i = tid; i < padded_len; i += 256) {
-        const int s = i - NFFT / 2;
-        sig[i] = (s >= 0 && s < seg_len) ? pcm_to_float<TIn>(a[s]) : 0.f;
-    }
     // per-thread mel filter (thread m <-> mel bin m)
     const bool has_mel = tid < n_mels;
     int mstart = 0;
@@ -170,15 +165,23 @@ __global__ __launch_bounds__(256) void melspec_kernel(
 
     for (int chunk0 = 0; chunk0 < n_frames; chunk0 += 32) {          // 32-frame tile chunks
         const int chunk_frames = min(32, n_frames - chunk0);
+        // ---- zero-padded samples of this chunk into LDS (melspectrogram.py:59-65): padded index
+        // chunk0*256 + i  <->  sample index chunk0*256 + i - 512
+        __syncthreads();
+        for (int i = tid; i < SIG_CHUNK; i += 256) {
+            const int s = chunk0 * HOP + i - NFFT / 2;
+            sig[i] = (s >= 0 && s < seg_len) ? pcm_to_float<TIn>(a[s]) : 0.f;
+        }
+        __syncthreads();
         for (int round = 0; round < 4; ++round) {                      // 4 waves x 2 frames
             const int pair = chunk0 / 2 + round * 4 + wave;
             const int f0 = 2 * pair, f1 = 2 * pair + 1;
             const bool live = pair < n_pairs && f0 < chunk0 + chunk_frames;
             if (live) {
                 // pass 1 reads the windowed frames straight from `sig`: z = w*(x_f0 + i x_f1)
-                const float* s0 = sig + f0 * HOP;
+                const float* s0 = sig + (f0 - chunk0) * HOP;
                 const bool has1 = f1 < n_frames;
-                const float* s1 = sig + (has1 ? f1 : f0) * HOP;
+                const float* s1 = sig + ((has1 ? f1 : f0) - chunk0) * HOP;
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int i = it * 64 + lane;
@@ -312,9 +315,7 @@ static int melspec_forward(nafp_melspec* p, const TIn* audio, int64_t n_seg, int
     const int n_groups = (int)((n_seg + group_size - 1) / group_size);
     melspec_init_stats<<<(n_groups + 255) / 256, 256, 0, st>>>(group_stat, n_groups);
     NAFP_LAUNCH_CHECK();
-    const int padded_len = p->seg_len + NFFT;
-    const int sig_alloc = (padded_len + 3) & ~3;
-    const size_t lds = (size_t)(sig_alloc + 8 * 2 * NFFT + p->n_mels * TILE_LD) * sizeof(float);
+    const size_t lds = (size_t)(SIG_CHUNK + 8 * 2 * NFFT + p->n_mels * TILE_LD) * sizeof(float);
     melspec_kernel<TIn><<<dim3((unsigned)n_seg), 256, lds, st>>>(
         audio, feat, group_stat, p->d_twiddle, p->d_window, p->d_mel_start, p->d_mel_w,
         p->seg_len, p->n_frames, p->n_mels, group_size);
@@ -384,8 +385,7 @@ extern "C" int nafp_melspec_create(nafp_melspec** plan, int fs, int seg_len, int
     if ((e = hipMemcpy(p->d_mel_start, start.data(), sizeof(int) * n_mels, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(p->d_mel_w, w.data(), sizeof(float) * n_mels * MAX_TAPS, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     // the kernel needs > 64 KiB of dynamic LDS
-    const int sig_alloc = (seg_len + NFFT + 3) & ~3;
-    const int lds = (sig_alloc + 8 * 2 * NFFT + n_mels * TILE_LD) * (int)sizeof(float);
+    const int lds = (SIG_CHUNK + 8 * 2 * NFFT + n_mels * TILE_LD) * (int)sizeof(float);
     if ((e = hipFuncSetAttribute((const void*)melspec_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return fail(e);
     if ((e = hipFuncSetAttribute((const void*)melspec_kernel<int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return fail(e);
     *plan = p;

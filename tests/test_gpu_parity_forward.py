@@ -96,3 +96,29 @@ def test_end_to_end_audio_to_fingerprint(nafp, cfg):
     cos = (emb * want).sum(1)
     assert (1 - cos).max() < 1e-5
     assert np.abs(np.linalg.norm(emb, axis=1) - 1).max() < 1e-5
+
+
+def test_two_second_input_geometry(nafp):
+    """nnfp.py:266-268 builds FingerPrinter on (256,63,1) as well (19,224,576 params, nnfp.py:271):
+    odd frame counts exercise symmetric SAME padding (1/1) and the ragged position tiles."""
+    rng = np.random.default_rng(42)
+    feat = (-rng.uniform(0, 1.2, size=(3, 256, 63, 1))).astype(np.float32)
+    w = o_nnfp.init_weights(seed=6, input_shape=(256, 63, 1), randomize_affine=True)
+    m_fp = nafp.FingerPrinter(input_shape=(256, 63, 1))
+    assert sum(v.numel() for v in m_fp.trainable_variables) == 19224576
+    _load_oracle_weights(m_fp, w)
+    emb = m_fp(torch.from_numpy(feat).cuda()).cpu().numpy()
+    want = o_nnfp.fingerprinter(feat, w, dtype=np.float64)
+    assert np.abs(emb - want).max() < 2e-5
+    assert (1 - (emb * want).sum(1)).max() < 1e-6
+
+
+def test_melspec_two_second_segments(nafp, cfg):
+    import copy
+    c = copy.deepcopy(cfg)
+    c['MODEL']['DUR'] = 2.
+    x = _audio(3, seed=9, T=16000)
+    got = nafp.get_melspec_layer(c)(torch.from_numpy(x).cuda()).cpu().numpy()
+    want = o_mel.melspec_layer(x, dtype=np.float64)
+    assert got.shape == want.shape == (3, 256, 63, 1)
+    assert np.abs(got - want).max() < 2e-5
