@@ -169,6 +169,34 @@ int nafp_ntxent_forward(const float* emb_org_local, const float* emb_rep_local,
                         float* d_org_all, float* d_rep_all,
                         void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Optimizer steps of the train step (model/trainer.py:47-48, 119-140)
+ * ---------------------------------------------------------------------- */
+
+/* One parameter tensor with its gradient and moment slots (all device pointers, float32).
+ * var_len = length of ONE keras variable inside the tensor: numel for the conv / LN tensors;
+ * the stacked divide-and-encode tensors hold 128 variables each (var_len = numel / 128), and
+ * LAMB takes its trust ratio per variable, as the reference does over its 576 variables. */
+typedef struct {
+    float* param; const float* grad; float* m; float* v;
+    int64_t numel; int64_t var_len;
+} nafp_opt_tensor;
+
+/* tf.keras.experimental.CosineDecay(lr0, decay_steps, alpha) at `step` (trainer.py:119-124). */
+float nafp_cosine_decay_lr_host(float lr0, int64_t step, int64_t decay_steps, float alpha);
+
+/* tf.keras.optimizers.Adam.apply_gradients (trainer.py:138): step is 1-based (iterations + 1);
+ * keras defaults beta1 0.9, beta2 0.999, eps 1e-7. */
+int nafp_adam_step(const nafp_opt_tensor* tensors_host, int n, float lr, float beta1, float beta2,
+                   float eps, int64_t step, void* stream);
+
+/* LAMB._resource_apply_dense (model/fp/lamb_optimizer.py:123-158): defaults beta1 0.9, beta2 0.999,
+ * eps 1e-6, weight_decay 1e-6, decay and layer adaptation on every variable. */
+int64_t nafp_lamb_workspace_bytes(const nafp_opt_tensor* tensors_host, int n);
+int nafp_lamb_step(const nafp_opt_tensor* tensors_host, int n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int64_t step, void* workspace,
+                   int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,180 @@
+// Multi-tensor optimizer steps for gfx950: keras Adam and the reference's LAMB.
+//
+// Replaces `opt.apply_gradients(zip(g, m_fp.trainable_variables))` of the reference's
+// train step (model/trainer.py:47-48) for
+//   * tf.keras.optimizers.Adam (trainer.py:138): lr_t = lr*sqrt(1-b2^t)/(1-b1^t),
+//     w -= lr_t * m / (sqrt(v) + eps), eps = 1e-7;
+//   * LAMB (model/fp/lamb_optimizer.py:123-158): m_hat/(sqrt(v_hat)+eps) + wd*w, trust ratio
+//     ||w|| / ||update|| per VARIABLE, eps 1e-6, wd 1e-6 on every variable.
+// The reference has 576 variables: 64 conv/LN tensors + 128 slices x (W1, b1, W2, b2).  Here the
+// slice variables are stacked into 4 tensors, so a tensor carries `var_len`: the length of one
+// keras variable inside it, and LAMB's norms are taken per var_len-segment -- 576 trust ratios,
+// as in the reference.  All tensors of one step go through a few launches (HBM-bound
+// elementwise work: 16.9 M parameters x (w, g, m, v)).
+#include "nafp_common.h"
+
+namespace nafp {
+
+constexpr int OPT_MAX_T = 48;            // tensors per launch (kernel-argument table)
+
+struct OptTable {
+    float* p[OPT_MAX_T];
+    const float* g[OPT_MAX_T];
+    float* m[OPT_MAX_T];
+    float* v[OPT_MAX_T];
+    long long numel[OPT_MAX_T];
+    long long var_len[OPT_MAX_T];
+    long long norm_off[OPT_MAX_T];       // first (w2, u2) pair of this tensor in the norm buffer
+    int n;
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(const OptTable t, float lr_t, float b1, float b2, float eps) {
+    const int ti = blockIdx.y;
+    float* __restrict__ p = t.p[ti]; const float* __restrict__ g = t.g[ti];
+    float* __restrict__ m = t.m[ti]; float* __restrict__ v = t.v[ti];
+    const long long n = t.numel[ti];
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+// LAMB phase 1: moments, and per-variable sum(w^2), sum(update^2) into `norms` (double pairs).
+__global__ __launch_bounds__(256) void lamb_moments_kernel(const OptTable t, float b1, float b2, float eps, float wd,
+                                                           float inv_bc1, float inv_bc2, double* __restrict__ norms) {
+    const int ti = blockIdx.y;
+    const float* __restrict__ p = t.p[ti]; const float* __restrict__ g = t.g[ti];
+    float* __restrict__ m = t.m[ti]; float* __restrict__ v = t.v[ti];
+    const long long n = t.numel[ti], vl = t.var_len[ti];
+    double* nb = norms + 2 * t.norm_off[ti];
+    const bool one_var = vl == n;
+    double w2 = 0.0, u2 = 0.0;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float gi = g[i], wi = p[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float u = (mi * inv_bc1) / (sqrtf(vi * inv_bc2) + eps) + wd * wi;
+        if (one_var) { w2 += (double)wi * wi; u2 += (double)u * u; }
+        else {
+            const long long s = i / vl;
+            atomicAdd(nb + 2 * s, (double)wi * wi);
+            atomicAdd(nb + 2 * s + 1, (double)u * u);
+        }
+    }
+    if (one_var) {
+        w2 = wave_sum(w2); u2 = wave_sum(u2);
+        __shared__ double red[8];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) { red[wave] = w2; red[4 + wave] = u2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(nb, red[0] + red[1] + red[2] + red[3]);
+            atomicAdd(nb + 1, red[4] + red[5] + red[6] + red[7]);
+        }
+    }
+}
+
+// LAMB phase 2: w -= ratio * lr * update, ratio = ||w||/||update|| (1 if either norm is 0).
+__global__ __launch_bounds__(256) void lamb_apply_kernel(const OptTable t, float lr, float eps, float wd,
+                                                         float inv_bc1, float inv_bc2, const double* __restrict__ norms) {
+    const int ti = blockIdx.y;
+    float* __restrict__ p = t.p[ti];
+    const float* __restrict__ m = t.m[ti]; const float* __restrict__ v = t.v[ti];
+    const long long n = t.numel[ti], vl = t.var_len[ti];
+    const double* nb = norms + 2 * t.norm_off[ti];
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long s = i / vl;
+        const float wn = (float)sqrt(nb[2 * s]), un = (float)sqrt(nb[2 * s + 1]);
+        const float ratio = (wn > 0.f && un > 0.f) ? wn / un : 1.f;
+        const float wi = p[i];
+        const float u = (m[i] * inv_bc1) / (sqrtf(v[i] * inv_bc2) + eps) + wd * wi;
+        p[i] = wi - ratio * lr * u;
+    }
+}
+
+static int fill_table(OptTable& tb, const nafp_opt_tensor* ts, int first, int n, long long& norm_cursor) {
+    tb.n = n;
+    for (int i = 0; i < n; ++i) {
+        const nafp_opt_tensor& t = ts[first + i];
+        if (!t.param || !t.grad || !t.m || !t.v || t.numel <= 0 || t.var_len <= 0 || t.numel % t.var_len != 0)
+            return NAFP_ERR_INVALID_ARG;
+        tb.p[i] = t.param; tb.g[i] = t.grad; tb.m[i] = t.m; tb.v[i] = t.v;
+        tb.numel[i] = t.numel; tb.var_len[i] = t.var_len; tb.norm_off[i] = norm_cursor;
+        norm_cursor += t.numel / t.var_len;
+    }
+    return NAFP_OK;
+}
+
+}  // namespace nafp
+
+using namespace nafp;
+
+extern "C" float nafp_cosine_decay_lr_host(float lr0, int64_t step, int64_t decay_steps, float alpha) {
+    // tf.keras.experimental.CosineDecay (trainer.py:119-124): lr0 * ((1-alpha) * 0.5 (1 + cos(pi s/S)) + alpha)
+    if (decay_steps <= 0) return lr0;
+    const double s = (double)(step < decay_steps ? step : decay_steps) / (double)decay_steps;
+    const double c = 0.5 * (1.0 + cos(M_PI * s));
+    return (float)((double)lr0 * ((1.0 - (double)alpha) * c + (double)alpha));
+}
+
+extern "C" int nafp_adam_step(const nafp_opt_tensor* tensors_host, int n, float lr, float beta1, float beta2,
+                              float eps, int64_t step, void* stream) {
+    if (!tensors_host || n <= 0 || step < 1) return NAFP_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float lr_t = (float)((double)lr * sqrt(bc2) / bc1);
+    long long cursor = 0;
+    for (int first = 0; first < n; first += OPT_MAX_T) {
+        OptTable tb;
+        const int cnt = n - first < OPT_MAX_T ? n - first : OPT_MAX_T;
+        int rc = fill_table(tb, tensors_host, first, cnt, cursor);
+        if (rc != NAFP_OK) return rc;
+        adam_kernel<<<dim3(64, cnt), 256, 0, st>>>(tb, lr_t, beta1, beta2, eps);
+        NAFP_LAUNCH_CHECK();
+    }
+    return NAFP_OK;
+}
+
+extern "C" int64_t nafp_lamb_workspace_bytes(const nafp_opt_tensor* tensors_host, int n) {
+    if (!tensors_host || n <= 0) return -1;
+    int64_t vars = 0;
+    for (int i = 0; i < n; ++i) {
+        if (tensors_host[i].var_len <= 0 || tensors_host[i].numel % tensors_host[i].var_len != 0) return -1;
+        vars += tensors_host[i].numel / tensors_host[i].var_len;
+    }
+    return vars * 2 * (int64_t)sizeof(double) + 256;
+}
+
+extern "C" int nafp_lamb_step(const nafp_opt_tensor* tensors_host, int n, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, int64_t step, void* workspace,
+                              int64_t workspace_bytes, void* stream) {
+    if (!tensors_host || n <= 0 || step < 1 || !workspace) return NAFP_ERR_INVALID_ARG;
+    const int64_t need = nafp_lamb_workspace_bytes(tensors_host, n);
+    if (need < 0) return NAFP_ERR_INVALID_ARG;
+    if (workspace_bytes < need) return NAFP_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    double* norms = (double*)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+    NAFP_HIP_CHECK(hipMemsetAsync(norms, 0, (size_t)(need - 256), st));
+    const float inv_bc1 = (float)(1.0 / (1.0 - pow((double)beta1, (double)step)));
+    const float inv_bc2 = (float)(1.0 / (1.0 - pow((double)beta2, (double)step)));
+    for (int pass = 0; pass < 2; ++pass) {
+        long long cursor = 0;
+        for (int first = 0; first < n; first += OPT_MAX_T) {
+            OptTable tb;
+            const int cnt = n - first < OPT_MAX_T ? n - first : OPT_MAX_T;
+            int rc = fill_table(tb, tensors_host, first, cnt, cursor);
+            if (rc != NAFP_OK) return rc;
+            if (pass == 0)
+                lamb_moments_kernel<<<dim3(64, cnt), 256, 0, st>>>(tb, beta1, beta2, eps, weight_decay, inv_bc1,
+                                                                   inv_bc2, norms);
+            else
+                lamb_apply_kernel<<<dim3(64, cnt), 256, 0, st>>>(tb, lr, eps, weight_decay, inv_bc1, inv_bc2, norms);
+            NAFP_LAUNCH_CHECK();
+        }
+    }
+    return NAFP_OK;
+}

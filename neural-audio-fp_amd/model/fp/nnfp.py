@@ -99,6 +99,11 @@ class FingerPrinter:
     def trainable_variables(self):
         return list(self._vars)
 
+    def variable_lengths(self):
+        """Length of one keras variable inside each tensor (LAMB's trust ratio is per keras
+        variable): the 4 divide-and-encode tensors stack emb_sz variables each."""
+        return [v.numel() if i < 64 else v.numel() // self.emb_sz for i, v in enumerate(self._vars)]
+
     def mark_dirty(self):
         """Call after modifying a variable in place (e.g. an optimizer step)."""
         self._dirty = True

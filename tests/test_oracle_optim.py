@@ -1,0 +1,50 @@
+"""CPU: optimizer / schedule oracle (lamb_optimizer.py:123-158, trainer.py:119-140) against
+independent formulations."""
+import numpy as np
+import torch
+
+from oracle import optim as o_opt
+
+
+def test_cosine_decay_endpoints_and_host_entry(nafp):
+    lib = nafp._lib.load()
+    assert np.isclose(o_opt.cosine_decay(1e-4, 0, 1000), 1e-4)
+    assert np.isclose(o_opt.cosine_decay(1e-4, 1000, 1000), 1e-4 * 1e-6)
+    assert np.isclose(o_opt.cosine_decay(1e-4, 5000, 1000), 1e-4 * 1e-6)          # clamps after decay_steps
+    assert np.isclose(o_opt.cosine_decay(1e-4, 500, 1000), 1e-4 * (0.5 * (1 - 1e-6) + 1e-6))
+    for s in (0, 1, 17, 500, 999, 1000, 1234):
+        assert np.isclose(lib.nafp_cosine_decay_lr_host(1e-4, s, 1000, 1e-6), o_opt.cosine_decay(1e-4, s, 1000), rtol=1e-6)
+
+
+def test_adam_matches_torch_with_rescaled_epsilon():
+    # torch: w -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps_t); keras puts eps outside the bias
+    # correction, i.e. eps_t = eps_keras / sqrt(1-b2^t).  One step at a time with that eps.
+    rng = np.random.default_rng(0)
+    w = rng.normal(size=50); m = np.zeros(50); v = np.zeros(50)
+    tw = torch.tensor(w.copy(), requires_grad=True)
+    for t in range(1, 6):
+        g = rng.normal(size=50)
+        eps_t = 1e-7 / np.sqrt(1 - 0.999 ** t)
+        opt = torch.optim.Adam([tw], lr=1e-3, eps=eps_t)
+        if t > 1:
+            opt.state[tw] = state
+            state['step'] = torch.tensor(float(t - 1))
+        tw.grad = torch.tensor(g)
+        opt.step()
+        state = opt.state[tw]
+        w, m, v = o_opt.adam_step(w, g, m, v, 1e-3, t)
+        assert np.abs(w - tw.detach().numpy()).max() < 1e-12
+
+
+def test_lamb_trust_ratio_properties():
+    rng = np.random.default_rng(1)
+    w = rng.normal(size=(8, 32)); g = rng.normal(size=(8, 32))
+    w1, m1, v1 = o_opt.lamb_step(w, g, np.zeros_like(w), np.zeros_like(w), lr=1e-3, step=1)
+    # first step: m_hat = g, v_hat = g^2 -> update ~ sign(g) + wd*w; step length = lr * ||w||
+    assert np.isclose(np.linalg.norm(w1 - w), 1e-3 * np.linalg.norm(w), rtol=1e-6)
+    # zero weights -> ratio 1 (tf.where(w_norm > 0, ..., 1.0))
+    z1, _, _ = o_opt.lamb_step(np.zeros(16), np.ones(16), np.zeros(16), np.zeros(16), lr=1e-3, step=1)
+    assert np.allclose(z1, -1e-3 * (1 / (1 + 1e-6)))
+    # scaling the gradient does not change the step (Adam normalisation + trust ratio)
+    w2, _, _ = o_opt.lamb_step(w, 10 * g, np.zeros_like(w), np.zeros_like(w), lr=1e-3, step=1)
+    assert np.abs(w2 - w1).max() < 2e-6          # up to eps / |g| relative, times lr * ratio
