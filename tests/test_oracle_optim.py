@@ -47,4 +47,4 @@ def test_lamb_trust_ratio_properties():
     assert np.allclose(z1, -1e-3 * (1 / (1 + 1e-6)))
     # scaling the gradient does not change the step (Adam normalisation + trust ratio)
     w2, _, _ = o_opt.lamb_step(w, 10 * g, np.zeros_like(w), np.zeros_like(w), lr=1e-3, step=1)
-    assert np.abs(w2 - w1).max() < 2e-6          # up to eps / |g| relative, times lr * ratio
+    assert np.abs(w2 - w1).max() < 1e-5          # up to eps / |g| relative (tiny |g| entries), times lr * ratio
