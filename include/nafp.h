@@ -170,6 +170,20 @@ int nafp_ntxent_forward(const float* emb_org_local, const float* emb_rep_local,
                         void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Spec-augment (train step only): SpecNCutout with uniform_mask=True
+ * (model/fp/specaug_chain/layers/ncutout_tarray.py:214-268)
+ * ---------------------------------------------------------------------- */
+
+/* A hole: frequency rows [f0, f1] x frames [t0, t1], INCLUSIVE on both ends
+ * (generate_single_mask, ncutout_tarray.py:117-128). */
+typedef struct { int f0, f1, t0, t1; } nafp_rect;
+
+/* In place on feat (n_seg, F, T): elements inside any of the <= 8 holes become fill_value for the
+ * samples whose `active` flag is set (active == NULL: every sample).  T % 4 == 0. */
+int nafp_specaug_apply(float* feat, int64_t n_seg, int F, int T, const nafp_rect* rects_host,
+                       int n_rects, const unsigned char* active, float fill_value, void* stream);
+
+/* ------------------------------------------------------------------------
  * Optimizer steps of the train step (model/trainer.py:47-48, 119-140)
  * ---------------------------------------------------------------------- */
 

@@ -48,6 +48,7 @@ PROTOTYPES = {
     'nafp_ntxent_workspace_bytes': (c_i64, [c_i64, c_i64]),
     'nafp_ntxent_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int,
                                     c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
+    'nafp_specaug_apply': (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_int, c_void_p, c_float, c_void_p]),
     'nafp_cosine_decay_lr_host': (c_float, [c_float, c_i64, c_i64, c_float]),
     'nafp_adam_step': (c_int, [c_void_p, c_int, c_float, c_float, c_float, c_float, c_i64, c_void_p]),
     'nafp_lamb_workspace_bytes': (c_i64, [c_void_p, c_int]),
@@ -60,6 +61,11 @@ class OptTensor(ctypes.Structure):
     """nafp_opt_tensor (include/nafp.h)."""
     _fields_ = [('param', c_void_p), ('grad', c_void_p), ('m', c_void_p), ('v', c_void_p),
                 ('numel', c_i64), ('var_len', c_i64)]
+
+
+class Rect(ctypes.Structure):
+    """nafp_rect (include/nafp.h): inclusive hole bounds."""
+    _fields_ = [('f0', c_int), ('f1', c_int), ('t0', c_int), ('t1', c_int)]
 
 
 class NafpError(RuntimeError):

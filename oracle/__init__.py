@@ -30,4 +30,4 @@ torch layer_norm, torch cross_entropy, autograd vs analytic gradients), and in
 float64 vs float32 to bound rounding.  The published algorithms restated from
 the pinned third-party versions are named in each docstring.
 """
-from . import melspec, nnfp, ntxent, segments  # noqa: F401
+from . import melspec, nnfp, ntxent, segments, optim, specaug  # noqa: F401
