@@ -118,3 +118,45 @@ def test_fused_conv0_option_is_bit_identical(nafp):
         # statistics are accumulated with double atomics in a different order: allow 1 ulp-level noise
         assert float((got_flat - ref_flat).abs().max()) < 1e-5
         assert float((got - ref).abs().max()) < 1e-6
+
+
+def test_run_py_generate_default_sources(nafp, cfg, tmp_path):
+    """`python run.py generate NAME` on the reference's dataset directory convention
+    (test-dummy-db-100k-full/, test-query-db-500-30s/{query,db}/): three memmaps, row counts,
+    query/db of equal size, files readable the way eval_faiss.load_memmap_data reads them."""
+    import subprocess
+    import sys
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    music = tmp_path / 'music'
+    rng = np.random.default_rng(9)
+    layout = {'test-dummy-db-100k-full/a': [12000, 9000, 30000], 'test-query-db-500-30s/query/x': [16000, 8000],
+              'test-query-db-500-30s/db/x': [16000, 8000]}
+    for sub, lens in layout.items():
+        d = music / sub; d.mkdir(parents=True)
+        for i, n in enumerate(lens):
+            _write_wav(str(d / f'{i:03d}.wav'), rng.integers(-5000, 5000, size=n))
+    c = copy.deepcopy(cfg)
+    c['DIR']['SOURCE_ROOT_DIR'] = str(music) + '/'
+    c['DIR']['LOG_ROOT_DIR'] = str(tmp_path) + '/logs/'
+    c['DIR']['OUTPUT_ROOT_DIR'] = str(tmp_path) + '/logs/emb/'
+    c['BSZ']['TS_BATCH_SZ'] = 4
+    (tmp_path / 'config').mkdir()
+    yaml.safe_dump(c, open(tmp_path / 'config' / 'tiny.yaml', 'w'))
+    from neural_audio_fp_amd.model import generate as g
+    m_fp = nafp.get_fingerprinter(c)
+    g.save_checkpoint(c['DIR']['LOG_ROOT_DIR'] + 'checkpoint/', 'exp', 1, m_fp)
+    r = subprocess.run([sys.executable, os.path.join(root, 'run.py'), 'generate', 'exp', '-c', 'tiny'],
+                       cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = c['DIR']['OUTPUT_ROOT_DIR'] + '/exp/1/'
+    want_rows = {'dummy_db': 2 + 1 + 6, 'query': 3 + 1, 'db': 3 + 1}
+    for key, n in want_rows.items():
+        shape = np.load(out + f'{key}_shape.npy')
+        assert tuple(shape) == (n, 128)
+        arr = np.memmap(out + f'{key}.mm', dtype='float32', mode='r', shape=(shape[0], shape[1]))
+        assert np.allclose(np.linalg.norm(np.asarray(arr), axis=1), 1.0, atol=1e-5)
+    # missing config -> sys.exit message of run.py:18
+    r2 = subprocess.run([sys.executable, os.path.join(root, 'run.py'), 'generate', 'exp', '-c', 'nope'],
+                        cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
+    assert r2.returncode != 0 and 'is missing' in (r2.stdout + r2.stderr)
