@@ -112,6 +112,9 @@ def main():
                          'durations are the kernels own).  With 1, a second region with 4 streams is '
                          'timed afterwards and reported as "pipelined".')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-pipelined', action='store_true',
+                    help='skip the extra 4-stream region (used under rocprofv3 so that its per-kernel '
+                         'averages cover the single-stream launches only)')
     args = ap.parse_args()
 
     import torch
@@ -197,7 +200,7 @@ def main():
     # occupancy late convs of one batch overlap the large convs of the next.  Reported
     # separately; `value` stays the single-stream figure that `roofline` is consistent with.
     pipelined = None
-    if n_str == 1:
+    if n_str == 1 and not args.no_pipelined:
         m_fp.profile_enable(0)
         ps = [torch.cuda.Stream(device=dev) for _ in range(4)]
 

@@ -110,8 +110,9 @@ for r in sq:
 
 with open(os.path.join(dst, f'{tag}_summary.md'), 'w') as f:
     f.write(f'# Profile summary {tag}\n\n')
-    f.write('Command profiled: `python bench.py --steps 30 --warmup 5` (1x MI355X, BSZ 640 per step), '
-            'under `rocprofv3 --kernel-trace --stats` (full CSV: `%s_kernel_stats.csv`).\n\n' % tag)
+    f.write('Command profiled: `python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-pipelined` '
+            '(1x MI355X, BSZ 640 per step, single stream) under `rocprofv3 --kernel-trace --stats` '
+            '(full CSV: `%s_kernel_stats.csv`).\n\n' % tag)
     f.write(f'Bench line of the same run (un-profiled): **{bj["value"]} {bj["unit"]}**, '
             f'roofline {bj["roofline"]["achieved"]} / {bj["roofline"]["peak"]} TFLOP/s '
             f'= {bj["roofline"]["frac"]} (HIP-event mean launch {bj["roofline"]["ms_per_launch_avg"]} ms).\n\n')
@@ -123,7 +124,10 @@ with open(os.path.join(dst, f'{tag}_summary.md'), 'w') as f:
     tot = sum(sum(v) for g, v in full); cnt = sum(len(v) for g, v in full)
     f.write(f'\nGEMM-conv launches of the bench steps only (the 30 one-off PLAIN launches of set_weights '
             f'excluded): {cnt} launches, mean {tot / cnt / 1e3:.1f} us under the profiler vs '
-            f'{bj["roofline"]["ms_per_launch_avg"] * 1e3:.1f} us from HIP events un-profiled.\n\n')
+            f'{bj["roofline"]["ms_per_launch_avg"] * 1e3:.1f} us from HIP events un-profiled.  The HIP events '
+            f'bracket each conv launch INCLUDING its split-K finish kernel where one exists '
+            f'(`splitk_finish_kernel`: 8 per step, ~16 us each = +8.5 us per conv launch on average), '
+            f'which is the difference.\n\n')
     f.write('## HBM traffic of the dominant kernel (separate PMC passes)\n\n')
     if traffic:
         f.write(f'* FETCH_SIZE (x2 gfx950 correction): {fetch_bytes_per_launch / 1e6:.1f} MB per launch (mean of {f_n})\n')
