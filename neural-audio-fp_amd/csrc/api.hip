@@ -244,7 +244,7 @@ extern "C" int nafp_encoder_forward(nafp_encoder* e, const float* feat, int64_t 
     // (NAFP_FUSE0=0 selects the materialised path).
     const bool fuse0 = e->opt_fuse_conv0 && e->geom[1].axis == 1 && e->geom[1].Cin % 16 == 0;
     int rc = fuse0 ? launch_conv0_stats(feat, e->d_w[0], e->d_bias[0], stats, n_seg, e->geom[0], st)
-                   : launch_conv0(feat, e->d_w[0], e->d_bias[0], e->d_gamma[0], bufA, stats, n_seg, e->geom[0], st);
+                   : launch_conv0(feat, e->d_w[0], e->d_bias[0], e->d_gamma[0], bufA, nullptr, stats, n_seg, e->geom[0], st);
     if (rc != NAFP_OK) return rc;
     if (ev) NAFP_HIP_CHECK(hipEventRecord(ev[1], st));
     float* cur = bufA;

@@ -43,8 +43,8 @@ constexpr int ROWS0 = 4;
 template <bool STORE, int ROWS0>
 __global__ __launch_bounds__(256) void conv0_kernel(
         const float* __restrict__ feat, const float* __restrict__ w3, const float* __restrict__ bias,
-        const float* __restrict__ gamma, float* __restrict__ y, double* __restrict__ stats,
-        int F, int Tin, int Tout, int Cout, int stride, int pad) {
+        const float* __restrict__ gamma, float* __restrict__ y, float* __restrict__ v_out,
+        double* __restrict__ stats, int F, int Tin, int Tout, int Cout, int stride, int pad) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int blocks_per_sample = (F + ROWS0 - 1) / ROWS0;
     const int64_t b = blockIdx.x / blocks_per_sample;
@@ -78,7 +78,10 @@ __global__ __launch_bounds__(256) void conv0_kernel(
         v.w = elu1(fmaf(x2, w2.w, fmaf(x1, w1.w, fmaf(x0, w0.w, bb.w))));
         s += (v.x + v.y) + (v.z + v.w);
         q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-        if (STORE) *(float4*)(yout + (int64_t)p * Cout + 4 * cg) = make_float4(v.x * g.x, v.y * g.y, v.z * g.z, v.w * g.w);
+        if (STORE) {
+            *(float4*)(yout + (int64_t)p * Cout + 4 * cg) = make_float4(v.x * g.x, v.y * g.y, v.z * g.z, v.w * g.w);
+            if (v_out) *(float4*)(v_out + (yout - y) + (int64_t)p * Cout + 4 * cg) = v;
+        }
     }
     double ds = wave_sum((double)s), dq = wave_sum((double)q);
     __shared__ double red[8];
@@ -91,11 +94,11 @@ __global__ __launch_bounds__(256) void conv0_kernel(
 }
 
 int launch_conv0(const float* feat, const float* w3, const float* bias, const float* gamma, float* y,
-                 double* stats, int64_t B, const ConvGeom& g, hipStream_t st) {
+                 float* v_out, double* stats, int64_t B, const ConvGeom& g, hipStream_t st) {
     if (g.Cin != 1 || g.axis != 0 || (g.Cout % 4) != 0 || 256 % (g.Cout / 4) != 0) return NAFP_ERR_UNSUPPORTED;
     const int64_t blocks = B * ((g.Fin + ROWS0 - 1) / ROWS0);
-    conv0_kernel<true, ROWS0><<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, gamma, y, stats, g.Fin, g.Tin,
-                                                                      g.Tout, g.Cout, g.stride, g.pad);
+    conv0_kernel<true, ROWS0><<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, gamma, y, v_out, stats, g.Fin,
+                                                                      g.Tin, g.Tout, g.Cout, g.stride, g.pad);
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }
@@ -105,8 +108,8 @@ int launch_conv0_stats(const float* feat, const float* w3, const float* bias, do
     if (g.Cin != 1 || g.axis != 0 || (g.Cout % 4) != 0 || 256 % (g.Cout / 4) != 0) return NAFP_ERR_UNSUPPORTED;
     constexpr int R = 32;
     const int64_t blocks = B * ((g.Fin + R - 1) / R);
-    conv0_kernel<false, R><<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, nullptr, nullptr, stats, g.Fin,
-                                                                   g.Tin, g.Tout, g.Cout, g.stride, g.pad);
+    conv0_kernel<false, R><<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, nullptr, nullptr, nullptr, stats,
+                                                                   g.Fin, g.Tin, g.Tout, g.Cout, g.stride, g.pad);
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }
@@ -151,6 +154,7 @@ struct ConvKernelParams {
     const double* stats_in;   // (B, 2)         FULL
     double* stats_out;        // (B, 2)         FULL
     float* y;                 // (B, P, Cout)
+    float* v_out;             // (B, P, Cout) or null: the ELU output itself (kept for the backward pass)
     int Fin, Tin, Cin, Tout, Cout;
     int axis, stride, pad;
     int B, P;                 // samples; output positions per sample (Fout*Tout)
@@ -160,6 +164,7 @@ struct ConvKernelParams {
     int tap_stride;           // elements between consecutive taps of one output row
     double inv_n_in;          // 1 / sample_in
     int mode;                 // 0 FULL, 1 PLAIN
+    int dgrad;                // 1: transposed conv (backward w.r.t. the conv input), see row_geom()
     unsigned wp_bytes;
     int n_split;              // split-K factor (blockIdx.z); > 1 writes raw partial sums to `y` = slab
     int abl;                  // ablation flags for kernel-time breakdown (NAFP_ABL env; 0 in production)
@@ -196,6 +201,39 @@ __device__ __forceinline__ void lds_dma16(unsigned lds_addr, unsigned voff, u32x
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 4\n\t"
                  "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+// Source geometry of one GEMM row (an output position `pos` of this launch).
+//   forward conv: output (fo,to) reads input positions pos0 + tap along the tap axis;
+//   DGRAD (transposed conv, backward w.r.t. the conv input): the row is an INPUT position u of the
+//   conv and tap k reads dT at o = (u + pad - k) / stride when that is an integer in [0, n_out).
+//   There p.Fin/p.Tin/p.Cin describe the source tensor dT, p.Tout the minor extent of the rows,
+//   and p.tap_stride = -S/stride (S = elements between neighbouring dT positions along the tap
+//   axis), so that  inner + k*tap_stride  is the address of tap k whenever the tap is valid.
+struct RowGeom { int inner; unsigned mask; };
+__device__ __forceinline__ RowGeom row_geom(const ConvKernelParams& p, int pos) {
+    const int fo = pos / p.Tout, to = pos - fo * p.Tout;
+    RowGeom g; g.mask = 0;
+    if (!p.dgrad) {
+        int pos0, lim;
+        if (p.axis == 0) { pos0 = to * p.stride - p.pad; lim = p.Tin; g.inner = (fo * p.Tin + pos0) * p.Cin; }
+        else             { pos0 = fo * p.stride - p.pad; lim = p.Fin; g.inner = (pos0 * p.Tin + to) * p.Cin; }
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            if (pos0 + t >= 0 && pos0 + t < lim) g.mask |= 1u << t;
+    } else {
+        const int u = (p.axis == 0 ? to : fo) + p.pad;
+        const int n_out = p.axis == 0 ? p.Tin : p.Fin;
+        const int S = p.axis == 0 ? p.Cin : p.Tin * p.Cin;
+        const int A0 = p.axis == 0 ? (fo * p.Tin) * p.Cin : to * p.Cin;
+        g.inner = A0 + (u * S) / p.stride;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int d = u - k;
+            if (d >= 0 && d % p.stride == 0 && d / p.stride < n_out) g.mask |= 1u << k;
+        }
+    }
+    return g;
 }
 
 template <int BK, int NSTAGE, bool FUSE0>
@@ -252,14 +290,9 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         const int sl = lr & ST1;
         voffA[q] = 0; vmaskA[q] = 0;
         if (pos < p.P && sl < nb) {
-            const int fo = pos / p.Tout, to = pos - fo * p.Tout;
-            int inner, pos0, lim;
-            if (p.axis == 0) { pos0 = to * p.stride - p.pad; lim = p.Tin; inner = (fo * p.Tin + pos0) * p.Cin; }
-            else             { pos0 = fo * p.stride - p.pad; lim = p.Fin; inner = (pos0 * p.Tin + to) * p.Cin; }
-            voffA[q] = (unsigned)(sl * (int)p.sample_in + inner + lc * 4) * 4u;   // may wrap for tap 0 in the padding: masked
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-                if (pos0 + t >= 0 && pos0 + t < lim) vmaskA[q] |= 1u << t;
+            const RowGeom rg = row_geom(p, pos);
+            voffA[q] = (unsigned)(sl * (int)p.sample_in + rg.inner + lc * 4) * 4u;   // may wrap for an invalid tap: masked
+            vmaskA[q] = rg.mask;
         }
         voffB[q] = (unsigned)((tile_n0 + lr) * K + lc * 4) * 4u;
     }
@@ -307,14 +340,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         for (int hrow = 0; hrow < 2; ++hrow) {
             const int lr = lane + 64 * hrow;
             const int pos = pb * p.PT + (lr >> p.log2ST);
-            if (pos < p.P && (lr & ST1) < nb) {
-                const int fo = pos / p.Tout, to = pos - fo * p.Tout;
-                const int pos0 = (p.axis == 0 ? to : fo) * p.stride - p.pad;
-                const int lim = p.axis == 0 ? p.Tin : p.Fin;
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-                    if (pos0 + t >= 0 && pos0 + t < lim) m |= 1u << t;
-            }
+            if (pos < p.P && (lr & ST1) < nb) m |= row_geom(p, pos).mask;
         }
 #pragma unroll
         for (int t = 0; t < 3; ++t)
@@ -528,7 +554,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
                 for (int ni = 0; ni < 2; ++ni) {
                     float v = elu1(fmaf(rb, acc[mi][ni][r], fmaf(cb, Gv[mi][rg][ni], Hv[mi][rg][ni])));
                     v = valid ? v : 0.f;
-                    if (valid) yrow[q * ystep + ni * 32] = v * gv[mi][rg][ni];
+                    if (valid) {
+                        yrow[q * ystep + ni * 32] = v * gv[mi][rg][ni];
+                        if (p.v_out) p.v_out[(yrow - p.y) + q * ystep + ni * 32] = v;
+                    }
                     rs += v; rq += v * v;
                 }
                 if (fast_stats) { s4[q] += rs; q4[q] += rq; }
@@ -599,7 +628,8 @@ static int launch_variant(KernelT kernel, int BK, int NSTAGE, const ConvKernelPa
 __global__ __launch_bounds__(256) void splitk_finish_kernel(
         const float* __restrict__ slab, int S, const float* __restrict__ G, const float* __restrict__ Hb,
         const float* __restrict__ gamma_out, const double* __restrict__ stats_in,
-        double* __restrict__ stats_out, float* __restrict__ y, int B, int P, int Cout, double inv_n_in) {
+        double* __restrict__ stats_out, float* __restrict__ y, float* __restrict__ v_out, int B, int P, int Cout,
+        double inv_n_in) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row = blockIdx.x;
     const int b = (int)(row / P), pos = (int)(row - (int64_t)b * P);
@@ -628,6 +658,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(
         s += (v.x + v.y) + (v.z + v.w);
         q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         *(float4*)(y + row * Cout + n) = make_float4(v.x * go.x, v.y * go.y, v.z * go.z, v.w * go.w);
+        if (v_out) *(float4*)(v_out + row * Cout + n) = v;
     }
     const double ds = wave_sum((double)s), dq = wave_sum((double)q);
     __shared__ double red[8];
@@ -689,7 +720,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     if (g.Cin % 32 != 0 || g.Cout % BN != 0 || B > (1 << 24)) return NAFP_ERR_UNSUPPORTED;
     ConvKernelParams p;
     p.x = a.x; p.wp = a.wp; p.G = a.G; p.Hb = a.Hb; p.gamma_out = a.gamma_out; p.bias = a.bias;
-    p.stats_in = a.stats_in; p.stats_out = a.stats_out; p.y = a.y;
+    p.stats_in = a.stats_in; p.stats_out = a.stats_out; p.y = a.y; p.v_out = a.v_out;
     p.Fin = g.Fin; p.Tin = g.Tin; p.Cin = g.Cin; p.Tout = g.Tout; p.Cout = g.Cout;
     p.axis = g.axis; p.stride = g.stride; p.pad = g.pad;
     p.B = (int)B; p.P = g.Fout * g.Tout;
@@ -704,6 +735,25 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     p.inv_n_in = 1.0 / (double)p.sample_in;
     p.mode = a.plain ? 1 : 0;
     p.n_split = 1;
+    p.dgrad = 0;
+    if (a.dgrad) {
+        // backward w.r.t. the conv input: rows = input positions, source = dT (B,Fout,Tout,Cout),
+        // weights = wp flipped to (Cin, 3*Cout); see row_geom()
+        if (!a.plain || g.Cout % 32 != 0 || g.Cin % BN != 0) return NAFP_ERR_UNSUPPORTED;
+        p.dgrad = 1;
+        p.Fin = g.Fout; p.Tin = g.Tout; p.Cin = g.Cout; p.Cout = g.Cin; p.Tout = g.Tin;
+        p.P = g.Fin * g.Tin;
+        pt = 1;
+        while (pt * 2 <= p.P && pt * 2 <= 32) pt *= 2;
+        p.PT = pt; p.ST = BM / pt;
+        p.log2ST = 0;
+        while ((1 << p.log2ST) < p.ST) ++p.log2ST;
+        p.n_sg = (int)((B + p.ST - 1) / p.ST);
+        p.sample_in = (int64_t)g.Fout * g.Tout * g.Cout;
+        const int S = g.axis == 0 ? g.Cout : g.Tout * g.Cout;
+        p.tap_stride = -(S / g.stride);
+        p.inv_n_in = 1.0;
+    }
     // per-tile A descriptor covers ST samples: must stay below the 2 GiB OOB marker
     if ((int64_t)p.ST * p.sample_in * 4 >= ((int64_t)1 << 31)) return NAFP_ERR_UNSUPPORTED;
     const int64_t wbytes = (int64_t)g.Cout * 3 * g.Cin * 4;
@@ -712,14 +762,14 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     static const int abl = []() { const char* e = getenv("NAFP_ABL"); return e ? atoi(e) : 0; }();
     p.abl = a.plain ? 0 : abl;
     const int n_pb = (p.P + p.PT - 1) / p.PT;
-    const int64_t n_tiles = (int64_t)p.n_sg * n_pb * (g.Cout / BN);
+    const int64_t n_tiles = (int64_t)p.n_sg * n_pb * (p.Cout / BN);
     int S = 1;
     if (!a.plain && a.slab && !a.f0_feat) {
         S = choose_split(n_tiles, live_k_steps(g), B * p.P * g.Cout);
         if ((int64_t)S * B * p.P * g.Cout > a.slab_floats) S = 1;
     }
     if (S > 1) { p.mode = 2; p.n_split = S; p.y = a.slab; p.bias = nullptr; }
-    const dim3 grid((unsigned)((int64_t)p.n_sg * n_pb), (unsigned)(g.Cout / BN), (unsigned)S);
+    const dim3 grid((unsigned)((int64_t)p.n_sg * n_pb), (unsigned)(p.Cout / BN), (unsigned)S);
     static const int variant = []() { const char* e = getenv("NAFP_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
     int rc;
     p.f0_feat = nullptr; p.f0_w = nullptr; p.f0_bias = nullptr; p.f0_gamma = nullptr;
@@ -743,7 +793,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     }
     if (rc != NAFP_OK || S == 1) return rc;
     splitk_finish_kernel<<<dim3((unsigned)(B * p.P)), 256, 0, st>>>(a.slab, S, a.G, a.Hb, a.gamma_out, a.stats_in,
-                                                                   a.stats_out, a.y, p.B, p.P, g.Cout, p.inv_n_in);
+                                                                   a.stats_out, a.y, a.v_out, p.B, p.P, g.Cout, p.inv_n_in);
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }

@@ -87,7 +87,7 @@ __device__ __forceinline__ void atomic_min_float(float* addr, float v) {
 // conv0: (B,F,T) x kernel(3,Cout) -> z0 = gamma0 . ELU(conv + bias), (B,F,Tout,Cout),
 // + per-sample sum/sumsq of the ELU output.
 int launch_conv0(const float* feat, const float* w3, const float* bias, const float* gamma, float* y,
-                 double* stats, int64_t B, const ConvGeom& g, hipStream_t st);
+                 float* v_out, double* stats, int64_t B, const ConvGeom& g, hipStream_t st);
 
 // implicit-GEMM conv (see conv.hip for the LayerNorm folding).
 struct ConvGemmArgs {
@@ -100,7 +100,9 @@ struct ConvGemmArgs {
     const double* stats_in;  // (B,2): sum, sumsq of the previous conv's ELU output   FULL
     double* stats_out;       // (B,2), must be zero on entry                          FULL
     float* y;                // (B,Fout,Tout,Cout): z = gamma_out . v (FULL) or acc + bias (PLAIN)
+    float* v_out;            // optional (FULL): v itself, kept for the backward pass
     bool plain;
+    bool dgrad;              // PLAIN only: y (B,Fin,Tin,Cin) = transposed conv of x = dT (B,Fout,Tout,Cout) with wp = (Cin, 3*Cout)
     float* slab;             // split-K partial sums workspace (or nullptr: never split)
     int64_t slab_floats;
     // optional: generate the A operand from the log-mel features (conv0 fused into conv1);

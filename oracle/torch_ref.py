@@ -46,21 +46,31 @@ def melspec_layer(x, group_size=None, segment_norm=False):
 class TorchFingerprinter:
     """Weights given in the keras shapes of oracle.nnfp.init_weights."""
 
-    def __init__(self, w, input_shape=(256, 32, 1)):
+    def __init__(self, w, input_shape=(256, 32, 1), dtype=torch.float32, requires_grad=False):
+        """`requires_grad=True` (use dtype=torch.float64): every parameter becomes a leaf in the
+        KERAS layout (self.params, ordered as include/nafp.h), so autograd yields the reference
+        gradients of the train step (trainer.py:43-47) for the backward-kernel parity tests."""
         self.geo = _nnfp.conv_geometry(input_shape)
+        self.dtype = dtype
+        self.params = []
+
+        def leaf(a):
+            t = torch.tensor(np.ascontiguousarray(a), dtype=dtype, requires_grad=requires_grad)
+            self.params.append(t)
+            return t
         self.k, self.b, self.g, self.bt = [], [], [], []
         for j, g in enumerate(self.geo):
-            k = torch.from_numpy(np.ascontiguousarray(w[f'conv{j}.kernel']))      # (kh,kw,Cin,Cout)
-            self.k.append(k.permute(3, 2, 0, 1).contiguous())                     # (Cout,Cin,kh,kw)
-            self.b.append(torch.from_numpy(w[f'conv{j}.bias']))
+            k = leaf(w[f'conv{j}.kernel'])                                         # (kh,kw,Cin,Cout)
+            self.k.append(k.permute(3, 2, 0, 1))                                   # (Cout,Cin,kh,kw)
+            self.b.append(leaf(w[f'conv{j}.bias']))
             # LN params (F,T,C) -> (C,F,T) for NCHW
-            self.g.append(torch.from_numpy(w[f'ln{j}.gamma']).permute(2, 0, 1).contiguous())
-            self.bt.append(torch.from_numpy(w[f'ln{j}.beta']).permute(2, 0, 1).contiguous())
-        self.w1 = torch.from_numpy(w['div.w1']); self.b1 = torch.from_numpy(w['div.b1'])
-        self.w2 = torch.from_numpy(w['div.w2']); self.b2 = torch.from_numpy(w['div.b2'])
+            self.g.append(leaf(w[f'ln{j}.gamma']).permute(2, 0, 1))
+            self.bt.append(leaf(w[f'ln{j}.beta']).permute(2, 0, 1))
+        self.w1 = leaf(w['div.w1']); self.b1 = leaf(w['div.b1'])
+        self.w2 = leaf(w['div.w2']); self.b2 = leaf(w['div.b2'])
 
     def front_conv(self, feat):
-        x = torch.as_tensor(feat, dtype=torch.float32).permute(0, 3, 1, 2)        # NCHW: (B,1,F,T)
+        x = torch.as_tensor(feat, dtype=self.dtype).permute(0, 3, 1, 2)           # NCHW: (B,1,F,T)
         for j, g in enumerate(self.geo):
             pb, pa = g['pad']
             if g['axis'] == 'T':
@@ -85,8 +95,9 @@ class TorchFingerprinter:
 
 def ntxent(emb_org, emb_rep, tau=0.05):
     """cross_entropy formulation of NTxent_loss_single_gpu.py:52-82."""
-    ha = torch.as_tensor(emb_org, dtype=torch.float64)
-    hb = torch.as_tensor(emb_rep, dtype=torch.float64)
+    ha = emb_org if torch.is_tensor(emb_org) else torch.as_tensor(emb_org, dtype=torch.float64)
+    hb = emb_rep if torch.is_tensor(emb_rep) else torch.as_tensor(emb_rep, dtype=torch.float64)
+    ha, hb = ha.double(), hb.double()
     n = ha.shape[0]
     mask = ~torch.eye(n, dtype=torch.bool)
     aa = (ha @ ha.T / tau)[mask].reshape(n, n - 1)
