@@ -132,6 +132,19 @@ int nafp_encoder_profile_enable(nafp_encoder* enc, int max_forwards);
 int nafp_encoder_profile_count(const nafp_encoder* enc);   /* forwards recorded so far */
 int nafp_encoder_profile_read(nafp_encoder* enc, int slot, float* ms_out_host);
 
+/* Training (model/trainer.py:41-47: emb = m_fp(feat) under tf.GradientTape, then
+ * tape.gradient(loss, m_fp.trainable_variables)).  forward_train is nafp_encoder_forward that
+ * keeps every activation in `workspace`; backward consumes the SAME workspace (untouched in
+ * between) and d_emb = dL/d(out_emb), and writes the 68 parameter gradients in the keras shapes
+ * and order of the parameter tensors (grads_host_array: host array of device pointers; the
+ * gradients are overwritten, not accumulated).  `feat` is the same (n_seg, in_f, in_t) input. */
+int64_t nafp_encoder_train_workspace_bytes(const nafp_encoder* enc, int64_t n_seg);
+int nafp_encoder_forward_train(nafp_encoder* enc, const float* feat, int64_t n_seg, void* workspace,
+                               int64_t workspace_bytes, float* out_emb, int l2norm, void* stream);
+int nafp_encoder_backward(nafp_encoder* enc, const float* feat, const float* d_emb, int64_t n_seg,
+                          void* workspace, int64_t workspace_bytes, float* const* grads_host_array,
+                          int l2norm, void* stream);
+
 /* Execution options of an encoder handle (results are identical either way).
  *   NAFP_OPT_FUSE_CONV0  0 (default): b0.conv1x3 writes its activation, b0.conv3x1 reads it back.
  *                        1: only conv0's LayerNorm statistics are computed up front and conv1

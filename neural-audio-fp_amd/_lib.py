@@ -44,6 +44,10 @@ PROTOTYPES = {
     'nafp_encoder_profile_count': (c_int, [c_void_p]),
     'nafp_encoder_profile_read': (c_int, [c_void_p, c_int, c_void_p]),
     'nafp_encoder_set_option': (c_int, [c_void_p, c_int, c_int]),
+    'nafp_encoder_train_workspace_bytes': (c_i64, [c_void_p, c_i64]),
+    'nafp_encoder_forward_train': (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p]),
+    'nafp_encoder_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64,
+                                      ctypes.POINTER(c_void_p), c_int, c_void_p]),
     'nafp_encoder_div_enc': (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_int, c_void_p]),
     'nafp_ntxent_workspace_bytes': (c_i64, [c_i64, c_i64]),
     'nafp_ntxent_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int,

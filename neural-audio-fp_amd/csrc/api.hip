@@ -47,6 +47,11 @@ struct nafp_encoder {
     std::vector<float*> d_bias, d_gamma, d_beta;
     std::vector<float*> d_G, d_Hb;        // per conv j >= 1: conv_j(gamma_{j-1}), conv_j(beta_{j-1}) + bias_j
     float *d_w1p = nullptr, *d_b1p = nullptr, *d_w2p = nullptr, *d_b2 = nullptr;
+    // training only: dgrad operand layout (Cin, 3*Cout) per conv j >= 1, keras-layout divide-and-encode
+    // weights for the tail backward, 1/n per layer for the statistics
+    std::vector<float*> d_wd;
+    float *d_w1k = nullptr, *d_b1k = nullptr, *d_w2k = nullptr;
+    double* d_inv_n = nullptr;
     bool has_weights = false;
     // NAFP_OPT_FUSE_CONV0 (default: NAFP_FUSE0 env, else off).  Measured at B = 640: conv0 0.35 ms +
     // conv1 1.17 ms materialised vs 0.17 ms (statistics pass) + 1.38 ms fused: the ELU evaluation is
@@ -113,6 +118,8 @@ extern "C" int nafp_encoder_create(nafp_encoder** out, int in_f, int in_t, int e
     int64_t total = 0;
     for (auto& s : e->shapes) total += (numel(s) + 63) / 64 * 64;      // 256-B aligned slots
     for (int j = 1; j < 16; ++j) total += 2 * ((numel(e->shapes[4 * j + 2]) + 63) / 64 * 64);   // G, Hb
+    for (int j = 1; j < 16; ++j) total += (numel(e->shapes[4 * j]) + 63) / 64 * 64;               // dgrad weights
+    total += (numel(e->shapes[64]) + 63) / 64 * 64 + 2 * ((numel(e->shapes[65]) + 63) / 64 * 64) + 64;   // keras div copies, inv_n
     e->blob_floats = total;
     hipError_t err = hipMalloc(&e->d_blob, sizeof(float) * total);
     if (err != hipSuccess) { g_last_hip_error = (int)err; delete e; return NAFP_ERR_HIP; }
@@ -127,6 +134,16 @@ extern "C" int nafp_encoder_create(nafp_encoder** out, int in_f, int in_t, int e
     e->d_w1p = take(64); e->d_b1p = take(65); e->d_w2p = take(66); e->d_b2 = take(67);
     e->d_G.push_back(nullptr); e->d_Hb.push_back(nullptr);
     for (int j = 1; j < 16; ++j) { e->d_G.push_back(take(4 * j + 2)); e->d_Hb.push_back(take(4 * j + 2)); }
+    e->d_wd.push_back(nullptr);
+    for (int j = 1; j < 16; ++j) e->d_wd.push_back(take(4 * j));
+    e->d_w1k = take(64); e->d_b1k = take(65); e->d_w2k = take(65);
+    e->d_inv_n = (double*)p; p += 64;
+    {
+        double inv_n[16];
+        for (int j = 0; j < 16; ++j) inv_n[j] = 1.0 / ((double)e->geom[j].Fout * e->geom[j].Tout * e->geom[j].Cout);
+        err = hipMemcpy(e->d_inv_n, inv_n, sizeof(inv_n), hipMemcpyHostToDevice);
+        if (err != hipSuccess) { g_last_hip_error = (int)err; (void)hipFree(e->d_blob); delete e; return NAFP_ERR_HIP; }
+    }
     for (int j = 0; j < 16; ++j) {
         const ConvGeom& g = e->geom[j];
         const int64_t n = (int64_t)g.Fout * g.Tout * g.Cout;
@@ -198,6 +215,13 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
         rc = launch_conv_gemm(a, 1, e->geom[j], st);
         if (rc != NAFP_OK) return rc;
     }
+    for (int j = 1; j < 16; ++j) {
+        int rcd = launch_pack_dgrad_weight(t[4 * j], e->d_wd[j], e->geom[j].Cin, e->geom[j].Cout, st);
+        if (rcd != NAFP_OK) return rcd;
+    }
+    NAFP_HIP_CHECK(hipMemcpyAsync(e->d_w1k, t[64], sizeof(float) * numel(e->shapes[64]), hipMemcpyDeviceToDevice, st));
+    NAFP_HIP_CHECK(hipMemcpyAsync(e->d_b1k, t[65], sizeof(float) * numel(e->shapes[65]), hipMemcpyDeviceToDevice, st));
+    NAFP_HIP_CHECK(hipMemcpyAsync(e->d_w2k, t[66], sizeof(float) * numel(e->shapes[66]), hipMemcpyDeviceToDevice, st));
     int rc = launch_pack_div(t[64], t[65], t[66], e->d_w1p, e->d_b1p, e->d_w2p, e->emb_sz, e->S, st);
     if (rc != NAFP_OK) return rc;
     NAFP_HIP_CHECK(hipMemcpyAsync(e->d_b2, t[67], sizeof(float) * e->emb_sz, hipMemcpyDeviceToDevice, st));
@@ -308,4 +332,141 @@ extern "C" int nafp_encoder_div_enc(nafp_encoder* e, const float* flat, int64_t 
     t.out_flat = nullptr; t.out_emb = out_emb;
     t.D = (int)e->flat_dim; t.Q = e->emb_sz; t.S = e->S; t.l2norm = l2norm;
     return launch_tail(t, n_seg, (hipStream_t)stream);
+}
+
+
+// ============================================================================================
+// Training: forward that keeps every activation, and the backward pass (model/trainer.py:41-47)
+// ============================================================================================
+namespace {
+struct TrainLayout {
+    int64_t B;
+    double* stats; float* mr; double* lnsum;
+    float* z[16]; float* v[16];
+    float* slab; int64_t slab_floats;
+    float* dA; float* dB; float* dS; float* S1; float* S2; float* dy;
+    int64_t bytes;
+};
+
+TrainLayout train_layout(const nafp_encoder* e, int64_t B, void* ws) {
+    TrainLayout L; L.B = B;
+    char* p = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    char* p0 = p;
+    auto take = [&](int64_t bytes) { char* r = p; p += (bytes + 255) / 256 * 256; return r; };
+    L.stats = (double*)take((int64_t)sizeof(double) * 2 * 16 * B);
+    L.mr = (float*)take((int64_t)sizeof(float) * 2 * 16 * B);
+    L.lnsum = (double*)take((int64_t)sizeof(double) * 2 * B);
+    int64_t max_n = 0;
+    for (int j = 0; j < 16; ++j) {
+        const int64_t n = (int64_t)e->geom[j].Fout * e->geom[j].Tout * e->geom[j].Cout;
+        max_n = std::max(max_n, n);
+        L.z[j] = (float*)take((int64_t)sizeof(float) * n * B);
+        L.v[j] = (float*)take((int64_t)sizeof(float) * n * B);
+    }
+    L.slab_floats = 0;
+    for (int j = 1; j < 16; ++j) L.slab_floats = std::max(L.slab_floats, conv_gemm_slab_floats(B, e->geom[j]));
+    L.slab = (float*)take((int64_t)sizeof(float) * L.slab_floats);
+    L.dA = (float*)take((int64_t)sizeof(float) * max_n * B);
+    L.dB = (float*)take((int64_t)sizeof(float) * max_n * B);
+    L.dS = (float*)take((int64_t)sizeof(float) * max_n * B);
+    L.S1 = (float*)take((int64_t)sizeof(float) * max_n);
+    L.S2 = (float*)take((int64_t)sizeof(float) * max_n);
+    L.dy = (float*)take((int64_t)sizeof(float) * e->emb_sz * B);
+    L.bytes = (p - p0) + 256;
+    return L;
+}
+}  // namespace
+
+extern "C" int64_t nafp_encoder_train_workspace_bytes(const nafp_encoder* e, int64_t n_seg) {
+    if (!e || n_seg < 0) return -1;
+    return train_layout(e, n_seg, nullptr).bytes;
+}
+
+extern "C" int nafp_encoder_forward_train(nafp_encoder* e, const float* feat, int64_t n_seg, void* workspace,
+                                          int64_t workspace_bytes, float* out_emb, int l2norm, void* stream) {
+    if (!e || !feat || !workspace || !out_emb || n_seg <= 0) return NAFP_ERR_INVALID_ARG;
+    if (!e->has_weights) return NAFP_ERR_NO_WEIGHTS;
+    if (workspace_bytes < nafp_encoder_train_workspace_bytes(e, n_seg)) return NAFP_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    TrainLayout L = train_layout(e, n_seg, workspace);
+    NAFP_HIP_CHECK(hipMemsetAsync(L.stats, 0, sizeof(double) * 2 * 16 * n_seg, st));
+    int rc = launch_conv0(feat, e->d_w[0], e->d_bias[0], e->d_gamma[0], L.z[0], L.v[0], L.stats, n_seg, e->geom[0], st);
+    if (rc != NAFP_OK) return rc;
+    for (int j = 1; j < 16; ++j) {
+        ConvGemmArgs a{};
+        a.x = L.z[j - 1]; a.stats_in = L.stats + 2 * n_seg * (j - 1);
+        a.wp = e->d_w[j]; a.G = e->d_G[j]; a.Hb = e->d_Hb[j]; a.gamma_out = e->d_gamma[j];
+        a.y = L.z[j]; a.v_out = L.v[j]; a.stats_out = L.stats + 2 * n_seg * j; a.plain = false;
+        a.slab = L.slab_floats ? L.slab : nullptr; a.slab_floats = L.slab_floats;
+        rc = launch_conv_gemm(a, n_seg, e->geom[j], st);
+        if (rc != NAFP_OK) return rc;
+    }
+    TailArgs t;
+    t.x = L.z[15]; t.stats = L.stats + 2 * n_seg * 15; t.gamma = e->d_gamma[15]; t.beta = e->d_beta[15];
+    t.w1p = e->d_w1p; t.b1p = e->d_b1p; t.w2p = e->d_w2p; t.b2 = e->d_b2;
+    t.out_flat = nullptr; t.out_emb = out_emb;
+    t.D = (int)e->flat_dim; t.Q = e->emb_sz; t.S = e->S; t.l2norm = l2norm;
+    return launch_tail(t, n_seg, st);
+}
+
+extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const float* d_emb, int64_t n_seg,
+                                     void* workspace, int64_t workspace_bytes, float* const* grads, int l2norm,
+                                     void* stream) {
+    if (!e || !feat || !d_emb || !workspace || !grads || n_seg <= 0) return NAFP_ERR_INVALID_ARG;
+    if (!e->has_weights) return NAFP_ERR_NO_WEIGHTS;
+    if (workspace_bytes < nafp_encoder_train_workspace_bytes(e, n_seg)) return NAFP_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t B = n_seg;
+    TrainLayout L = train_layout(e, B, workspace);
+    for (size_t i = 0; i < e->shapes.size(); ++i) {
+        if (!grads[i]) return NAFP_ERR_INVALID_ARG;
+        NAFP_HIP_CHECK(hipMemsetAsync(grads[i], 0, sizeof(float) * numel(e->shapes[i]), st));
+    }
+    int rc = launch_stats_to_mr(L.stats, L.mr, e->d_inv_n, B, 16, st);
+    if (rc != NAFP_OK) return rc;
+    // tail: d_emb -> dxhat of the last conv + divide-and-encode gradients
+    TailBwdArgs tb;
+    tb.z = L.z[15]; tb.stats = L.stats + 2 * B * 15; tb.gamma = e->d_gamma[15]; tb.beta = e->d_beta[15];
+    tb.w1 = e->d_w1k; tb.b1 = e->d_b1k; tb.w2 = e->d_w2k; tb.b2 = e->d_b2;
+    tb.d_emb = d_emb; tb.dy = L.dy; tb.dxh = L.dA;
+    tb.dw1 = grads[64]; tb.db1 = grads[65]; tb.dw2 = grads[66]; tb.db2 = grads[67];
+    tb.D = (int)e->flat_dim; tb.Q = e->emb_sz; tb.S = e->S; tb.l2norm = l2norm;
+    rc = launch_tail_bwd(tb, B, st);
+    if (rc != NAFP_OK) return rc;
+    float* cur = L.dA; float* other = L.dB;
+    for (int j = 15; j >= 1; --j) {
+        const ConvGeom& g = e->geom[j];
+        const int P = g.Fout * g.Tout;
+        const int64_t n = (int64_t)P * g.Cout;
+        const float* mr_j = L.mr + 2 * B * j; const float* mr_p = L.mr + 2 * B * (j - 1);
+        rc = launch_ln_bwd(cur, L.v[j], e->d_gamma[j], mr_j, mr_p, L.lnsum, grads[4 * j + 2], grads[4 * j + 3], L.dS,
+                           grads[4 * j + 1], B, P, g.Cout, st);
+        if (rc != NAFP_OK) return rc;
+        // dW_j = wgrad(z_{j-1}, r dt) + wgrad(gamma_{j-1}, sum_b c_b dt) + wgrad(beta_{j-1}, sum_b dt)
+        NAFP_HIP_CHECK(hipMemsetAsync(L.S1, 0, sizeof(float) * n, st));
+        NAFP_HIP_CHECK(hipMemsetAsync(L.S2, 0, sizeof(float) * n, st));
+        rc = launch_batch_reduce(cur, mr_p, L.S1, L.S2, n, B, st);
+        if (rc != NAFP_OK) return rc;
+        rc = launch_wgrad(L.z[j - 1], L.dS, grads[4 * j], B, g, st);
+        if (rc != NAFP_OK) return rc;
+        rc = launch_wgrad(e->d_gamma[j - 1], L.S1, grads[4 * j], 1, g, st);
+        if (rc != NAFP_OK) return rc;
+        rc = launch_wgrad(e->d_beta[j - 1], L.S2, grads[4 * j], 1, g, st);
+        if (rc != NAFP_OK) return rc;
+        // dxhat_{j-1} = transposed conv of dt_j
+        ConvGemmArgs a{};
+        a.x = cur; a.wp = e->d_wd[j]; a.y = other; a.plain = true; a.dgrad = true;
+        rc = launch_conv_gemm(a, B, g, st);
+        if (rc != NAFP_OK) return rc;
+        std::swap(cur, other);
+    }
+    {
+        const ConvGeom& g = e->geom[0];
+        rc = launch_ln_bwd(cur, L.v[0], e->d_gamma[0], L.mr, nullptr, L.lnsum, grads[2], grads[3], nullptr, grads[1], B,
+                           g.Fout * g.Tout, g.Cout, st);
+        if (rc != NAFP_OK) return rc;
+        rc = launch_conv0_bwd(feat, cur, grads[0], nullptr, B, g, st);
+        if (rc != NAFP_OK) return rc;
+    }
+    return NAFP_OK;
 }

@@ -1,0 +1,528 @@
+// Backward pass of the encoder for gfx950 (train step, model/trainer.py:41-48: the reference
+// gets these gradients from tf.GradientTape over m_fp).
+//
+// Per conv layer j the forward graph is  t = conv_j(xhat_{j-1}) + bias,  v = ELU(t),
+// xt = (v - mu_b) r_b,  xhat_j = xt*gamma_j + beta_j  (LayerNorm over (F,T,C) per sample).
+// Given dxh = dL/dxhat_j the kernels here produce
+//   ln_bwd_reduce   s1_b = sum g, s2_b = sum g*xt            (g = dxh*gamma)
+//   ln_bwd_param    dgamma = sum_b dxh*xt, dbeta = sum_b dxh
+//   ln_bwd_apply    dt = r_b (g - s1/n - xt*s2/n) * ELU'(v)  [in place], dts = r_{j-1,b} * dt, dbias
+//   batch_reduce    S1 = sum_b c_{j-1,b} dt, S2 = sum_b dt   (c = -mu r of the layer below)
+//   wgrad           dW_j[tap,c,n] += sum_{b,pos} X[b, in(pos,tap), c] * D[b,pos,n]   (fp32 MFMA)
+// and the transposed conv (dgrad) comes from conv_gemm in DGRAD mode.  With the LayerNorm fold
+// of the forward pass, xhat_{j-1} = r z + c gamma + beta, so
+//   dW_j = wgrad(z_{j-1}, dts_j) + wgrad(gamma_{j-1}, S1_j) + wgrad(beta_{j-1}, S2_j)
+// -- the first term streams the stored z tiles raw (DMA), the other two are one-sample problems.
+#include "nafp_common.h"
+
+#include <algorithm>
+
+namespace nafp {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// (mean, rstd) per sample and layer from the double (sum, sumsq) statistics.
+__global__ void stats_to_mr_kernel(const double* __restrict__ stats, float* __restrict__ mr, int64_t n_pairs,
+                                   const double* __restrict__ inv_n_per_layer, int64_t B) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    const double inv_n = inv_n_per_layer[i / B];
+    const double mean = stats[2 * i] * inv_n;
+    double var = stats[2 * i + 1] * inv_n - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    mr[2 * i] = (float)mean;
+    mr[2 * i + 1] = (float)(1.0 / sqrt(var + (double)LN_EPS));
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(
+        const float* __restrict__ dxh, const float* __restrict__ v, const float* __restrict__ gamma,
+        const float* __restrict__ mr, double* __restrict__ lnsum, int64_t n) {
+    const int64_t b = blockIdx.y;
+    const float mean = mr[2 * b], rstd = mr[2 * b + 1];
+    const float4* d4 = (const float4*)(dxh + b * n);
+    const float4* v4 = (const float4*)(v + b * n);
+    const float4* g4 = (const float4*)gamma;
+    float s1 = 0.f, s2 = 0.f;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n / 4; i += (int64_t)gridDim.x * 256) {
+        const float4 d = d4[i], vv = v4[i], gg = g4[i];
+        const float g0 = d.x * gg.x, g1 = d.y * gg.y, g2 = d.z * gg.z, g3 = d.w * gg.w;
+        s1 += (g0 + g1) + (g2 + g3);
+        s2 += g0 * ((vv.x - mean) * rstd) + g1 * ((vv.y - mean) * rstd) + g2 * ((vv.z - mean) * rstd) +
+              g3 * ((vv.w - mean) * rstd);
+    }
+    const double d1 = wave_sum((double)s1), d2 = wave_sum((double)s2);
+    __shared__ double red[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave] = d1; red[4 + wave] = d2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(lnsum + 2 * b, red[0] + red[1] + red[2] + red[3]);
+        atomicAdd(lnsum + 2 * b + 1, red[4] + red[5] + red[6] + red[7]);
+    }
+}
+
+// dgamma[e] += sum_{b in chunk} dxh*xt, dbeta[e] += sum dxh.  grid.y splits the batch.
+__global__ __launch_bounds__(256) void ln_bwd_param_kernel(
+        const float* __restrict__ dxh, const float* __restrict__ v, const float* __restrict__ mr,
+        float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t n, int64_t B) {
+    const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= n / 4) return;
+    const int64_t per = (B + gridDim.y - 1) / gridDim.y;
+    const int64_t b0 = blockIdx.y * per, b1 = std::min<int64_t>(B, b0 + per);
+    float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag;
+    for (int64_t b = b0; b < b1; ++b) {
+        const float mean = mr[2 * b], rstd = mr[2 * b + 1];
+        const float4 d = ((const float4*)(dxh + b * n))[i], vv = ((const float4*)(v + b * n))[i];
+        ag.x += d.x * ((vv.x - mean) * rstd); ag.y += d.y * ((vv.y - mean) * rstd);
+        ag.z += d.z * ((vv.z - mean) * rstd); ag.w += d.w * ((vv.w - mean) * rstd);
+        ab.x += d.x; ab.y += d.y; ab.z += d.z; ab.w += d.w;
+    }
+    float* g = dgamma + 4 * i; float* bt = dbeta + 4 * i;
+    atomicAdd(g, ag.x); atomicAdd(g + 1, ag.y); atomicAdd(g + 2, ag.z); atomicAdd(g + 3, ag.w);
+    atomicAdd(bt, ab.x); atomicAdd(bt + 1, ab.y); atomicAdd(bt + 2, ab.z); atomicAdd(bt + 3, ab.w);
+}
+
+// dt (in place over dxh), dts = r_prev * dt (optional), dbias[c] += sum dt.
+// One workgroup = R positions of one sample; thread <-> fixed float4 channel group.
+__global__ __launch_bounds__(256) void ln_bwd_apply_kernel(
+        float* __restrict__ dxh, const float* __restrict__ v, const float* __restrict__ gamma,
+        const float* __restrict__ mr, const double* __restrict__ lnsum, const float* __restrict__ mr_prev,
+        float* __restrict__ dts, float* __restrict__ dbias, int P, int C, int R) {
+    const int64_t b = blockIdx.y;
+    const int64_t n = (int64_t)P * C;
+    const float mean = mr[2 * b], rstd = mr[2 * b + 1];
+    const float m1 = (float)(lnsum[2 * b] / (double)n), m2 = (float)(lnsum[2 * b + 1] / (double)n);
+    const float rprev = mr_prev ? mr_prev[2 * b + 1] : 0.f;
+    const int cg = C / 4, rows_per_iter = 256 / cg;
+    const int my_cg = threadIdx.x % cg, my_row = threadIdx.x / cg;
+    const int p0 = blockIdx.x * R, p1 = min(P, p0 + R);
+    float4 db = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int pp = p0 + my_row; pp < p1; pp += rows_per_iter) {
+        const int64_t e = (int64_t)pp * C + 4 * my_cg;
+        const float4 d = *(const float4*)(dxh + b * n + e), vv = *(const float4*)(v + b * n + e);
+        const float4 gg = *(const float4*)(gamma + e);
+        float4 o;
+#define NAFP_LN_ONE(c_)                                                                  \
+        {                                                                                \
+            const float xt = (vv.c_ - mean) * rstd;                                      \
+            const float dv = rstd * (d.c_ * gg.c_ - m1 - xt * m2);                       \
+            o.c_ = dv * (vv.c_ > 0.f ? 1.f : vv.c_ + 1.f);      /* ELU'(t) = exp(t) = v + 1 for t <= 0 */ \
+        }
+        NAFP_LN_ONE(x) NAFP_LN_ONE(y) NAFP_LN_ONE(z) NAFP_LN_ONE(w)
+#undef NAFP_LN_ONE
+        *(float4*)(dxh + b * n + e) = o;
+        if (dts) *(float4*)(dts + b * n + e) = make_float4(o.x * rprev, o.y * rprev, o.z * rprev, o.w * rprev);
+        db.x += o.x; db.y += o.y; db.z += o.z; db.w += o.w;
+    }
+    __shared__ float4 red[256];
+    red[threadIdx.x] = db;
+    __syncthreads();
+    if (threadIdx.x < cg) {
+        float4 t = red[threadIdx.x];
+        for (int r = 1; r < rows_per_iter; ++r) {
+            const float4 u = red[threadIdx.x + r * cg];
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        float* o = dbias + 4 * threadIdx.x;
+        atomicAdd(o, t.x); atomicAdd(o + 1, t.y); atomicAdd(o + 2, t.z); atomicAdd(o + 3, t.w);
+    }
+}
+
+// S1[e] += sum_b c_b * dt[b,e], S2[e] += sum_b dt[b,e]  with c_b = -mean_b * rstd_b of the layer below.
+__global__ __launch_bounds__(256) void batch_reduce_kernel(
+        const float* __restrict__ dt, const float* __restrict__ mr_prev, float* __restrict__ S1,
+        float* __restrict__ S2, int64_t n, int64_t B) {
+    const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= n / 4) return;
+    const int64_t per = (B + gridDim.y - 1) / gridDim.y;
+    const int64_t b0 = blockIdx.y * per, b1 = std::min<int64_t>(B, b0 + per);
+    float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
+    for (int64_t b = b0; b < b1; ++b) {
+        const float c = -mr_prev[2 * b] * mr_prev[2 * b + 1];
+        const float4 d = ((const float4*)(dt + b * n))[i];
+        a1.x += c * d.x; a1.y += c * d.y; a1.z += c * d.z; a1.w += c * d.w;
+        a2.x += d.x; a2.y += d.y; a2.z += d.z; a2.w += d.w;
+    }
+    float* o1 = S1 + 4 * i; float* o2 = S2 + 4 * i;
+    atomicAdd(o1, a1.x); atomicAdd(o1 + 1, a1.y); atomicAdd(o1 + 2, a1.z); atomicAdd(o1 + 3, a1.w);
+    atomicAdd(o2, a2.x); atomicAdd(o2 + 1, a2.y); atomicAdd(o2 + 2, a2.z); atomicAdd(o2 + 3, a2.w);
+}
+
+// ============================================================================
+// wgrad: dW[tap, c, n] += sum_{rows m = (b,pos)} X[b, in(pos,tap), c] * D[m, n]      fp32 MFMA
+//   workgroup tile = 128 c x 128 n for ONE tap, over a chunk of rows (split-K over the rows);
+//   K-step = 16 rows: X rows (128 floats) and D rows (128 floats) are staged by LDS-DMA exactly
+//   as they lie in memory (row-contiguous), and the MFMA operands are read ALONG the rows
+//   (lane <-> c resp. n), so no transpose and no swizzle is needed.  Padding taps and rows
+//   beyond the batch are out-of-range DMA lanes (zeros).  Partial sums of the row chunks meet in
+//   dW (keras layout, n contiguous across lanes) through fp32 atomics.
+// ============================================================================
+typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u32x4b make_rsrc_b(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    u32x4b r;
+    r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+    r.z = __builtin_amdgcn_readfirstlane(bytes);
+    r.w = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ void lds_dma16_b(unsigned lds_addr, unsigned voff, u32x4b rsrc, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 4\n\t"
+                 "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+struct WgradParams {
+    const float* X; const float* D; float* dW;
+    int B, P, Tout, Fin, Tin, Cin, Cout, axis, stride, pad;
+    long long sample_in;
+    int rows_per_wg;
+};
+
+__global__ __launch_bounds__(256, 3) void wgrad_kernel(const WgradParams p) {
+    constexpr int NST = 3, KR = 16;
+    constexpr int TILE = KR * 128, STAGE = 2 * TILE;           // X rows | D rows
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave >> 1, wn = wave & 1;
+    const int ctiles = p.Cin / 128;
+    const int tap = blockIdx.z / ctiles, c0 = (blockIdx.z % ctiles) * 128, n0 = blockIdx.y * 128;
+    const long long M = (long long)p.B * p.P;
+    const long long m0 = (long long)blockIdx.x * p.rows_per_wg;
+    const long long m_end = std::min<long long>(M, m0 + p.rows_per_wg);
+    const int n_steps = (int)((m_end - m0 + KR - 1) / KR);
+    const int b_first = (int)(m0 / p.P);
+
+    // this lane's DMA rows: instruction i (0,1) of wave w covers rows 4w + 2i + (lane>>5).
+    // (b, pos) of those rows are carried from step to step (no division in the loop); scalars and
+    // a macro rather than arrays captured by a lambda, which hipcc would place in scratch.
+    const int q16 = KR / p.P, r16 = KR % p.P;
+    const long long mA = m0 + 4 * wave + (lane >> 5), mB = mA + 2;
+    int rbA = (int)(mA / p.P), rposA = (int)(mA - (long long)rbA * p.P);
+    int rbB = (int)(mB / p.P), rposB = (int)(mB - (long long)rbB * p.P);
+    const int chunk = lane & 31;
+    const long long x_bytes = ((long long)(m_end - 1) / p.P - b_first + 1) * p.sample_in * 4;
+    const u32x4b rsX = make_rsrc_b(p.X + (long long)b_first * p.sample_in, (unsigned)std::min<long long>(x_bytes, 0x7fffffffll));
+    const u32x4b rsD = make_rsrc_b(p.D + m0 * p.Cout, (unsigned)((m_end - m0) * p.Cout * 4));
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
+
+#define NAFP_WG_DMA_ROW(i_, RB, RPOS, s_, slot_)                                                       \
+    {                                                                                                   \
+        const int r_l = 4 * wave + 2 * (i_);                   /* wave-uniform first row */             \
+        const long long m_l = m0 + (long long)(s_) * KR + r_l + (lane >> 5);                            \
+        unsigned vx_l = OOB, vd_l = OOB;                                                                \
+        if (m_l < m_end) {                                                                              \
+            const int fo_l = RPOS / p.Tout, to_l = RPOS - fo_l * p.Tout;                                \
+            int src_l; bool ok_l;                                                                       \
+            if (p.axis == 0) { const int t_l = to_l * p.stride - p.pad + tap; ok_l = t_l >= 0 && t_l < p.Tin; src_l = (fo_l * p.Tin + t_l) * p.Cin; } \
+            else             { const int f_l = fo_l * p.stride - p.pad + tap; ok_l = f_l >= 0 && f_l < p.Fin; src_l = (f_l * p.Tin + to_l) * p.Cin; } \
+            if (ok_l) vx_l = (unsigned)(((long long)(RB - b_first) * p.sample_in + src_l + c0 + 4 * chunk) * 4); \
+            vd_l = (unsigned)((((long long)(s_) * KR + r_l + (lane >> 5)) * p.Cout + n0 + 4 * chunk) * 4); \
+        }                                                                                               \
+        const unsigned la_l = lds0 + (unsigned)(((slot_) * STAGE + r_l * 128) * 4);                     \
+        lds_dma16_b(la_l, vx_l, rsX, 0u);                                                               \
+        lds_dma16_b(la_l + TILE * 4, vd_l, rsD, 0u);                                                    \
+        RB += q16; RPOS += r16;                                /* advance by KR rows */                 \
+        if (RPOS >= p.P) { RPOS -= p.P; RB += 1; }                                                      \
+    }
+#define NAFP_WG_DMA_STEP(s_, slot_) { NAFP_WG_DMA_ROW(0, rbA, rposA, s_, slot_) NAFP_WG_DMA_ROW(1, rbB, rposB, s_, slot_) }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ci][ni][r] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < n_steps) NAFP_WG_DMA_STEP(s, s)
+
+    const int rl = lane & 31, hh = lane >> 5;
+    int slot = 0;
+    for (int s = 0; s < n_steps; ++s) {
+        if (s + NST - 2 >= n_steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // one younger step (4 DMA) may stay in flight
+        __builtin_amdgcn_s_barrier();
+        if (s + NST - 1 < n_steps) {
+            int nslot = slot + NST - 1; if (nslot >= NST) nslot -= NST;
+            NAFP_WG_DMA_STEP(s + NST - 1, nslot)
+        }
+        const float* Xt = smem + slot * STAGE;
+        const float* Dt = Xt + TILE;
+#pragma unroll
+        for (int kp = 0; kp < KR / 2; ++kp) {
+            float a[2], bq[2];
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) a[ci] = Xt[(2 * kp + hh) * 128 + wc * 64 + ci * 32 + rl];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) bq[ni] = Dt[(2 * kp + hh) * 128 + wn * 64 + ni * 32 + rl];
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[ci][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ci], bq[ni], acc[ci][ni], 0, 0, 0);
+        }
+        if (++slot == NST) slot = 0;
+    }
+    // D[i = c][j = n]: lane holds n = lane & 31, rows c = (r&3) + 8(r>>2) + 4*hh
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = c0 + wc * 64 + ci * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const int n = n0 + wn * 64 + ni * 32 + rl;
+                atomicAdd(p.dW + ((long long)tap * p.Cin + c) * p.Cout + n, acc[ci][ni][r]);
+            }
+}
+
+int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const ConvGeom& g, hipStream_t st) {
+    if (g.Cin % 128 != 0 || g.Cout % 128 != 0) return NAFP_ERR_UNSUPPORTED;
+    WgradParams p;
+    p.X = X; p.D = D; p.dW = dW; p.B = (int)B; p.P = g.Fout * g.Tout; p.Tout = g.Tout;
+    p.Fin = g.Fin; p.Tin = g.Tin; p.Cin = g.Cin; p.Cout = g.Cout; p.axis = g.axis; p.stride = g.stride; p.pad = g.pad;
+    p.sample_in = (long long)g.Fin * g.Tin * g.Cin;
+    const long long M = (long long)B * p.P;
+    const int col_tiles = (g.Cout / 128) * (3 * g.Cin / 128);
+    long long chunks = std::max<long long>(1, 1536 / col_tiles);
+    long long rpw = (M + chunks - 1) / chunks;
+    rpw = std::max<long long>(64, (rpw + 15) / 16 * 16);
+    // the X descriptor of a workgroup spans (rows/P + 2) samples: keep it below 2 GiB
+    while (rpw > 64 && (rpw / p.P + 2) * p.sample_in * 4 >= (1ll << 31)) rpw = std::max<long long>(64, rpw / 2 / 16 * 16);
+    p.rows_per_wg = (int)rpw;
+    const unsigned gx = (unsigned)((M + rpw - 1) / rpw);
+    static bool attr = false;
+    const int lds = 3 * 2 * 16 * 128 * (int)sizeof(float);
+    if (!attr) {
+        NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
+    }
+    wgrad_kernel<<<dim3(gx, g.Cout / 128, 3 * g.Cin / 128), 256, lds, st>>>(p);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}
+
+// ============================================================================
+// conv0 backward: dW0[k][c] = sum feat[b, f, t*s - p + k] * dt0[b,f,t,c], dbias0[c] = sum dt0.
+// ============================================================================
+__global__ __launch_bounds__(256) void conv0_bwd_kernel(
+        const float* __restrict__ feat, const float* __restrict__ dt, float* __restrict__ dW0,
+        float* __restrict__ dbias0, int F, int Tin, int Tout, int Cout, int stride, int pad, int rows) {
+    const int tid = threadIdx.x;
+    const int blocks_per_sample = (F + rows - 1) / rows;
+    const int64_t b = blockIdx.x / blocks_per_sample;
+    const int f0 = (blockIdx.x % blocks_per_sample) * rows;
+    const int cgroups = Cout / 4, pos_per_iter = 256 / cgroups;
+    const int cg = tid % cgroups, pslot = tid / cgroups;
+    const int nrows = min(rows, F - f0), npos = nrows * Tout;
+    const float* xin = feat + (b * F + f0) * (int64_t)Tin;
+    const float* din = dt + ((b * F + f0) * (int64_t)Tout) * Cout;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, ab = a0;
+    for (int pp = pslot; pp < npos; pp += pos_per_iter) {
+        const int r = pp / Tout, to = pp % Tout;
+        const int t0 = to * stride - pad;
+        const float* xr = xin + r * Tin;
+        const float x0 = (t0 >= 0 && t0 < Tin) ? xr[t0] : 0.f;
+        const float x1 = (t0 + 1 >= 0 && t0 + 1 < Tin) ? xr[t0 + 1] : 0.f;
+        const float x2 = (t0 + 2 >= 0 && t0 + 2 < Tin) ? xr[t0 + 2] : 0.f;
+        const float4 d = *(const float4*)(din + (int64_t)pp * Cout + 4 * cg);
+        a0.x += x0 * d.x; a0.y += x0 * d.y; a0.z += x0 * d.z; a0.w += x0 * d.w;
+        a1.x += x1 * d.x; a1.y += x1 * d.y; a1.z += x1 * d.z; a1.w += x1 * d.w;
+        a2.x += x2 * d.x; a2.y += x2 * d.y; a2.z += x2 * d.z; a2.w += x2 * d.w;
+        ab.x += d.x; ab.y += d.y; ab.z += d.z; ab.w += d.w;
+    }
+    __shared__ float4 red[4][256];
+    red[0][tid] = a0; red[1][tid] = a1; red[2][tid] = a2; red[3][tid] = ab;
+    __syncthreads();
+    if (tid < cgroups) {
+        for (int k = 0; k < 4; ++k) {
+            float4 t = red[k][tid];
+            for (int r = 1; r < pos_per_iter; ++r) {
+                const float4 u = red[k][tid + r * cgroups];
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            if (k == 3 && !dbias0) continue;
+            float* o = (k < 3 ? dW0 + k * Cout : dbias0) + 4 * tid;
+            atomicAdd(o, t.x); atomicAdd(o + 1, t.y); atomicAdd(o + 2, t.z); atomicAdd(o + 3, t.w);
+        }
+    }
+}
+
+// ============================================================================
+// tail backward: L2 normalisation, divide-and-encode, flatten (nnfp.py:141-156, 224-231).
+//   kernel A (one workgroup per segment, thread <-> slice q): dy, then dxhat of the last conv;
+//   kernel B (one workgroup per slice, thread <-> (i, j)): batch-reduced weight gradients,
+//   deterministic (fixed order over the batch).
+// ============================================================================
+template <int S>
+__device__ __forceinline__ void tail_slice_forward(const TailBwdArgs& a, int64_t b, int q, float lnA, float lnC,
+                                                   float (&x)[S], float (&act)[32], float& y) {
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        const int d = q * S + i;
+        x[i] = fmaf(lnA, a.z[b * a.D + d], fmaf(lnC, a.gamma[d], a.beta[d]));
+    }
+    y = a.b2[q];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        float h = a.b1[q * 32 + j];
+#pragma unroll
+        for (int i = 0; i < S; ++i) h = fmaf(x[i], a.w1[(q * S + i) * 32 + j], h);
+        act[j] = h;                                              // pre-activation
+        y = fmaf(elu1(h), a.w2[q * 32 + j], y);
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void tail_bwd_a_kernel(const TailBwdArgs a) {
+    const int q = threadIdx.x, Q = a.Q;
+    const int64_t b = blockIdx.x;
+    const double mean = a.stats[2 * b] / (double)a.D;
+    double var = a.stats[2 * b + 1] / (double)a.D - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
+    const float lnA = (float)rstd, lnC = (float)(-mean * rstd);
+    float x[S], act[32], y;
+    tail_slice_forward<S>(a, b, q, lnA, lnC, x, act, y);
+    float dyq = a.d_emb[b * Q + q];
+    if (a.l2norm) {
+        __shared__ float red[2][8];
+        const float ss = wave_sum(y * y), sd = wave_sum(y * dyq);
+        if ((q & 63) == 0) { red[0][q >> 6] = ss; red[1][q >> 6] = sd; }
+        __syncthreads();
+        float n2 = 0.f, yd = 0.f;
+        for (int w = 0; w < (Q + 63) / 64; ++w) { n2 += red[0][w]; yd += red[1][w]; }
+        // e = y * rn, rn = rsqrt(max(n2, eps)); d/dy: rn*de - (n2 > eps) * y * rn^3 * (y.de)
+        const float rn = rsqrtf(fmaxf(n2, 1e-12f));
+        dyq = rn * dyq - (n2 > 1e-12f ? y * rn * rn * rn * yd : 0.f);
+    }
+    a.dy[b * Q + q] = dyq;
+    float dx[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) dx[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const float h = act[j];
+        const float da = dyq * a.w2[q * 32 + j] * (h > 0.f ? 1.f : __expf(h));
+#pragma unroll
+        for (int i = 0; i < S; ++i) dx[i] = fmaf(a.w1[(q * S + i) * 32 + j], da, dx[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < S; ++i) a.dxh[b * a.D + q * S + i] = dx[i];
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void tail_bwd_b_kernel(const TailBwdArgs a, int64_t B) {
+    const int q = blockIdx.x;
+    const int j = threadIdx.x & 31, i = threadIdx.x >> 5;         // 32 x 8 threads; i < S computes dw1[q][i][j]
+    float aw1 = 0.f, ab1 = 0.f, aw2 = 0.f, ab2 = 0.f;
+    for (int64_t b = 0; b < B; ++b) {
+        const double mean = a.stats[2 * b] / (double)a.D;
+        double var = a.stats[2 * b + 1] / (double)a.D - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
+        const float lnA = (float)rstd, lnC = (float)(-mean * rstd);
+        float x[S];
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            const int d = q * S + k;
+            x[k] = fmaf(lnA, a.z[b * a.D + d], fmaf(lnC, a.gamma[d], a.beta[d]));
+        }
+        float h = a.b1[q * 32 + j];
+#pragma unroll
+        for (int k = 0; k < S; ++k) h = fmaf(x[k], a.w1[(q * S + k) * 32 + j], h);
+        const float dyq = a.dy[b * a.Q + q];
+        const float da = dyq * a.w2[q * 32 + j] * (h > 0.f ? 1.f : __expf(h));
+        float xi = 0.f;
+#pragma unroll
+        for (int k = 0; k < S; ++k) xi = (k == i) ? x[k] : xi;
+        aw1 += xi * da;
+        ab1 += da;
+        aw2 += dyq * elu1(h);
+        ab2 += dyq;
+    }
+    if (i < S) a.dw1[(q * S + i) * 32 + j] = aw1;
+    if (i == 0) { a.db1[q * 32 + j] = ab1; a.dw2[q * 32 + j] = aw2; }
+    if (threadIdx.x == 0) a.db2[q] = ab2;
+}
+
+int launch_tail_bwd(const TailBwdArgs& a, int64_t B, hipStream_t st) {
+    if (a.S != 8 || a.Q % 64 != 0 || a.Q > 256) return NAFP_ERR_UNSUPPORTED;
+    tail_bwd_a_kernel<8><<<dim3((unsigned)B), a.Q, 0, st>>>(a);
+    NAFP_LAUNCH_CHECK();
+    tail_bwd_b_kernel<8><<<dim3((unsigned)a.Q), 256, 0, st>>>(a, B);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}
+
+// keras kernel (3, Cin, Cout) -> dgrad operand (Cin, 3*Cout): Wd[c][k*Cout + n] = W[k][c][n]
+__global__ void pack_dgrad_weight_kernel(const float* __restrict__ k3, float* __restrict__ wd, int Cin, int Cout) {
+    const int64_t total = (int64_t)3 * Cin * Cout;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int n = (int)(i % Cout);
+        const int64_t r = i / Cout;
+        const int c = (int)(r % Cin), k = (int)(r / Cin);
+        wd[((int64_t)c * 3 + k) * Cout + n] = k3[i];
+    }
+}
+
+// ---- host launch helpers used by api.hip -------------------------------------------------
+int launch_stats_to_mr(const double* stats, float* mr, const double* inv_n_dev, int64_t B, int n_layers, hipStream_t st) {
+    const int64_t n = (int64_t)n_layers * B;
+    stats_to_mr_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(stats, mr, n, inv_n_dev, B);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}
+
+int launch_ln_bwd(float* dxh, const float* v, const float* gamma, const float* mr, const float* mr_prev,
+                  double* lnsum, float* dgamma, float* dbeta, float* dts, float* dbias, int64_t B, int P, int C,
+                  hipStream_t st) {
+    const int64_t n = (int64_t)P * C;
+    if (C % 4 != 0 || 256 % (C / 4) != 0 || n % 4 != 0) return NAFP_ERR_UNSUPPORTED;
+    NAFP_HIP_CHECK(hipMemsetAsync(lnsum, 0, sizeof(double) * 2 * B, st));
+    const int chunks = (int)std::min<int64_t>(std::max<int64_t>(1, n / 4 / 2048), 64);
+    ln_bwd_reduce_kernel<<<dim3(chunks, (unsigned)B), 256, 0, st>>>(dxh, v, gamma, mr, lnsum, n);
+    NAFP_LAUNCH_CHECK();
+    const int by = (int)std::min<int64_t>(B, n >= (1 << 16) ? 4 : 16);
+    ln_bwd_param_kernel<<<dim3((unsigned)((n / 4 + 255) / 256), by), 256, 0, st>>>(dxh, v, mr, dgamma, dbeta, n, B);
+    NAFP_LAUNCH_CHECK();
+    const int R = std::max(1, 16384 / C);
+    ln_bwd_apply_kernel<<<dim3((unsigned)((P + R - 1) / R), (unsigned)B), 256, 0, st>>>(dxh, v, gamma, mr, lnsum, mr_prev, dts,
+                                                                                       dbias, P, C, R);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}
+
+int launch_batch_reduce(const float* dt, const float* mr_prev, float* S1, float* S2, int64_t n, int64_t B, hipStream_t st) {
+    const int by = (int)std::min<int64_t>(B, n >= (1 << 16) ? 4 : 16);
+    batch_reduce_kernel<<<dim3((unsigned)((n / 4 + 255) / 256), by), 256, 0, st>>>(dt, mr_prev, S1, S2, n, B);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}
+
+int launch_conv0_bwd(const float* feat, const float* dt, float* dW0, float* dbias0, int64_t B, const ConvGeom& g,
+                     hipStream_t st) {
+    if (g.Cin != 1 || g.axis != 0 || (g.Cout % 4) != 0 || 256 % (g.Cout / 4) != 0) return NAFP_ERR_UNSUPPORTED;
+    const int rows = 32;
+    const int64_t blocks = B * ((g.Fin + rows - 1) / rows);
+    conv0_bwd_kernel<<<dim3((unsigned)blocks), 256, 0, st>>>(feat, dt, dW0, dbias0, g.Fin, g.Tin, g.Tout, g.Cout,
+                                                            g.stride, g.pad, rows);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}
+
+int launch_pack_dgrad_weight(const float* k3, float* wd, int Cin, int Cout, hipStream_t st) {
+    pack_dgrad_weight_kernel<<<256, 256, 0, st>>>(k3, wd, Cin, Cout);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}
+
+}  // namespace nafp

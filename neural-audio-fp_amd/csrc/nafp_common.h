@@ -132,6 +132,29 @@ struct TailArgs {
 };
 int launch_tail(const TailArgs& a, int64_t B, hipStream_t st);
 
+// ---- backward pass (backward.hip) ----------------------------------------------------------
+struct TailBwdArgs {
+    const float* z; const double* stats; const float* gamma; const float* beta;     // last conv (z = gamma . v)
+    const float* w1; const float* b1; const float* w2; const float* b2;             // keras layouts
+    const float* d_emb;                                                             // (B,Q)
+    float* dy;            // (B,Q) scratch
+    float* dxh;           // (B,D) out: dL/dxhat of the last conv
+    float* dw1; float* db1; float* dw2; float* db2;                                 // keras layouts, out
+    int D, Q, S, l2norm;
+};
+int launch_tail_bwd(const TailBwdArgs& a, int64_t B, hipStream_t st);
+int launch_stats_to_mr(const double* stats, float* mr, const double* inv_n_dev, int64_t B, int n_layers, hipStream_t st);
+// LayerNorm + ELU backward of one layer: dxh -> dt in place; dgamma/dbeta/dbias accumulate (zeroed by the caller)
+int launch_ln_bwd(float* dxh, const float* v, const float* gamma, const float* mr, const float* mr_prev,
+                  double* lnsum, float* dgamma, float* dbeta, float* dts, float* dbias, int64_t B, int P, int C,
+                  hipStream_t st);
+int launch_batch_reduce(const float* dt, const float* mr_prev, float* S1, float* S2, int64_t n, int64_t B, hipStream_t st);
+// dW (keras (3,Cin,Cout), accumulated) += sum_rows X[b, in(pos,tap), :] (x) D[b,pos,:]
+int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const ConvGeom& g, hipStream_t st);
+int launch_conv0_bwd(const float* feat, const float* dt, float* dW0, float* dbias0, int64_t B, const ConvGeom& g,
+                     hipStream_t st);
+int launch_pack_dgrad_weight(const float* k3, float* wd, int Cin, int Cout, hipStream_t st);
+
 // weight packing
 int launch_pack_conv_weight(const float* k3, float* wp, int Cin, int Cout, hipStream_t st);
 int launch_pack_div(const float* w1, const float* b1, const float* w2, float* w1p, float* b1p,

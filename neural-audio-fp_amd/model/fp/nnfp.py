@@ -173,6 +173,40 @@ class FingerPrinter:
                        'encoder_forward')
         return flat, emb
 
+    # ---- training: forward that keeps activations + backward (trainer.py:41-47) ----------
+    def forward_train(self, feat):
+        """emb = m_fp(feat) keeping every activation for `backward`."""
+        feat = self._prep(feat, self.input_shape)
+        self._sync()
+        B = feat.shape[0]
+        need = int(self._lib.nafp_encoder_train_workspace_bytes(self._h, B))
+        if getattr(self, '_train_ws', None) is None or self._train_ws.numel() < need:
+            self._train_ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
+        emb = torch.empty((B, self.emb_sz), dtype=torch.float32, device=feat.device)
+        with torch.cuda.device(feat.device):
+            _lib.check(self._lib.nafp_encoder_forward_train(self._h, _lib.ptr(feat), B, _lib.ptr(self._train_ws), need,
+                                                            _lib.ptr(emb), int(bool(self.use_L2layer)),
+                                                            _lib.current_stream()), 'encoder_forward_train')
+        self._train_feat = feat
+        return emb
+
+    def backward(self, d_emb):
+        """Gradients of the 68 parameter tensors (keras shapes, library order) for dL/d(emb) of the
+        last forward_train call; the counterpart of tape.gradient(loss, m_fp.trainable_variables)."""
+        feat = self._train_feat
+        B = feat.shape[0]
+        d_emb = _lib.require_cuda(torch.as_tensor(d_emb), 'd_emb').float().contiguous()
+        if getattr(self, '_grads', None) is None:
+            self._grads = [torch.empty_like(v) for v in self._vars]
+        arr = (ctypes.c_void_p * len(self._grads))(*[g.data_ptr() for g in self._grads])
+        need = int(self._lib.nafp_encoder_train_workspace_bytes(self._h, B))
+        with torch.cuda.device(feat.device):
+            _lib.check(self._lib.nafp_encoder_backward(self._h, _lib.ptr(feat), _lib.ptr(d_emb), B,
+                                                       _lib.ptr(self._train_ws), need, arr,
+                                                       int(bool(self.use_L2layer)), _lib.current_stream()),
+                       'encoder_backward')
+        return self._grads
+
     def set_option(self, option, value):
         """Execution options of the library handle (include/nafp.h NAFP_OPT_*); results do not change."""
         _lib.check(self._lib.nafp_encoder_set_option(self._h, int(option), int(value)), 'encoder_set_option')
