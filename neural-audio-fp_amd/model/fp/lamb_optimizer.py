@@ -39,8 +39,32 @@ class _MultiTensorOptimizer:
         lr = self.learning_rate
         return lr(self.iterations) if callable(lr) else float(lr)   # keras evaluates the schedule at `iterations`
 
+    def state_dict(self, variables):
+        """Slots in the order of `variables` (what tf.train.Checkpoint(optimizer=...) keeps:
+        experiment_helper.py:100-107)."""
+        zeros = lambda w: (torch.zeros_like(w), torch.zeros_like(w))
+        mv = [self._slots.get(w.data_ptr()) or zeros(w) for w in variables]
+        return {'iterations': int(self.iterations), 'm': [m.detach().cpu() for m, _ in mv],
+                'v': [v.detach().cpu() for _, v in mv]}
+
+    def load_state_dict(self, sd, variables):
+        self.iterations = int(sd['iterations'])
+        self._cache = None
+        for w, m, v in zip(variables, sd['m'], sd['v']):
+            self._slots[w.data_ptr()] = (m.to(w.device, torch.float32).contiguous().clone(),
+                                         v.to(w.device, torch.float32).contiguous().clone())
+
     def _table(self, grads_and_vars, var_lens):
         gv = [(g, w) for g, w in grads_and_vars]
+        key_all = tuple((g.data_ptr(), w.data_ptr(), g.dtype, g.is_contiguous()) for g, w in gv)
+        cache = getattr(self, '_cache', None)
+        if cache is not None and cache[0] == key_all and all(k[2] == torch.float32 and k[3] for k in key_all):
+            return cache[1], cache[2], cache[3]          # same buffers as last step: reuse the table
+        out = self._build_table(gv, var_lens)
+        self._cache = (key_all,) + out
+        return out
+
+    def _build_table(self, gv, var_lens):
         arr = (_lib.OptTensor * len(gv))()
         keep = []
         for i, (g, w) in enumerate(gv):

@@ -119,7 +119,7 @@ class FingerPrinter:
             t = torch.as_tensor(sd[n], dtype=torch.float32)
             if tuple(t.shape) != self._shapes[i]:
                 raise ValueError(f'{n}: shape {tuple(t.shape)} != {self._shapes[i]}')
-            self._vars[i] = t.to(self.device).contiguous()
+            self._vars[i].copy_(t)             # in place: optimizer slots and gradient views stay valid
         self._dirty = True
 
     def set_weights(self, arrays):

@@ -38,7 +38,7 @@ def build_fp(cfg):
     return get_melspec_layer(cfg, trainable=False), get_fingerprinter(cfg, trainable=False)
 
 
-def load_checkpoint(checkpoint_root_dir, checkpoint_name, checkpoint_index, m_fp):
+def load_checkpoint(checkpoint_root_dir, checkpoint_name, checkpoint_index, m_fp, optimizer=None):
     """generate.py:26-52: latest index when none is given; FileNotFoundError if absent."""
     checkpoint_dir = checkpoint_root_dir + f'/{checkpoint_name}/'
     if checkpoint_index is None:
@@ -54,6 +54,8 @@ def load_checkpoint(checkpoint_root_dir, checkpoint_name, checkpoint_index, m_fp
         raise FileNotFoundError(f'Cannot find checkpoint {fpath}')
     ck = torch.load(fpath, map_location='cpu', weights_only=True)
     m_fp.load_state_dict(ck['model'] if 'model' in ck else ck)
+    if optimizer is not None and 'optimizer' in ck:
+        optimizer.load_state_dict(ck['optimizer'], m_fp.trainable_variables)
     print(f'---Restored from {fpath}---')
     return int(checkpoint_index)
 

@@ -1,0 +1,201 @@
+"""Training driver on the HIP path.
+
+Mirrors the reference's `build_fp`, `train_step`, `val_step`, `test_step` and `trainer`
+(model/trainer.py:19-77, 111-230): same roles and call order -- X = concat(Xa, Xp); feat =
+m_specaug(m_pre(X)) outside the differentiated region; emb = m_fp(feat); NT-Xent on
+(emb[:nA], emb[nA:]); gradients w.r.t. m_fp.trainable_variables; optimizer step (Adam or LAMB
+with a cosine schedule).  tf.GradientTape is replaced by the library's explicit backward pass
+(`FingerPrinter.forward_train` / `.backward`) and the fused NT-Xent backward.
+
+Data parallel (one process per GPU, torch.distributed over RCCL): every rank holds n_a anchors
+and their replicas; the L2-normalised embeddings are all-gathered before the loss
+(NTxent_loss_tpu.py:57-87, 110-126), each rank scores its local rows against all columns, the
+gradient w.r.t. the gathered embeddings is summed over ranks (what TF's all_reduce-in-the-forward
+yields in its backward) and each rank back-propagates its slice; parameter gradients are then
+all-reduced (sum) in one flat buffer, so every rank applies the gradient of the GLOBAL mean loss
+and the replicas stay bit-identical.
+
+What is NOT here: the reference's training dataset (time-domain augmentation on the host,
+model/dataset.py + dataloader_keras.py) -- `trainer` takes any iterable of (Xa, Xp) batches --
+TensorBoard, and the mini-search validation.
+"""
+import torch
+
+from .fp.melspec.melspectrogram import get_melspec_layer
+from .fp.nnfp import get_fingerprinter
+from .fp.NTxent_loss_single_gpu import NTxentLoss, _ntxent_call
+from .fp.lamb_optimizer import LAMB, Adam, CosineDecay
+from .fp.specaug_chain.specaug_chain import get_specaug_chain_layer
+from . import generate as _gen
+
+
+def build_fp(cfg):
+    """trainer.py:19-30."""
+    m_pre = get_melspec_layer(cfg, trainable=False)
+    m_specaug = get_specaug_chain_layer(cfg, trainable=False)
+    assert m_specaug.bypass is False
+    m_fp = get_fingerprinter(cfg, trainable=False)
+    return m_pre, m_specaug, m_fp
+
+
+def _dist():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist
+    return None
+
+
+class GradientBucket:
+    """All parameter gradients as views into ONE flat buffer: a single all-reduce per step
+    (67.8 MB for the 1-s model) instead of 68."""
+
+    def __init__(self, m_fp):
+        vs = m_fp.trainable_variables
+        self.flat = torch.zeros(sum(v.numel() for v in vs), dtype=torch.float32, device=vs[0].device)
+        self.views, o = [], 0
+        for v in vs:
+            self.views.append(self.flat[o:o + v.numel()].view_as(v))
+            o += v.numel()
+        m_fp._grads = self.views          # FingerPrinter.backward writes straight into the views
+
+
+def train_step(X, m_pre, m_specaug, m_fp, loss_obj, opt, bucket=None):
+    """trainer.py:33-50.  Returns (loss, None): loss is the GLOBAL batch loss (identical on every
+    rank).  `bucket` (GradientBucket) is required for data-parallel runs."""
+    Xa, Xp = X
+    n_anchors = len(Xa)
+    X = torch.cat([torch.as_tensor(Xa), torch.as_tensor(Xp)], dim=0)
+    feat = m_specaug(m_pre(X))                      # outside the tape (trainer.py:41)
+    m_fp.trainable = True
+    emb = m_fp.forward_train(feat)
+    ha, hb = emb[:n_anchors].contiguous(), emb[n_anchors:].contiguous()
+    dist = _dist()
+    if dist is None:
+        loss, d_a, d_b = loss_obj.loss_and_grad(ha, hb)
+    else:
+        world, rank = dist.get_world_size(), dist.get_rank()
+        ga = [torch.empty_like(ha) for _ in range(world)]
+        gb = [torch.empty_like(hb) for _ in range(world)]
+        dist.all_gather(ga, ha)
+        dist.all_gather(gb, hb)
+        a_all, b_all = torch.cat(ga).contiguous(), torch.cat(gb).contiguous()
+        loss_sum, _, d_a_all, d_b_all = _ntxent_call(loss_obj._lib, ha, hb, a_all, b_all, rank * n_anchors,
+                                                     loss_obj.tau, False, True)
+        loss = loss_sum[0] / a_all.shape[0]
+        dist.all_reduce(loss)
+        dist.all_reduce(d_a_all)
+        dist.all_reduce(d_b_all)
+        d_a = d_a_all[rank * n_anchors:(rank + 1) * n_anchors]
+        d_b = d_b_all[rank * n_anchors:(rank + 1) * n_anchors]
+    grads = m_fp.backward(torch.cat([d_a, d_b], dim=0))
+    if dist is not None:
+        if bucket is None:
+            raise ValueError('data-parallel train_step needs a GradientBucket')
+        dist.all_reduce(bucket.flat)
+    opt.apply_gradients(zip(grads, m_fp.trainable_variables), var_lens=m_fp.variable_lengths())
+    m_fp.mark_dirty()
+    return loss, None
+
+
+def val_step(X, m_pre, m_fp, loss_obj):
+    """trainer.py:53-64 (no augmentation, no gradient)."""
+    Xa, Xp = X
+    n_anchors = len(Xa)
+    X = torch.cat([torch.as_tensor(Xa), torch.as_tensor(Xp)], dim=0)
+    m_fp.trainable = False
+    emb = m_fp(m_pre(X))
+    loss, sim_mtx, _ = loss_obj.compute_loss(emb[:n_anchors], emb[n_anchors:])
+    return loss, sim_mtx
+
+
+def test_step(X, m_pre, m_fp):
+    """trainer.py:67-77: f(.), L2(f(.)), L2(g(f(.)))."""
+    X = torch.cat([torch.as_tensor(x) for x in X], dim=0)
+    m_fp.trainable = False
+    emb_f = m_fp.front_conv(m_pre(X))
+    emb_f_postL2 = torch.nn.functional.normalize(emb_f, dim=1, eps=1e-6)
+    emb_gf = torch.nn.functional.normalize(m_fp.div_enc(emb_f), dim=1, eps=1e-6)
+    return emb_f, emb_f_postL2, emb_gf
+
+
+def make_optimizer(cfg, total_nsteps):
+    """trainer.py:119-140."""
+    sched = cfg['TRAIN']['LR_SCHEDULE'].upper()
+    if sched == 'COS':
+        lr = CosineDecay(float(cfg['TRAIN']['LR']), total_nsteps, alpha=1e-06)
+    elif sched == 'COS-RESTART':
+        raise NotImplementedError('CosineDecayRestarts')
+    else:
+        lr = float(cfg['TRAIN']['LR'])
+    name = cfg['TRAIN']['OPTIMIZER'].upper()
+    if name == 'LAMB':
+        return LAMB(learning_rate=lr)
+    elif name == 'ADAM':
+        return Adam(learning_rate=lr)
+    raise NotImplementedError(cfg['TRAIN']['OPTIMIZER'])
+
+
+def synthetic_batches(cfg, steps_per_epoch, device=None, snr_db=5.0):
+    """SURVEY.md section 8(d) config 3/4 input: Xa = seeded noise segments, Xp = Xa + noise at
+    5 dB SNR, float32 (n_local, 1, T) on the device; seeds differ per rank and per step."""
+    import torch.distributed as td
+    world = td.get_world_size() if (td.is_available() and td.is_initialized()) else 1
+    rank = td.get_rank() if world > 1 else 0
+    n_a = cfg['BSZ']['TR_N_ANCHOR']
+    if n_a % world or cfg['BSZ']['TR_BATCH_SZ'] != 2 * n_a:
+        raise ValueError('TR_BATCH_SZ must be 2*TR_N_ANCHOR and TR_N_ANCHOR divisible by the world size')
+    n_l = n_a // world
+    T = int(cfg['MODEL']['DUR'] * cfg['MODEL']['FS'])
+    device = device or torch.device('cuda', torch.cuda.current_device())
+    amp = 10.0 ** (-snr_db / 20.0)
+
+    def epoch(ep):
+        g = torch.Generator(device=device)
+        for i in range(steps_per_epoch):
+            g.manual_seed(1_000_003 * (100 + rank) + 7919 * ep + i)
+            xa = 0.1 * torch.randn((n_l, 1, T), generator=g, device=device)
+            xp = xa + 0.1 * amp * torch.randn((n_l, 1, T), generator=g, device=device)
+            yield xa, xp
+    return epoch
+
+
+def trainer(cfg, checkpoint_name, train_batches=None, steps_per_epoch=None, max_epoch=None):
+    """trainer.py:111-230 without the host data pipeline: `train_batches` is a callable
+    epoch -> iterable of (Xa, Xp) CUDA (or host) batches of shape (n, 1, T)."""
+    if train_batches is None:
+        raise NotImplementedError('the augmenting training dataset (model/dataset.py) is outside the built path: '
+                                  'pass train_batches=callable(epoch) -> iterable of (Xa, Xp)')
+    if cfg['LOSS']['LOSS_MODE'].upper() != 'NTXENT':
+        raise NotImplementedError(cfg['LOSS']['LOSS_MODE'])
+    m_pre, m_specaug, m_fp = build_fp(cfg)
+    max_epoch = max_epoch or cfg['TRAIN']['MAX_EPOCH']
+    if steps_per_epoch is None:
+        steps_per_epoch = len(train_batches(1))
+    opt = make_optimizer(cfg, max_epoch * steps_per_epoch)
+    dist = _dist()
+    world = dist.get_world_size() if dist is not None else 1
+    n_a = cfg['BSZ']['TR_N_ANCHOR'] // world            # TR_BATCH_SZ is the global batch (trainer.py:148-151)
+    loss_obj = NTxentLoss(n_org=n_a, n_rep=(cfg['BSZ']['TR_BATCH_SZ'] - cfg['BSZ']['TR_N_ANCHOR']) // world,
+                          tau=cfg['LOSS']['TAU'])
+    bucket = GradientBucket(m_fp)
+    ck_root = cfg['DIR']['LOG_ROOT_DIR'] + 'checkpoint/'
+    start = 1
+    try:                                            # resume from the latest checkpoint (experiment_helper.py:125-136)
+        start = _gen.load_checkpoint(ck_root, checkpoint_name, None, m_fp, optimizer=opt) + 1
+    except FileNotFoundError:
+        pass
+    if dist is not None:                            # replicas start from rank 0's variables and slots
+        for v in m_fp.trainable_variables:
+            dist.broadcast(v, src=0)
+        m_fp.mark_dirty()
+    history = []
+    for ep in range(start, max_epoch + 1):
+        tot, n = 0.0, 0
+        for X in train_batches(ep):
+            loss, _ = train_step(X, m_pre, m_specaug, m_fp, loss_obj, opt, bucket)
+            tot += float(loss); n += 1
+        history.append(tot / max(n, 1))
+        print(f'epoch {ep}: train loss {history[-1]:.6f}')
+        if dist is None or dist.get_rank() == 0:
+            _gen.save_checkpoint(ck_root, checkpoint_name, ep, m_fp, extra={'optimizer': opt.state_dict(m_fp.trainable_variables)})
+    return history

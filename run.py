@@ -5,8 +5,9 @@
     python run.py evaluate CHECKPOINT_NAME CHECKPOINT_INDEX [-c CONFIG] [-i INDEX_TYPE] ...
 
 Same commands, arguments, options and config resolution (./config/<name>.yaml) as
-the reference's run.py:13-162.  `generate` runs the HIP hot path.  `train` and
-`evaluate` sit outside the path built so far and say so.
+the reference's run.py:13-162.  `generate` and `train` run the HIP hot path (train on a
+caller-supplied or synthetic batch source: the augmenting dataset is SURVEY.md section 8f);
+`evaluate` sits outside the path built so far and says so.
 
 Multi-GPU generate: launch one process per GPU, e.g.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -65,15 +66,24 @@ def cli():
 @click.option('--config', '-c', default='default', type=click.STRING,
               help="Name of model configuration located in './config/.'")
 @click.option('--max_epoch', default=None, type=click.INT, help='Max epoch.')
-def train(checkpoint_name, config, max_epoch):
-    """Train a neural audio fingerprinter (not built yet for MI355X: forward kernels and the
-    NT-Xent loss exist, the backward kernels do not)."""
+@click.option('--synthetic', default=None, type=click.INT,
+              help='Train on N synthetic steps per epoch (anchors: seeded noise; replicas: anchors + noise at 5 dB '
+                   'SNR) instead of the augmenting dataset, which is outside the built path.')
+def train(checkpoint_name, config, max_epoch, synthetic):
+    """Train a neural audio fingerprinter (HIP forward + backward, NT-Xent, Adam/LAMB).
+
+    Multi-GPU: launch with torch.distributed.run; TR_BATCH_SZ is the GLOBAL batch, split evenly."""
+    from neural_audio_fp_amd.model.trainer import trainer, synthetic_batches
     cfg = load_config(config)
     if max_epoch:
         update_config(cfg, 'TRAIN', 'MAX_EPOCH', max_epoch)
     print_config(cfg)
-    raise NotImplementedError('train: backward kernels of the encoder are not built yet '
-                              '(DESIGN.md, "out of scope this round")')
+    _init_distributed()
+    if synthetic is None:
+        raise NotImplementedError('train: the augmenting training dataset (model/dataset.py of the reference) is '
+                                  'outside the built path; use --synthetic N or call '
+                                  'neural_audio_fp_amd.model.trainer.trainer(cfg, name, train_batches=...)')
+    trainer(cfg, checkpoint_name, train_batches=synthetic_batches(cfg, synthetic), steps_per_epoch=synthetic)
 
 
 @cli.command()

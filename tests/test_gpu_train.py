@@ -1,0 +1,120 @@
+"""GPU: the train step (trainer.py:33-50) on the HIP path -- one-step parameter parity against the
+float64 restatement (melspec -> encoder -> NT-Xent -> autograd -> keras Adam), descent on a fixed
+batch for Adam and LAMB, and the epoch loop with checkpoint resume."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import optim as o_optim
+from oracle import torch_ref
+import _inputs
+
+pytestmark = pytest.mark.gpu
+
+
+class _NoAug:
+    bypass = False
+
+    def __call__(self, x):
+        return x
+
+
+def _pairs(n, seed):
+    xa = _inputs.audio(n, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    xp = (xa + 0.05 * rng.normal(size=xa.shape)).astype(np.float32)
+    return xa, xp
+
+
+def test_one_adam_step_matches_float64_reference(nafp, cfg):
+    from neural_audio_fp_amd.model import trainer as T
+    from neural_audio_fp_amd.model.fp.lamb_optimizer import Adam
+    from neural_audio_fp_amd.model.fp.NTxent_loss_single_gpu import NTxentLoss
+    n = 6
+    xa, xp = _pairs(n, 5)
+    w = _inputs.weights(seed=21)
+    m_pre = nafp.get_melspec_layer(cfg)
+    m_fp = nafp.FingerPrinter(seed=0)
+    m_fp.set_weights(_inputs.weight_list(w))
+    lr = 1e-3
+    opt = Adam(learning_rate=lr)
+    loss, _ = T.train_step((torch.from_numpy(xa).cuda(), torch.from_numpy(xp).cuda()), m_pre, _NoAug(), m_fp,
+                           NTxentLoss(n_org=n, n_rep=n, tau=0.05), opt)
+    # reference: the same step in float64 (feature extraction in float32 like the layer itself)
+    feat = torch_ref.melspec_layer(np.concatenate([xa, xp]))
+    tf = torch_ref.TorchFingerprinter(w, dtype=torch.float64, requires_grad=True)
+    emb = tf(feat.double())
+    want_loss = torch_ref.ntxent(emb[:n], emb[n:], tau=0.05)
+    want_loss.backward()
+    assert abs(float(loss) - float(want_loss)) < 1e-4 * max(1.0, abs(float(want_loss)))
+    worst = 0.0
+    for p, new in zip(tf.params, m_fp.trainable_variables):
+        w0, g = p.detach().numpy(), p.grad.numpy()
+        want, _, _ = o_optim.adam_step(w0, g, np.zeros_like(w0), np.zeros_like(w0), lr, 1)
+        got = new.cpu().numpy().astype(np.float64)
+        # the first Adam step is lr*g/(|g|+eps'): compare where the gradient is not at rounding level
+        sel = np.abs(g) > 1e-4 * (np.abs(g).max() + 1e-30)
+        if sel.any():
+            err = np.abs(got - want)[sel].max() / lr
+            worst = max(worst, err)
+            assert err < 2e-2, err
+        assert np.abs(got - w0).max() <= lr * 1.0001 + 1e-7
+    print('worst update error / lr', worst)
+    assert opt.iterations == 1
+
+
+@pytest.mark.parametrize('which', ['adam', 'lamb'])
+def test_loss_decreases_on_fixed_batch(nafp, cfg, which):
+    from neural_audio_fp_amd.model import trainer as T
+    from neural_audio_fp_amd.model.fp.lamb_optimizer import Adam, LAMB
+    from neural_audio_fp_amd.model.fp.NTxent_loss_single_gpu import NTxentLoss
+    n = 16
+    xa, xp = _pairs(n, 9)
+    X = (torch.from_numpy(xa).cuda(), torch.from_numpy(xp).cuda())
+    m_pre, m_specaug, m_fp = T.build_fp(cfg)
+    m_fp.set_weights(_inputs.weight_list(_inputs.weights(seed=4, randomize_affine=False)))
+    opt = Adam(learning_rate=1e-4) if which == 'adam' else LAMB(learning_rate=1e-3)
+    loss_obj = NTxentLoss(n_org=n, n_rep=n, tau=0.05)
+    losses = [float(T.train_step(X, m_pre, _NoAug(), m_fp, loss_obj, opt)[0]) for _ in range(12)]
+    print(which, losses)
+    assert all(np.isfinite(losses))
+    assert losses[-1] < losses[0] - 0.05
+    # validation step sees the trained variables (set_weights after mark_dirty) and agrees with the train loss scale
+    vloss, sim = T.val_step(X, m_pre, m_fp, loss_obj)
+    assert sim.shape == (n, 2 * n - 1) and float(vloss) < losses[0]
+    # augmented step runs too
+    l_aug, _ = T.train_step(X, m_pre, m_specaug, m_fp, loss_obj, opt)
+    assert np.isfinite(float(l_aug))
+
+
+def test_test_step_shapes(nafp, cfg):
+    from neural_audio_fp_amd.model import trainer as T
+    m_pre, _, m_fp = T.build_fp(cfg)
+    xa, xp = _pairs(3, 2)
+    f, f2, gf = T.test_step((torch.from_numpy(xa).cuda(), torch.from_numpy(xp).cuda()), m_pre, m_fp)
+    assert f.shape == (6, m_fp.flat_dim) and f2.shape == f.shape and gf.shape == (6, 128)
+    assert torch.allclose(gf.norm(dim=1), torch.ones(6, device='cuda'), atol=1e-5)
+    assert torch.allclose(f2.norm(dim=1), torch.ones(6, device='cuda'), atol=1e-5)
+    emb = m_fp(m_pre(torch.from_numpy(np.concatenate([xa, xp])).cuda()))
+    assert torch.allclose(emb, gf, atol=1e-5)
+
+
+def test_trainer_epochs_and_resume(nafp, cfg, tmp_path):
+    from neural_audio_fp_amd.model import trainer as T
+    c = copy.deepcopy(cfg)
+    c['BSZ']['TR_BATCH_SZ'], c['BSZ']['TR_N_ANCHOR'] = 16, 8
+    c['DIR']['LOG_ROOT_DIR'] = str(tmp_path) + '/'
+    c['TRAIN']['MAX_EPOCH'] = 2
+    hist = T.trainer(c, 'unit', train_batches=T.synthetic_batches(c, 3), steps_per_epoch=3)
+    assert len(hist) == 2 and all(np.isfinite(hist))
+    assert (tmp_path / 'checkpoint' / 'unit' / 'ckpt-2.pt').exists()
+    c['TRAIN']['MAX_EPOCH'] = 3
+    hist2 = T.trainer(c, 'unit', train_batches=T.synthetic_batches(c, 3), steps_per_epoch=3)
+    assert len(hist2) == 1                         # resumed at epoch 3
+    ck = torch.load(tmp_path / 'checkpoint' / 'unit' / 'ckpt-3.pt', weights_only=True)
+    assert ck['optimizer']['iterations'] == 9 and len(ck['optimizer']['m']) == 68
+    with pytest.raises(NotImplementedError):
+        c['TRAIN']['OPTIMIZER'] = 'SGD'
+        T.trainer(c, 'unit2', train_batches=T.synthetic_batches(c, 1), steps_per_epoch=1)
