@@ -30,6 +30,28 @@ std::vector<ConvGeom> encoder_geometry(int in_f, int in_t) {
     return g;
 }
 
+// set_weights helpers: all plain tensor copies in ONE launch, and bias_j added to every Hb_j in one launch.
+struct CopyTable { const float* src[64]; float* dst[64]; int64_t n[64]; int count; };
+__global__ __launch_bounds__(256) void multi_copy_kernel(const CopyTable t) {
+    const int e = blockIdx.y;
+    const float* __restrict__ s = t.src[e]; float* __restrict__ d = t.dst[e];
+    const int64_t n = t.n[e];
+    if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) {
+        for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n / 4; i += (int64_t)gridDim.x * 256)
+            ((float4*)d)[i] = ((const float4*)s)[i];
+        for (int64_t i = n / 4 * 4 + blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+    } else {
+        for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+    }
+}
+struct BiasTable { float* hb[16]; const float* bias[16]; int64_t n[16]; int cout[16]; int count; };
+__global__ __launch_bounds__(256) void add_bias_kernel(const BiasTable t) {
+    const int e = blockIdx.y;
+    float* __restrict__ h = t.hb[e]; const float* __restrict__ b = t.bias[e];
+    const int64_t n = t.n[e]; const int C = t.cout[e];
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) h[i] += b[i % C];
+}
+
 }  // namespace nafp
 
 using namespace nafp;
@@ -52,6 +74,7 @@ struct nafp_encoder {
     std::vector<float*> d_wd;
     float *d_w1k = nullptr, *d_b1k = nullptr, *d_w2k = nullptr;
     double* d_inv_n = nullptr;
+    float* d_sw_slab = nullptr; int64_t sw_slab_floats = 0;      // split-K slab of the G/Hb launches in set_weights
     bool has_weights = false;
     // NAFP_OPT_FUSE_CONV0 (default: NAFP_FUSE0 env, else off).  Measured at B = 640: conv0 0.35 ms +
     // conv1 1.17 ms materialised vs 0.17 ms (statistics pass) + 1.38 ms fused: the ELU evaluation is
@@ -120,6 +143,8 @@ extern "C" int nafp_encoder_create(nafp_encoder** out, int in_f, int in_t, int e
     for (int j = 1; j < 16; ++j) total += 2 * ((numel(e->shapes[4 * j + 2]) + 63) / 64 * 64);   // G, Hb
     for (int j = 1; j < 16; ++j) total += (numel(e->shapes[4 * j]) + 63) / 64 * 64;               // dgrad weights
     total += (numel(e->shapes[64]) + 63) / 64 * 64 + 2 * ((numel(e->shapes[65]) + 63) / 64 * 64) + 64;   // keras div copies, inv_n
+    for (int j = 1; j < 16; ++j) e->sw_slab_floats = std::max(e->sw_slab_floats, conv_gemm_slab_floats(2, e->geom[j]));
+    total += e->sw_slab_floats + 64;
     e->blob_floats = total;
     hipError_t err = hipMalloc(&e->d_blob, sizeof(float) * total);
     if (err != hipSuccess) { g_last_hip_error = (int)err; delete e; return NAFP_ERR_HIP; }
@@ -138,6 +163,14 @@ extern "C" int nafp_encoder_create(nafp_encoder** out, int in_f, int in_t, int e
     for (int j = 1; j < 16; ++j) e->d_wd.push_back(take(4 * j));
     e->d_w1k = take(64); e->d_b1k = take(65); e->d_w2k = take(65);
     e->d_inv_n = (double*)p; p += 64;
+    e->d_sw_slab = p; p += e->sw_slab_floats;
+    // set_weights runs G_j and Hb_j as the two "samples" of one launch: the pairs must be adjacent
+    for (int j = 0; j < 16; ++j) {
+        const int64_t n = numel(e->shapes[4 * j + 2]);
+        if (e->d_beta[j] != e->d_gamma[j] + n || (j >= 1 && e->d_Hb[j] != e->d_G[j] + n)) {
+            (void)hipFree(e->d_blob); delete e; return NAFP_ERR_UNSUPPORTED;
+        }
+    }
     {
         double inv_n[16];
         for (int j = 0; j < 16; ++j) inv_n[j] = 1.0 / ((double)e->geom[j].Fout * e->geom[j].Tout * e->geom[j].Cout);
@@ -191,40 +224,47 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
     for (size_t i = 0; i < e->shapes.size(); ++i)
         if (!t[i]) return NAFP_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
+    CopyTable ct; ct.count = 0;
+    auto add_copy = [&](const float* src, float* dst, int64_t n) { ct.src[ct.count] = src; ct.dst[ct.count] = dst; ct.n[ct.count] = n; ++ct.count; };
+    add_copy(t[0], e->d_w[0], 3 * e->geom[0].Cout);
     for (int j = 0; j < 16; ++j) {
         const ConvGeom& g = e->geom[j];
-        if (j == 0) {
-            NAFP_HIP_CHECK(hipMemcpyAsync(e->d_w[0], t[0], sizeof(float) * 3 * g.Cout, hipMemcpyDeviceToDevice, st));
-        } else {
-            int rc = launch_pack_conv_weight(t[4 * j], e->d_w[j], g.Cin, g.Cout, st);
-            if (rc != NAFP_OK) return rc;
-        }
         const int64_t nln = (int64_t)g.Fout * g.Tout * g.Cout;
-        NAFP_HIP_CHECK(hipMemcpyAsync(e->d_bias[j], t[4 * j + 1], sizeof(float) * g.Cout, hipMemcpyDeviceToDevice, st));
-        NAFP_HIP_CHECK(hipMemcpyAsync(e->d_gamma[j], t[4 * j + 2], sizeof(float) * nln, hipMemcpyDeviceToDevice, st));
-        NAFP_HIP_CHECK(hipMemcpyAsync(e->d_beta[j], t[4 * j + 3], sizeof(float) * nln, hipMemcpyDeviceToDevice, st));
+        add_copy(t[4 * j + 1], e->d_bias[j], g.Cout);
+        add_copy(t[4 * j + 2], e->d_gamma[j], nln);
+        add_copy(t[4 * j + 3], e->d_beta[j], nln);
     }
-    // positional epilogue terms of conv j: G = conv_j(gamma_{j-1}), Hb = conv_j(beta_{j-1}) + bias_j
+    add_copy(t[64], e->d_w1k, numel(e->shapes[64]));
+    add_copy(t[65], e->d_b1k, numel(e->shapes[65]));
+    add_copy(t[66], e->d_w2k, numel(e->shapes[66]));
+    add_copy(t[67], e->d_b2, e->emb_sz);
+    multi_copy_kernel<<<dim3(32, ct.count), 256, 0, st>>>(ct);
+    NAFP_LAUNCH_CHECK();
+    for (int j = 1; j < 16; ++j) {
+        int rc = launch_pack_conv_weight(t[4 * j], e->d_w[j], e->geom[j].Cin, e->geom[j].Cout, st);
+        if (rc != NAFP_OK) return rc;
+    }
+    // positional epilogue terms of conv j: G = conv_j(gamma_{j-1}), Hb = conv_j(beta_{j-1}) + bias_j:
+    // one 2-"sample" PLAIN launch per conv (gamma | beta adjacent in, G | Hb adjacent out), then all biases at once
+    BiasTable bt; bt.count = 0;
     for (int j = 1; j < 16; ++j) {
         ConvGemmArgs a{};
         a.wp = e->d_w[j]; a.plain = true;
         a.x = e->d_gamma[j - 1]; a.bias = nullptr; a.y = e->d_G[j];
-        int rc = launch_conv_gemm(a, 1, e->geom[j], st);
+        a.slab = e->sw_slab_floats ? e->d_sw_slab : nullptr; a.slab_floats = e->sw_slab_floats;
+        int rc = launch_conv_gemm(a, 2, e->geom[j], st);
         if (rc != NAFP_OK) return rc;
-        a.x = e->d_beta[j - 1]; a.bias = e->d_bias[j]; a.y = e->d_Hb[j];
-        rc = launch_conv_gemm(a, 1, e->geom[j], st);
-        if (rc != NAFP_OK) return rc;
+        bt.hb[bt.count] = e->d_Hb[j]; bt.bias[bt.count] = e->d_bias[j];
+        bt.n[bt.count] = numel(e->shapes[4 * j + 2]); bt.cout[bt.count] = e->geom[j].Cout; ++bt.count;
     }
+    add_bias_kernel<<<dim3(32, bt.count), 256, 0, st>>>(bt);
+    NAFP_LAUNCH_CHECK();
     for (int j = 1; j < 16; ++j) {
         int rcd = launch_pack_dgrad_weight(t[4 * j], e->d_wd[j], e->geom[j].Cin, e->geom[j].Cout, st);
         if (rcd != NAFP_OK) return rcd;
     }
-    NAFP_HIP_CHECK(hipMemcpyAsync(e->d_w1k, t[64], sizeof(float) * numel(e->shapes[64]), hipMemcpyDeviceToDevice, st));
-    NAFP_HIP_CHECK(hipMemcpyAsync(e->d_b1k, t[65], sizeof(float) * numel(e->shapes[65]), hipMemcpyDeviceToDevice, st));
-    NAFP_HIP_CHECK(hipMemcpyAsync(e->d_w2k, t[66], sizeof(float) * numel(e->shapes[66]), hipMemcpyDeviceToDevice, st));
     int rc = launch_pack_div(t[64], t[65], t[66], e->d_w1p, e->d_b1p, e->d_w2p, e->emb_sz, e->S, st);
     if (rc != NAFP_OK) return rc;
-    NAFP_HIP_CHECK(hipMemcpyAsync(e->d_b2, t[67], sizeof(float) * e->emb_sz, hipMemcpyDeviceToDevice, st));
     e->has_weights = true;
     return NAFP_OK;
 }
@@ -341,10 +381,13 @@ extern "C" int nafp_encoder_div_enc(nafp_encoder* e, const float* flat, int64_t 
 namespace {
 struct TrainLayout {
     int64_t B;
-    double* stats; float* mr; double* lnsum;
+    double* stats; float* mr; float* sc;
+    // zeroed together at the start of the backward pass: per-layer LN sums, S1/S2 of every layer
+    char* zero_begin; int64_t zero_bytes;
+    double* lnsum[16]; float* S1[16]; float* S2[16];
     float* z[16]; float* v[16];
     float* slab; int64_t slab_floats;
-    float* dA; float* dB; float* dS; float* S1; float* S2; float* dy;
+    float* dA; float* dB; float* dy;
     int64_t bytes;
 };
 
@@ -355,7 +398,15 @@ TrainLayout train_layout(const nafp_encoder* e, int64_t B, void* ws) {
     auto take = [&](int64_t bytes) { char* r = p; p += (bytes + 255) / 256 * 256; return r; };
     L.stats = (double*)take((int64_t)sizeof(double) * 2 * 16 * B);
     L.mr = (float*)take((int64_t)sizeof(float) * 2 * 16 * B);
-    L.lnsum = (double*)take((int64_t)sizeof(double) * 2 * B);
+    L.sc = (float*)take((int64_t)sizeof(float) * 8 * B);
+    L.zero_begin = p;
+    for (int j = 0; j < 16; ++j) L.lnsum[j] = (double*)take((int64_t)sizeof(double) * 2 * B);
+    for (int j = 0; j < 16; ++j) {
+        const int64_t n = (int64_t)e->geom[j].Fout * e->geom[j].Tout * e->geom[j].Cout;
+        L.S1[j] = (float*)take((int64_t)sizeof(float) * n);
+        L.S2[j] = (float*)take((int64_t)sizeof(float) * n);
+    }
+    L.zero_bytes = p - L.zero_begin;
     int64_t max_n = 0;
     for (int j = 0; j < 16; ++j) {
         const int64_t n = (int64_t)e->geom[j].Fout * e->geom[j].Tout * e->geom[j].Cout;
@@ -364,13 +415,10 @@ TrainLayout train_layout(const nafp_encoder* e, int64_t B, void* ws) {
         L.v[j] = (float*)take((int64_t)sizeof(float) * n * B);
     }
     L.slab_floats = 0;
-    for (int j = 1; j < 16; ++j) L.slab_floats = std::max(L.slab_floats, conv_gemm_slab_floats(B, e->geom[j]));
+    for (int j = 1; j < 16; ++j) L.slab_floats = std::max(L.slab_floats, conv_gemm_slab_floats(B, e->geom[j], true));
     L.slab = (float*)take((int64_t)sizeof(float) * L.slab_floats);
     L.dA = (float*)take((int64_t)sizeof(float) * max_n * B);
     L.dB = (float*)take((int64_t)sizeof(float) * max_n * B);
-    L.dS = (float*)take((int64_t)sizeof(float) * max_n * B);
-    L.S1 = (float*)take((int64_t)sizeof(float) * max_n);
-    L.S2 = (float*)take((int64_t)sizeof(float) * max_n);
     L.dy = (float*)take((int64_t)sizeof(float) * e->emb_sz * B);
     L.bytes = (p - p0) + 256;
     return L;
@@ -418,13 +466,20 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
     hipStream_t st = (hipStream_t)stream;
     const int64_t B = n_seg;
     TrainLayout L = train_layout(e, B, workspace);
-    for (size_t i = 0; i < e->shapes.size(); ++i) {
+    for (size_t i = 0; i < e->shapes.size(); ++i)
         if (!grads[i]) return NAFP_ERR_INVALID_ARG;
-        NAFP_HIP_CHECK(hipMemsetAsync(grads[i], 0, sizeof(float) * numel(e->shapes[i]), st));
+    // every gradient accumulates through atomics: zero them (adjacent tensors -- e.g. views into one flat
+    // all-reduce bucket -- in one memset) together with the LN sums and S1/S2
+    for (size_t i = 0; i < e->shapes.size();) {
+        size_t k = i; int64_t run = numel(e->shapes[i]);
+        while (k + 1 < e->shapes.size() && grads[k + 1] == grads[i] + run) { ++k; run += numel(e->shapes[k]); }
+        NAFP_HIP_CHECK(hipMemsetAsync(grads[i], 0, sizeof(float) * run, st));
+        i = k + 1;
     }
+    NAFP_HIP_CHECK(hipMemsetAsync(L.zero_begin, 0, L.zero_bytes, st));
     int rc = launch_stats_to_mr(L.stats, L.mr, e->d_inv_n, B, 16, st);
     if (rc != NAFP_OK) return rc;
-    // tail: d_emb -> dxhat of the last conv + divide-and-encode gradients
+    // tail: d_emb -> r * dxhat of the last conv + divide-and-encode gradients
     TailBwdArgs tb;
     tb.z = L.z[15]; tb.stats = L.stats + 2 * B * 15; tb.gamma = e->d_gamma[15]; tb.beta = e->d_beta[15];
     tb.w1 = e->d_w1k; tb.b1 = e->d_b1k; tb.w2 = e->d_w2k; tb.b2 = e->d_b2;
@@ -433,37 +488,34 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
     tb.D = (int)e->flat_dim; tb.Q = e->emb_sz; tb.S = e->S; tb.l2norm = l2norm;
     rc = launch_tail_bwd(tb, B, st);
     if (rc != NAFP_OK) return rc;
+    // `cur` holds r_j * dL/dxhat_j on entry of iteration j and r_{j-1} * dL/dt_j (dts) after launch_ln_bwd
     float* cur = L.dA; float* other = L.dB;
     for (int j = 15; j >= 1; --j) {
         const ConvGeom& g = e->geom[j];
         const int P = g.Fout * g.Tout;
-        const int64_t n = (int64_t)P * g.Cout;
         const float* mr_j = L.mr + 2 * B * j; const float* mr_p = L.mr + 2 * B * (j - 1);
-        rc = launch_ln_bwd(cur, L.v[j], e->d_gamma[j], mr_j, mr_p, L.lnsum, grads[4 * j + 2], grads[4 * j + 3], L.dS,
-                           grads[4 * j + 1], B, P, g.Cout, st);
+        rc = launch_ln_bwd(cur, L.v[j], e->d_gamma[j], mr_j, mr_p, L.lnsum[j], L.sc, grads[4 * j + 2], grads[4 * j + 3],
+                           grads[4 * j + 1], L.S1[j], L.S2[j], B, P, g.Cout, st);
         if (rc != NAFP_OK) return rc;
         // dW_j = wgrad(z_{j-1}, r dt) + wgrad(gamma_{j-1}, sum_b c_b dt) + wgrad(beta_{j-1}, sum_b dt)
-        NAFP_HIP_CHECK(hipMemsetAsync(L.S1, 0, sizeof(float) * n, st));
-        NAFP_HIP_CHECK(hipMemsetAsync(L.S2, 0, sizeof(float) * n, st));
-        rc = launch_batch_reduce(cur, mr_p, L.S1, L.S2, n, B, st);
+        rc = launch_wgrad(L.z[j - 1], cur, grads[4 * j], B, g, st);
         if (rc != NAFP_OK) return rc;
-        rc = launch_wgrad(L.z[j - 1], L.dS, grads[4 * j], B, g, st);
+        rc = launch_wgrad(e->d_gamma[j - 1], L.S1[j], grads[4 * j], 1, g, st);
         if (rc != NAFP_OK) return rc;
-        rc = launch_wgrad(e->d_gamma[j - 1], L.S1, grads[4 * j], 1, g, st);
+        rc = launch_wgrad(e->d_beta[j - 1], L.S2[j], grads[4 * j], 1, g, st);
         if (rc != NAFP_OK) return rc;
-        rc = launch_wgrad(e->d_beta[j - 1], L.S2, grads[4 * j], 1, g, st);
-        if (rc != NAFP_OK) return rc;
-        // dxhat_{j-1} = transposed conv of dt_j
+        // r_{j-1} * dxhat_{j-1} = transposed conv of dts_j
         ConvGemmArgs a{};
         a.x = cur; a.wp = e->d_wd[j]; a.y = other; a.plain = true; a.dgrad = true;
+        a.slab = L.slab_floats ? L.slab : nullptr; a.slab_floats = L.slab_floats;
         rc = launch_conv_gemm(a, B, g, st);
         if (rc != NAFP_OK) return rc;
         std::swap(cur, other);
     }
     {
         const ConvGeom& g = e->geom[0];
-        rc = launch_ln_bwd(cur, L.v[0], e->d_gamma[0], L.mr, nullptr, L.lnsum, grads[2], grads[3], nullptr, grads[1], B,
-                           g.Fout * g.Tout, g.Cout, st);
+        rc = launch_ln_bwd(cur, L.v[0], e->d_gamma[0], L.mr, nullptr, L.lnsum[0], L.sc, grads[2], grads[3], grads[1],
+                           nullptr, nullptr, B, g.Fout * g.Tout, g.Cout, st);
         if (rc != NAFP_OK) return rc;
         rc = launch_conv0_bwd(feat, cur, grads[0], nullptr, B, g, st);
         if (rc != NAFP_OK) return rc;

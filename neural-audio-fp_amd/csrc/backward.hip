@@ -5,9 +5,10 @@
 // xt = (v - mu_b) r_b,  xhat_j = xt*gamma_j + beta_j  (LayerNorm over (F,T,C) per sample).
 // Given dxh = dL/dxhat_j the kernels here produce
 //   ln_bwd_reduce   s1_b = sum g, s2_b = sum g*xt            (g = dxh*gamma)
-//   ln_bwd_param    dgamma = sum_b dxh*xt, dbeta = sum_b dxh
-//   ln_bwd_apply    dt = r_b (g - s1/n - xt*s2/n) * ELU'(v)  [in place], dts = r_{j-1,b} * dt, dbias
-//   batch_reduce    S1 = sum_b c_{j-1,b} dt, S2 = sum_b dt   (c = -mu r of the layer below)
+//   ln_bwd_fused    dt = r_b (g - s1/n - xt*s2/n) * ELU'(v); dts = r_{j-1,b} * dt [in place];
+//                   dgamma = sum_b dxh*xt, dbeta = sum_b dxh, dbias = sum dt,
+//                   S1 = sum_b c_{j-1,b} dt, S2 = sum_b dt   (c = -mu r of the layer below)
+//                   (one pass: 2 reads + 1 write of the activation-sized arrays)
 //   wgrad           dW_j[tap,c,n] += sum_{b,pos} X[b, in(pos,tap), c] * D[b,pos,n]   (fp32 MFMA)
 // and the transposed conv (dgrad) comes from conv_gemm in DGRAD mode.  With the LayerNorm fold
 // of the forward pass, xhat_{j-1} = r z + c gamma + beta, so
@@ -61,91 +62,93 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(
     }
 }
 
-// dgamma[e] += sum_{b in chunk} dxh*xt, dbeta[e] += sum dxh.  grid.y splits the batch.
-__global__ __launch_bounds__(256) void ln_bwd_param_kernel(
-        const float* __restrict__ dxh, const float* __restrict__ v, const float* __restrict__ mr,
-        float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t n, int64_t B) {
-    const int64_t i = blockIdx.x * 256ll + threadIdx.x;
-    if (i >= n / 4) return;
-    const int64_t per = (B + gridDim.y - 1) / gridDim.y;
-    const int64_t b0 = blockIdx.y * per, b1 = std::min<int64_t>(B, b0 + per);
-    float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag;
-    for (int64_t b = b0; b < b1; ++b) {
-        const float mean = mr[2 * b], rstd = mr[2 * b + 1];
-        const float4 d = ((const float4*)(dxh + b * n))[i], vv = ((const float4*)(v + b * n))[i];
-        ag.x += d.x * ((vv.x - mean) * rstd); ag.y += d.y * ((vv.y - mean) * rstd);
-        ag.z += d.z * ((vv.z - mean) * rstd); ag.w += d.w * ((vv.w - mean) * rstd);
-        ab.x += d.x; ab.y += d.y; ab.z += d.z; ab.w += d.w;
-    }
-    float* g = dgamma + 4 * i; float* bt = dbeta + 4 * i;
-    atomicAdd(g, ag.x); atomicAdd(g + 1, ag.y); atomicAdd(g + 2, ag.z); atomicAdd(g + 3, ag.w);
-    atomicAdd(bt, ab.x); atomicAdd(bt + 1, ab.y); atomicAdd(bt + 2, ab.z); atomicAdd(bt + 3, ab.w);
+// Per-sample scalars of one layer's LayerNorm backward, one 32-B record per sample (read with a
+// scalar load in the fused kernel): mean, rstd, s1/n, s2/n, 1/rstd, r of the layer below, -mu of
+// the layer below.
+__global__ void ln_bwd_scalars_kernel(const float* __restrict__ mr, const double* __restrict__ lnsum,
+                                      const float* __restrict__ mr_prev, float* __restrict__ sc, int64_t B, double inv_n) {
+    const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float mean = mr[2 * b], rstd = mr[2 * b + 1];
+    float* o = sc + 8 * b;
+    o[0] = mean; o[1] = rstd;
+    o[2] = (float)(lnsum[2 * b] * inv_n); o[3] = (float)(lnsum[2 * b + 1] * inv_n);
+    o[4] = 1.f / rstd;
+    o[5] = mr_prev ? mr_prev[2 * b + 1] : 1.f;
+    o[6] = mr_prev ? -mr_prev[2 * b] : 0.f;
+    o[7] = 0.f;
 }
 
-// dt (in place over dxh), dts = r_prev * dt (optional), dbias[c] += sum dt.
-// One workgroup = R positions of one sample; thread <-> fixed float4 channel group.
-__global__ __launch_bounds__(256) void ln_bwd_apply_kernel(
-        float* __restrict__ dxh, const float* __restrict__ v, const float* __restrict__ gamma,
-        const float* __restrict__ mr, const double* __restrict__ lnsum, const float* __restrict__ mr_prev,
-        float* __restrict__ dts, float* __restrict__ dbias, int P, int C, int R) {
-    const int64_t b = blockIdx.y;
-    const int64_t n = (int64_t)P * C;
-    const float mean = mr[2 * b], rstd = mr[2 * b + 1];
-    const float m1 = (float)(lnsum[2 * b] / (double)n), m2 = (float)(lnsum[2 * b + 1] / (double)n);
-    const float rprev = mr_prev ? mr_prev[2 * b + 1] : 0.f;
-    const int cg = C / 4, rows_per_iter = 256 / cg;
-    const int my_cg = threadIdx.x % cg, my_row = threadIdx.x / cg;
-    const int p0 = blockIdx.x * R, p1 = min(P, p0 + R);
-    float4 db = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int pp = p0 + my_row; pp < p1; pp += rows_per_iter) {
-        const int64_t e = (int64_t)pp * C + 4 * my_cg;
-        const float4 d = *(const float4*)(dxh + b * n + e), vv = *(const float4*)(v + b * n + e);
-        const float4 gg = *(const float4*)(gamma + e);
+// The fused LayerNorm + ELU backward of one layer.  Convention: the incoming gradient is
+// D' = r_{j,b} * dL/dxhat_j (pre-scaled by the layer's own rstd: the transposed conv that produced
+// it consumed dts of the layer above, see below), so with g' = D' gamma, s1' = sum g', s2' = sum g' xt:
+//   dt  = (g' - s1'/n - xt s2'/n) * ELU'(v)                      = dL/dt_j
+//   dts = r_{j-1,b} * dt     written IN PLACE: operand of wgrad (against the raw z_{j-1}) and of
+//                            the transposed conv, whose output is then D' of layer j-1
+//   dgamma += sum_b D' xt / r_b,  dbeta += sum_b D' / r_b,  dbias[c] += sum dt,
+//   S1 += sum_b (-mu_{j-1,b}) dts = sum_b c_b dt,   S2 += sum_b dt.
+// Thread <-> one float4 of the (P, C) plane, loop over a chunk of the batch (blockIdx.y): every
+// per-element sum over b stays in registers and meets the other chunks through one atomic each.
+__global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
+        float* __restrict__ d, const float* __restrict__ v, const float* __restrict__ gamma,
+        const float* __restrict__ sc, float* __restrict__ dgamma, float* __restrict__ dbeta,
+        float* __restrict__ dbias, float* __restrict__ S1, float* __restrict__ S2, int64_t n, int64_t B, int C) {
+    const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+    const bool live = i < n / 4;
+    const int64_t ii = live ? i : 0;
+    const int64_t per = (B + gridDim.y - 1) / gridDim.y;
+    const int64_t b0 = blockIdx.y * per, b1 = std::min<int64_t>(B, b0 + per);
+    const float4 gg = ((const float4*)gamma)[ii];
+    float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag, a1 = ag, a2 = ag;
+#pragma unroll 2
+    for (int64_t b = b0; b < b1; ++b) {
+        const float4 s0 = *(const float4*)(sc + 8 * b), s1 = *(const float4*)(sc + 8 * b + 4);
+        const float mean = s0.x, rstd = s0.y, m1 = s0.z, m2 = s0.w, inv_r = s1.x, rprev = s1.y, cprev = s1.z;
+        float4* dp = (float4*)(d + b * n) + ii;
+        const float4 dd = *dp, vv = ((const float4*)(v + b * n))[ii];
         float4 o;
-#define NAFP_LN_ONE(c_)                                                                  \
-        {                                                                                \
-            const float xt = (vv.c_ - mean) * rstd;                                      \
-            const float dv = rstd * (d.c_ * gg.c_ - m1 - xt * m2);                       \
-            o.c_ = dv * (vv.c_ > 0.f ? 1.f : vv.c_ + 1.f);      /* ELU'(t) = exp(t) = v + 1 for t <= 0 */ \
+#define NAFP_LN_ONE(c_)                                                                     \
+        {                                                                                   \
+            const float xt = (vv.c_ - mean) * rstd;                                         \
+            const float dt = (dd.c_ * gg.c_ - m1 - xt * m2) * (vv.c_ > 0.f ? 1.f : vv.c_ + 1.f);   /* ELU'(t) = v + 1, t <= 0 */ \
+            const float du = dd.c_ * inv_r;                                                 \
+            ag.c_ = fmaf(du, xt, ag.c_); ab.c_ += du;                                       \
+            o.c_ = dt * rprev;                                                              \
+            a1.c_ = fmaf(cprev, o.c_, a1.c_); a2.c_ += dt;                                  \
         }
         NAFP_LN_ONE(x) NAFP_LN_ONE(y) NAFP_LN_ONE(z) NAFP_LN_ONE(w)
 #undef NAFP_LN_ONE
-        *(float4*)(dxh + b * n + e) = o;
-        if (dts) *(float4*)(dts + b * n + e) = make_float4(o.x * rprev, o.y * rprev, o.z * rprev, o.w * rprev);
-        db.x += o.x; db.y += o.y; db.z += o.z; db.w += o.w;
+        if (live) *dp = o;
     }
+    if (live) {
+        float* g = dgamma + 4 * i; float* bt = dbeta + 4 * i;
+        atomicAdd(g, ag.x); atomicAdd(g + 1, ag.y); atomicAdd(g + 2, ag.z); atomicAdd(g + 3, ag.w);
+        atomicAdd(bt, ab.x); atomicAdd(bt + 1, ab.y); atomicAdd(bt + 2, ab.z); atomicAdd(bt + 3, ab.w);
+        if (S1) {
+            float* o1 = S1 + 4 * i; float* o2 = S2 + 4 * i;
+            atomicAdd(o1, a1.x); atomicAdd(o1 + 1, a1.y); atomicAdd(o1 + 2, a1.z); atomicAdd(o1 + 3, a1.w);
+            atomicAdd(o2, a2.x); atomicAdd(o2 + 1, a2.y); atomicAdd(o2 + 2, a2.z); atomicAdd(o2 + 3, a2.w);
+        }
+    }
+    // dbias[c] = sum over positions and samples of dt = the a2 sums of every thread on channel c
     __shared__ float4 red[256];
-    red[threadIdx.x] = db;
+    red[threadIdx.x] = live ? a2 : make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
-    if (threadIdx.x < cg) {
+    const int cg = C / 4;                                   // float4 channel groups; 256 % cg == 0 or cg % 256 == 0
+    if (cg >= 256) {
+        if (live) {
+            float* o = dbias + (4 * i) % C;
+            atomicAdd(o, a2.x); atomicAdd(o + 1, a2.y); atomicAdd(o + 2, a2.z); atomicAdd(o + 3, a2.w);
+        }
+    } else if ((int)threadIdx.x < cg) {
         float4 t = red[threadIdx.x];
-        for (int r = 1; r < rows_per_iter; ++r) {
-            const float4 u = red[threadIdx.x + r * cg];
+        for (int r = threadIdx.x + cg; r < 256; r += cg) {
+            const float4 u = red[r];
             t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
         }
-        float* o = dbias + 4 * threadIdx.x;
+        float* o = dbias + 4 * threadIdx.x;                 // block start is a multiple of 1024 elements, C | 1024
         atomicAdd(o, t.x); atomicAdd(o + 1, t.y); atomicAdd(o + 2, t.z); atomicAdd(o + 3, t.w);
     }
-}
-
-// S1[e] += sum_b c_b * dt[b,e], S2[e] += sum_b dt[b,e]  with c_b = -mean_b * rstd_b of the layer below.
-__global__ __launch_bounds__(256) void batch_reduce_kernel(
-        const float* __restrict__ dt, const float* __restrict__ mr_prev, float* __restrict__ S1,
-        float* __restrict__ S2, int64_t n, int64_t B) {
-    const int64_t i = blockIdx.x * 256ll + threadIdx.x;
-    if (i >= n / 4) return;
-    const int64_t per = (B + gridDim.y - 1) / gridDim.y;
-    const int64_t b0 = blockIdx.y * per, b1 = std::min<int64_t>(B, b0 + per);
-    float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
-    for (int64_t b = b0; b < b1; ++b) {
-        const float c = -mr_prev[2 * b] * mr_prev[2 * b + 1];
-        const float4 d = ((const float4*)(dt + b * n))[i];
-        a1.x += c * d.x; a1.y += c * d.y; a1.z += c * d.z; a1.w += c * d.w;
-        a2.x += d.x; a2.y += d.y; a2.z += d.z; a2.w += d.w;
-    }
-    float* o1 = S1 + 4 * i; float* o2 = S2 + 4 * i;
-    atomicAdd(o1, a1.x); atomicAdd(o1 + 1, a1.y); atomicAdd(o1 + 2, a1.z); atomicAdd(o1 + 3, a1.w);
-    atomicAdd(o2, a2.x); atomicAdd(o2 + 1, a2.y); atomicAdd(o2 + 2, a2.z); atomicAdd(o2 + 3, a2.w);
 }
 
 // ============================================================================
@@ -359,8 +362,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(
 // ============================================================================
 // tail backward: L2 normalisation, divide-and-encode, flatten (nnfp.py:141-156, 224-231).
 //   kernel A (one workgroup per segment, thread <-> slice q): dy, then dxhat of the last conv;
-//   kernel B (one workgroup per slice, thread <-> (i, j)): batch-reduced weight gradients,
-//   deterministic (fixed order over the batch).
+//   kernel B (workgroup = slice x batch chunk, thread <-> (i, j)): batch-reduced weight gradients.
 // ============================================================================
 template <int S>
 __device__ __forceinline__ void tail_slice_forward(const TailBwdArgs& a, int64_t b, int q, float lnA, float lnC,
@@ -416,15 +418,17 @@ __global__ __launch_bounds__(256) void tail_bwd_a_kernel(const TailBwdArgs a) {
         for (int i = 0; i < S; ++i) dx[i] = fmaf(a.w1[(q * S + i) * 32 + j], da, dx[i]);
     }
 #pragma unroll
-    for (int i = 0; i < S; ++i) a.dxh[b * a.D + q * S + i] = dx[i];
+    for (int i = 0; i < S; ++i) a.dxh[b * a.D + q * S + i] = lnA * dx[i];      // r_b * dL/dxhat: ln_bwd_fused's convention
 }
 
 template <int S>
 __global__ __launch_bounds__(256) void tail_bwd_b_kernel(const TailBwdArgs a, int64_t B) {
     const int q = blockIdx.x;
     const int j = threadIdx.x & 31, i = threadIdx.x >> 5;         // 32 x 8 threads; i < S computes dw1[q][i][j]
+    const int64_t per = (B + gridDim.y - 1) / gridDim.y;
+    const int64_t bb0 = blockIdx.y * per, bb1 = std::min<int64_t>(B, bb0 + per);
     float aw1 = 0.f, ab1 = 0.f, aw2 = 0.f, ab2 = 0.f;
-    for (int64_t b = 0; b < B; ++b) {
+    for (int64_t b = bb0; b < bb1; ++b) {
         const double mean = a.stats[2 * b] / (double)a.D;
         double var = a.stats[2 * b + 1] / (double)a.D - mean * mean;
         var = var > 0.0 ? var : 0.0;
@@ -449,16 +453,18 @@ __global__ __launch_bounds__(256) void tail_bwd_b_kernel(const TailBwdArgs a, in
         aw2 += dyq * elu1(h);
         ab2 += dyq;
     }
-    if (i < S) a.dw1[(q * S + i) * 32 + j] = aw1;
-    if (i == 0) { a.db1[q * 32 + j] = ab1; a.dw2[q * 32 + j] = aw2; }
-    if (threadIdx.x == 0) a.db2[q] = ab2;
+    // the batch chunks (blockIdx.y) meet through atomics; the gradients are zeroed by the caller
+    if (i < S) atomicAdd(a.dw1 + (q * S + i) * 32 + j, aw1);
+    if (i == 0) { atomicAdd(a.db1 + q * 32 + j, ab1); atomicAdd(a.dw2 + q * 32 + j, aw2); }
+    if (threadIdx.x == 0) atomicAdd(a.db2 + q, ab2);
 }
 
 int launch_tail_bwd(const TailBwdArgs& a, int64_t B, hipStream_t st) {
     if (a.S != 8 || a.Q % 64 != 0 || a.Q > 256) return NAFP_ERR_UNSUPPORTED;
     tail_bwd_a_kernel<8><<<dim3((unsigned)B), a.Q, 0, st>>>(a);
     NAFP_LAUNCH_CHECK();
-    tail_bwd_b_kernel<8><<<dim3((unsigned)a.Q), 256, 0, st>>>(a, B);
+    const unsigned chunks = (unsigned)std::min<int64_t>(16, std::max<int64_t>(1, B / 16));
+    tail_bwd_b_kernel<8><<<dim3((unsigned)a.Q, chunks), 256, 0, st>>>(a, B);
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }
@@ -482,28 +488,20 @@ int launch_stats_to_mr(const double* stats, float* mr, const double* inv_n_dev, 
     return NAFP_OK;
 }
 
-int launch_ln_bwd(float* dxh, const float* v, const float* gamma, const float* mr, const float* mr_prev,
-                  double* lnsum, float* dgamma, float* dbeta, float* dts, float* dbias, int64_t B, int P, int C,
-                  hipStream_t st) {
+int launch_ln_bwd(float* d, const float* v, const float* gamma, const float* mr, const float* mr_prev,
+                  double* lnsum, float* sc, float* dgamma, float* dbeta, float* dbias, float* S1, float* S2,
+                  int64_t B, int P, int C, hipStream_t st) {
     const int64_t n = (int64_t)P * C;
-    if (C % 4 != 0 || 256 % (C / 4) != 0 || n % 4 != 0) return NAFP_ERR_UNSUPPORTED;
-    NAFP_HIP_CHECK(hipMemsetAsync(lnsum, 0, sizeof(double) * 2 * B, st));
+    if (C % 4 != 0 || (256 % (C / 4) != 0 && (C / 4) % 256 != 0) || n % 1024 != 0 || 1024 % C != 0) return NAFP_ERR_UNSUPPORTED;
     const int chunks = (int)std::min<int64_t>(std::max<int64_t>(1, n / 4 / 2048), 64);
-    ln_bwd_reduce_kernel<<<dim3(chunks, (unsigned)B), 256, 0, st>>>(dxh, v, gamma, mr, lnsum, n);
+    ln_bwd_reduce_kernel<<<dim3(chunks, (unsigned)B), 256, 0, st>>>(d, v, gamma, mr, lnsum, n);
     NAFP_LAUNCH_CHECK();
-    const int by = (int)std::min<int64_t>(B, n >= (1 << 16) ? 4 : 16);
-    ln_bwd_param_kernel<<<dim3((unsigned)((n / 4 + 255) / 256), by), 256, 0, st>>>(dxh, v, mr, dgamma, dbeta, n, B);
+    ln_bwd_scalars_kernel<<<(unsigned)((B + 255) / 256), 256, 0, st>>>(mr, lnsum, mr_prev, sc, B, 1.0 / (double)n);
     NAFP_LAUNCH_CHECK();
-    const int R = std::max(1, 16384 / C);
-    ln_bwd_apply_kernel<<<dim3((unsigned)((P + R - 1) / R), (unsigned)B), 256, 0, st>>>(dxh, v, gamma, mr, lnsum, mr_prev, dts,
-                                                                                       dbias, P, C, R);
-    NAFP_LAUNCH_CHECK();
-    return NAFP_OK;
-}
-
-int launch_batch_reduce(const float* dt, const float* mr_prev, float* S1, float* S2, int64_t n, int64_t B, hipStream_t st) {
-    const int by = (int)std::min<int64_t>(B, n >= (1 << 16) ? 4 : 16);
-    batch_reduce_kernel<<<dim3((unsigned)((n / 4 + 255) / 256), by), 256, 0, st>>>(dt, mr_prev, S1, S2, n, B);
+    // batch chunks: enough workgroups to fill the chip, few enough that the per-element atomics stay cheap
+    const int64_t bx = n / 1024;
+    const int by = (int)std::min<int64_t>(B, std::max<int64_t>(4, (2048 + bx - 1) / bx));
+    ln_bwd_fused_kernel<<<dim3((unsigned)bx, by), 256, 0, st>>>(d, v, gamma, sc, dgamma, dbeta, dbias, S1, S2, n, B, C);
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }

@@ -165,6 +165,7 @@ struct ConvKernelParams {
     double inv_n_in;          // 1 / sample_in
     int mode;                 // 0 FULL, 1 PLAIN
     int dgrad;                // 1: transposed conv (backward w.r.t. the conv input), see row_geom()
+    int perm_on, perm_n0, perm_c0;   // DGRAD, stride 2: tile rows enumerate positions parity class by class (tile_pos())
     unsigned wp_bytes;
     int n_split;              // split-K factor (blockIdx.z); > 1 writes raw partial sums to `y` = slab
     int abl;                  // ablation flags for kernel-time breakdown (NAFP_ABL env; 0 in production)
@@ -236,6 +237,26 @@ __device__ __forceinline__ RowGeom row_geom(const ConvKernelParams& p, int pos) 
     return g;
 }
 
+// Position served by row-index `idx` of the launch.  Identity, except for the transposed conv of a
+// stride-2 layer: there an input coordinate u (+pad) of even parity receives taps {0, 2} and an odd
+// one only tap {1}, so the positions are enumerated class by class (first all positions whose tap
+// coordinate is = perm_c0 mod 2, then the others).  A tile then holds rows of ONE class (up to the
+// single boundary tile) and the tile-wide dead-tap skip removes the structurally zero half of the
+// K-steps instead of multiplying zeros.
+__device__ __forceinline__ int tile_pos(const ConvKernelParams& p, int idx) {
+    if (!p.perm_on || idx >= p.P) return idx;
+    const int n0 = p.perm_n0;
+    if (p.axis == 0) {            // tap axis = minor coordinate, L = p.Tout per line
+        const int L = p.Tout, lines = p.P / L, n1 = L - n0;
+        if (idx < lines * n0) { const int line = idx / n0; return line * L + 2 * (idx - line * n0) + p.perm_c0; }
+        const int j = idx - lines * n0, line = j / n1;
+        return line * L + 2 * (j - line * n1) + 1 - p.perm_c0;
+    }
+    if (idx < n0 * p.Tout) { const int e = idx / p.Tout; return (2 * e + p.perm_c0) * p.Tout + (idx - e * p.Tout); }
+    const int j = idx - n0 * p.Tout, e = j / p.Tout;
+    return (2 * e + 1 - p.perm_c0) * p.Tout + (j - e * p.Tout);
+}
+
 template <int BK, int NSTAGE, bool FUSE0>
 __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     static_assert(!FUSE0 || BK == 16, "the in-kernel conv0 generator is written for BK = 16");
@@ -245,10 +266,11 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     constexpr int TILE = BM * BK;                  // floats per operand tile
     constexpr int STAGE = 2 * TILE;                // A | B
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // [stage 0: A | B] ... [stage NSTAGE-1] [sRB[128]] [sCB[128]] [FUSE0: conv0 w (3,Cin) | bias (Cin)]
+    // [stage 0: A | B] ... [stage NSTAGE-1] [sRB[128]] [sCB[128]] [sPos[32]] [FUSE0: conv0 w (3,Cin) | bias (Cin)]
     float* sRB = smem + NSTAGE * STAGE;
     float* sCB = sRB + BM;
-    float* sW0 = sCB + BM;
+    int* sPos = (int*)(sCB + BM);                  // position of each of the tile's PT position slots (epilogue)
+    float* sW0 = sCB + BM + 32;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -272,6 +294,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         }
         sRB[tid] = r; sCB[tid] = c;
     }
+    if (tid >= 128 && tid < 128 + p.PT) sPos[tid - 128] = tile_pos(p, pb * p.PT + tid - 128);
 
     // ---- DMA geometry.  Wave w stages rows [32w, 32w+32) of A and of B; instruction q
     // covers rows 32w + q*RPI + lane/CH, physical chunk pc = lane % CH, which must hold
@@ -286,7 +309,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         const int pc = lane % CH;
         const int swz = BK == 32 ? ((lr >> 1) & 7) : ((lr >> 2) & 3);
         const int lc = pc ^ swz;
-        const int pos = pb * p.PT + (lr >> p.log2ST);
+        const int pos = tile_pos(p, pb * p.PT + (lr >> p.log2ST));
         const int sl = lr & ST1;
         voffA[q] = 0; vmaskA[q] = 0;
         if (pos < p.P && sl < nb) {
@@ -339,7 +362,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
 #pragma unroll
         for (int hrow = 0; hrow < 2; ++hrow) {
             const int lr = lane + 64 * hrow;
-            const int pos = pb * p.PT + (lr >> p.log2ST);
+            const int pos = tile_pos(p, pb * p.PT + (lr >> p.log2ST));
             if (pos < p.P && (lr & ST1) < nb) m |= row_geom(p, pos).mask;
         }
 #pragma unroll
@@ -496,7 +519,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int lr = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int pos = pb * p.PT + (lr >> p.log2ST);
+                const int pos = sPos[lr >> p.log2ST];
                 const int b = sg * p.ST + (lr & ST1);
                 if (pos < p.P && b < p.B) {
 #pragma unroll
@@ -615,7 +638,7 @@ NAFP_GEMM_KERNEL(conv_gemm_k16s3_fuse0, 16, 3, 3, true)    // conv1 with conv0 g
 
 template <typename KernelT>
 static int launch_variant(KernelT kernel, int BK, int NSTAGE, const ConvKernelParams& p, dim3 grid, hipStream_t st) {
-    const int lds = (NSTAGE * 2 * BM * BK + 2 * BM + (p.f0_feat ? 4 * p.Cin : 0)) * (int)sizeof(float);
+    const int lds = (NSTAGE * 2 * BM * BK + 2 * BM + 32 + (p.f0_feat ? 4 * p.Cin : 0)) * (int)sizeof(float);
     NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     kernel<<<grid, 256, lds, st>>>(p);
     NAFP_LAUNCH_CHECK();
@@ -706,14 +729,47 @@ static int choose_split(int64_t n_tiles, int k_steps, int64_t out_floats) {
     return best;
 }
 
-int64_t conv_gemm_slab_floats(int64_t B, const ConvGeom& g) {
-    const int P = g.Fout * g.Tout;
+// Split-K finish of a PLAIN launch (transposed conv, G/Hb images): y = sum of the S slabs (+ bias).
+__global__ __launch_bounds__(256) void plain_finish_kernel(const float* __restrict__ slab, int S, const float* __restrict__ bias,
+                                                          float* __restrict__ y, int64_t n4, int Cout) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 acc = ((const float4*)slab)[i];
+        for (int sp = 1; sp < S; ++sp) {
+            const float4 t = ((const float4*)slab)[i + sp * n4];
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+        if (bias) {
+            const float4 bv = *(const float4*)(bias + (4 * i) % Cout);
+            acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w;
+        }
+        ((float4*)y)[i] = acc;
+    }
+}
+
+// K-steps (BK = 16) of a tile of the transposed conv: with stride 2 the parity classes of tile_pos()
+// carry 2 resp. 1 live taps (1.5 on average), with stride 1 all three.
+static int dgrad_k_steps(const ConvGeom& g) { return (g.stride == 2 ? 3 : 6) * g.Cout / 32; }
+
+static int tile_pt(int P) {
     int pt = 1;
-    while (pt * 2 <= P && pt * 2 <= 32) pt *= 2;
-    const int ST = BM / pt;
+    while (pt * 2 <= P && pt * 2 <= 32) pt *= 2;          // largest power of two <= min(P, 32)
+    return pt;
+}
+
+int64_t conv_gemm_slab_floats(int64_t B, const ConvGeom& g, bool with_dgrad) {
+    const int P = g.Fout * g.Tout;
+    const int pt = tile_pt(P), ST = BM / pt;
     const int64_t n_tiles = ((B + ST - 1) / ST) * ((P + pt - 1) / pt) * (g.Cout / BN);
     const int S = choose_split(n_tiles, live_k_steps(g), B * P * g.Cout);
-    return S > 1 ? (int64_t)S * B * P * g.Cout : 0;
+    int64_t need = S > 1 ? (int64_t)S * B * P * g.Cout : 0;
+    if (with_dgrad && g.Cin % BN == 0) {
+        const int Pd = g.Fin * g.Tin;
+        const int ptd = tile_pt(Pd), STd = BM / ptd;
+        const int64_t tiles_d = ((B + STd - 1) / STd) * ((Pd + ptd - 1) / ptd) * (g.Cin / BN);
+        const int Sd = choose_split(tiles_d, dgrad_k_steps(g), B * Pd * g.Cin);
+        if (Sd > 1) need = std::max(need, (int64_t)Sd * B * Pd * g.Cin);
+    }
+    return need;
 }
 
 int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStream_t st) {
@@ -724,8 +780,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     p.Fin = g.Fin; p.Tin = g.Tin; p.Cin = g.Cin; p.Tout = g.Tout; p.Cout = g.Cout;
     p.axis = g.axis; p.stride = g.stride; p.pad = g.pad;
     p.B = (int)B; p.P = g.Fout * g.Tout;
-    int pt = 1;
-    while (pt * 2 <= p.P && pt * 2 <= 32) pt *= 2;          // largest power of two <= min(P, 32)
+    int pt = tile_pt(p.P);
     p.PT = pt; p.ST = BM / pt;
     p.log2ST = 0;
     while ((1 << p.log2ST) < p.ST) ++p.log2ST;
@@ -735,7 +790,8 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     p.inv_n_in = 1.0 / (double)p.sample_in;
     p.mode = a.plain ? 1 : 0;
     p.n_split = 1;
-    p.dgrad = 0;
+    p.dgrad = 0; p.perm_on = 0; p.perm_n0 = 0; p.perm_c0 = 0;
+    int k_steps = live_k_steps(g);
     if (a.dgrad) {
         // backward w.r.t. the conv input: rows = input positions, source = dT (B,Fout,Tout,Cout),
         // weights = wp flipped to (Cin, 3*Cout); see row_geom()
@@ -743,8 +799,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
         p.dgrad = 1;
         p.Fin = g.Fout; p.Tin = g.Tout; p.Cin = g.Cout; p.Cout = g.Cin; p.Tout = g.Tin;
         p.P = g.Fin * g.Tin;
-        pt = 1;
-        while (pt * 2 <= p.P && pt * 2 <= 32) pt *= 2;
+        pt = tile_pt(p.P);
         p.PT = pt; p.ST = BM / pt;
         p.log2ST = 0;
         while ((1 << p.log2ST) < p.ST) ++p.log2ST;
@@ -753,6 +808,12 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
         const int S = g.axis == 0 ? g.Cout : g.Tout * g.Cout;
         p.tap_stride = -(S / g.stride);
         p.inv_n_in = 1.0;
+        const int L = g.axis == 0 ? g.Tin : g.Fin;             // extent of the rows along the tap axis
+        if (g.stride == 2 && L >= 2) {
+            p.perm_on = 1; p.perm_c0 = g.pad & 1;              // class 0: coordinate + pad even -> taps {0, 2}
+            p.perm_n0 = (L - p.perm_c0 + 1) / 2;
+        }
+        k_steps = dgrad_k_steps(g);
     }
     // per-tile A descriptor covers ST samples: must stay below the 2 GiB OOB marker
     if ((int64_t)p.ST * p.sample_in * 4 >= ((int64_t)1 << 31)) return NAFP_ERR_UNSUPPORTED;
@@ -764,11 +825,12 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     const int n_pb = (p.P + p.PT - 1) / p.PT;
     const int64_t n_tiles = (int64_t)p.n_sg * n_pb * (p.Cout / BN);
     int S = 1;
-    if (!a.plain && a.slab && !a.f0_feat) {
-        S = choose_split(n_tiles, live_k_steps(g), B * p.P * g.Cout);
-        if ((int64_t)S * B * p.P * g.Cout > a.slab_floats) S = 1;
+    const int64_t out_floats = B * p.P * p.Cout;
+    if (a.slab && !a.f0_feat) {
+        S = choose_split(n_tiles, k_steps, out_floats);
+        if ((int64_t)S * out_floats > a.slab_floats) S = 1;
     }
-    if (S > 1) { p.mode = 2; p.n_split = S; p.y = a.slab; p.bias = nullptr; }
+    if (S > 1) { p.mode = a.plain ? 1 : 2; p.n_split = S; p.y = a.slab; p.bias = nullptr; }
     const dim3 grid((unsigned)((int64_t)p.n_sg * n_pb), (unsigned)(p.Cout / BN), (unsigned)S);
     static const int variant = []() { const char* e = getenv("NAFP_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
     int rc;
@@ -792,6 +854,13 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
         default: rc = launch_variant(conv_gemm_k16s3, 16, 3, p, grid, st); break;   // best measured (profiles/)
     }
     if (rc != NAFP_OK || S == 1) return rc;
+    if (a.plain) {
+        const int64_t n4 = out_floats / 4;
+        plain_finish_kernel<<<dim3((unsigned)std::min<int64_t>((n4 + 255) / 256, 8192)), 256, 0, st>>>(a.slab, S, a.bias, a.y, n4,
+                                                                                                    p.Cout);
+        NAFP_LAUNCH_CHECK();
+        return NAFP_OK;
+    }
     splitk_finish_kernel<<<dim3((unsigned)(B * p.P)), 256, 0, st>>>(a.slab, S, a.G, a.Hb, a.gamma_out, a.stats_in,
                                                                    a.stats_out, a.y, a.v_out, p.B, p.P, g.Cout, p.inv_n_in);
     NAFP_LAUNCH_CHECK();

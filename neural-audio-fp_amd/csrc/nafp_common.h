@@ -113,7 +113,7 @@ struct ConvGemmArgs {
 // statistics (sum, sum of squares of ELU(conv0 + bias) per sample) without storing the activation
 int launch_conv0_stats(const float* feat, const float* w3, const float* bias, double* stats, int64_t B,
                        const ConvGeom& g, hipStream_t st);
-int64_t conv_gemm_slab_floats(int64_t B, const ConvGeom& g);   // workspace the split-K policy wants
+int64_t conv_gemm_slab_floats(int64_t B, const ConvGeom& g, bool with_dgrad = false);   // workspace the split-K policy wants
 int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStream_t st);
 
 // tail: LN of the last conv + flatten + divide-and-encode + optional L2 norm.
@@ -144,11 +144,11 @@ struct TailBwdArgs {
 };
 int launch_tail_bwd(const TailBwdArgs& a, int64_t B, hipStream_t st);
 int launch_stats_to_mr(const double* stats, float* mr, const double* inv_n_dev, int64_t B, int n_layers, hipStream_t st);
-// LayerNorm + ELU backward of one layer: dxh -> dt in place; dgamma/dbeta/dbias accumulate (zeroed by the caller)
-int launch_ln_bwd(float* dxh, const float* v, const float* gamma, const float* mr, const float* mr_prev,
-                  double* lnsum, float* dgamma, float* dbeta, float* dts, float* dbias, int64_t B, int P, int C,
-                  hipStream_t st);
-int launch_batch_reduce(const float* dt, const float* mr_prev, float* S1, float* S2, int64_t n, int64_t B, hipStream_t st);
+// LayerNorm + ELU backward of one layer (backward.hip): d = r_j * dL/dxhat_j -> dts = r_{j-1} * dL/dt_j in place;
+// dgamma/dbeta/dbias/S1/S2 accumulate (zeroed by the caller, like lnsum); sc = (B, 8) scratch.
+int launch_ln_bwd(float* d, const float* v, const float* gamma, const float* mr, const float* mr_prev,
+                  double* lnsum, float* sc, float* dgamma, float* dbeta, float* dbias, float* S1, float* S2,
+                  int64_t B, int P, int C, hipStream_t st);
 // dW (keras (3,Cin,Cout), accumulated) += sum_rows X[b, in(pos,tap), :] (x) D[b,pos,:]
 int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const ConvGeom& g, hipStream_t st);
 int launch_conv0_bwd(const float* feat, const float* dt, float* dW0, float* dbias0, int64_t B, const ConvGeom& g,
