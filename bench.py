@@ -102,6 +102,49 @@ def cpu_baseline(target_s=12.0, max_batches=40):
                       f'of melspec+encoder (oracle/torch_ref.py), {el:.1f} s, best of the thread counts tried'}
 
 
+def train_region(cfg, world, rank, dist, global_bsz, steps, torch, warmup=2):
+    """Second half of BASELINE.json's metric: contrastive-train steps/s at a GLOBAL batch of 5120
+    (configs[3]: config/640_lamb.yaml scaled, LAMB, tau 0.05), strong scaling: every rank takes
+    5120/N segments (anchors + replicas), all-gathers the embeddings, all-reduces the gradients.
+    A step = melspec + spec-augment + forward + NT-Xent + backward + (collectives) + LAMB."""
+    import copy
+    from neural_audio_fp_amd.model import trainer as T
+    c = copy.deepcopy(cfg)
+    c['BSZ']['TR_BATCH_SZ'], c['BSZ']['TR_N_ANCHOR'] = global_bsz, global_bsz // 2
+    c['TRAIN']['OPTIMIZER'], c['TRAIN']['LR'] = 'LAMB', 1e-4
+    if (global_bsz // 2) % world:
+        return {'skipped': f'global batch {global_bsz} does not split over {world} ranks'}
+    m_pre, m_specaug, m_fp, opt, loss_obj, bucket = T.setup(c, 1000)
+    batches = list(T.synthetic_batches(c, 2)(1))
+    for i in range(warmup):
+        T.train_step(batches[i % 2], m_pre, m_specaug, m_fp, loss_obj, opt, bucket)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss, _ = T.train_step(batches[i % 2], m_pre, m_specaug, m_fp, loss_obj, opt, bucket)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([el], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t[0])
+    enc = 2.0 * (sum(conv_effective_macs()) + 36864)               # forward FLOPs per segment
+    flops = 3.0 * enc * global_bsz + 3.0 * 2.0 * global_bsz * global_bsz * 128   # fwd + dgrad + wgrad, NT-Xent x3
+    tf = flops / (el / steps) / 1e12
+    return {'metric': 'contrastive train steps/s', 'value': round(steps / el, 4), 'unit': 'steps/s',
+            'global_batch': global_bsz, 'per_gpu_batch': global_bsz // world, 'n_gpus': world, 'steps': steps,
+            'warmup': warmup, 'ms_per_step': round(el / steps * 1e3, 3), 'scaling': 'strong', 'optimizer': 'LAMB',
+            'segments_per_s': round(global_bsz * steps / el, 1), 'loss': round(float(loss), 4),
+            'algorithmic_TFLOP_per_step': round(flops / 1e12, 3), 'achieved_TFLOP/s': round(tf, 2),
+            'mfma_frac_of_peak': round(tf / (FP32_MFMA_PEAK_TFLOPS * world), 4),
+            'collectives': 'none' if world == 1 else 'all_gather(emb) + all_reduce(d emb) + all_reduce(67.8 MB grads)',
+            'data': 'synthetic (seeded noise anchors, replicas = anchors + noise at 5 dB SNR), resident in HBM'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -112,6 +155,9 @@ def main():
                          'durations are the kernels own).  With 1, a second region with 4 streams is '
                          'timed afterwards and reported as "pipelined".')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-train', action='store_true', help='skip the contrastive-train region (reported as "train")')
+    ap.add_argument('--train-steps', type=int, default=6)
+    ap.add_argument('--train-bsz', type=int, default=5120, help='GLOBAL train batch (BASELINE.json configs[3])')
     ap.add_argument('--no-pipelined', action='store_true',
                     help='skip the extra 4-stream region (used under rocprofv3 so that its per-kernel '
                          'averages cover the single-stream launches only)')
@@ -225,6 +271,9 @@ def main():
             pel = float(t[0])
         pipelined = {'streams': 4, 'value': round(world * BSZ * args.steps / pel, 1), 'unit': 'segments/s',
                      'ms_per_step': round(pel / args.steps * 1e3, 4)}
+    train = None
+    if not args.no_train:
+        train = train_region(cfg, world, rank, dist, args.train_bsz, args.train_steps, torch)
     iso = None
     if n_str > 1:
         m_fp.profile_enable(6)
@@ -276,6 +325,8 @@ def main():
         out['config']['streams'] = n_str
         if pipelined:
             out['pipelined'] = pipelined
+        if train:
+            out['train'] = train
         if iso:
             iso_ms = sum(sum(p[1:16]) for p in iso) / len(iso)
             iso_ach = gemm_flops_per_step / (iso_ms * 1e-3) / 1e12

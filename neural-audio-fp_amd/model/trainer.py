@@ -73,20 +73,21 @@ def train_step(X, m_pre, m_specaug, m_fp, loss_obj, opt, bucket=None):
     if dist is None:
         loss, d_a, d_b = loss_obj.loss_and_grad(ha, hb)
     else:
+        # 2 small collectives: all-gather of [ha; hb], then ONE all-reduce of [d/d a_all; d/d b_all; loss]
         world, rank = dist.get_world_size(), dist.get_rank()
-        ga = [torch.empty_like(ha) for _ in range(world)]
-        gb = [torch.empty_like(hb) for _ in range(world)]
-        dist.all_gather(ga, ha)
-        dist.all_gather(gb, hb)
-        a_all, b_all = torch.cat(ga).contiguous(), torch.cat(gb).contiguous()
+        d = emb.shape[1]
+        gathered = torch.empty((world * 2 * n_anchors, d), dtype=emb.dtype, device=emb.device)
+        dist.all_gather_into_tensor(gathered, emb.contiguous())
+        g4 = gathered.view(world, 2, n_anchors, d)
+        a_all, b_all = g4[:, 0].reshape(-1, d), g4[:, 1].reshape(-1, d)
+        n_g = world * n_anchors
         loss_sum, _, d_a_all, d_b_all = _ntxent_call(loss_obj._lib, ha, hb, a_all, b_all, rank * n_anchors,
                                                      loss_obj.tau, False, True)
-        loss = loss_sum[0] / a_all.shape[0]
-        dist.all_reduce(loss)
-        dist.all_reduce(d_a_all)
-        dist.all_reduce(d_b_all)
-        d_a = d_a_all[rank * n_anchors:(rank + 1) * n_anchors]
-        d_b = d_b_all[rank * n_anchors:(rank + 1) * n_anchors]
+        red = torch.cat([d_a_all.view(-1), d_b_all.view(-1), loss_sum / n_g])
+        dist.all_reduce(red)
+        loss = red[-1]
+        sl = slice(rank * n_anchors, (rank + 1) * n_anchors)
+        d_a, d_b = red[:n_g * d].view(n_g, d)[sl], red[n_g * d:2 * n_g * d].view(n_g, d)[sl]
     grads = m_fp.backward(torch.cat([d_a, d_b], dim=0))
     if dist is not None:
         if bucket is None:
@@ -159,35 +160,50 @@ def synthetic_batches(cfg, steps_per_epoch, device=None, snr_db=5.0):
     return epoch
 
 
+def setup(cfg, total_nsteps):
+    """Models, optimizer, loss object and gradient bucket of one rank (trainer.py:113-176).
+    TR_BATCH_SZ / TR_N_ANCHOR are the GLOBAL batch; each rank takes 1/world of it."""
+    if cfg['LOSS']['LOSS_MODE'].upper() != 'NTXENT':
+        raise NotImplementedError(cfg['LOSS']['LOSS_MODE'])
+    m_pre, m_specaug, m_fp = build_fp(cfg)
+    opt = make_optimizer(cfg, total_nsteps)
+    dist = _dist()
+    world = dist.get_world_size() if dist is not None else 1
+    n_a = cfg['BSZ']['TR_N_ANCHOR'] // world
+    loss_obj = NTxentLoss(n_org=n_a, n_rep=(cfg['BSZ']['TR_BATCH_SZ'] - cfg['BSZ']['TR_N_ANCHOR']) // world,
+                          tau=cfg['LOSS']['TAU'])
+    bucket = GradientBucket(m_fp)
+    sync_replicas(m_fp)
+    return m_pre, m_specaug, m_fp, opt, loss_obj, bucket
+
+
+def sync_replicas(m_fp):
+    """Replicas start from rank 0's variables."""
+    dist = _dist()
+    if dist is not None:
+        for v in m_fp.trainable_variables:
+            dist.broadcast(v, src=0)
+        m_fp.mark_dirty()
+
+
 def trainer(cfg, checkpoint_name, train_batches=None, steps_per_epoch=None, max_epoch=None):
     """trainer.py:111-230 without the host data pipeline: `train_batches` is a callable
     epoch -> iterable of (Xa, Xp) CUDA (or host) batches of shape (n, 1, T)."""
     if train_batches is None:
         raise NotImplementedError('the augmenting training dataset (model/dataset.py) is outside the built path: '
                                   'pass train_batches=callable(epoch) -> iterable of (Xa, Xp)')
-    if cfg['LOSS']['LOSS_MODE'].upper() != 'NTXENT':
-        raise NotImplementedError(cfg['LOSS']['LOSS_MODE'])
-    m_pre, m_specaug, m_fp = build_fp(cfg)
     max_epoch = max_epoch or cfg['TRAIN']['MAX_EPOCH']
     if steps_per_epoch is None:
         steps_per_epoch = len(train_batches(1))
-    opt = make_optimizer(cfg, max_epoch * steps_per_epoch)
-    dist = _dist()
-    world = dist.get_world_size() if dist is not None else 1
-    n_a = cfg['BSZ']['TR_N_ANCHOR'] // world            # TR_BATCH_SZ is the global batch (trainer.py:148-151)
-    loss_obj = NTxentLoss(n_org=n_a, n_rep=(cfg['BSZ']['TR_BATCH_SZ'] - cfg['BSZ']['TR_N_ANCHOR']) // world,
-                          tau=cfg['LOSS']['TAU'])
-    bucket = GradientBucket(m_fp)
+    m_pre, m_specaug, m_fp, opt, loss_obj, bucket = setup(cfg, max_epoch * steps_per_epoch)
     ck_root = cfg['DIR']['LOG_ROOT_DIR'] + 'checkpoint/'
     start = 1
     try:                                            # resume from the latest checkpoint (experiment_helper.py:125-136)
         start = _gen.load_checkpoint(ck_root, checkpoint_name, None, m_fp, optimizer=opt) + 1
     except FileNotFoundError:
         pass
-    if dist is not None:                            # replicas start from rank 0's variables and slots
-        for v in m_fp.trainable_variables:
-            dist.broadcast(v, src=0)
-        m_fp.mark_dirty()
+    dist = _dist()
+    sync_replicas(m_fp)
     history = []
     for ep in range(start, max_epoch + 1):
         tot, n = 0.0, 0
