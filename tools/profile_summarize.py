@@ -147,4 +147,29 @@ with open(os.path.join(dst, f'{tag}_summary.md'), 'w') as f:
         f.write(f'| {g} | {a["_dur"] / 1e3:.1f} | {clk:.2f} | {mf:.1f} | {occ:.1f} | '
                 f'{a["SQ_WAIT_ANY"] / a["SQ_WAVE_CYCLES"] * 100:.1f} | {a["SQ_WAIT_INST_ANY"] / a["SQ_WAVE_CYCLES"] * 100:.1f} | '
                 f'{a.get("SQ_LDS_BANK_CONFLICT", 0):.0f} |\n')
+# ---- train step (tools/train_probe.py 1280 adam 5 under --kernel-trace --stats) ----
+tt = os.path.join(src, 'train_trace', 't_kernel_stats.csv')
+if os.path.exists(tt):
+    shutil.copy(tt, os.path.join(dst, f'{tag}_train_kernel_stats.csv'))
+    tstats = read_csv(tt)
+    ttrace = read_csv(os.path.join(src, 'train_trace', 't_kernel_trace.csv'))
+    ttrace.sort(key=lambda r: int(r['Start_Timestamp']))
+    idx = [i for i, r in enumerate(ttrace) if 'melspec_kernel' in r['Kernel_Name']]
+    a, b = idx[-2], idx[-1]
+    agg2 = defaultdict(lambda: [0, 0.0])
+    for r in ttrace[a:b]:
+        n = r['Kernel_Name'].replace('nafp::', '').replace('void ', '').split('(')[0]
+        agg2[n][0] += 1; agg2[n][1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    span = (int(ttrace[b]['Start_Timestamp']) - int(ttrace[a]['Start_Timestamp'])) / 1e3
+    probe = open(os.path.join(src, 'train_probe.txt')).read() if os.path.exists(os.path.join(src, 'train_probe.txt')) else ''
+    with open(os.path.join(dst, f'{tag}_summary.md'), 'a') as f:
+        f.write('\n## Train step (SURVEY 8d config 3: BSZ 1280 = 640 anchors + 640 replicas, Adam, 1 GPU)\n\n')
+        f.write('Command: `python tools/train_probe.py 1280 adam 5` under `rocprofv3 --kernel-trace --stats` '
+                f'(full CSV: `{tag}_train_kernel_stats.csv`).  One step (second to last of the run): '
+                f'{b - a} launches, {span / 1e3:.2f} ms from first to next-first kernel.\n\n')
+        f.write('| kernel | launches/step | us/step |\n|---|---|---|\n')
+        for n, (c, d) in sorted(agg2.items(), key=lambda kv: -kv[1][1])[:14]:
+            f.write(f'| `{n[:60]}` | {c} | {d:.0f} |\n')
+        if probe:
+            f.write('\nUn-profiled stage timing of the same script (torch events):\n\n```\n' + probe.strip() + '\n```\n')
 print(open(os.path.join(dst, f'{tag}_summary.md')).read())
