@@ -27,7 +27,11 @@ nothing from the reference itself to pin the oracle against beyond:
 What stands in: each stage here is checked in tests/ against an INDEPENDENT
 formulation (torch.stft / scipy.fft, torch conv2d with explicit padding,
 torch layer_norm, torch cross_entropy, autograd vs analytic gradients), and in
-float64 vs float32 to bound rounding.  The published algorithms restated from
-the pinned third-party versions are named in each docstring.
+float64 vs float32 to bound rounding; the front end additionally against a
+third-party implementation this repository did not write
+(transformers.audio_utils.mel_filter_bank / window_function / spectrogram, which
+reproduce librosa's Slaney filterbank and an STFT: same 941 taps, |d log-mel| < 1e-6,
+tests/test_oracle_melspec.py).  The published algorithms restated from the pinned
+third-party versions are named in each docstring.
 """
 from . import melspec, nnfp, ntxent, segments, optim, specaug  # noqa: F401

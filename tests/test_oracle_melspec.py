@@ -1,6 +1,7 @@
 """CPU: the melspec oracle against independent formulations and known facts
 (melspectrogram.py:25-112)."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import melspec as o_mel, torch_ref
@@ -78,3 +79,35 @@ def test_golden_mel(golden):
     fb = o_mel.mel_filterbank()
     assert int(golden['melbank_nnz'][0]) == 941
     assert np.array_equal(fb.sum(1), golden['melbank_rowsum'])
+
+
+def test_mel_filterbank_matches_independent_slaney_implementation():
+    """Pin against a published third-party implementation present in this image:
+    transformers.audio_utils.mel_filter_bank(norm='slaney', mel_scale='slaney') is written to
+    reproduce librosa.filters.mel, which is what kapre's ApplyFilterbank calls
+    (melspectrogram.py:93-98).  Same 941 non-zero taps, values equal to float32 rounding."""
+    tau = pytest.importorskip('transformers.audio_utils')
+    fb = tau.mel_filter_bank(num_frequency_bins=513, num_mel_filters=256, min_frequency=300.0, max_frequency=4000.0,
+                             sampling_rate=8000, norm='slaney', mel_scale='slaney')
+    ours = o_mel.mel_filterbank()
+    assert fb.shape == (513, 256) and ours.shape == (256, 513)
+    assert np.array_equal(fb.T > 0, ours > 0) and int((ours > 0).sum()) == 941
+    assert np.abs(fb.T - ours).max() < 2e-8
+
+
+def test_logmel_matches_independent_spectrogram_implementation():
+    """The whole front end (framing of the 512+512 padded segment, periodic Hann, |rfft|, Slaney mel,
+    +0.06, log10, batch-max subtraction: melspectrogram.py:82-112) against transformers.audio_utils
+    (window_function / spectrogram / mel_filter_bank), an implementation this repo did not write."""
+    tau = pytest.importorskip('transformers.audio_utils')
+    x = _inputs.audio(3, seed=4)
+    fb = tau.mel_filter_bank(513, 256, 300.0, 4000.0, 8000, norm='slaney', mel_scale='slaney')
+    win = tau.window_function(1024, 'hann', periodic=True)
+    s = np.stack([tau.spectrogram(np.pad(x[b, 0].astype(np.float64), (512, 512)), win, frame_length=1024, hop_length=256,
+                                  fft_length=1024, power=1.0, center=False, mel_filters=fb, mel_floor=0.0)
+                  for b in range(3)])
+    y = np.log10(np.maximum(s + 0.06, 1e-10))
+    y = y - y.max()
+    ours = o_mel.melspec_layer(x)[..., 0]
+    assert ours.shape == y.shape == (3, 256, 32)
+    assert np.abs(ours - y).max() < 1e-6
