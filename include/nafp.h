@@ -85,6 +85,16 @@ int nafp_melspec_forward_i16(nafp_melspec* plan, const int16_t* audio, int64_t n
                              int group_size, int segment_norm, float* feat,
                              float* group_stat, void* stream);
 
+/* The same layer fed by WINDOWS of one int16 PCM arena instead of a materialised (n_seg, seg_len)
+ * array: segment i starts at sample seg_offset[i] of `pcm` and has seg_valid[i] (<= seg_len) real
+ * samples, the rest being the zero tail.  Replaces the segment assembly of the reference's loader
+ * (get_fns_seg_list + load_audio per segment, model/utils/audio_utils.py:140-264; np.vstack per
+ * batch, model/utils/dataloader_keras.py:389-397): whole files are uploaded once and the 50 %
+ * overlap between consecutive segments (HOP = 0.5 s) is never duplicated.  All device pointers. */
+int nafp_melspec_forward_windows_i16(nafp_melspec* plan, const int16_t* pcm, const int64_t* seg_offset,
+                                     const int32_t* seg_valid, int64_t n_seg, int group_size,
+                                     int segment_norm, float* feat, float* group_stat, void* stream);
+
 /* ------------------------------------------------------------------------
  * Encoder: FingerPrinter (model/fp/nnfp.py:159-231)
  * ---------------------------------------------------------------------- */

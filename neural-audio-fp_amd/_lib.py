@@ -31,6 +31,8 @@ PROTOTYPES = {
     'nafp_melspec_n_mels': (c_int, [c_void_p]),
     'nafp_melspec_forward_f32': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'nafp_melspec_forward_i16': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'nafp_melspec_forward_windows_i16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p,
+                                                 c_void_p, c_void_p]),
     'nafp_encoder_create': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int]),
     'nafp_encoder_destroy': (c_int, [c_void_p]),
     'nafp_encoder_n_tensors': (c_int, [c_void_p]),

@@ -132,7 +132,8 @@ __global__ void melspec_init_stats(float* group_stat, int n_groups) {
 //   tile [n_mels][TILE_LD]            log-mel tile (<=32 frames per chunk)
 template <typename TIn>
 __global__ __launch_bounds__(256) void melspec_kernel(
-        const TIn* __restrict__ audio, float* __restrict__ feat, float* __restrict__ group_stat,
+        const TIn* __restrict__ audio, const int64_t* __restrict__ seg_offset, const int* __restrict__ seg_valid,
+        float* __restrict__ feat, float* __restrict__ group_stat,
         const float2* __restrict__ tw, const float* __restrict__ window,
         const int* __restrict__ mel_start, const float* __restrict__ mel_w,
         int seg_len, int n_frames, int n_mels, int group_size) {
@@ -145,7 +146,11 @@ __global__ __launch_bounds__(256) void melspec_kernel(
     float2* fftY = (float2*)(smem + sig_alloc + 4 * 2 * NFFT) + wave * NFFT;
     float* tile = smem + sig_alloc + 8 * 2 * NFFT;
 
-    const TIn* a = audio + seg * seg_len;
+    // rows of a (n_seg, seg_len) array, or -- window mode -- segment `seg` starts at sample
+    // seg_offset[seg] of one PCM arena and has seg_valid[seg] real samples (the rest is the zero
+    // tail load_audio pads, audio_utils.py:261-263)
+    const TIn* a = audio + (seg_offset ? seg_offset[seg] : seg * seg_len);
+    const int n_valid = seg_valid ? min(seg_valid[seg], seg_len) : seg_len;
     // per-thread mel filter (thread m <-> mel bin m)
     const bool has_mel = tid < n_mels;
     int mstart = 0;
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(256) void melspec_kernel(
         __syncthreads();
         for (int i = tid; i < SIG_CHUNK; i += 256) {
             const int s = chunk0 * HOP + i - NFFT / 2;
-            sig[i] = (s >= 0 && s < seg_len) ? pcm_to_float<TIn>(a[s]) : 0.f;
+            sig[i] = (s >= 0 && s < n_valid) ? pcm_to_float<TIn>(a[s]) : 0.f;
         }
         __syncthreads();
         for (int round = 0; round < 4; ++round) {                      // 4 waves x 2 frames
@@ -307,7 +312,8 @@ __global__ __launch_bounds__(256) void melspec_finalize_kernel(
 
 template <typename TIn>
 static int melspec_forward(nafp_melspec* p, const TIn* audio, int64_t n_seg, int group_size,
-                           int segment_norm, float* feat, float* group_stat, void* stream) {
+                           int segment_norm, float* feat, float* group_stat, void* stream,
+                           const int64_t* seg_offset = nullptr, const int* seg_valid = nullptr) {
     if (!p || !audio || !feat || !group_stat || n_seg < 0) return NAFP_ERR_INVALID_ARG;
     if (n_seg == 0) return NAFP_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -317,7 +323,7 @@ static int melspec_forward(nafp_melspec* p, const TIn* audio, int64_t n_seg, int
     NAFP_LAUNCH_CHECK();
     const size_t lds = (size_t)(SIG_CHUNK + 8 * 2 * NFFT + p->n_mels * TILE_LD) * sizeof(float);
     melspec_kernel<TIn><<<dim3((unsigned)n_seg), 256, lds, st>>>(
-        audio, feat, group_stat, p->d_twiddle, p->d_window, p->d_mel_start, p->d_mel_w,
+        audio, seg_offset, seg_valid, feat, group_stat, p->d_twiddle, p->d_window, p->d_mel_start, p->d_mel_w,
         p->seg_len, p->n_frames, p->n_mels, group_size);
     NAFP_LAUNCH_CHECK();
     const int per_seg = p->n_mels * p->n_frames;     // multiple of 4 (n_mels % 64 == 0)
@@ -414,4 +420,12 @@ extern "C" int nafp_melspec_forward_i16(nafp_melspec* plan, const int16_t* audio
                                         int group_size, int segment_norm, float* feat,
                                         float* group_stat, void* stream) {
     return melspec_forward<int16_t>(plan, audio, n_seg, group_size, segment_norm, feat, group_stat, stream);
+}
+
+extern "C" int nafp_melspec_forward_windows_i16(nafp_melspec* plan, const int16_t* pcm, const int64_t* seg_offset,
+                                                const int32_t* seg_valid, int64_t n_seg, int group_size,
+                                                int segment_norm, float* feat, float* group_stat, void* stream) {
+    if (!seg_offset || !seg_valid) return NAFP_ERR_INVALID_ARG;
+    return melspec_forward<int16_t>(plan, pcm, n_seg, group_size, segment_norm, feat, group_stat, stream, seg_offset,
+                                    seg_valid);
 }

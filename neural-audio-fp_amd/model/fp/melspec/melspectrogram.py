@@ -73,6 +73,29 @@ class Melspec_layer:
         return feat
 
 
+    def forward_windows(self, pcm, seg_offset, seg_valid, group_size=None):
+        """Same output as __call__ on the materialised segments: segment i = pcm[seg_offset[i] :
+        seg_offset[i] + seg_len] with samples >= seg_valid[i] read as zero.  pcm int16 (n,),
+        seg_offset int64 (B,), seg_valid int32 (B,), all CUDA."""
+        for t, dt, nm in ((pcm, torch.int16, 'pcm'), (seg_offset, torch.int64, 'seg_offset'), (seg_valid, torch.int32, 'seg_valid')):
+            _lib.require_cuda(t, nm)
+            if t.dtype != dt or not t.is_contiguous() or t.dim() != 1:
+                raise ValueError(f'{nm}: expected a contiguous 1-D {dt} tensor')
+        B = seg_offset.shape[0]
+        if seg_valid.shape[0] != B:
+            raise ValueError('seg_offset and seg_valid differ in length')
+        g = group_size if group_size is not None else self.group_size
+        g = int(g) if g else 0
+        n_groups = 1 if g <= 0 else (B + g - 1) // g
+        feat = torch.empty((B, self.n_mels, self.n_frames, 1), dtype=torch.float32, device=pcm.device)
+        gstat = torch.empty((2 * max(n_groups, 1),), dtype=torch.float32, device=pcm.device)
+        with torch.cuda.device(pcm.device):
+            _lib.check(self._lib.nafp_melspec_forward_windows_i16(
+                self._h, _lib.ptr(pcm), _lib.ptr(seg_offset), _lib.ptr(seg_valid), B, g, int(bool(self.segment_norm)),
+                _lib.ptr(feat), _lib.ptr(gstat), _lib.current_stream()), 'melspec_forward_windows')
+        return feat
+
+
 def get_melspec_layer(cfg, trainable=False):
     """melspectrogram.py:115-141."""
     fs = cfg['MODEL']['FS']

@@ -127,9 +127,15 @@ def write_fingerprints(source, embed_fn, arr, group, rank=0, world=1, launch_row
             st, n, fut = pending.pop(0)
             arr[st:st + n, :] = fut.result() if hasattr(fut, 'result') else fut
 
-    for start, chunk in source.iter_rows(r0, r1, launch_rows):
-        pending.append((start, len(chunk), embed_fn(chunk, group)))
-        drain(depth - 1)
+    if getattr(embed_fn, 'windows', False) and hasattr(source, 'iter_windows'):
+        # whole-file upload + on-device windowing (no segment assembly on the host)
+        for start, n, arena, used, off, valid in source.iter_windows(r0, r1, launch_rows, alloc=embed_fn.alloc):
+            pending.append((start, n, embed_fn.embed_windows(arena, used, off, valid, group)))
+            drain(depth - 1)
+    else:
+        for start, chunk in source.iter_rows(r0, r1, launch_rows):
+            pending.append((start, len(chunk), embed_fn(chunk, group)))
+            drain(depth - 1)
     drain(0)
     return r0, r1
 
@@ -148,13 +154,16 @@ class StreamedEmbedder:
     staging buffers for the int16 upload and the float32 download (the reference does a
     synchronous `emb.numpy()` per batch, generate.py:180)."""
 
-    def __init__(self, m_pre, m_fp, n_streams=N_STREAMS):
+    def __init__(self, m_pre, m_fp, n_streams=N_STREAMS, windows=True):
         self.m_pre, self.m_fp = m_pre, m_fp
         self.streams = [torch.cuda.Stream() for _ in range(n_streams)]
         self.depth = n_streams
         self.i = 0
         self.h_in = [None] * n_streams
         self.h_out = [None] * n_streams
+        self.windows = windows
+        self.h_pcm = [None] * n_streams        # pinned PCM arenas of the window path
+        self.h_idx = [None] * n_streams
 
     def __call__(self, chunk_i16, group):
         k = self.i % len(self.streams)
@@ -167,6 +176,40 @@ class StreamedEmbedder:
         with torch.cuda.stream(self.streams[k]):
             x = self.h_in[k][:n].cuda(non_blocking=True)
             emb = test_step(x, self.m_pre, self.m_fp, group_size=group)
+            out = self.h_out[k][:n]
+            out.copy_(emb, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        return _Pending(out, ev)
+
+
+    # ---- window path: the next launch's PCM is read straight into this slot's pinned arena ----
+    def alloc(self, n_samples):
+        k = self.i % len(self.streams)
+        if self.h_pcm[k] is None or self.h_pcm[k].shape[0] < n_samples:
+            self.h_pcm[k] = torch.empty((max(n_samples, 1) * 5 // 4,), dtype=torch.int16).pin_memory()
+        return self.h_pcm[k].numpy()
+
+    def embed_windows(self, arena, used, seg_offset, seg_valid, group):
+        k = self.i % len(self.streams)
+        self.i += 1
+        n = len(seg_offset)
+        if self.h_idx[k] is None or self.h_idx[k].shape[1] < n:
+            self.h_idx[k] = torch.empty((2, n), dtype=torch.int64).pin_memory()
+        if self.h_out[k] is None or self.h_out[k].shape[0] < n:
+            self.h_out[k] = torch.empty((n, self.m_fp.emb_sz), dtype=torch.float32).pin_memory()
+        idx = self.h_idx[k]
+        idx[0, :n].copy_(torch.from_numpy(seg_offset))
+        idx[1, :n].copy_(torch.from_numpy(seg_valid))
+        pcm_host = self.h_pcm[k]
+        if pcm_host is None or pcm_host.data_ptr() != arena.ctypes.data:
+            pcm_host = torch.from_numpy(arena)              # caller-provided arena (not pinned): still correct
+        with torch.cuda.stream(self.streams[k]):
+            pcm = pcm_host[:max(used, 1)].cuda(non_blocking=True)
+            d_idx = idx[:, :n].cuda(non_blocking=True)
+            self.m_fp.trainable = False
+            feat = self.m_pre.forward_windows(pcm, d_idx[0].contiguous(), d_idx[1].to(torch.int32), group_size=group)
+            emb = self.m_fp(feat)
             out = self.h_out[k][:n]
             out.copy_(emb, non_blocking=True)
             ev = torch.cuda.Event()

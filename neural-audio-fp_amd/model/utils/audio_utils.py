@@ -12,6 +12,8 @@ np.vstack row by row, dataloader_keras.py:389-397), and segments stay int16 -- t
 HIP front end scales by 2^-15 itself, which is exactly `x / 2**15`
 (audio_utils.py:245-246) in float32.
 """
+import os
+import struct
 import wave
 
 import numpy as np
@@ -23,6 +25,36 @@ def n_segments(n_frames, fs=8000, duration=1., hop=.5):
     if n_frames > n_seg_frames:
         return int((n_frames - n_seg_frames + n_hop_frames) // n_hop_frames)
     return 1
+
+
+def riff_scan(filename):
+    """Header scan of a RIFF/WAVE file WITHOUT reading the samples: (fs, channels, sample width in
+    bytes, byte offset of the first sample, frame count).  What `wave.open(...).getnframes()` reports
+    (audio_utils.py:160-169), plus where the data chunk starts, so that a sample range can be read
+    straight into a staging buffer."""
+    size = os.path.getsize(filename)
+    with open(filename, 'rb') as f:
+        head = f.read(12)
+        if len(head) < 12 or head[:4] != b'RIFF' or head[8:12] != b'WAVE':
+            raise ValueError(f'{filename}: not a RIFF/WAVE file')
+        fmt = None
+        while True:
+            hdr = f.read(8)
+            if len(hdr) < 8:
+                raise ValueError(f'{filename}: no data chunk')
+            cid, csz = hdr[:4], struct.unpack('<I', hdr[4:])[0]
+            if cid == b'fmt ':
+                body = f.read(csz + (csz & 1))
+                tag, ch, rate, _, align, bits = struct.unpack('<HHIIHH', body[:16])
+                fmt = (tag, ch, rate, align, bits)
+            elif cid == b'data':
+                if fmt is None:
+                    raise ValueError(f'{filename}: data chunk before fmt chunk')
+                off = f.tell()
+                csz = min(csz, size - off)
+                return fmt[2], fmt[1], fmt[4] // 8, off, csz // fmt[3]
+            else:
+                f.seek(csz + (csz & 1), 1)
 
 
 def wav_info(filename, fs):
@@ -78,7 +110,18 @@ class SegmentSource:
     def __init__(self, fns_list, bsz, duration=1., hop=.5, fs=8000):
         self.fns, self.bsz, self.duration, self.hop, self.fs = list(fns_list), int(bsz), duration, hop, fs
         self.seg_len = int(fs * duration)
-        counts = [n_segments(wav_info(fn, fs), fs, duration, hop) for fn in self.fns]
+        self.hop_len = int(np.floor(hop * fs))
+        self.n_frames, self.data_offset = [], []
+        for fn in self.fns:                      # ONE header scan per file (the reference re-opens per segment)
+            if fn[-3:] != 'wav':
+                raise NotImplementedError(fn[-3:])
+            rate, ch, width, off, nfr = riff_scan(fn)
+            if rate != fs:
+                raise ValueError('Sample rate should be {} but got {}'.format(str(fs), str(rate)))
+            if width != 2 or ch != 1:
+                raise ValueError(f'{fn}: expected 16-bit mono PCM')
+            self.n_frames.append(nfr); self.data_offset.append(off)
+        counts = [n_segments(nfr, fs, duration, hop) for nfr in self.n_frames]
         self.file_first = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         self.n_samples = int(self.file_first[-1])
 
@@ -122,4 +165,42 @@ class SegmentSource:
                 out[q - r:q - r + (b - a), 0] = cache[a:b]
                 q += b - a
             yield r, out
+            r = end
+
+    def iter_windows(self, row0, row1, rows_per_chunk, alloc=None):
+        """Yield (start_row, n_rows, arena, used, seg_offset, seg_valid) over rows [row0, row1):
+        the PCM every row needs is read ONCE from each file (contiguous sample range, straight into
+        `arena` = alloc(n_samples), e.g. pinned memory) and row i is the window
+        arena[seg_offset[i] : seg_offset[i] + seg_len] with samples >= seg_valid[i] meaning zero --
+        the same segments `iter_rows` materialises, without the 2x duplication of HOP = DUR/2."""
+        seg_len, hop_len = self.seg_len, self.hop_len
+        r = row0
+        while r < row1:
+            end = min(r + rows_per_chunk, row1)
+            n = end - r
+            pieces, total, q = [], 0, r
+            while q < end:
+                f = int(np.searchsorted(self.file_first, q, side='right') - 1)
+                first, nxt = int(self.file_first[f]), int(self.file_first[f + 1])
+                a, b = q - first, min(end, nxt) - first
+                s0 = a * hop_len
+                s1 = max(s0, min((b - 1) * hop_len + seg_len, self.n_frames[f]))
+                pieces.append((f, a, b, s0, s1, total, q - r))
+                total += (s1 - s0 + 7) // 8 * 8                      # 16-B aligned piece starts
+                q += b - a
+            arena = alloc(total) if alloc is not None else np.empty(max(total, 1), np.int16)
+            seg_offset = np.empty(n, np.int64)
+            seg_valid = np.empty(n, np.int32)
+            for f, a, b, s0, s1, base, o in pieces:
+                if s1 > s0:
+                    with open(self.fns[f], 'rb', buffering=0) as fh:
+                        fh.seek(self.data_offset[f] + 2 * s0)
+                        dst = memoryview(arena[base:base + (s1 - s0)]).cast('B')
+                        got = fh.readinto(dst)
+                        if got != 2 * (s1 - s0):
+                            raise IOError(f'{self.fns[f]}: short read')
+                k = np.arange(a, b, dtype=np.int64)
+                seg_offset[o:o + (b - a)] = base + (k - a) * hop_len
+                seg_valid[o:o + (b - a)] = np.clip(self.n_frames[f] - k * hop_len, 0, seg_len)
+            yield r, n, arena, total, seg_offset, seg_valid
             r = end

@@ -160,3 +160,26 @@ def test_run_py_generate_default_sources(nafp, cfg, tmp_path):
     r2 = subprocess.run([sys.executable, os.path.join(root, 'run.py'), 'generate', 'exp', '-c', 'nope'],
                         cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
     assert r2.returncode != 0 and 'is missing' in (r2.stdout + r2.stderr)
+
+
+def test_window_ingest_is_bit_identical_to_row_ingest(nafp, cfg, tmp_path):
+    """nafp_melspec_forward_windows_i16 (whole files uploaded once, windows indexed on the device) vs the
+    materialised int16 rows: same arithmetic, so the fingerprints are equal bit for bit, across file
+    boundaries, short files, zero-padded tails and ragged launches."""
+    from neural_audio_fp_amd.model import generate as g
+    from neural_audio_fp_amd.model.utils.audio_utils import SegmentSource
+    rng = np.random.default_rng(11)
+    paths = []
+    for i, n in enumerate([100, 8000, 8001, 23999, 64000, 4000, 40000]):
+        p = str(tmp_path / f'{i:02d}.wav')
+        _write_wav(p, rng.integers(-9000, 9000, size=n))
+        paths.append(p)
+    src = SegmentSource(paths, bsz=7)
+    m_pre, m_fp = g.build_fp(cfg)
+    outs = []
+    for windows in (False, True):
+        arr = np.zeros((src.n_samples, 128), np.float32)
+        g.write_fingerprints(src, g.StreamedEmbedder(m_pre, m_fp, windows=windows), arr, group=7, launch_rows=21)
+        outs.append(arr)
+    assert np.abs(outs[0]).sum() > 0
+    assert np.array_equal(outs[0], outs[1])
