@@ -129,7 +129,10 @@ def write_fingerprints(source, embed_fn, arr, group, rank=0, world=1, launch_row
 
     if getattr(embed_fn, 'windows', False) and hasattr(source, 'iter_windows'):
         # whole-file upload + on-device windowing (no segment assembly on the host)
-        for start, n, arena, used, off, valid in source.iter_windows(r0, r1, launch_rows, alloc=embed_fn.alloc):
+        it = source.iter_windows(r0, r1, launch_rows, alloc=embed_fn.alloc)
+        if getattr(embed_fn, 'prefetch', 0) > 0:
+            it = _prefetch(it, embed_fn.prefetch)          # file reads of the next launches on a reader thread
+        for start, n, arena, used, off, valid in it:
             pending.append((start, n, embed_fn.embed_windows(arena, used, off, valid, group)))
             drain(depth - 1)
     else:
@@ -138,6 +141,31 @@ def write_fingerprints(source, embed_fn, arr, group, rank=0, world=1, launch_row
             drain(depth - 1)
     drain(0)
     return r0, r1
+
+
+def _prefetch(gen, ahead):
+    """Run generator `gen` on a reader thread, at most `ahead` items ahead of the consumer."""
+    import queue
+    import threading
+    q = queue.Queue(maxsize=max(1, ahead - 1))
+    end = object()
+
+    def work():
+        try:
+            for item in gen:
+                q.put(item)
+            q.put(end)
+        except BaseException as e:              # re-raised in the consumer
+            q.put(e)
+
+    threading.Thread(target=work, daemon=True).start()
+    while True:
+        item = q.get()
+        if item is end:
+            return
+        if isinstance(item, BaseException):
+            raise item
+        yield item
 
 
 class _Pending:
@@ -162,7 +190,12 @@ class StreamedEmbedder:
         self.h_in = [None] * n_streams
         self.h_out = [None] * n_streams
         self.windows = windows
-        self.h_pcm = [None] * n_streams        # pinned PCM arenas of the window path
+        self.prefetch = 0                      # launches a reader thread may run ahead (measured: no gain, the
+                                               # path is GPU-bound with the reads on the launching thread)
+        # pinned PCM arenas of the window path: one per launch in flight + one per launch being read ahead
+        # (an arena is reused n_streams + prefetch launches later, when its upload has been waited for)
+        self.h_pcm = [None] * (n_streams + self.prefetch)
+        self.a = 0
         self.h_idx = [None] * n_streams
 
     def __call__(self, chunk_i16, group):
@@ -185,7 +218,8 @@ class StreamedEmbedder:
 
     # ---- window path: the next launch's PCM is read straight into this slot's pinned arena ----
     def alloc(self, n_samples):
-        k = self.i % len(self.streams)
+        k = self.a % len(self.h_pcm)
+        self.a += 1
         if self.h_pcm[k] is None or self.h_pcm[k].shape[0] < n_samples:
             self.h_pcm[k] = torch.empty((max(n_samples, 1) * 5 // 4,), dtype=torch.int16).pin_memory()
         return self.h_pcm[k].numpy()
@@ -201,8 +235,8 @@ class StreamedEmbedder:
         idx = self.h_idx[k]
         idx[0, :n].copy_(torch.from_numpy(seg_offset))
         idx[1, :n].copy_(torch.from_numpy(seg_valid))
-        pcm_host = self.h_pcm[k]
-        if pcm_host is None or pcm_host.data_ptr() != arena.ctypes.data:
+        pcm_host = next((t for t in self.h_pcm if t is not None and t.data_ptr() == arena.ctypes.data), None)
+        if pcm_host is None:
             pcm_host = torch.from_numpy(arena)              # caller-provided arena (not pinned): still correct
         with torch.cuda.stream(self.streams[k]):
             pcm = pcm_host[:max(used, 1)].cuda(non_blocking=True)

@@ -40,12 +40,18 @@ src = SegmentSource(paths, bsz=cfg['BSZ']['TS_BATCH_SZ'])
 print(f'header scan of {len(paths)} files: {time.perf_counter() - t0:.2f} s, {src.n_samples} segments')
 m_pre, m_fp = g.build_fp(cfg)
 group = cfg['BSZ']['TS_BATCH_SZ']
-for windows in (False, True, False, True):
+configs = [(False, 640, 0), (True, 640, 0), (True, 640, 2), (True, 1920, 0), (True, 1920, 2), (True, 3840, 0), (True, 7680, 0)]
+for windows, launch, prefetch in configs:
+    g.LAUNCH_SEGMENTS = launch
     arr = np.memmap(os.path.join(d, 'out.mm'), dtype='float32', mode='w+', shape=(src.n_samples, 128))
     emb = g.StreamedEmbedder(m_pre, m_fp, windows=windows)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    g.write_fingerprints(src, emb, arr, group)
-    arr.flush()
-    dt = time.perf_counter() - t0
-    print(f'{"windows" if windows else "rows   "}: {src.n_samples / dt:10.0f} segments/s end to end ({dt:.2f} s)')
+    emb.prefetch = prefetch
+    emb.h_pcm = [None] * (len(emb.streams) + prefetch)
+    best = 0.0
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        g.write_fingerprints(src, emb, arr, group)
+        arr.flush()
+        best = max(best, src.n_samples / (time.perf_counter() - t0))
+    print(f'{"windows" if windows else "rows   "} launch~{launch:5d} prefetch {prefetch}: {best:10.0f} segments/s end to end')
     del arr
