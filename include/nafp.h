@@ -234,6 +234,32 @@ int nafp_lamb_step(const nafp_opt_tensor* tensors_host, int n, float lr, float b
                    float eps, float weight_decay, int64_t step, void* workspace,
                    int64_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Search / evaluation over resident fingerprints (consumer of the generate path's output).
+ * Replaces faiss.IndexFlatL2 as eval/eval_faiss.py uses it with index_type 'L2'
+ * (eval/utils/get_index_faiss.py:57-62; index.add at eval_faiss.py:145-146; index.search at :209)
+ * and the sequence-score loop of eval_faiss.py:221-230.  The index is the caller's device array
+ * [dummy_db ; db] (n_index x dim float32, dim 64 or 128); nothing is trained or quantised.
+ * ------------------------------------------------------------------------------------------- */
+
+/* floats of the auxiliary array (|x|^2/2 per row, padded) nafp_search_index_prepare fills */
+int64_t nafp_search_index_aux_floats(int64_t n_index);
+int nafp_search_index_prepare(const float* index, int64_t n_index, int dim, float* aux, void* stream);
+
+int64_t nafp_search_workspace_bytes(int64_t n_query, int64_t n_index, int k);
+/* out_dist / out_ids (n_query, k): the k smallest squared L2 distances and their row ids, nearest
+ * first; equal distances: smaller id first; fewer than k rows: id -1, distance +inf.  k <= 32. */
+int nafp_search_topk_l2(const float* query, int64_t n_query, const float* index, const float* aux,
+                        int64_t n_index, int dim, int k, float* out_dist, int32_t* out_ids,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+
+/* out_scores[t, s] = mean_{i < min(task_len[t], n_index - c)} query[task_q0[t] + i] . index[c + i]
+ * for the candidate sequence start c = cand[t, s] (>= 0; -1 -> -inf): np.mean(np.diag(np.dot(q,
+ * index[c:c+l].T))) of eval_faiss.py:224-230.  All device pointers. */
+int nafp_search_seq_scores(const float* query, const float* index, int64_t n_index, int dim,
+                           const int32_t* task_q0, const int32_t* task_len, int64_t n_tasks,
+                           const int32_t* cand, int n_slots, float* out_scores, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

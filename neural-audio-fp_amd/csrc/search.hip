@@ -1,0 +1,320 @@
+// Exact nearest-neighbour search over resident fingerprints + sequence scoring, gfx950.
+//
+// The consumer side of the hot path's output: eval/eval_faiss.py:115-289 with the exact index
+// (faiss.IndexFlatL2, eval/utils/get_index_faiss.py:57-62).  The whole index ([dummy_db ; db], N x d
+// float32: 51 GB for 100 M fingerprints) stays resident in HBM; there is no training, no
+// quantisation and no host round trip per query.
+//
+//   search_half_norms_kernel   h[i] = |x_i|^2 / 2   (+inf padding after N)
+//   search_topk_kernel<D,K>    per query the K index rows with the smallest |q - x|^2, i.e. the
+//                              largest key = q.x - |x|^2/2.  fp32 MFMA (v_mfma_f32_32x32x2_f32):
+//                              A = a 64-row index tile staged by LDS-DMA (XOR-swizzled chunks,
+//                              2-stage ring), B = the workgroup's 128 queries held in REGISTERS for the
+//                              whole scan (lane <-> one query column), so the index streams through
+//                              the chip once per 128 queries.  In the 32x32 C/D layout a lane owns ONE
+//                              query and 16 index rows per block: it keeps that query's running top-K
+//                              as a sorted register list (threshold test per score, unrolled insertion
+//                              only when a score beats the K-th best).  blockIdx.y splits the index.
+//   search_merge_kernel<K>     merges the 2 x splits partial lists of a query (key desc, id asc)
+//   search_seq_score_kernel<D> mean_i q[t+i] . x[c+i] for candidate sequence starts c (eval_faiss.py:221-230)
+#include "nafp_common.h"
+
+#include <algorithm>
+
+namespace nafp {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u32x4s make_rsrc_s(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    u32x4s r;
+    r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+    r.z = __builtin_amdgcn_readfirstlane(bytes);
+    r.w = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ void lds_dma16_s(unsigned lds_addr, unsigned voff, u32x4s rsrc) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 4\n\t"
+                 "buffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
+}
+
+__global__ __launch_bounds__(256) void search_half_norms_kernel(const float* __restrict__ x, float* __restrict__ hn,
+                                                                int64_t N, int64_t n_pad, int D) {
+    const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= n_pad) return;
+    if (i >= N) { hn[i] = INFINITY; return; }
+    const float4* r = (const float4*)(x + i * D);
+    float s = 0.f;
+    for (int c = 0; c < D / 4; ++c) { const float4 v = r[c]; s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
+    hn[i] = 0.5f * s;
+}
+
+constexpr int TILE_ROWS = 64;
+
+template <int D, int K>
+__global__ __launch_bounds__(256, 2) void search_topk_kernel(
+        const float* __restrict__ Q, const float* __restrict__ X, const float* __restrict__ hn,
+        float* __restrict__ out_key, int* __restrict__ out_id, int nq, int64_t N, int tiles_per_split, int n_lists) {
+    constexpr int CH = D / 4;                        // 16-B chunks per row
+    constexpr int RPI = 64 / CH;                     // rows per DMA wave-instruction
+    constexpr int NI = 16 / RPI;                     // DMA instructions per wave per tile (16 rows per wave)
+    constexpr int TILE = TILE_ROWS * D;              // floats
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [2][64][D]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rl = lane & 31, hh = lane >> 5;
+    const int qn = blockIdx.x * 128 + wave * 32 + rl;
+    const int64_t n_tiles = (N + TILE_ROWS - 1) / TILE_ROWS;
+    const int64_t t0 = (int64_t)blockIdx.y * tiles_per_split;
+    const int64_t t1 = std::min<int64_t>(n_tiles, t0 + tiles_per_split);
+
+    // the query column of this lane: q[8kk + 4hh + j], j = 0..3 (the k permutation A uses too)
+    float4 qr[D / 8];
+#pragma unroll
+    for (int kk = 0; kk < D / 8; ++kk)
+        qr[kk] = qn < nq ? *(const float4*)(Q + (int64_t)qn * D + 8 * kk + 4 * hh) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    float sc[K]; int id[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { sc[j] = -INFINITY; id[j] = -1; }
+
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
+    // DMA geometry: wave w stages rows [16w, 16w+16) of the tile; instruction i covers rows
+    // 16w + i*RPI + lane/CH, physical chunk lane%CH holding logical chunk pc ^ swz(row)
+    unsigned voff[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int row = wave * 16 + i * RPI + lane / CH;
+        const int lc = (lane % CH) ^ (row & (CH - 1));
+        voff[i] = (unsigned)(row * D + lc * 4) * 4u;
+    }
+#define NAFP_S_DMA(t_, slot_)                                                                       \
+    {                                                                                               \
+        const int64_t row0_l = (t_) * TILE_ROWS;                                                    \
+        const int64_t left_l = (N - row0_l) * D * 4;                                                \
+        const u32x4s rs_l = make_rsrc_s(X + row0_l * D, (unsigned)std::min<int64_t>(left_l, TILE * 4)); \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i)                                              \
+            lds_dma16_s(lds0 + (unsigned)(((slot_) * TILE + (wave * 16 + i * RPI) * D) * 4), voff[i], rs_l); \
+    }
+    (void)OOB;
+    if (t0 < t1) NAFP_S_DMA(t0, 0)
+    int slot = 0;
+    for (int64_t t = t0; t < t1; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 1 < t1) NAFP_S_DMA(t + 1, slot ^ 1)
+        const float* St = smem + slot * TILE;
+        f32x16 acc[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < D / 8; ++kk) {
+            float4 a[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int row = mi * 32 + rl;
+                a[mi] = *(const float4*)(St + row * D + (((2 * kk + hh) ^ (row & (CH - 1))) * 4));
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].x, qr[kk].x, acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].y, qr[kk].y, acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].z, qr[kk].z, acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, qr[kk].w, acc[mi], 0, 0, 0);
+            }
+        }
+        // selection: D[i = index row][j = query]: this lane holds rows (r&3) + 8(r>>2) + 4hh of block mi
+        const float* hp = hn + t * TILE_ROWS;                  // wave-uniform -> scalar loads
+        const int base_id = (int)(t * TILE_ROWS);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = mi * 32 + 8 * (r >> 2) + (r & 3);
+                const float h = hh ? hp[o + 4] : hp[o];
+                const float key = acc[mi][r] - h;
+                if (key > sc[K - 1]) {
+                    const int nid = base_id + o + 4 * hh;
+#pragma unroll
+                    for (int j = K - 1; j >= 1; --j) {
+                        const bool cj = key > sc[j], cp = key > sc[j - 1];
+                        id[j] = cj ? (cp ? id[j - 1] : nid) : id[j];
+                        sc[j] = cj ? (cp ? sc[j - 1] : key) : sc[j];
+                    }
+                    if (key > sc[0]) { sc[0] = key; id[0] = nid; }
+                }
+            }
+        slot ^= 1;
+    }
+#undef NAFP_S_DMA
+    if (qn < nq) {
+        const int64_t o = ((int64_t)qn * n_lists + blockIdx.y * 2 + hh) * K;
+#pragma unroll
+        for (int j = 0; j < K; ++j) { out_key[o + j] = sc[j]; out_id[o + j] = id[j]; }
+    }
+}
+
+__device__ __forceinline__ unsigned long long pack_key(float key, int id) {
+    unsigned u = __float_as_uint(key);
+    u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;                 // order-preserving map
+    return ((unsigned long long)u << 32) | (unsigned)(0x7fffffff - id);      // ties: smaller id is larger
+}
+
+// one wave per query: K rounds of wave-wide arg-max over the n_lists*K partial results
+template <int K>
+__global__ __launch_bounds__(64) void search_merge_kernel(const float* __restrict__ in_key, const int* __restrict__ in_id,
+                                                          const float* __restrict__ Q, float* __restrict__ out_dist,
+                                                          int* __restrict__ out_ids, int n_lists, int D, int k_out) {
+    extern __shared__ unsigned long long cand[];
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const int M = n_lists * K;
+    for (int i = lane; i < M; i += 64) {
+        const int idv = in_id[(int64_t)q * M + i];
+        cand[i] = idv >= 0 ? pack_key(in_key[(int64_t)q * M + i], idv) : 0ull;
+    }
+    float qq = 0.f;
+    for (int c = lane; c < D; c += 64) { const float v = Q[(int64_t)q * D + c]; qq += v * v; }
+    qq = wave_sum(qq);
+    __syncthreads();
+    for (int j = 0; j < k_out; ++j) {
+        unsigned long long best = 0ull; int bi = -1;
+        for (int i = lane; i < M; i += 64)
+            if (cand[i] > best) { best = cand[i]; bi = i; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best) { best = ob; bi = oi; }
+        }
+        if (lane == 0) {
+            if (best == 0ull) { out_ids[(int64_t)q * k_out + j] = -1; out_dist[(int64_t)q * k_out + j] = INFINITY; }
+            else {
+                out_ids[(int64_t)q * k_out + j] = in_id[(int64_t)q * M + bi];
+                out_dist[(int64_t)q * k_out + j] = fmaxf(qq - 2.f * in_key[(int64_t)q * M + bi], 0.f);
+                cand[bi] = 0ull;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// out[task, slot] = mean_{i < min(len, N - c)} Q[q0 + i] . X[c + i]  for c = cand[task, slot] >= 0, else -inf.
+// One wave per (task, slot).
+template <int D>
+__global__ __launch_bounds__(256) void search_seq_score_kernel(
+        const float* __restrict__ Q, const float* __restrict__ X, const int* __restrict__ task_q0,
+        const int* __restrict__ task_len, const int* __restrict__ cand, float* __restrict__ out, int64_t N,
+        int n_slots, int64_t total) {
+    const int64_t w = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (w >= total) return;
+    const int task = (int)(w / n_slots);
+    const int c = cand[w];
+    if (c < 0 || c >= N) { if (lane == 0) out[w] = -INFINITY; return; }
+    const int q0 = task_q0[task];
+    const int len = (int)std::min<int64_t>(task_len[task], N - c);
+    float s = 0.f;
+    for (int i = 0; i < len; ++i) {
+        const float* qp = Q + (int64_t)(q0 + i) * D; const float* xp = X + (int64_t)(c + i) * D;
+        for (int e = lane; e < D; e += 64) s = fmaf(qp[e], xp[e], s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[w] = s / (float)len;
+}
+
+template <int D, int K>
+static int launch_topk(const float* Q, int nq, const float* X, const float* hn, int64_t N, float* pk, int* pi, int splits,
+                       int tps, hipStream_t st) {
+    const int lds = 2 * TILE_ROWS * D * (int)sizeof(float);
+    NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)search_topk_kernel<D, K>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    search_topk_kernel<D, K><<<dim3((unsigned)((nq + 127) / 128), (unsigned)splits), 256, lds, st>>>(Q, X, hn, pk, pi, nq, N, tps,
+                                                                                                  2 * splits);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}
+
+static void plan_splits(int nq, int64_t N, int K, int* splits, int* tps) {
+    const int64_t n_tiles = (N + TILE_ROWS - 1) / TILE_ROWS;
+    const int q_tiles = (nq + 127) / 128;
+    int64_t s = std::max<int64_t>(1, 2048 / q_tiles);
+    s = std::min<int64_t>(s, std::max<int64_t>(1, n_tiles / 8));     // at least 8 tiles per workgroup
+    s = std::min<int64_t>(s, 4096 / (2 * K));                          // merge kernel: <= 4096 partial results
+    *tps = (int)((n_tiles + s - 1) / s);
+    *splits = (int)((n_tiles + *tps - 1) / *tps);
+}
+
+}  // namespace nafp
+
+using namespace nafp;
+
+extern "C" int64_t nafp_search_index_aux_floats(int64_t n_index) {
+    return n_index < 0 ? -1 : (n_index + 63) / 64 * 64 + 64;
+}
+
+extern "C" int nafp_search_index_prepare(const float* index, int64_t n_index, int dim, float* aux, void* stream) {
+    if (!index || !aux || n_index <= 0) return NAFP_ERR_INVALID_ARG;
+    if (dim != 64 && dim != 128) return NAFP_ERR_UNSUPPORTED;
+    const int64_t n_pad = nafp_search_index_aux_floats(n_index);
+    search_half_norms_kernel<<<(unsigned)((n_pad + 255) / 256), 256, 0, (hipStream_t)stream>>>(index, aux, n_index, n_pad, dim);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}
+
+extern "C" int64_t nafp_search_workspace_bytes(int64_t n_query, int64_t n_index, int k) {
+    if (n_query < 0 || n_index <= 0 || k <= 0 || k > 32 || n_query > (1 << 30)) return -1;
+    const int K = k <= 20 ? 20 : 32;
+    int splits, tps;
+    plan_splits((int)n_query, n_index, K, &splits, &tps);
+    return (int64_t)n_query * 2 * splits * K * 8 + 256;
+}
+
+extern "C" int nafp_search_topk_l2(const float* query, int64_t n_query, const float* index, const float* aux,
+                                   int64_t n_index, int dim, int k, float* out_dist, int32_t* out_ids,
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!query || !index || !aux || !out_dist || !out_ids || !workspace || n_query < 0 || n_index <= 0 || k <= 0)
+        return NAFP_ERR_INVALID_ARG;
+    if ((dim != 64 && dim != 128) || k > 32 || n_index >= ((int64_t)1 << 31) || n_query > (1 << 30)) return NAFP_ERR_UNSUPPORTED;
+    if (n_query == 0) return NAFP_OK;
+    if (workspace_bytes < nafp_search_workspace_bytes(n_query, n_index, k)) return NAFP_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int K = k <= 20 ? 20 : 32;
+    int splits, tps;
+    plan_splits((int)n_query, n_index, K, &splits, &tps);
+    char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    float* pk = (float*)ws;
+    int* pi = (int*)(ws + (int64_t)n_query * 2 * splits * K * 4);
+    int rc;
+    if (dim == 128) rc = K == 20 ? launch_topk<128, 20>(query, (int)n_query, index, aux, n_index, pk, pi, splits, tps, st)
+                                 : launch_topk<128, 32>(query, (int)n_query, index, aux, n_index, pk, pi, splits, tps, st);
+    else            rc = K == 20 ? launch_topk<64, 20>(query, (int)n_query, index, aux, n_index, pk, pi, splits, tps, st)
+                                 : launch_topk<64, 32>(query, (int)n_query, index, aux, n_index, pk, pi, splits, tps, st);
+    if (rc != NAFP_OK) return rc;
+    const int M = 2 * splits * K;
+    if (K == 20) search_merge_kernel<20><<<(unsigned)n_query, 64, M * 8, st>>>(pk, pi, query, out_dist, out_ids, 2 * splits, dim, k);
+    else         search_merge_kernel<32><<<(unsigned)n_query, 64, M * 8, st>>>(pk, pi, query, out_dist, out_ids, 2 * splits, dim, k);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}
+
+extern "C" int nafp_search_seq_scores(const float* query, const float* index, int64_t n_index, int dim,
+                                      const int32_t* task_q0, const int32_t* task_len, int64_t n_tasks,
+                                      const int32_t* cand, int n_slots, float* out_scores, void* stream) {
+    if (!query || !index || !task_q0 || !task_len || !cand || !out_scores || n_tasks < 0 || n_slots <= 0 || n_index <= 0)
+        return NAFP_ERR_INVALID_ARG;
+    if (dim != 64 && dim != 128) return NAFP_ERR_UNSUPPORTED;
+    const int64_t total = n_tasks * n_slots;
+    if (total == 0) return NAFP_OK;
+    const unsigned blocks = (unsigned)((total + 3) / 4);
+    if (dim == 128) search_seq_score_kernel<128><<<blocks, 256, 0, (hipStream_t)stream>>>(query, index, task_q0, task_len, cand, out_scores, n_index, n_slots, total);
+    else            search_seq_score_kernel<64><<<blocks, 256, 0, (hipStream_t)stream>>>(query, index, task_q0, task_len, cand, out_scores, n_index, n_slots, total);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}

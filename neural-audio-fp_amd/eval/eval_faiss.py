@@ -1,0 +1,244 @@
+"""Segment/sequence-wise audio search experiment and evaluation on the HIP exact index.
+
+Host mirror of the reference's eval/eval_faiss.py (`load_memmap_data` :18-62, `eval_faiss` :93-275)
+and of `get_index` (eval/utils/get_index_faiss.py:10-121) for index_type 'L2' -- the exact
+faiss.IndexFlatL2 -- backed by libnafp's search kernels (include/nafp.h "Search / evaluation").
+The approximate index types (IVF, IVFPQ, IVFPQ-RR, IVFPQ-ONDISK, HNSW) raise NotImplementedError:
+on an MI355X the whole [dummy_db ; db] table stays resident in HBM (51 GB for 100 M fingerprints
+out of 288 GB) and is searched exactly.
+
+Same inputs ({query, db, dummy_db}.mm + *_shape.npy written by `generate`), same outputs
+(`raw_score.npy` = [top1_exact | top1_near | top3_exact | top10_exact] per test id and sequence
+length, `test_ids.npy`), same metrics.  Differences in mechanism, not in result:
+  * all test ids x sequence lengths are evaluated in ONE batched search over the distinct query
+    rows, one batched sequence-score launch, and a vectorised ranking -- not a Python loop with an
+    index.search call per (id, length);
+  * `dummy_db.mm` is NOT extended on disk (the reference appends `db` to it as its
+    "fake_recon_index", eval_faiss.py:158-167): the concatenated table lives on the device;
+  * equal scores/distances rank the smaller id first (faiss/argsort leave ties unspecified);
+  * a plain printed table instead of curses.
+"""
+import glob
+import os
+import time
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+def load_memmap_data(source_dir, fname, append_extra_length=None, shape_only=False, display=True):
+    """eval_faiss.py:18-62."""
+    path_shape = source_dir + fname + '_shape.npy'
+    path_data = source_dir + fname + '.mm'
+    data_shape = np.load(path_shape)
+    if shape_only:
+        return data_shape
+    if append_extra_length:
+        data_shape[0] += append_extra_length
+        data = np.memmap(path_data, dtype='float32', mode='r+', shape=(data_shape[0], data_shape[1]))
+    else:
+        data = np.memmap(path_data, dtype='float32', mode='r', shape=(data_shape[0], data_shape[1]))
+    if display:
+        print(f'Load {data_shape[0]:,} items from \033[32m{path_data}\033[0m.')
+    return data, data_shape
+
+
+class FlatL2Index:
+    """faiss.IndexFlatL2 as the reference uses it: `.add(x)` (repeatedly), `.ntotal`, `.search(q, k)`
+    -> (D, I) with squared L2 distances, nearest first; plus `.reconstruct_n` and the batched
+    `.sequence_scores` the evaluation needs.  The vectors live in ONE device array."""
+
+    def __init__(self, d, capacity=0, device=None):
+        if d not in (64, 128):
+            raise NotImplementedError(f'fingerprint dimension {d}')
+        self.d = int(d)
+        self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        self._lib = _lib.load()
+        self._x = torch.empty((int(capacity), self.d), dtype=torch.float32, device=self.device)
+        self.ntotal = 0
+        self._aux = None
+
+    def add(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32) if not torch.is_tensor(x) else x
+        n = x.shape[0]
+        if x.shape[1] != self.d:
+            raise ValueError(f'expected (n, {self.d}) vectors')
+        if self.ntotal + n > self._x.shape[0]:
+            grown = torch.empty((max(self.ntotal + n, 2 * self._x.shape[0]), self.d), dtype=torch.float32, device=self.device)
+            grown[:self.ntotal] = self._x[:self.ntotal]
+            self._x = grown
+        step = 1 << 20                                        # upload in 512 MB pieces (memmap friendly)
+        for a in range(0, n, step):
+            b = min(n, a + step)
+            piece = x[a:b] if torch.is_tensor(x) else torch.from_numpy(np.array(x[a:b], dtype=np.float32))
+            self._x[self.ntotal + a:self.ntotal + b].copy_(piece)
+        self.ntotal += n
+        self._aux = None
+
+    def _prepare(self):
+        if self._aux is None:
+            n_aux = int(self._lib.nafp_search_index_aux_floats(self.ntotal))
+            self._aux = torch.empty((n_aux,), dtype=torch.float32, device=self.device)
+            with torch.cuda.device(self.device):
+                _lib.check(self._lib.nafp_search_index_prepare(_lib.ptr(self._x), self.ntotal, self.d, _lib.ptr(self._aux),
+                                                               _lib.current_stream()), 'search_index_prepare')
+        return self._aux
+
+    def search_device(self, q, k):
+        """q: (nq, d) CUDA float32 -> (D, I) CUDA tensors (float32, int32)."""
+        q = _lib.require_cuda(q, 'q').float().contiguous()
+        if self.ntotal == 0:
+            raise ValueError('empty index')
+        aux = self._prepare()
+        nq = q.shape[0]
+        D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+        I = torch.empty((nq, k), dtype=torch.int32, device=self.device)
+        need = int(self._lib.nafp_search_workspace_bytes(nq, self.ntotal, k))
+        if need < 0:
+            raise NotImplementedError(f'k = {k} (the HIP search keeps k <= 32 results per query)')
+        ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.nafp_search_topk_l2(_lib.ptr(q), nq, _lib.ptr(self._x), _lib.ptr(aux), self.ntotal, self.d,
+                                                     int(k), _lib.ptr(D), _lib.ptr(I), _lib.ptr(ws), need,
+                                                     _lib.current_stream()), 'search_topk_l2')
+        return D, I
+
+    def search(self, q, k):
+        """faiss signature: numpy in, (D float32, I int64) numpy out."""
+        qd = torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)).to(self.device)
+        D, I = self.search_device(qd, k)
+        return D.cpu().numpy(), I.cpu().numpy().astype(np.int64)
+
+    def reconstruct_n(self, i0, n):
+        return self._x[i0:i0 + n].cpu().numpy()
+
+    def sequence_scores(self, q, task_q0, task_len, cand):
+        """scores[t, s] = mean_i q[task_q0[t] + i] . index[cand[t, s] + i] (eval_faiss.py:224-230);
+        q (nq, d) CUDA, task_q0 / task_len (T,) int32 CUDA, cand (T, S) int32 CUDA (-1 = none)."""
+        T, S = cand.shape
+        out = torch.empty((T, S), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.nafp_search_seq_scores(_lib.ptr(q), _lib.ptr(self._x), self.ntotal, self.d, _lib.ptr(task_q0),
+                                                        _lib.ptr(task_len), T, _lib.ptr(cand), S, _lib.ptr(out),
+                                                        _lib.current_stream()), 'search_seq_scores')
+        return out
+
+
+def get_index(index_type, train_data, train_data_shape, use_gpu=True, max_nitem_train=2e7):
+    """get_index_faiss.py:10-121 for the exact index."""
+    mode = index_type.lower()
+    if mode == 'l2':
+        if not use_gpu:
+            raise NotImplementedError('--nogpu: this build has no CPU search path')
+        return FlatL2Index(int(train_data_shape[1]))
+    if mode in ('ivf', 'ivfpq', 'ivfpq-rr', 'ivfpq-ondisk', 'hnsw'):
+        raise NotImplementedError(f"index_type '{index_type}': approximate faiss indexes are not part of this build; "
+                                  "use 'L2' (exact search over the HBM-resident table)")
+    raise ValueError(mode.lower())
+
+
+def resolve_test_ids(test_ids, n_query, test_seq_len):
+    """eval_faiss.py:170-181."""
+    if isinstance(test_ids, np.ndarray):
+        return test_ids
+    if test_ids.lower() == 'all':
+        return np.arange(0, n_query - max(test_seq_len), 1)
+    if test_ids.lower() == 'icassp':
+        return np.load(glob.glob('./**/test_ids_icassp2021.npy', recursive=True)[0])
+    if test_ids.isnumeric():
+        return np.random.permutation(n_query - max(test_seq_len))[:int(test_ids)]
+    return np.load(test_ids)
+
+
+def search_and_score(index, query, test_ids, test_seq_len, k_probe, n_dummy, chunk_tasks=1 << 16):
+    """The batched form of the loop at eval_faiss.py:199-246.
+    Returns (top1_exact, top1_near, top3_exact, top10_exact, pred_ids (n_test, n_len, 10))."""
+    test_ids = np.asarray(test_ids, dtype=np.int64)
+    test_seq_len = np.asarray(test_seq_len, dtype=np.int64)
+    n_test, n_len = len(test_ids), len(test_seq_len)
+    max_sl = int(test_seq_len.max())
+    n_query = len(query)
+    assert np.all(test_ids <= n_query)
+    # distinct query rows any task touches (python slicing clips at the end of `query`)
+    rows = (test_ids[:, None] + np.arange(max_sl)[None, :]).reshape(-1)
+    rows = np.unique(rows[rows < n_query])
+    pos = -np.ones(n_query + max_sl + 1, np.int64)
+    pos[rows] = np.arange(len(rows))
+    dev = index.device
+    q_dev = torch.from_numpy(np.ascontiguousarray(query[rows], dtype=np.float32)).to(dev)
+    _, I = index.search_device(q_dev, k_probe)                      # (n_rows, k) int32
+    I = I.to(torch.int64)
+    out = [np.zeros((n_test, n_len), int) for _ in range(4)]
+    preds = -np.ones((n_test, n_len, 10), np.int64)
+    S = max_sl * k_probe
+    offs = torch.arange(max_sl, device=dev)
+    for si, sl in enumerate(test_seq_len.tolist()):
+        sl_eff = np.minimum(sl, n_query - test_ids)                  # q = query[t : t+sl] clips at the end
+        for a in range(0, n_test, chunk_tasks):
+            b = min(n_test, a + chunk_tasks)
+            t_ids = test_ids[a:b]
+            T = b - a
+            row_idx = pos[np.minimum(t_ids[:, None] + np.arange(max_sl)[None, :], n_query + max_sl)]   # (T, max_sl)
+            valid = (np.arange(max_sl)[None, :] < sl_eff[a:b, None]) & (row_idx >= 0)
+            ri = torch.from_numpy(np.where(valid, row_idx, 0)).to(dev)
+            cand = I[ri] - offs[None, :, None]                       # offset compensation (eval_faiss.py:213-215)
+            ok = torch.from_numpy(valid).to(dev)[:, :, None] & (I[ri] >= 0) & (cand >= 0)
+            cand = torch.where(ok, cand, torch.full_like(cand, -1)).reshape(T, S).to(torch.int32).contiguous()
+            q0 = torch.from_numpy(pos[t_ids].astype(np.int32)).to(dev)
+            ln = torch.from_numpy(sl_eff[a:b].astype(np.int32)).to(dev)
+            scores = index.sequence_scores(q_dev, q0, ln, cand)      # rows of a task are consecutive in q_dev
+            c = cand.cpu().numpy().astype(np.int64)
+            s = scores.cpu().numpy().astype(np.float64)
+            # unique candidates (np.unique, eval_faiss.py:218), then score descending / id ascending
+            order = np.argsort(c, axis=1, kind='stable')
+            c = np.take_along_axis(c, order, 1); s = np.take_along_axis(s, order, 1)
+            dup = np.zeros_like(c, dtype=bool)
+            dup[:, 1:] = c[:, 1:] == c[:, :-1]
+            s[dup | (c < 0)] = -np.inf
+            rank = np.lexsort((c, -s), axis=1)[:, :10]
+            p = np.take_along_axis(c, rank, 1)
+            p[np.take_along_axis(s, rank, 1) == -np.inf] = -1
+            preds[a:b, si, :p.shape[1]] = p
+            gt = (t_ids + n_dummy)[:, None]
+            out[0][a:b, si] = (p[:, :1] == gt).any(1)
+            out[1][a:b, si] = (np.abs(p[:, :1] - gt) <= 1).any(1) & (p[:, 0] >= 0)
+            out[2][a:b, si] = (p[:, :3] == gt).any(1)
+            out[3][a:b, si] = (p[:, :10] == gt).any(1)
+    return out[0], out[1], out[2], out[3], preds
+
+
+def eval_faiss(emb_dir, emb_dummy_dir=None, index_type='l2', nogpu=False, max_train=1e7, test_ids='icassp',
+               test_seq_len='1 3 5 9 11 19', k_probe=20, display_interval=5):
+    """eval_faiss.py:93-275."""
+    if isinstance(test_seq_len, str):
+        test_seq_len = np.asarray(list(map(int, test_seq_len.split())))
+    query, query_shape = load_memmap_data(emb_dir, 'query')
+    db, db_shape = load_memmap_data(emb_dir, 'db')
+    if emb_dummy_dir is None:
+        emb_dummy_dir = emb_dir
+    dummy_db, dummy_db_shape = load_memmap_data(emb_dummy_dir, 'dummy_db')
+    index = get_index(index_type, dummy_db, dummy_db.shape, (not nogpu), max_train)
+    start_time = time.time()
+    index.add(dummy_db); print(f'{len(dummy_db)} items from dummy DB')
+    index.add(db); print(f'{len(db)} items from reference DB')
+    print(f'Added total {index.ntotal} items to DB. {time.time() - start_time:>4.2f} sec.')
+    print(f'test_id: \033[93m{test_ids}\033[0m,  ', end='')
+    test_ids = resolve_test_ids(test_ids, len(query), test_seq_len)
+    n_test = len(test_ids)
+    print(f'n_test: \033[93m{n_test:n}\033[0m')
+    start_time = time.time()
+    top1_exact, top1_near, top3_exact, top10_exact, _ = search_and_score(index, query, test_ids, test_seq_len, k_probe,
+                                                                        int(dummy_db_shape[0]))
+    torch.cuda.synchronize()
+    dt = time.time() - start_time
+    rates = [100. * np.mean(m, axis=0) for m in (top1_exact, top1_near, top3_exact, top10_exact)]
+    print(f'{n_test} test ids x {len(test_seq_len)} lengths in {dt:.2f} s ({dt / max(n_test * len(test_seq_len), 1) * 1e3:.3f} ms per query sequence)')
+    print('segments      ' + ''.join(f'{int(s):>8d}' for s in test_seq_len))
+    for name, r in zip(['Top1 exact', 'Top1 near', 'Top3 exact', 'Top10 exact'], rates):
+        print(f'{name:<14s}' + ''.join(f'{v:8.2f}' for v in r))
+    np.save(f'{emb_dir}/raw_score.npy', np.concatenate((top1_exact, top1_near, top3_exact, top10_exact), axis=1))
+    np.save(f'{emb_dir}/test_ids.npy', test_ids)
+    print(f'Saved test_ids and raw score to {emb_dir}.')
+    return rates

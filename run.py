@@ -7,7 +7,7 @@
 Same commands, arguments, options and config resolution (./config/<name>.yaml) as
 the reference's run.py:13-162.  `generate` and `train` run the HIP hot path (train on a
 caller-supplied or synthetic batch source: the augmenting dataset is SURVEY.md section 8f);
-`evaluate` sits outside the path built so far and says so.
+`evaluate` runs the exact ('L2') search on the device; the approximate faiss index types say so.
 
 Multi-GPU generate: launch one process per GPU, e.g.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -113,17 +113,22 @@ def generate(checkpoint_name, checkpoint_index, config, source, output, skip_dum
 @click.argument('checkpoint_name', required=True)
 @click.argument('checkpoint_index', required=True)
 @click.option('--config', '-c', default='default', required=False, type=click.STRING)
-@click.option('--index_type', '-i', default='ivfpq', type=click.STRING)
-@click.option('--test_seq_len', default='1 3 5 9 11 19', type=click.STRING)
-@click.option('--test_ids', '-t', default='icassp', type=click.STRING)
-@click.option('--nogpu', default=False, is_flag=True)
+@click.option('--index_type', '-i', default='L2', type=click.STRING,
+              help="'L2' = exact search over the HBM-resident table (the reference's faiss.IndexFlatL2). The "
+                   "approximate faiss types {'IVF', 'IVFPQ', 'IVFPQ-RR', 'IVFPQ-ONDISK', 'HNSW'} are not built "
+                   "(the reference's default is 'ivfpq').")
+@click.option('--test_seq_len', default='1 3 5 9 11 19', type=click.STRING,
+              help="Numbers of segments to test, separated by spaces. Default '1 3 5 9 11 19' = 1s, 2s, 3s, 5s, 6s, 10s.")
+@click.option('--test_ids', '-t', default='icassp', type=click.STRING,
+              help="One of {'all', 'icassp', 'path/file.npy', (int)}: all ids, the 2,000 ids of "
+                   "eval/test_ids_icassp2021.npy, a 1-D array file, or N random ids.")
+@click.option('--nogpu', default=False, is_flag=True, help='(reference flag) CPU-only search: not built here.')
 def evaluate(checkpoint_name, checkpoint_index, config, index_type, test_seq_len, test_ids, nogpu):
-    """Search and evaluation over the generated .mm files (consumer of the hot path's output;
-    the reference uses faiss, which is outside the built path)."""
+    """Search and evaluation over the generated {query, db, dummy_db}.mm (run.py:140-161 of the reference)."""
+    from neural_audio_fp_amd.eval.eval_faiss import eval_faiss
     cfg = load_config(config)
     emb_dir = cfg['DIR']['OUTPUT_ROOT_DIR'] + checkpoint_name + '/' + str(checkpoint_index) + '/'
-    raise NotImplementedError(f'evaluate: the search/eval side is outside the built path; the fingerprints in '
-                              f'{emb_dir} are drop-in for the reference\'s eval/eval_faiss.py')
+    eval_faiss(emb_dir, index_type=index_type, test_seq_len=test_seq_len, test_ids=test_ids, nogpu=nogpu)
 
 
 if __name__ == '__main__':

@@ -1,0 +1,134 @@
+"""GPU: exact search + sequence evaluation through the C ABI vs the oracle (oracle/search.py =
+eval/eval_faiss.py:199-246 with faiss.IndexFlatL2)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import search as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _unit(n, d, seed, scale=None):
+    x = np.random.default_rng(seed).normal(size=(n, d))
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    if scale is not None:
+        x *= scale
+    return x.astype(np.float32)
+
+
+def _check_topk(D, I, q, x, k):
+    """ids equal to the float64 oracle except where two distances tie within fp32 rounding."""
+    Dw, Iw = S.flat_l2_search(q, x, k)
+    assert D.shape == Dw.shape and I.shape == Iw.shape
+    assert np.abs(D - Dw).max() < 2e-5 * max(1.0, np.abs(Dw).max())
+    bad = I != Iw
+    if bad.any():
+        d_true = ((q.astype(np.float64)[:, None, :] - x.astype(np.float64)[None]) ** 2).sum(-1) if len(q) * len(x) < 4e6 else None
+        assert d_true is not None, f'{bad.sum()} id mismatches'
+        rows, cols = np.nonzero(bad)
+        for r, c in zip(rows, cols):
+            assert abs(d_true[r, I[r, c]] - d_true[r, Iw[r, c]]) < 1e-5
+    return bad.sum()
+
+
+@pytest.mark.parametrize('n,nq,d,k', [(1000, 37, 128, 20), (64, 5, 128, 20), (50, 3, 128, 20), (5000, 300, 64, 20),
+                                      (20001, 130, 128, 32), (777, 129, 128, 1), (100000, 40, 128, 20)])
+def test_topk_matches_oracle(nafp, n, nq, d, k):
+    from neural_audio_fp_amd.eval.eval_faiss import FlatL2Index
+    x = _unit(n, d, n)
+    q = _unit(nq, d, n + 1)
+    idx = FlatL2Index(d)
+    idx.add(x[:n // 2]); idx.add(x[n // 2:])                # add() twice like dummy_db then db
+    assert idx.ntotal == n
+    D, I = idx.search(q, k)
+    assert I.dtype == np.int64 and D.dtype == np.float32
+    _check_topk(D, I, q, x, k)
+    assert np.all(np.diff(D, axis=1) >= 0)
+
+
+def test_topk_l2_is_not_inner_product_and_handles_ties_and_short_index(nafp):
+    from neural_audio_fp_amd.eval.eval_faiss import FlatL2Index
+    rng = np.random.default_rng(0)
+    x = _unit(3000, 128, 1, scale=rng.uniform(0.5, 2.0, size=(3000, 1)))      # norms differ: L2 != max inner product
+    q = _unit(50, 128, 2)
+    idx = FlatL2Index(128); idx.add(x)
+    D, I = idx.search(q, 20)
+    _check_topk(D, I, q, x, 20)
+    ip_top = np.argsort(-(q @ x.T), axis=1)[:, 0]
+    assert (ip_top != I[:, 0]).any()
+    # duplicates: smaller id first (both copies are returned, adjacent)
+    xd = np.concatenate([x[:200], x[:200]])
+    idx2 = FlatL2Index(128); idx2.add(xd)
+    _, I2 = idx2.search(x[:10], 2)
+    assert [list(r) for r in I2] == [[i, i + 200] for i in range(10)]
+    # fewer rows than k: -1 / +inf padding like faiss
+    idx3 = FlatL2Index(128); idx3.add(x[:7])
+    D3, I3 = idx3.search(q[:4], 20)
+    assert (I3[:, 7:] == -1).all() and np.isinf(D3[:, 7:]).all() and (I3[:, :7] >= 0).all()
+    with pytest.raises(NotImplementedError):
+        idx3.search(q[:1], 33)
+    with pytest.raises(NotImplementedError):
+        from neural_audio_fp_amd.eval.eval_faiss import get_index
+        get_index('ivfpq', x, x.shape)
+
+
+def test_sequence_evaluation_matches_oracle_and_writes_reference_files(nafp, tmp_path):
+    from neural_audio_fp_amd.eval import eval_faiss as E
+    rng = np.random.default_rng(5)
+    d = 128
+    dummy = _unit(3000, d, 6)
+    db = _unit(800, d, 7)
+    # queries: noisy copies (some heavily) so that the hit rates are neither 0 nor 100 %
+    noise = rng.choice([0.05, 0.8, 1.5], size=(800, 1))
+    query = db + noise * rng.normal(size=db.shape) / np.sqrt(d) * 3
+    query = (query / np.linalg.norm(query, axis=1, keepdims=True)).astype(np.float32)
+    test_ids = np.sort(rng.choice(800 - 19, size=120, replace=False))
+    test_ids[-1] = 795                                       # a sequence that is clipped by the end of `query`
+    lens = (1, 3, 5, 9, 11, 19)
+    want = S.evaluate(query, db, dummy, test_ids, lens, k_probe=20)
+    out = str(tmp_path) + '/'
+    for name, arr in (('query', query), ('db', db), ('dummy_db', dummy)):
+        mm = np.memmap(out + name + '.mm', dtype='float32', mode='w+', shape=arr.shape); mm[:] = arr; mm.flush()
+        np.save(out + name + '_shape.npy', arr.shape)
+    np.save(out + 'ids.npy', test_ids)
+    size_before = os.path.getsize(out + 'dummy_db.mm')
+    rates = E.eval_faiss(out, index_type='L2', test_ids=out + 'ids.npy', test_seq_len='1 3 5 9 11 19')
+    raw = np.load(out + 'raw_score.npy')
+    assert raw.shape == (120, 24) and np.array_equal(np.load(out + 'test_ids.npy'), test_ids)
+    got = [raw[:, 6 * i:6 * (i + 1)] for i in range(4)]
+    for g, w in zip(got, want[:4]):
+        assert np.array_equal(g, w)
+    assert 5 < rates[0][0] < 99                              # the case is not trivial
+    assert os.path.getsize(out + 'dummy_db.mm') == size_before      # dummy_db.mm is NOT extended (see module docstring)
+    # predicted ids of the batched path equal the oracle's, position by position
+    idx = E.FlatL2Index(d); idx.add(dummy); idx.add(db)
+    preds = E.search_and_score(idx, query, test_ids, lens, 20, len(dummy))[4]
+    assert np.array_equal(preds, want[4])
+
+
+def test_identical_top1_hits_for_gpu_and_oracle_fingerprints(nafp, cfg):
+    """north star parity gate: the fingerprints of the HIP path and of the oracle give identical top-1
+    segment hits in the same search."""
+    import _inputs
+    from oracle import melspec as o_mel, nnfp as o_nnfp
+    from neural_audio_fp_amd.eval import eval_faiss as E
+    w = _inputs.weights(seed=8)
+    m_pre = nafp.get_melspec_layer(cfg)
+    m_fp = nafp.get_fingerprinter(cfg)
+    m_fp.set_weights(_inputs.weight_list(w))
+    x_db = _inputs.audio(60, seed=21)
+    rng = np.random.default_rng(22)
+    x_q = (x_db + 0.05 * rng.normal(size=x_db.shape)).astype(np.float32)
+    embs = {}
+    for name, x in (('db', x_db), ('q', x_q)):
+        embs['gpu_' + name] = m_fp(m_pre(torch.from_numpy(x).cuda())).cpu().numpy()
+        embs['cpu_' + name] = o_nnfp.fingerprinter(o_mel.melspec_layer(x), w).astype(np.float32)
+    hits = {}
+    for side in ('gpu', 'cpu'):
+        idx = E.FlatL2Index(128); idx.add(embs[side + '_db'])
+        hits[side] = idx.search(embs[side + '_q'], 1)[1][:, 0]
+    assert np.array_equal(hits['gpu'], hits['cpu'])
+    assert (hits['gpu'] == np.arange(60)).mean() > 0.9
