@@ -463,20 +463,34 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         __builtin_amdgcn_s_barrier();
         const bool has_next = s + NSTAGE - 1 < n_steps && !(p.abl & 1);
         int nslot = slot + NSTAGE - 1; if (nslot >= NSTAGE) nslot -= NSTAGE;
+        const float* St = smem + slot * STAGE;
+        if (p.abl & 4) {
+            if (has_next) { NAFP_DMA_STEP(s + NSTAGE - 1, nslot) }
+            if (++slot == NSTAGE) slot = 0;
+            continue;
+        }
+        // the first operand fragments are requested BEFORE the next DMA is issued: the DMA issue
+        // (descriptor moves, m0 writes) then runs under the LDS read latency instead of ahead of it
+        float4 a0[2], b0[2];
+        {
+            const int pc4 = ((0 + hh) ^ rswz) * 4;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) a0[mi] = *(const float4*)(St + aoff + mi * 32 * BK + pc4);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) b0[ni] = *(const float4*)(St + boff + ni * 32 * BK + pc4);
+        }
         if (has_next) {
             NAFP_DMA_STEP(s + NSTAGE - 1, nslot)
             if (FUSE0) NAFP_GEN_LOAD(s + NSTAGE - 1)
         }
-        const float* St = smem + slot * STAGE;
-        if (p.abl & 4) { if (++slot == NSTAGE) slot = 0; continue; }
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             const int pc4 = ((2 * kk + hh) ^ rswz) * 4;
             float4 a[2], b[2];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) a[mi] = *(const float4*)(St + aoff + mi * 32 * BK + pc4);
+            for (int mi = 0; mi < 2; ++mi) a[mi] = kk == 0 ? a0[mi] : *(const float4*)(St + aoff + mi * 32 * BK + pc4);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) b[ni] = *(const float4*)(St + boff + ni * 32 * BK + pc4);
+            for (int ni = 0; ni < 2; ++ni) b[ni] = kk == 0 ? b0[ni] : *(const float4*)(St + boff + ni * 32 * BK + pc4);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll

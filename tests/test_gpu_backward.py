@@ -40,3 +40,28 @@ def test_encoder_backward_matches_autograd(nafp, B):
         # fp32 through 16 layers of forward + backward vs float64 autograd: 2e-3 of the largest entry
         assert err < 2e-3, (names[i], err, scale)
     print('worst relative gradient error', worst)
+
+
+def test_backward_is_additive_over_the_batch_at_bsz_5120(nafp):
+    """Size-independent property at BASELINE's full train batch (5120 per GPU when N = 1): the encoder's
+    parameter gradient for a given dL/d(emb) is a sum over samples, so one backward over 5120 samples
+    equals the sum of four backwards over its 1280-sample quarters (also guards the >2^31-element
+    activation tensors of this size against 32-bit indexing)."""
+    B, Q = 5120, 4
+    g = torch.Generator(device='cuda').manual_seed(3)
+    feat = -1.2 * torch.rand((B, 256, 32, 1), generator=g, device='cuda')
+    d_emb = torch.randn((B, 128), generator=g, device='cuda')
+    m_fp = nafp.FingerPrinter(seed=5)
+    emb = m_fp.forward_train(feat)
+    full = [t.clone() for t in m_fp.backward(d_emb)]
+    parts = None
+    n = B // Q
+    for k in range(Q):
+        e = m_fp.forward_train(feat[k * n:(k + 1) * n])
+        # per-sample forward; not bit-identical: the split-K factor of the late convs depends on the batch
+        assert float((e - emb[k * n:(k + 1) * n]).abs().max()) < 2e-5
+        gk = m_fp.backward(d_emb[k * n:(k + 1) * n])
+        parts = [t.clone() for t in gk] if parts is None else [a + b for a, b in zip(parts, gk)]
+    for i, (a, b) in enumerate(zip(full, parts)):
+        scale = float(b.abs().max()) + 1e-20
+        assert float((a - b).abs().max()) / scale < 2e-4, i
