@@ -235,6 +235,32 @@ int nafp_lamb_step(const nafp_opt_tensor* tensors_host, int n, float lr, float b
                    int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Training batch assembly + time-domain augmentation on the device.  Replaces, per output row, the host
+ * work of genUnbalSequence.__getitem__ (model/utils/dataloader_keras.py:223-311): load_audio
+ * (model/utils/audio_utils.py:221-264), bg_mix_batch (:82-117, background_mix :28-72) and
+ * ir_aug_batch (:120-137).  All windows index ONE int16 PCM arena; the random draws (offsets, SNR,
+ * amplitude ratio) are made by the caller, as the reference makes them on the host.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct nafp_aug_row {
+    int64_t ev_off;      /* event window: first sample in the arena                                   */
+    int64_t nz_off;      /* background window (same length), or -1                                    */
+    int64_t nz2_off;     /* second noise window added to the first (speech), or -1                    */
+    int64_t ir_off;      /* impulse response, or -1                                                   */
+    int32_t ev_valid;    /* real samples of the event window (<= seg_len; the tail is zero)           */
+    int32_t nz_valid, nz2_valid;
+    int32_t ir_len;      /* taps used (<= 600 = MAX_IR_LENGTH, dataloader_keras.py:8)                 */
+    float snr_db;        /* bg_mix_batch's uniform draw in snr_range (audio_utils.py:92-95)           */
+    float amp;           /* its log-uniform amplitude ratio in (0.1, 1) (audio_utils.py:98-99)        */
+    int32_t mix;         /* 1: run bg_mix_batch's arithmetic for this row (replicas with BG/speech)   */
+    int32_t reserved;
+} nafp_aug_row;
+
+/* out (n_rows, seg_len) float32; rows is a DEVICE array.  A row with mix = 0 and ir_off = -1 is the
+ * plain window / 2^15 (the anchors).  seg_len % 4 == 0. */
+int nafp_augment_rows(const int16_t* pcm, const nafp_aug_row* rows, int64_t n_rows, int seg_len, float* out,
+                      void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Search / evaluation over resident fingerprints (consumer of the generate path's output).
  * Replaces faiss.IndexFlatL2 as eval/eval_faiss.py uses it with index_type 'L2'
  * (eval/utils/get_index_faiss.py:57-62; index.add at eval_faiss.py:145-146; index.search at :209)

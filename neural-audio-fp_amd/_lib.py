@@ -58,6 +58,7 @@ PROTOTYPES = {
     'nafp_cosine_decay_lr_host': (c_float, [c_float, c_i64, c_i64, c_float]),
     'nafp_adam_step': (c_int, [c_void_p, c_int, c_float, c_float, c_float, c_float, c_i64, c_void_p]),
     'nafp_lamb_workspace_bytes': (c_i64, [c_void_p, c_int]),
+    'nafp_augment_rows': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     'nafp_search_index_aux_floats': (c_i64, [c_i64]),
     'nafp_search_index_prepare': (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     'nafp_search_workspace_bytes': (c_i64, [c_i64, c_i64, c_int]),
@@ -79,6 +80,12 @@ class OptTensor(ctypes.Structure):
 class Rect(ctypes.Structure):
     """nafp_rect (include/nafp.h): inclusive hole bounds."""
     _fields_ = [('f0', c_int), ('f1', c_int), ('t0', c_int), ('t1', c_int)]
+
+
+# nafp_aug_row (include/nafp.h) as a numpy structured dtype: 64 bytes per row
+AUG_ROW_DTYPE = [('ev_off', '<i8'), ('nz_off', '<i8'), ('nz2_off', '<i8'), ('ir_off', '<i8'), ('ev_valid', '<i4'),
+                 ('nz_valid', '<i4'), ('nz2_valid', '<i4'), ('ir_len', '<i4'), ('snr_db', '<f4'), ('amp', '<f4'),
+                 ('mix', '<i4'), ('reserved', '<i4')]
 
 
 class NafpError(RuntimeError):

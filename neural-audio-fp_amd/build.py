@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libnafp.so')
 STAMP = os.path.join(HERE, '.libnafp.stamp')
-SOURCES = ['api.hip', 'melspec.hip', 'conv.hip', 'tail.hip', 'ntxent.hip', 'optim.hip', 'specaug.hip', 'backward.hip', 'search.hip']
+SOURCES = ['api.hip', 'melspec.hip', 'conv.hip', 'tail.hip', 'ntxent.hip', 'optim.hip', 'specaug.hip', 'backward.hip', 'search.hip', 'augment.hip']
 HEADERS = ['nafp_common.h', os.path.join('..', '..', 'include', 'nafp.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
          '-Wall', '-Wno-unused-result', '-fno-gpu-rdc']

@@ -4,14 +4,15 @@ Mirrors the parts of the reference's `Dataset` (model/dataset.py:10-323) that
 `generate_fingerprint` uses: `get_test_dummy_db_ds`, `get_test_query_db_ds`
 ('unseen_icassp': fixed query/db WAV pairs, no augmentation) and
 `get_custom_db_ds`; same directory conventions, same sorted-glob order, same
-`NotImplementedError` / `ValueError` behaviour.  The training split, background /
-IR / speech augmentation and 'unseen_syn' (real-time query synthesis) are host-side
-augmentation code outside this path and raise
-NotImplementedError here.
+`NotImplementedError` / `ValueError` behaviour.  `get_train_ds` / `get_val_ds`
+(dataset.py:118-186) return the device-side `genUnbalSequence`
+(utils/dataloader_keras.py: PCM resident in HBM, augmentation in one kernel).
+'unseen_syn' (real-time query synthesis for the test set) raises NotImplementedError.
 """
 import glob
 
 from .utils.audio_utils import SegmentSource
+from .utils.dataloader_keras import genUnbalSequence
 
 
 class Dataset:
@@ -26,12 +27,54 @@ class Dataset:
         self.fs = cfg['MODEL']['FS']
         self.ts_dummy_db_source_fps = None
         self.ts_query_icassp_fps = self.ts_db_icassp_fps = None
+        # training / validation (dataset.py:24-83)
+        self.bg_root_dir = cfg['DIR']['BG_ROOT_DIR']
+        self.ir_root_dir = cfg['DIR']['IR_ROOT_DIR']
+        self.speech_root_dir = cfg['DIR']['SPEECH_ROOT_DIR']
+        self.tr_batch_sz, self.tr_n_anchor = cfg['BSZ']['TR_BATCH_SZ'], cfg['BSZ']['TR_N_ANCHOR']
+        self.val_batch_sz, self.val_n_anchor = cfg['BSZ']['VAL_BATCH_SZ'], cfg['BSZ']['VAL_N_ANCHOR']
+        aug = cfg['TD_AUG']
+        self.tr_snr, self.val_snr = aug['TR_SNR'], aug['VAL_SNR']
+        self.tr_use_bg_aug, self.val_use_bg_aug = aug['TR_BG_AUG'], aug['VAL_BG_AUG']
+        self.tr_use_ir_aug, self.val_use_ir_aug = aug['TR_IR_AUG'], aug['VAL_IR_AUG']
+        self.tr_use_speech_aug, self.val_use_speech_aug = aug['TR_SPEECH_AUG'], aug['VAL_SPEECH_AUG']
+        g = lambda root, sub: sorted(glob.glob(root + sub + '/**/*.wav', recursive=True))
+        # dataset.py:86-125: validation reuses the training split of bg / ir, speech has train / dev
+        self.tr_bg_fps = g(self.bg_root_dir, 'tr') if self.tr_use_bg_aug else None
+        self.val_bg_fps = g(self.bg_root_dir, 'tr') if self.val_use_bg_aug else None
+        self.tr_ir_fps = g(self.ir_root_dir, 'tr') if self.tr_use_ir_aug else None
+        self.val_ir_fps = g(self.ir_root_dir, 'tr') if self.val_use_ir_aug else None
+        self.tr_speech_fps = g(self.speech_root_dir, 'train') if self.tr_use_speech_aug else None
+        self.val_speech_fps = g(self.speech_root_dir, 'dev') if self.val_use_speech_aug else None
+        self.tr_source_fps = self.val_source_fps = None
 
     def _source(self, fps):
         return SegmentSource(fps, self.ts_batch_sz, self.dur, self.hop, self.fs)
 
-    def get_train_ds(self, reduce_items_p=0):
-        raise NotImplementedError('training data pipeline (host augmentation) is outside the built path')
+    def get_train_ds(self, reduce_items_p=0, n_anchor=None, bsz=None, seed=0):
+        """dataset.py:128-153.  n_anchor / bsz: this rank's share of the global batch (data parallel)."""
+        if self.datasel_train == '10k_icassp':
+            _prefix = 'train-10k-30s/'
+        else:
+            raise NotImplementedError(self.datasel_train)
+        self.tr_source_fps = sorted(glob.glob(self.source_root_dir + _prefix + '**/*.wav', recursive=True))
+        return genUnbalSequence(
+            fns_event_list=self.tr_source_fps, bsz=bsz or self.tr_batch_sz, n_anchor=n_anchor or self.tr_n_anchor,
+            duration=self.dur, hop=self.hop, fs=self.fs, shuffle=True, random_offset_anchor=True,
+            bg_mix_parameter=[self.tr_use_bg_aug, self.tr_bg_fps, self.tr_snr],
+            ir_mix_parameter=[self.tr_use_ir_aug, self.tr_ir_fps],
+            speech_mix_parameter=[self.tr_use_speech_aug, self.tr_speech_fps, self.tr_snr],
+            reduce_items_p=reduce_items_p, seed=seed)
+
+    def get_val_ds(self, max_song=500):
+        """dataset.py:156-186."""
+        self.val_source_fps = sorted(glob.glob(self.source_root_dir + 'val-query-db-500-30s/' + '**/*.wav',
+                                               recursive=True))[:max_song]
+        return genUnbalSequence(
+            self.val_source_fps, self.val_batch_sz, self.val_n_anchor, self.dur, self.hop, self.fs, shuffle=False,
+            random_offset_anchor=False, bg_mix_parameter=[self.val_use_bg_aug, self.val_bg_fps, self.val_snr],
+            ir_mix_parameter=[self.val_use_ir_aug, self.val_ir_fps],
+            speech_mix_parameter=[self.val_use_speech_aug, self.val_speech_fps, self.val_snr])
 
     def get_test_dummy_db_ds(self):
         """dataset.py:189-215."""

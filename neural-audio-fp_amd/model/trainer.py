@@ -15,9 +15,10 @@ yields in its backward) and each rank back-propagates its slice; parameter gradi
 all-reduced (sum) in one flat buffer, so every rank applies the gradient of the GLOBAL mean loss
 and the replicas stay bit-identical.
 
-What is NOT here: the reference's training dataset (time-domain augmentation on the host,
-model/dataset.py + dataloader_keras.py) -- `trainer` takes any iterable of (Xa, Xp) batches --
-TensorBoard, and the mini-search validation.
+The training set comes from `Dataset(cfg).get_train_ds()` (model/dataset.py, utils/dataloader_keras.py:
+PCM resident in HBM, time-domain augmentation in one kernel) unless the caller passes its own
+iterable of (Xa, Xp) batches.  What is NOT here: TensorBoard, the per-epoch validation loop and the
+mini-search validation.
 """
 import torch
 
@@ -187,11 +188,25 @@ def sync_replicas(m_fp):
 
 
 def trainer(cfg, checkpoint_name, train_batches=None, steps_per_epoch=None, max_epoch=None):
-    """trainer.py:111-230 without the host data pipeline: `train_batches` is a callable
-    epoch -> iterable of (Xa, Xp) CUDA (or host) batches of shape (n, 1, T)."""
+    """trainer.py:111-230.  `train_batches`: optional callable epoch -> iterable of (Xa, Xp) CUDA (or host)
+    batches of shape (n, 1, T); default = the reference's training set (cfg DIR / DATA_SEL / TD_AUG) through the
+    device-side loader (every rank draws its own share of each global batch)."""
     if train_batches is None:
-        raise NotImplementedError('the augmenting training dataset (model/dataset.py) is outside the built path: '
-                                  'pass train_batches=callable(epoch) -> iterable of (Xa, Xp)')
+        # the reference's loader (trainer.py:113, 181-197): anchors + augmented replicas, assembled on the device
+        from .dataset import Dataset
+        dist = _dist()
+        world = dist.get_world_size() if dist is not None else 1
+        rank = dist.get_rank() if dist is not None else 0
+        ds = Dataset(cfg).get_train_ds(cfg['DATA_SEL']['REDUCE_ITEMS_P'], n_anchor=cfg['BSZ']['TR_N_ANCHOR'] // world,
+                                       bsz=cfg['BSZ']['TR_BATCH_SZ'] // world, seed=1000 + rank)
+        if ds.n_pos_per_anchor != 1:
+            raise NotImplementedError('NT-Xent trains with one replica per anchor (TR_BATCH_SZ = 2 * TR_N_ANCHOR)')
+
+        def train_batches(ep, ds=ds):
+            for i in range(len(ds)):
+                yield ds[i]
+            ds.on_epoch_end()
+        steps_per_epoch = steps_per_epoch or len(ds)
     max_epoch = max_epoch or cfg['TRAIN']['MAX_EPOCH']
     if steps_per_epoch is None:
         steps_per_epoch = len(train_batches(1))

@@ -68,7 +68,7 @@ def cli():
 @click.option('--max_epoch', default=None, type=click.INT, help='Max epoch.')
 @click.option('--synthetic', default=None, type=click.INT,
               help='Train on N synthetic steps per epoch (anchors: seeded noise; replicas: anchors + noise at 5 dB '
-                   'SNR) instead of the augmenting dataset, which is outside the built path.')
+                   'SNR) instead of the training set of the config.')
 def train(checkpoint_name, config, max_epoch, synthetic):
     """Train a neural audio fingerprinter (HIP forward + backward, NT-Xent, Adam/LAMB).
 
@@ -80,10 +80,9 @@ def train(checkpoint_name, config, max_epoch, synthetic):
     print_config(cfg)
     _init_distributed()
     if synthetic is None:
-        raise NotImplementedError('train: the augmenting training dataset (model/dataset.py of the reference) is '
-                                  'outside the built path; use --synthetic N or call '
-                                  'neural_audio_fp_amd.model.trainer.trainer(cfg, name, train_batches=...)')
-    trainer(cfg, checkpoint_name, train_batches=synthetic_batches(cfg, synthetic), steps_per_epoch=synthetic)
+        trainer(cfg, checkpoint_name)          # the reference's training set under cfg['DIR'] (device-side loader)
+    else:
+        trainer(cfg, checkpoint_name, train_batches=synthetic_batches(cfg, synthetic), steps_per_epoch=synthetic)
 
 
 @cli.command()

@@ -118,3 +118,36 @@ def test_trainer_epochs_and_resume(nafp, cfg, tmp_path):
     with pytest.raises(NotImplementedError):
         c['TRAIN']['OPTIMIZER'] = 'SGD'
         T.trainer(c, 'unit2', train_batches=T.synthetic_batches(c, 1), steps_per_epoch=1)
+
+
+def test_trainer_on_a_dataset_directory(nafp, cfg, tmp_path):
+    """`trainer(cfg, name)` with no batch source: the reference's directory layout (music/train-10k-30s,
+    aug/bg/tr, aug/ir/tr) through the device-side loader + augmentation + train step."""
+    import wave
+    from neural_audio_fp_amd.model import trainer as T
+    rng = np.random.default_rng(31)
+    t = np.arange(80000) / 8000.0
+
+    def wav(path, pcm):
+        path.parent.mkdir(parents=True, exist_ok=True)
+        with wave.open(str(path), 'w') as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(8000)
+            w.writeframes(np.asarray(pcm).astype('<i2').tobytes())
+    root = tmp_path / 'ds'
+    for i in range(6):
+        wav(root / 'music' / 'train-10k-30s' / 'a' / f'{i}.wav',
+            rng.integers(-1500, 1500, size=80000) + 8000 * np.sin(2 * np.pi * (300 + 400 * i) * t))
+    for i in range(2):
+        wav(root / 'aug' / 'bg' / 'tr' / f'{i}.wav', rng.integers(-5000, 5000, size=30000))
+        wav(root / 'aug' / 'ir' / 'tr' / f'{i}.wav', 12000 * rng.normal(size=900) * np.exp(-np.arange(900) / 60.0))
+    c = copy.deepcopy(cfg)
+    c['DIR'].update({'SOURCE_ROOT_DIR': str(root / 'music') + '/', 'BG_ROOT_DIR': str(root / 'aug' / 'bg') + '/',
+                     'IR_ROOT_DIR': str(root / 'aug' / 'ir') + '/', 'LOG_ROOT_DIR': str(tmp_path) + '/logs/'})
+    c['BSZ']['TR_BATCH_SZ'], c['BSZ']['TR_N_ANCHOR'] = 32, 16
+    c['TRAIN']['MAX_EPOCH'] = 2
+    hist = T.trainer(c, 'dirs')
+    n_seg = 6 * 19                                             # 10-s clips: 19 segments each
+    assert len(hist) == 2 and all(np.isfinite(hist))
+    ck = torch.load(tmp_path / 'logs' / 'checkpoint' / 'dirs' / 'ckpt-2.pt', weights_only=True)
+    assert ck['optimizer']['iterations'] == 2 * (n_seg // 16)
+    assert hist[1] < hist[0]

@@ -1,0 +1,119 @@
+"""CPU: the augmentation oracle (oracle/augment.py = audio_utils.py:10-137) against independent
+formulations, and the host logic of the device-side training loader (window tables of
+neural-audio-fp_amd/model/utils/dataloader_keras.py) against the reference's enumeration rules."""
+import wave
+
+import numpy as np
+import pytest
+
+from oracle import augment as A
+
+
+def _write_wav(path, pcm, fs=8000):
+    with wave.open(path, 'w') as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(fs)
+        w.writeframes(np.asarray(pcm).astype('<i2').tobytes())
+
+
+def test_ir_fft_equals_direct_circular_convolution():
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(3, 400))
+    ir = [rng.normal(size=37) * np.exp(-np.arange(37) / 6.0) for _ in range(3)]
+    a, b = A.ir_aug_rows(x, ir), A.ir_aug_rows_direct(x, ir)
+    assert np.abs(a - b).max() < 1e-12 and np.allclose(np.abs(a).max(1), 1.0)
+    z = A.ir_aug_rows(np.zeros((1, 64)), [np.ones(5)])
+    assert np.all(z == 0)                                     # max == 0: left as is (audio_utils.py:131-134)
+
+
+def test_bg_mix_snr_and_normalisation():
+    rng = np.random.default_rng(1)
+    ev, bg = rng.normal(size=(4, 8000)) * 0.1, rng.normal(size=(4, 8000)) * 0.3
+    snrs, amps = np.array([0.0, 10.0, 6.0, 3.0]), np.array([1.0, 0.5, 0.1, 0.7])
+    ev[3] = 0.0                                               # silent event: plain sum, then max-normalise
+    out = A.bg_mix_rows(ev, bg, snrs, amps)
+    assert np.allclose(np.abs(out).max(1), amps)
+    # the mix is a * ev + b * bg with 20 log10(rms(a ev) / rms(b bg)) = snr
+    for i in range(3):
+        coef, *_ = np.linalg.lstsq(np.stack([ev[i], bg[i]], 1), out[i], rcond=None)
+        snr = 20 * np.log10(np.sqrt(np.mean((coef[0] * ev[i]) ** 2)) / np.sqrt(np.mean((coef[1] * bg[i]) ** 2)))
+        assert abs(snr - snrs[i]) < 1e-9
+    assert np.allclose(out[3], amps[3] * bg[3] / np.abs(bg[3]).max())
+
+
+@pytest.fixture()
+def corpus(tmp_path):
+    rng = np.random.default_rng(2)
+    mk = lambda sub, lens: [(_write_wav(str(tmp_path / f'{sub}{i}.wav'), rng.integers(-9000, 9000, size=n)), str(tmp_path / f'{sub}{i}.wav'))[1]
+                            for i, n in enumerate(lens)]
+    return {'ev': mk('ev', [240000, 100000, 36001, 8000]), 'bg': mk('bg', [40000, 17000]), 'ir': mk('ir', [300, 2000, 650]),
+            'sp': mk('sp', [30000])}
+
+
+def test_segment_table_matches_oracle_rule():
+    from neural_audio_fp_amd.model.utils.dataloader_keras import segment_table
+    for n in (100, 8000, 8001, 12000, 36001, 240000):
+        assert segment_table(n, 8000, 1., .5) == A.segment_offsets(n)
+    assert segment_table(240000, 8000, 1., .5)[0] == (0, 0, 4000)
+    assert segment_table(240000, 8000, 1., .5)[-1] == (58, -4000, 0)
+    assert segment_table(36001, 8000, 1., .5)[-1][2] == 1        # residual frames of the last segment
+
+
+def test_plan_rows_follow_the_reference_batch_rules(corpus):
+    from neural_audio_fp_amd.model.utils.dataloader_keras import genUnbalSequence, MAX_IR_LENGTH
+    ds = genUnbalSequence(corpus['ev'], bsz=20, n_anchor=4, shuffle=True, random_offset_anchor=True,
+                          bg_mix_parameter=[True, corpus['bg'], (0, 10)], ir_mix_parameter=[True, corpus['ir']], seed=3)
+    n_seg = sum(len(A.segment_offsets(n)) for n in (240000, 100000, 36001, 8000))
+    assert ds.n_pos_per_anchor == 4 and ds.n_pos_bsz == 16
+    assert ds.n_samples == (n_seg // 4) * 4 and len(ds) == ds.n_samples // 4
+    assert sorted(ds.index_event) == list(range(ds.n_samples))
+    arena = ds.arena.host()
+    pcm = {f: np.frombuffer(wave.open(f).readframes(10 ** 7), dtype='<i2') for k in corpus for f in corpus[k]}
+    for idx in (0, 1, len(ds) - 1):
+        rows = ds.plan(idx)
+        assert len(rows) == 20
+        anchors = ds.index_event[idx * 4:(idx + 1) * 4]
+        for a, i in enumerate(anchors):
+            f, seg, lo, hi = ds.fns_event_seg_list[i]
+            st_a = rows['ev_off'][a] - ds.ev.start[f]
+            off_a = st_a - seg * 4000
+            assert max(lo, -1600) <= off_a <= min(hi, 1600) and (off_a < min(hi, 1600) or min(hi, 1600) <= max(lo, -1600))
+            for k in range(4):
+                r = 4 + a * 4 + k
+                off_p = rows['ev_off'][r] - ds.ev.start[f] - seg * 4000
+                assert max(off_a - 1600, lo) <= off_p <= min(off_a + 1600, hi)
+                assert rows['mix'][r] == 1 and 0 <= rows['snr_db'][r] <= 10 and 0.1 <= rows['amp'][r] <= 1.0
+                assert rows['ir_len'][r] <= MAX_IR_LENGTH and rows['ir_off'][r] >= ds.ir.base
+                assert ds.bg.base <= rows['nz_off'][r] < ds.bg.end and rows['nz2_off'][r] == -1
+            assert rows['mix'][a] == 0 and rows['ir_off'][a] == -1 and rows['nz_off'][a] == -1
+            # the window is the reference's load_audio of that file at that start
+            want = A.window(pcm[ds.ev.fns[f]], int(st_a), 8000)
+            got = np.zeros(8000); v = rows['ev_valid'][a]
+            got[:v] = arena[rows['ev_off'][a]:rows['ev_off'][a] + v] / 2 ** 15
+            assert np.array_equal(got, want)
+        # background item of replica j of batch idx: index_bg[(idx*n_pos_bsz + j) % n_bg] (dataloader_keras.py:262-266)
+        j = 5
+        sid = ds.index_bg[(idx * 16 + j) % ds.n_bg_samples]
+        f, seg, _, off_max = ds.fns_bg_seg_list[sid]
+        st = rows['nz_off'][4 + j] - ds.bg.start[f]
+        assert seg * 8000 <= st <= seg * 8000 + min(3999, off_max)
+    before = ds.index_event.copy()
+    ds.on_epoch_end()
+    assert not np.array_equal(before, ds.index_event) and sorted(ds.index_event) == sorted(before)
+    assert not np.array_equal(ds.plan(0)['ev_off'], rows['ev_off'][:0])     # runs after the reshuffle
+
+
+def test_validation_sequence_is_deterministic_and_unshuffled(corpus):
+    from neural_audio_fp_amd.model.utils.dataloader_keras import genUnbalSequence
+    ds = genUnbalSequence(corpus['ev'], 8, 4, 1, .5, 8000, shuffle=False, random_offset_anchor=False,
+                          bg_mix_parameter=[True, corpus['bg'], (0, 10)], ir_mix_parameter=[False],
+                          speech_mix_parameter=[True, corpus['sp'], (5, 5)])
+    rows = ds.plan(0)
+    assert list(ds.index_event[:4]) == [0, 1, 2, 3]
+    assert list(rows['ev_off'][:4] - ds.ev.start[0]) == [0, 4000, 8000, 12000]        # no anchor offset
+    assert (rows['nz2_off'][4:] >= ds.sp.base).all() and (rows['snr_db'][4:] == 5).all()   # bg + speech at speech SNR
+    with pytest.raises(NotImplementedError):
+        genUnbalSequence(corpus['ev'], experimental_mode=True)
+    with pytest.raises(ValueError):
+        p = corpus['ev'][0][:-4] + '_16k.wav'
+        _write_wav(p, np.zeros(100), fs=16000)
+        genUnbalSequence([p])
