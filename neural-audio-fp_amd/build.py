@@ -2,31 +2,38 @@
 
     python neural-audio-fp_amd/build.py [--force]
 
-hipcc cross-compiles without a GPU.  The .so lands next to this file
-(git-ignored; it travels to the GPU box with the repo snapshot).
+hipcc cross-compiles without a GPU.  Every csrc/*.hip is compiled to an object in parallel
+(unchanged sources are skipped), then linked; the .so lands next to this file (git-ignored;
+it travels to the GPU box with the repo snapshot).
 """
 import hashlib
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libnafp.so')
 STAMP = os.path.join(HERE, '.libnafp.stamp')
-SOURCES = ['api.hip', 'melspec.hip', 'conv.hip', 'tail.hip', 'ntxent.hip', 'optim.hip', 'specaug.hip', 'backward.hip', 'search.hip', 'augment.hip']
+SOURCES = ['api.hip', 'melspec.hip', 'conv.hip', 'tail.hip', 'ntxent.hip', 'optim.hip', 'specaug.hip', 'backward.hip',
+           'search.hip', 'augment.hip']
 HEADERS = ['nafp_common.h', os.path.join('..', '..', 'include', 'nafp.h')]
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-         '-Wall', '-Wno-unused-result', '-fno-gpu-rdc']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-result', '-fno-gpu-rdc']
+
+
+def _sha(paths, extra=''):
+    h = hashlib.sha256()
+    for f in paths:
+        with open(os.path.join(CSRC, f), 'rb') as fh:
+            h.update(fh.read())
+    h.update(extra.encode())
+    return h.hexdigest()
 
 
 def _digest():
-    h = hashlib.sha256()
-    for f in SOURCES + HEADERS:
-        with open(os.path.join(CSRC, f), 'rb') as fh:
-            h.update(fh.read())
-    h.update(' '.join(FLAGS).encode())
-    return h.hexdigest()
+    return _sha(SOURCES + HEADERS, ' '.join(FLAGS))
 
 
 def build(force=False, verbose=True):
@@ -36,7 +43,25 @@ def build(force=False, verbose=True):
             if fh.read().strip() == want:
                 return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', LIB]
+    os.makedirs(OBJ, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(OBJ, src[:-4] + '.o')
+        tag = _sha([src] + HEADERS, ' '.join(FLAGS))
+        tag_path = obj + '.sha'
+        if not force and os.path.exists(obj) and os.path.exists(tag_path) and open(tag_path).read().strip() == tag:
+            return obj
+        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+        if verbose:
+            print('[nafp build]', ' '.join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        with open(tag_path, 'w') as fh:
+            fh.write(tag)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1, 8)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-fno-gpu-rdc'] + objs + ['-o', LIB]
     if verbose:
         print('[nafp build]', ' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True)

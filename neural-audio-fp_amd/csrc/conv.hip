@@ -643,11 +643,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     __global__ __launch_bounds__(256, MINW_) void name_(const ConvKernelParams p) {          \
         conv_gemm_body<BK_, NSTAGE_, FUSE0_>(p);                                             \
     }
-NAFP_GEMM_KERNEL(conv_gemm_k32s2, 32, 2, 2, false)
-NAFP_GEMM_KERNEL(conv_gemm_k16s2, 16, 2, 4, false)
+// BK = 16, 3 stages, 3 workgroups/CU.  The other staging points were built and measured on the MI355X
+// (segments/s at BSZ 640, same run): k16s3 148.2 k | k32s2 (2 WG/CU) 143.6 k | k16s2 (4 WG/CU) 142.7 k |
+// k16s4 (2 WG/CU) 140.9 k | k32s3 (1 WG/CU) 116.4 k; they are not compiled any more.
 NAFP_GEMM_KERNEL(conv_gemm_k16s3, 16, 3, 3, false)
-NAFP_GEMM_KERNEL(conv_gemm_k16s4, 16, 4, 2, false)
-NAFP_GEMM_KERNEL(conv_gemm_k32s3, 32, 3, 1, false)
 NAFP_GEMM_KERNEL(conv_gemm_k16s3_fuse0, 16, 3, 3, true)    // conv1 with conv0 generated in-kernel
 
 template <typename KernelT>
@@ -846,7 +845,6 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     }
     if (S > 1) { p.mode = a.plain ? 1 : 2; p.n_split = S; p.y = a.slab; p.bias = nullptr; }
     const dim3 grid((unsigned)((int64_t)p.n_sg * n_pb), (unsigned)(p.Cout / BN), (unsigned)S);
-    static const int variant = []() { const char* e = getenv("NAFP_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
     int rc;
     p.f0_feat = nullptr; p.f0_w = nullptr; p.f0_bias = nullptr; p.f0_gamma = nullptr;
     p.f0_T = 0; p.f0_stride = 1; p.f0_pad = 0;
@@ -859,14 +857,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
         p.f0_T = a.f0_geom->Tin; p.f0_stride = a.f0_geom->stride; p.f0_pad = a.f0_geom->pad;
         return launch_variant(conv_gemm_k16s3_fuse0, 16, 3, p, grid, st);
     }
-    switch (variant) {
-        case 1: rc = launch_variant(conv_gemm_k32s2, 32, 2, p, grid, st); break;
-        case 2: rc = launch_variant(conv_gemm_k16s2, 16, 2, p, grid, st); break;
-        case 3: rc = launch_variant(conv_gemm_k16s3, 16, 3, p, grid, st); break;
-        case 4: rc = launch_variant(conv_gemm_k16s4, 16, 4, p, grid, st); break;
-        case 5: rc = launch_variant(conv_gemm_k32s3, 32, 3, p, grid, st); break;
-        default: rc = launch_variant(conv_gemm_k16s3, 16, 3, p, grid, st); break;   // best measured (profiles/)
-    }
+    rc = launch_variant(conv_gemm_k16s3, 16, 3, p, grid, st);
     if (rc != NAFP_OK || S == 1) return rc;
     if (a.plain) {
         const int64_t n4 = out_floats / 4;
