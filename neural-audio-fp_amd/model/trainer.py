@@ -17,8 +17,8 @@ and the replicas stay bit-identical.
 
 The training set comes from `Dataset(cfg).get_train_ds()` (model/dataset.py, utils/dataloader_keras.py:
 PCM resident in HBM, time-domain augmentation in one kernel) unless the caller passes its own
-iterable of (Xa, Xp) batches.  What is NOT here: TensorBoard, the per-epoch validation loop and the
-mini-search validation.
+iterable of (Xa, Xp) batches; the validation loss (trainer.py:200-213) is printed per epoch when the
+validation directory exists.  What is NOT here: TensorBoard and the mini-search validation.
 """
 import torch
 
@@ -191,6 +191,7 @@ def trainer(cfg, checkpoint_name, train_batches=None, steps_per_epoch=None, max_
     """trainer.py:111-230.  `train_batches`: optional callable epoch -> iterable of (Xa, Xp) CUDA (or host)
     batches of shape (n, 1, T); default = the reference's training set (cfg DIR / DATA_SEL / TD_AUG) through the
     device-side loader (every rank draws its own share of each global batch)."""
+    own_dataset = train_batches is None
     if train_batches is None:
         # the reference's loader (trainer.py:113, 181-197): anchors + augmented replicas, assembled on the device
         from .dataset import Dataset
@@ -219,6 +220,19 @@ def trainer(cfg, checkpoint_name, train_batches=None, steps_per_epoch=None, max_
         pass
     dist = _dist()
     sync_replicas(m_fp)
+    # validation set (trainer.py:200-213): only rank 0 evaluates it, only if the directory exists
+    val_ds, loss_obj_val = None, None
+    if own_dataset and (dist is None or dist.get_rank() == 0):
+        from .dataset import Dataset
+        try:
+            val_ds = Dataset(cfg).get_val_ds(max_song=250)
+            if val_ds.n_samples == 0 or val_ds.n_pos_per_anchor != 1:
+                val_ds = None
+        except (ValueError, IndexError):
+            val_ds = None
+        if val_ds is not None:
+            loss_obj_val = NTxentLoss(n_org=cfg['BSZ']['VAL_N_ANCHOR'], n_rep=cfg['BSZ']['VAL_BATCH_SZ'] - cfg['BSZ']['VAL_N_ANCHOR'],
+                                      tau=cfg['LOSS']['TAU'])
     history = []
     for ep in range(start, max_epoch + 1):
         tot, n = 0.0, 0
@@ -226,7 +240,18 @@ def trainer(cfg, checkpoint_name, train_batches=None, steps_per_epoch=None, max_
             loss, _ = train_step(X, m_pre, m_specaug, m_fp, loss_obj, opt, bucket)
             tot += float(loss); n += 1
         history.append(tot / max(n, 1))
-        print(f'epoch {ep}: train loss {history[-1]:.6f}')
+        msg = f'epoch {ep}: tr_loss:{history[-1]:.4f}'
+        if val_ds is not None:
+            vt, vn = 0.0, 0
+            for i in range(len(val_ds)):
+                Xv = val_ds[i]
+                if len(Xv[0]) != cfg['BSZ']['VAL_N_ANCHOR']:
+                    continue
+                vloss, _ = val_step(Xv, m_pre, m_fp, loss_obj_val)
+                vt += float(vloss); vn += 1
+            if vn:
+                msg += f', val_loss:{vt / vn:.4f}'
+        print(msg)
         if dist is None or dist.get_rank() == 0:
             _gen.save_checkpoint(ck_root, checkpoint_name, ep, m_fp, extra={'optimizer': opt.state_dict(m_fp.trainable_variables)})
     return history

@@ -140,12 +140,20 @@ def test_trainer_on_a_dataset_directory(nafp, cfg, tmp_path):
     for i in range(2):
         wav(root / 'aug' / 'bg' / 'tr' / f'{i}.wav', rng.integers(-5000, 5000, size=30000))
         wav(root / 'aug' / 'ir' / 'tr' / f'{i}.wav', 12000 * rng.normal(size=900) * np.exp(-np.arange(900) / 60.0))
+    for i in range(3):
+        wav(root / 'music' / 'val-query-db-500-30s' / 'v' / f'{i}.wav',
+            rng.integers(-1500, 1500, size=80000) + 8000 * np.sin(2 * np.pi * (350 + 300 * i) * t))
     c = copy.deepcopy(cfg)
+    c['BSZ']['VAL_BATCH_SZ'], c['BSZ']['VAL_N_ANCHOR'] = 16, 8
     c['DIR'].update({'SOURCE_ROOT_DIR': str(root / 'music') + '/', 'BG_ROOT_DIR': str(root / 'aug' / 'bg') + '/',
                      'IR_ROOT_DIR': str(root / 'aug' / 'ir') + '/', 'LOG_ROOT_DIR': str(tmp_path) + '/logs/'})
     c['BSZ']['TR_BATCH_SZ'], c['BSZ']['TR_N_ANCHOR'] = 32, 16
     c['TRAIN']['MAX_EPOCH'] = 2
-    hist = T.trainer(c, 'dirs')
+    import io, contextlib
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        hist = T.trainer(c, 'dirs')
+    assert buf.getvalue().count('val_loss:') == 2
     n_seg = 6 * 19                                             # 10-s clips: 19 segments each
     assert len(hist) == 2 and all(np.isfinite(hist))
     ck = torch.load(tmp_path / 'logs' / 'checkpoint' / 'dirs' / 'ckpt-2.pt', weights_only=True)
