@@ -15,3 +15,6 @@ find $O -name "*.csv" | head -20
 tail -c 600 $O/bench.json
 # train step (BSZ 1280, Adam: SURVEY 8d config 3) kernel trace
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_trace -o t -- python tools/train_probe.py 1280 adam 5 > $O/train_probe.txt 2> $O/train_trace.err
+# eval side: exact search of 38,000 query segments over 10 M resident fingerprints; training loader
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/search_trace -o t -- python tools/search_bench.py 10000000 38000 2 > $O/search_bench.txt 2> $O/search_trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/loader_trace -o t -- python tools/loader_bench.py 300 > $O/loader_bench.txt 2> $O/loader_trace.err

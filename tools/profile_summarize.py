@@ -172,4 +172,17 @@ if os.path.exists(tt):
             f.write(f'| `{n[:60]}` | {c} | {d:.0f} |\n')
         if probe:
             f.write('\nUn-profiled stage timing of the same script (torch events):\n\n```\n' + probe.strip() + '\n```\n')
+for name, title in (('search', 'Exact search (eval side): `python tools/search_bench.py 10000000 38000 2`'),
+                    ('loader', 'Training loader + augmentation: `python tools/loader_bench.py 300`')):
+    st = os.path.join(src, f'{name}_trace', 't_kernel_stats.csv')
+    if not os.path.exists(st):
+        continue
+    shutil.copy(st, os.path.join(dst, f'{tag}_{name}_kernel_stats.csv'))
+    txt = open(os.path.join(src, f'{name}_bench.txt')).read().strip().splitlines()[-4:]
+    with open(os.path.join(dst, f'{tag}_summary.md'), 'a') as f:
+        f.write(f'\n## {title}\n\nunder `rocprofv3 --kernel-trace --stats` (full CSV: `{tag}_{name}_kernel_stats.csv`).\n\n')
+        f.write('| kernel | calls | avg us | total ms |\n|---|---|---|---|\n')
+        for r in read_csv(st)[:5]:
+            f.write(f'| `{r["Name"][:70]}` | {r["Calls"]} | {float(r["AverageNs"]) / 1e3:.1f} | {float(r["TotalDurationNs"]) / 1e6:.2f} |\n')
+        f.write('\n```\n' + '\n'.join(txt) + '\n```\n')
 print(open(os.path.join(dst, f'{tag}_summary.md')).read())
