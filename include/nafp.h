@@ -234,6 +234,16 @@ int nafp_lamb_step(const nafp_opt_tensor* tensors_host, int n, float lr, float b
                    float eps, float weight_decay, int64_t step, void* workspace,
                    int64_t workspace_bytes, void* stream);
 
+/* Online triplet loss of the now-playing baseline: OnlineTripletLoss.compute_loss with use_anc_as_pos = True
+ * (model/fp/online_triplet_loss.py:199-239; masks :98-121; distances :185-196).  mode 0 = 'semi-hard'
+ * (training, trainer.py:160-164), 1 = 'all' (validation, :165-169).  n_pos = n_anchor * n_pos_per_anchor,
+ * replicas in anchor order.  loss_out (1); pairwise_dist (n_anchor, n_pos + n_anchor) or NULL; d_anchor /
+ * d_pos: gradients of the loss (both or neither).  All device pointers. */
+int64_t nafp_triplet_workspace_bytes(int64_t n_anchor, int64_t n_pos);
+int nafp_triplet_forward(const float* emb_anchor, const float* emb_pos, int64_t n_anchor, int64_t n_pos, int dim,
+                         int mode, float margin, float* loss_out, float* pairwise_dist, float* d_anchor,
+                         float* d_pos, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Training batch assembly + time-domain augmentation on the device.  Replaces, per output row, the host
  * work of genUnbalSequence.__getitem__ (model/utils/dataloader_keras.py:223-311): load_audio

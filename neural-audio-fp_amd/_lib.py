@@ -58,6 +58,9 @@ PROTOTYPES = {
     'nafp_cosine_decay_lr_host': (c_float, [c_float, c_i64, c_i64, c_float]),
     'nafp_adam_step': (c_int, [c_void_p, c_int, c_float, c_float, c_float, c_float, c_i64, c_void_p]),
     'nafp_lamb_workspace_bytes': (c_i64, [c_void_p, c_int]),
+    'nafp_triplet_workspace_bytes': (c_i64, [c_i64, c_i64]),
+    'nafp_triplet_forward': (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_i64, c_void_p]),
     'nafp_augment_rows': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     'nafp_search_index_aux_floats': (c_i64, [c_i64]),
     'nafp_search_index_prepare': (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p]),

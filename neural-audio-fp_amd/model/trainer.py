@@ -25,6 +25,7 @@ import torch
 from .fp.melspec.melspectrogram import get_melspec_layer
 from .fp.nnfp import get_fingerprinter
 from .fp.NTxent_loss_single_gpu import NTxentLoss, _ntxent_call
+from .fp.online_triplet_loss import OnlineTripletLoss
 from .fp.lamb_optimizer import LAMB, Adam, CosineDecay
 from .fp.specaug_chain.specaug_chain import get_specaug_chain_layer
 from . import generate as _gen
@@ -164,15 +165,22 @@ def synthetic_batches(cfg, steps_per_epoch, device=None, snr_db=5.0):
 def setup(cfg, total_nsteps):
     """Models, optimizer, loss object and gradient bucket of one rank (trainer.py:113-176).
     TR_BATCH_SZ / TR_N_ANCHOR are the GLOBAL batch; each rank takes 1/world of it."""
-    if cfg['LOSS']['LOSS_MODE'].upper() != 'NTXENT':
+    loss_mode = cfg['LOSS']['LOSS_MODE'].upper()
+    if loss_mode not in ('NTXENT', 'ONLINE-TRIPLET'):
         raise NotImplementedError(cfg['LOSS']['LOSS_MODE'])
     m_pre, m_specaug, m_fp = build_fp(cfg)
     opt = make_optimizer(cfg, total_nsteps)
     dist = _dist()
     world = dist.get_world_size() if dist is not None else 1
     n_a = cfg['BSZ']['TR_N_ANCHOR'] // world
-    loss_obj = NTxentLoss(n_org=n_a, n_rep=(cfg['BSZ']['TR_BATCH_SZ'] - cfg['BSZ']['TR_N_ANCHOR']) // world,
-                          tau=cfg['LOSS']['TAU'])
+    if loss_mode == 'NTXENT':
+        loss_obj = NTxentLoss(n_org=n_a, n_rep=(cfg['BSZ']['TR_BATCH_SZ'] - cfg['BSZ']['TR_N_ANCHOR']) // world,
+                              tau=cfg['LOSS']['TAU'])
+    else:                                           # trainer.py:159-164 (single device only: no cross-replica form exists)
+        if world > 1:
+            raise NotImplementedError('Online-Triplet loss with more than one rank')
+        loss_obj = OnlineTripletLoss(bsz=cfg['BSZ']['TR_BATCH_SZ'], n_anchor=cfg['BSZ']['TR_N_ANCHOR'], mode='semi-hard',
+                                     margin=cfg['LOSS']['MARGIN'])
     bucket = GradientBucket(m_fp)
     sync_replicas(m_fp)
     return m_pre, m_specaug, m_fp, opt, loss_obj, bucket
@@ -200,7 +208,7 @@ def trainer(cfg, checkpoint_name, train_batches=None, steps_per_epoch=None, max_
         rank = dist.get_rank() if dist is not None else 0
         ds = Dataset(cfg).get_train_ds(cfg['DATA_SEL']['REDUCE_ITEMS_P'], n_anchor=cfg['BSZ']['TR_N_ANCHOR'] // world,
                                        bsz=cfg['BSZ']['TR_BATCH_SZ'] // world, seed=1000 + rank)
-        if ds.n_pos_per_anchor != 1:
+        if ds.n_pos_per_anchor != 1 and cfg['LOSS']['LOSS_MODE'].upper() == 'NTXENT':
             raise NotImplementedError('NT-Xent trains with one replica per anchor (TR_BATCH_SZ = 2 * TR_N_ANCHOR)')
 
         def train_batches(ep, ds=ds):
@@ -226,13 +234,15 @@ def trainer(cfg, checkpoint_name, train_batches=None, steps_per_epoch=None, max_
         from .dataset import Dataset
         try:
             val_ds = Dataset(cfg).get_val_ds(max_song=250)
-            if val_ds.n_samples == 0 or val_ds.n_pos_per_anchor != 1:
+            if val_ds.n_samples == 0 or (val_ds.n_pos_per_anchor != 1 and cfg['LOSS']['LOSS_MODE'].upper() == 'NTXENT'):
                 val_ds = None
         except (ValueError, IndexError):
             val_ds = None
-        if val_ds is not None:
+        if val_ds is not None and cfg['LOSS']['LOSS_MODE'].upper() == 'NTXENT':
             loss_obj_val = NTxentLoss(n_org=cfg['BSZ']['VAL_N_ANCHOR'], n_rep=cfg['BSZ']['VAL_BATCH_SZ'] - cfg['BSZ']['VAL_N_ANCHOR'],
                                       tau=cfg['LOSS']['TAU'])
+        elif val_ds is not None:                                    # trainer.py:165-169
+            loss_obj_val = OnlineTripletLoss(bsz=cfg['BSZ']['VAL_BATCH_SZ'], n_anchor=cfg['BSZ']['VAL_N_ANCHOR'], mode='all', margin=0.)
     history = []
     for ep in range(start, max_epoch + 1):
         tot, n = 0.0, 0

@@ -1,0 +1,59 @@
+"""GPU: nafp_triplet_forward (loss, distance matrix, gradients) vs the oracle and float64 autograd, and one
+now-playing style train step (config/now_playing.yaml: Online-Triplet, 4 replicas per anchor)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from oracle import triplet as T
+
+pytestmark = pytest.mark.gpu
+
+
+def _emb(nA, npa, d, seed, noise):
+    rng = np.random.default_rng(seed)
+    a = rng.normal(size=(nA, d))
+    p = np.repeat(a, npa, axis=0) + noise * rng.normal(size=(nA * npa, d))
+    a /= np.linalg.norm(a, axis=1, keepdims=True); p /= np.linalg.norm(p, axis=1, keepdims=True)
+    return a.astype(np.float32), p.astype(np.float32)
+
+
+@pytest.mark.parametrize('mode,margin', [('semi-hard', 0.4), ('all', 0.0), ('all', 0.25)])
+@pytest.mark.parametrize('nA,npa,d', [(64, 4, 128), (7, 3, 64), (1, 5, 128)])
+def test_loss_distances_and_gradients(nafp, mode, margin, nA, npa, d):
+    from neural_audio_fp_amd.model.fp.online_triplet_loss import OnlineTripletLoss
+    a, p = _emb(nA, npa, d, 3 + nA, 0.7)
+    obj = OnlineTripletLoss(bsz=nA * (npa + 1), n_anchor=nA, mode=mode, margin=margin)
+    loss, dist, act = obj.compute_loss(torch.from_numpy(a).cuda(), torch.from_numpy(p).cuda())
+    wl, wd, wact = T.compute_loss(a, p, mode, margin)
+    assert abs(float(loss) - wl) < 2e-6 * max(1.0, abs(wl)) and float(act) == wact
+    far = wd > 1e-2                                              # sqrt near 0 amplifies the float32 rounding of the dot product
+    assert np.abs(dist.cpu().numpy() - wd)[far].max() < 2e-6 and np.abs(dist.cpu().numpy() - wd).max() < 2e-3
+    ta, tp = torch.tensor(a, dtype=torch.float64, requires_grad=True), torch.tensor(p, dtype=torch.float64, requires_grad=True)
+    T.torch_loss(ta, tp, mode, margin).backward()
+    l2, da, dp = obj.loss_and_grad(torch.from_numpy(a).cuda(), torch.from_numpy(p).cuda())
+    assert abs(float(l2) - wl) < 2e-6 * max(1.0, abs(wl))
+    scale = max(float(ta.grad.abs().max()), float(tp.grad.abs().max()), 1e-12)
+    assert np.abs(da.cpu().numpy() - ta.grad.numpy()).max() < 2e-4 * scale + 1e-9
+    assert np.abs(dp.cpu().numpy() - tp.grad.numpy()).max() < 2e-4 * scale + 1e-9
+
+
+def test_now_playing_config_trains(nafp, tmp_path):
+    from neural_audio_fp_amd.model import trainer as TR
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    c = yaml.safe_load(open(os.path.join(root, 'config', 'now_playing.yaml')))
+    assert c['LOSS']['LOSS_MODE'] == 'Online-Triplet'
+    c['BSZ']['TR_BATCH_SZ'], c['BSZ']['TR_N_ANCHOR'] = 40, 8
+    m_pre, m_specaug, m_fp, opt, loss_obj, bucket = TR.setup(c, 100)
+    assert loss_obj.n_pos_per_anchor == 4 and loss_obj.mode == 'semi-hard' and abs(loss_obj.margin - 0.4) < 1e-9
+    g = torch.Generator(device='cuda').manual_seed(0)
+    xa = 0.1 * torch.randn((8, 1, 8000), generator=g, device='cuda')
+    xp = xa.repeat_interleave(4, dim=0) + 0.03 * torch.randn((32, 1, 8000), generator=g, device='cuda')
+    losses = [float(TR.train_step((xa, xp), m_pre, m_specaug, m_fp, loss_obj, opt, bucket)[0]) for _ in range(8)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    with pytest.raises(NotImplementedError):
+        from neural_audio_fp_amd.model.fp.online_triplet_loss import OnlineTripletLoss
+        OnlineTripletLoss(bsz=10, n_anchor=2, mode='hardest')
