@@ -58,6 +58,22 @@ def test_argument_checking_without_gpu(nafp):
     assert lib.nafp_melspec_create(ctypes.byref(h), 8000, 8000, 512, 256, 256, 300., 4000.) == 2   # UNSUPPORTED n_fft
     assert lib.nafp_melspec_create(ctypes.byref(h), 8000, 8000, 1024, 256, 100, 300., 4000.) == 2  # n_mels % 64
     assert lib.nafp_encoder_create(None, 256, 32, 128) == 1
+    # entry points added with the training / ingest / search rows: argument validation precedes any HIP call
+    assert lib.nafp_melspec_forward_windows_i16(None, None, None, None, 4, 0, 0, None, None, None) == 1
+    assert lib.nafp_search_index_aux_floats(1000) == 1088 and lib.nafp_search_index_aux_floats(-1) == -1
+    assert lib.nafp_search_index_prepare(None, 10, 128, None, None) == 1
+    assert lib.nafp_search_workspace_bytes(10, 1000, 20) > 0
+    assert lib.nafp_search_workspace_bytes(10, 1000, 33) == -1 and lib.nafp_search_workspace_bytes(10, 0, 20) == -1
+    assert lib.nafp_search_topk_l2(None, 1, None, None, 10, 128, 20, None, None, None, 0, None) == 1
+    assert lib.nafp_search_seq_scores(None, None, 10, 128, None, None, 1, None, 4, None, None) == 1
+    assert lib.nafp_augment_rows(None, None, 4, 8000, None, None) == 1
+    assert lib.nafp_triplet_workspace_bytes(64, 256) > 0 and lib.nafp_triplet_workspace_bytes(0, 4) == -1
+    assert lib.nafp_triplet_forward(None, None, 4, 8, 128, 0, 0.5, None, None, None, None, None, 0, None) == 1
+    assert lib.nafp_encoder_train_workspace_bytes(None, 4) == -1
+    assert lib.nafp_encoder_backward(None, None, None, 4, None, 0, None, 1, None) == 1
+    assert lib.nafp_adam_step(None, 0, 1e-3, 0.9, 0.999, 1e-7, 1, None) in (0, 1)
+    assert abs(lib.nafp_cosine_decay_lr_host(1e-4, 0, 100, 1e-6) - 1e-4) < 1e-11          # float32 return
+    assert abs(lib.nafp_cosine_decay_lr_host(1e-4, 100, 100, 1e-6) - 1e-10) < 1e-15
 
 
 def test_missing_library_fails_loudly(nafp, monkeypatch):
