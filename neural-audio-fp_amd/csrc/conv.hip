@@ -452,6 +452,11 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     const int rswz = BK == 32 ? ((rl >> 1) & 7) : ((rl >> 2) & 3);     // wm*64, 32*mi do not change swz
     const int aoff = (wm * 64 + rl) * BK, boff = TILE + (wn * 64 + rl) * BK;
     int slot = 0;
+    if (p.abl & 8) {          // ablation: prologue + pipeline fill only (wait for the prefilled stages, then leave)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (acc[0][0][0] == 12345.678f) p.y[tid] = smem[tid];
+        return;
+    }
     for (int s = s_begin; s < n_steps; ++s) {
         // my DMA of step s has landed; after the barrier everybody's has, and everybody has
         // finished reading slot (s-1) % NSTAGE, which the next DMA overwrites.
