@@ -2,7 +2,6 @@
 `run.py evaluate` (run.py:13-162 of the reference) -- on a synthetic dataset tree in the reference's
 directory layout."""
 import os
-import shutil
 import subprocess
 import sys
 import wave
@@ -51,7 +50,6 @@ def test_train_generate_evaluate_cli(tmp_path):
                        'OUTPUT_ROOT_DIR': str(work) + '/logs/emb/', 'LOG_ROOT_DIR': str(work) + '/logs/'})
     cfg['BSZ'].update({'TR_BATCH_SZ': 32, 'TR_N_ANCHOR': 16})
     yaml.safe_dump(cfg, open(work / 'config' / 'tiny.yaml', 'w'))
-    shutil.copytree(os.path.join(ROOT, 'eval'), work / 'eval')            # `-t icassp` looks for ./**/test_ids_icassp2021.npy
     env = dict(os.environ, PYTHONPATH=ROOT)
 
     def run(*args, inp=None):
