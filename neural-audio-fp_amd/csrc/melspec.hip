@@ -112,6 +112,10 @@ __device__ __forceinline__ void stockham_pass(const float2* __restrict__ src, fl
     }
 }
 
+// order this wave's LDS writes before its later LDS reads (no workgroup barrier)
+#define NAFP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
 template <typename T> __device__ __forceinline__ float pcm_to_float(T v);
 template <> __device__ __forceinline__ float pcm_to_float<float>(float v) { return v; }
 template <> __device__ __forceinline__ float pcm_to_float<int16_t>(int16_t v) {
@@ -208,15 +212,17 @@ __global__ __launch_bounds__(256) void melspec_kernel(
                     fftX[j + 3] = make_float2(v1.x - v3.x, v1.y - v3.y);
                 }
             }
-            __syncthreads();
+            // the five passes of a frame pair touch only this wave's two buffers: wave-level ordering is enough
+            // (LDS operations of one wave execute in order), so the four waves are not forced into lockstep
+            NAFP_WAVE_SYNC();
             if (live) stockham_pass<4>(fftX, fftY, tw, lane);
-            __syncthreads();
+            NAFP_WAVE_SYNC();
             if (live) stockham_pass<16>(fftY, fftX, tw, lane);
-            __syncthreads();
+            NAFP_WAVE_SYNC();
             if (live) stockham_pass<64>(fftX, fftY, tw, lane);
-            __syncthreads();
+            NAFP_WAVE_SYNC();
             if (live) stockham_pass<256>(fftY, fftX, tw, lane);
-            __syncthreads();
+            NAFP_WAVE_SYNC();
             if (live) {
                 // un-pack: X0[k] = (Z[k]+conj Z[N-k])/2, X1[k] = (Z[k]-conj Z[N-k])/(2i); keep |.|
                 float* mag0 = (float*)fftY;            // [0..512]
