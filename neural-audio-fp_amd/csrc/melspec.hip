@@ -149,6 +149,10 @@ __global__ __launch_bounds__(256) void melspec_kernel(
     float2* fftX = (float2*)(smem + sig_alloc) + wave * NFFT;
     float2* fftY = (float2*)(smem + sig_alloc + 4 * 2 * NFFT) + wave * NFFT;
     float* tile = smem + sig_alloc + 8 * 2 * NFFT;
+    // twiddles and window in LDS: the FFT passes then touch no global memory at all
+    float2* stw = (float2*)(tile + n_mels * TILE_LD);
+    float* swin = (float*)(stw + NFFT);
+    for (int i = tid; i < NFFT; i += 256) { stw[i] = tw[i]; swin[i] = window[i]; }
 
     // rows of a (n_seg, seg_len) array, or -- window mode -- segment `seg` starts at sample
     // seg_offset[seg] of one PCM arena and has seg_valid[seg] real samples (the rest is the zero
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(256) void melspec_kernel(
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int n = i + q * 256;
-                        const float w = window[n];
+                        const float w = swin[n];
                         u[q] = make_float2(w * s0[n], has1 ? w * s1[n] : 0.f);
                     }
                     const float2 v0 = make_float2(u[0].x + u[2].x, u[0].y + u[2].y);
@@ -215,13 +219,13 @@ __global__ __launch_bounds__(256) void melspec_kernel(
             // the five passes of a frame pair touch only this wave's two buffers: wave-level ordering is enough
             // (LDS operations of one wave execute in order), so the four waves are not forced into lockstep
             NAFP_WAVE_SYNC();
-            if (live) stockham_pass<4>(fftX, fftY, tw, lane);
+            if (live) stockham_pass<4>(fftX, fftY, stw, lane);
             NAFP_WAVE_SYNC();
-            if (live) stockham_pass<16>(fftY, fftX, tw, lane);
+            if (live) stockham_pass<16>(fftY, fftX, stw, lane);
             NAFP_WAVE_SYNC();
-            if (live) stockham_pass<64>(fftX, fftY, tw, lane);
+            if (live) stockham_pass<64>(fftX, fftY, stw, lane);
             NAFP_WAVE_SYNC();
-            if (live) stockham_pass<256>(fftY, fftX, tw, lane);
+            if (live) stockham_pass<256>(fftY, fftX, stw, lane);
             NAFP_WAVE_SYNC();
             if (live) {
                 // un-pack: X0[k] = (Z[k]+conj Z[N-k])/2, X1[k] = (Z[k]-conj Z[N-k])/(2i); keep |.|
@@ -327,7 +331,7 @@ static int melspec_forward(nafp_melspec* p, const TIn* audio, int64_t n_seg, int
     const int n_groups = (int)((n_seg + group_size - 1) / group_size);
     melspec_init_stats<<<(n_groups + 255) / 256, 256, 0, st>>>(group_stat, n_groups);
     NAFP_LAUNCH_CHECK();
-    const size_t lds = (size_t)(SIG_CHUNK + 8 * 2 * NFFT + p->n_mels * TILE_LD) * sizeof(float);
+    const size_t lds = (size_t)(SIG_CHUNK + 8 * 2 * NFFT + p->n_mels * TILE_LD + 3 * NFFT) * sizeof(float);
     melspec_kernel<TIn><<<dim3((unsigned)n_seg), 256, lds, st>>>(
         audio, seg_offset, seg_valid, feat, group_stat, p->d_twiddle, p->d_window, p->d_mel_start, p->d_mel_w,
         p->seg_len, p->n_frames, p->n_mels, group_size);
@@ -397,7 +401,7 @@ extern "C" int nafp_melspec_create(nafp_melspec** plan, int fs, int seg_len, int
     if ((e = hipMemcpy(p->d_mel_start, start.data(), sizeof(int) * n_mels, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(p->d_mel_w, w.data(), sizeof(float) * n_mels * MAX_TAPS, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     // the kernel needs > 64 KiB of dynamic LDS
-    const int lds = (SIG_CHUNK + 8 * 2 * NFFT + n_mels * TILE_LD) * (int)sizeof(float);
+    const int lds = (SIG_CHUNK + 8 * 2 * NFFT + n_mels * TILE_LD + 3 * NFFT) * (int)sizeof(float);
     if ((e = hipFuncSetAttribute((const void*)melspec_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return fail(e);
     if ((e = hipFuncSetAttribute((const void*)melspec_kernel<int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return fail(e);
     *plan = p;
