@@ -181,9 +181,42 @@ __global__ __launch_bounds__(256) void melspec_kernel(
         // ---- zero-padded samples of this chunk into LDS (melspectrogram.py:59-65): padded index
         // chunk0*256 + i  <->  sample index chunk0*256 + i - 512
         __syncthreads();
-        for (int i = tid; i < SIG_CHUNK; i += 256) {
-            const int s = chunk0 * HOP + i - NFFT / 2;
-            sig[i] = (s >= 0 && s < n_valid) ? pcm_to_float<TIn>(a[s]) : 0.f;
+        {
+            // all loads of the chunk are issued before the first LDS write (35 dependent load -> store round
+            // trips per thread otherwise): 4 samples per lane and step, 9 steps.  Vector loads need the
+            // segment start 4-sample aligned (always true for rows of a (n_seg, seg_len) array with seg_len % 4 == 0;
+            // window mode checks the offset).
+            constexpr int STEPS = (SIG_CHUNK / 4 + 255) / 256;            // 9
+            const int s_base = chunk0 * HOP - NFFT / 2;                    // multiple of 4
+            const bool vec_ok = ((uintptr_t)a % (4 * sizeof(TIn))) == 0;
+            float4 v[STEPS];
+#pragma unroll
+            for (int st = 0; st < STEPS; ++st) {
+                const int i4 = st * 256 + tid;                             // vector index inside the chunk
+                const int s = s_base + 4 * i4;
+                v[st] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i4 < SIG_CHUNK / 4 && s + 3 >= 0 && s < n_valid) {
+                    if (vec_ok && s >= 0 && s + 3 < n_valid) {
+                        if (sizeof(TIn) == 4) {
+                            v[st] = *(const float4*)((const float*)a + s);
+                        } else {
+                            const short4 q = *(const short4*)((const int16_t*)a + s);
+                            v[st] = make_float4(pcm_to_float<int16_t>(q.x), pcm_to_float<int16_t>(q.y),
+                                                pcm_to_float<int16_t>(q.z), pcm_to_float<int16_t>(q.w));
+                        }
+                    } else {
+                        v[st].x = (s >= 0 && s < n_valid) ? pcm_to_float<TIn>(a[s]) : 0.f;
+                        v[st].y = (s + 1 >= 0 && s + 1 < n_valid) ? pcm_to_float<TIn>(a[s + 1]) : 0.f;
+                        v[st].z = (s + 2 >= 0 && s + 2 < n_valid) ? pcm_to_float<TIn>(a[s + 2]) : 0.f;
+                        v[st].w = (s + 3 >= 0 && s + 3 < n_valid) ? pcm_to_float<TIn>(a[s + 3]) : 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int st = 0; st < STEPS; ++st) {
+                const int i4 = st * 256 + tid;
+                if (i4 < SIG_CHUNK / 4) *(float4*)(sig + 4 * i4) = v[st];
+            }
         }
         __syncthreads();
         for (int round = 0; round < 4; ++round) {                      // 4 waves x 2 frames
