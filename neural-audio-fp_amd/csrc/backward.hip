@@ -510,7 +510,9 @@ int launch_ln_bwd(float* d, const float* v, const float* gamma, const float* mr,
 int launch_conv0_bwd(const float* feat, const float* dt, float* dW0, float* dbias0, int64_t B, const ConvGeom& g,
                      hipStream_t st) {
     if (g.Cin != 1 || g.axis != 0 || (g.Cout % 4) != 0 || 256 % (g.Cout / 4) != 0) return NAFP_ERR_UNSUPPORTED;
-    const int rows = 32;
+    // 64 rows per workgroup: every workgroup ends in 512 atomics onto the same 512 addresses (dW0, dbias0), so
+    // fewer, longer workgroups win (measured at B = 1280: rows 16/32/64/128/256 -> backward 24.4/23.5/22.7/23.0/22.8 ms)
+    const int rows = 64;
     const int64_t blocks = B * ((g.Fin + rows - 1) / rows);
     conv0_bwd_kernel<<<dim3((unsigned)blocks), 256, 0, st>>>(feat, dt, dW0, dbias0, g.Fin, g.Tin, g.Tout, g.Cout,
                                                             g.stride, g.pad, rows);
