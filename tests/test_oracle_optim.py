@@ -48,3 +48,33 @@ def test_lamb_trust_ratio_properties():
     # scaling the gradient does not change the step (Adam normalisation + trust ratio)
     w2, _, _ = o_opt.lamb_step(w, 10 * g, np.zeros_like(w), np.zeros_like(w), lr=1e-3, step=1)
     assert np.abs(w2 - w1).max() < 1e-5          # up to eps / |g| relative (tiny |g| entries), times lr * ratio
+
+
+def test_adam_and_cosine_against_torch_implementations():
+    """Independent implementations present in the image: torch.optim.Adam (same moment updates; its epsilon
+    sits inside the bias-corrected denominator, so one keras step equals one torch step with
+    eps_torch = eps_keras / sqrt(1 - b2^t)) and torch's CosineAnnealingLR (eta_min = alpha * lr0)."""
+    import torch
+    from oracle import optim as O
+    rng = np.random.default_rng(0)
+    w0, g = rng.normal(size=50), rng.normal(size=50) * 1e-2
+    for t in (1, 2):
+        m = np.zeros(50) if t == 1 else 0.1 * g_prev
+        v = np.zeros(50) if t == 1 else 0.001 * g_prev ** 2
+        want, m2, v2 = O.adam_step(w0, g, m, v, 1e-3, t, eps=1e-7)
+        p = torch.tensor(w0.copy(), dtype=torch.float64, requires_grad=True)
+        opt = torch.optim.Adam([p], lr=1e-3, betas=(0.9, 0.999), eps=1e-7 / np.sqrt(1 - 0.999 ** t))
+        opt.state[p] = {'step': torch.tensor(float(t - 1)), 'exp_avg': torch.tensor(m.copy()), 'exp_avg_sq': torch.tensor(v.copy())}
+        p.grad = torch.tensor(g.copy())
+        opt.step()
+        assert np.abs(p.detach().numpy() - want).max() < 1e-15
+        assert np.abs(opt.state[p]['exp_avg'].numpy() - m2).max() < 1e-18 and np.abs(opt.state[p]['exp_avg_sq'].numpy() - v2).max() < 1e-18
+        g_prev = g
+    lr0, S, alpha = 1e-4, 200, 1e-6
+    q = torch.nn.Parameter(torch.zeros(1))
+    o = torch.optim.SGD([q], lr=lr0)
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(o, T_max=S, eta_min=alpha * lr0)
+    for s in range(S + 1):
+        assert abs(o.param_groups[0]['lr'] - O.cosine_decay(lr0, s, S, alpha)) < 1e-15
+        o.step(); sch.step()
+    assert abs(O.cosine_decay(lr0, S + 50, S, alpha) - alpha * lr0) < 1e-18      # keras clamps after decay_steps
