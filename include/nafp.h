@@ -1,7 +1,9 @@
 /*
  * nafp.h -- C ABI of libnafp.so: the MI355X (gfx950) hot path of neural audio
- * fingerprinting (1-s segment -> log-mel -> conv encoder -> 128-d fingerprint,
- * and the NT-Xent loss).
+ * fingerprinting: 1-s segment -> log-mel -> conv encoder -> 128-d fingerprint
+ * (generate), the contrastive train step around it (batch assembly + time-domain
+ * augmentation, spec-augment, NT-Xent / online-triplet loss, the encoder's backward
+ * pass, Adam / LAMB), and the exact search that consumes the fingerprints.
  *
  * The reference (mimbres/neural-audio-fp) is pure Python on TensorFlow; it has no
  * FFI of its own.  Each entry point below replaces the device work behind one

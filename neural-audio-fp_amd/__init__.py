@@ -7,7 +7,9 @@ name).  Contents:
   csrc/     hand-written HIP kernels for gfx950 + the C ABI (include/nafp.h)
   _lib.py   ctypes binding of libnafp.so (fails loudly when it is not built)
   model/    host-side mirror of the reference's operator interface for this path
-            (get_melspec_layer, get_fingerprinter, NTxentLoss, generate_fingerprint)
+            (get_melspec_layer, get_fingerprinter, NTxentLoss, OnlineTripletLoss, LAMB, Dataset /
+            genUnbalSequence, trainer, generate_fingerprint)
+  eval/     eval_faiss mirror on the exact HIP index (load_memmap_data, get_index, eval_faiss)
 """
 from . import _lib  # noqa: F401
 from .model.fp.melspec.melspectrogram import Melspec_layer, get_melspec_layer  # noqa: F401

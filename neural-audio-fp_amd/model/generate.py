@@ -7,7 +7,8 @@ order, same keys (`dummy_db`, `query`, `db`, or `custom_source`), the same
 overwrite prompt, FileNotFoundError and size warning.
 
 What is different underneath:
-  * the device work is the HIP path (`m_fp(m_pre(X))`, generate.py:83-88);
+  * the device work is the HIP path (`m_fp(m_pre(X))`, generate.py:83-88); every WAV is read once into a
+    pinned arena and the 1-s windows are indexed on the device (`nafp_melspec_forward_windows_i16`);
   * one launch carries several TS_BATCH_SZ batches; the log-mel max-normalisation
     group stays TS_BATCH_SZ (melspectrogram.py:108), so every fingerprint equals what
     the reference computes batch by batch;
