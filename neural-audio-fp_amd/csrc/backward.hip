@@ -426,10 +426,13 @@ __global__ __launch_bounds__(256) void tail_bwd_a_kernel(const TailBwdArgs a) {
 template <int S>
 __global__ __launch_bounds__(256) void tail_bwd_b_kernel(const TailBwdArgs a, int64_t B) {
     const int q = blockIdx.x;
-    const int j = threadIdx.x & 31, i = threadIdx.x >> 5;         // 32 x 8 threads; i < S computes dw1[q][i][j]
+    const int j = threadIdx.x & 31, i = threadIdx.x >> 5;         // 32 x 8 threads; row i computes dw1[q][i + 8t][j]
+    constexpr int NI = (S + 7) / 8;
     const int64_t per = (B + gridDim.y - 1) / gridDim.y;
     const int64_t bb0 = blockIdx.y * per, bb1 = std::min<int64_t>(B, bb0 + per);
-    float aw1 = 0.f, ab1 = 0.f, aw2 = 0.f, ab2 = 0.f;
+    float aw1[NI], ab1 = 0.f, aw2 = 0.f, ab2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < NI; ++t) aw1[t] = 0.f;
     for (int64_t b = bb0; b < bb1; ++b) {
         const double mean = a.stats[2 * b] / (double)a.D;
         double var = a.stats[2 * b + 1] / (double)a.D - mean * mean;
@@ -447,28 +450,43 @@ __global__ __launch_bounds__(256) void tail_bwd_b_kernel(const TailBwdArgs a, in
         for (int k = 0; k < S; ++k) h = fmaf(x[k], a.w1[(q * S + k) * 32 + j], h);
         const float dyq = a.dy[b * a.Q + q];
         const float da = dyq * a.w2[q * 32 + j] * (h > 0.f ? 1.f : __expf(h));
-        float xi = 0.f;
 #pragma unroll
-        for (int k = 0; k < S; ++k) xi = (k == i) ? x[k] : xi;
-        aw1 += xi * da;
+        for (int t = 0; t < NI; ++t) {
+            float xi = 0.f;
+#pragma unroll
+            for (int k = 0; k < S; ++k) xi = (k == i + 8 * t) ? x[k] : xi;
+            aw1[t] += xi * da;
+        }
         ab1 += da;
         aw2 += dyq * elu1(h);
         ab2 += dyq;
     }
     // the batch chunks (blockIdx.y) meet through atomics; the gradients are zeroed by the caller
-    if (i < S) atomicAdd(a.dw1 + (q * S + i) * 32 + j, aw1);
+#pragma unroll
+    for (int t = 0; t < NI; ++t)
+        if (i + 8 * t < S) atomicAdd(a.dw1 + (q * S + i + 8 * t) * 32 + j, aw1[t]);
     if (i == 0) { atomicAdd(a.db1 + q * 32 + j, ab1); atomicAdd(a.dw2 + q * 32 + j, aw2); }
     if (threadIdx.x == 0) atomicAdd(a.db2 + q, ab2);
 }
 
-int launch_tail_bwd(const TailBwdArgs& a, int64_t B, hipStream_t st) {
-    if (a.S != 8 || a.Q % 64 != 0 || a.Q > 256) return NAFP_ERR_UNSUPPORTED;
-    tail_bwd_a_kernel<8><<<dim3((unsigned)B), a.Q, 0, st>>>(a);
+template <int S>
+static int launch_tail_bwd_s(const TailBwdArgs& a, int64_t B, hipStream_t st) {
+    tail_bwd_a_kernel<S><<<dim3((unsigned)B), a.Q, 0, st>>>(a);
     NAFP_LAUNCH_CHECK();
     const unsigned chunks = (unsigned)std::min<int64_t>(16, std::max<int64_t>(1, B / 16));
-    tail_bwd_b_kernel<8><<<dim3((unsigned)a.Q, chunks), 256, 0, st>>>(a, B);
+    tail_bwd_b_kernel<S><<<dim3((unsigned)a.Q, chunks), 256, 0, st>>>(a, B);
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
+}
+
+int launch_tail_bwd(const TailBwdArgs& a, int64_t B, hipStream_t st) {
+    if (a.Q % 64 != 0 || a.Q > 256 || a.S * a.Q != a.D) return NAFP_ERR_UNSUPPORTED;
+    switch (a.S) {                       // emb_sz 256 / 128 / 64 on the 1024-wide flatten
+        case 4: return launch_tail_bwd_s<4>(a, B, st);
+        case 8: return launch_tail_bwd_s<8>(a, B, st);
+        case 16: return launch_tail_bwd_s<16>(a, B, st);
+        default: return NAFP_ERR_UNSUPPORTED;
+    }
 }
 
 // keras kernel (3, Cin, Cout) -> dgrad operand (Cin, 3*Cout): Wd[c][k*Cout + n] = W[k][c][n]

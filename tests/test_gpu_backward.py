@@ -65,3 +65,27 @@ def test_backward_is_additive_over_the_batch_at_bsz_5120(nafp):
     for i, (a, b) in enumerate(zip(full, parts)):
         scale = float(b.abs().max()) + 1e-20
         assert float((a - b).abs().max()) / scale < 2e-4, i
+
+
+@pytest.mark.parametrize('emb_sz', [64, 256])
+def test_other_fingerprint_dimensions_forward_and_backward(nafp, emb_sz):
+    """EMB_SZ 64 / 256 (divide-and-encode slices of 16 / 4 of the 1024-wide flatten)."""
+    from oracle import nnfp as o_nnfp
+    B = 3
+    rng = np.random.default_rng(emb_sz)
+    feat = (-rng.uniform(0, 1.2, size=(B, 256, 32, 1))).astype(np.float32)
+    w = o_nnfp.init_weights(seed=5, emb_sz=emb_sz, randomize_affine=True)
+    d_emb = rng.normal(size=(B, emb_sz)).astype(np.float32)
+    m_fp = nafp.FingerPrinter(emb_sz=emb_sz, seed=0)
+    m_fp.set_weights(_inputs.weight_list(w))
+    emb = m_fp(torch.from_numpy(feat).cuda())
+    assert emb.shape == (B, emb_sz)
+    assert np.abs(emb.cpu().numpy() - o_nnfp.fingerprinter(feat, w)).max() < 2e-5
+    emb_t = m_fp.forward_train(torch.from_numpy(feat).cuda())
+    grads = m_fp.backward(torch.from_numpy(d_emb).cuda())
+    want_emb, want = _reference(feat, w, d_emb)
+    assert np.abs(emb_t.cpu().numpy() - want_emb).max() < 2e-5
+    for i, (g, wg) in enumerate(zip(grads, want)):
+        err = np.abs(g.cpu().numpy() - wg).max() / (np.abs(wg).max() + 1e-12)
+        assert err < 2e-3, (i, err)
+    assert m_fp.variable_lengths()[64] == w['div.w1'].size // emb_sz
