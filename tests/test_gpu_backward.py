@@ -89,3 +89,27 @@ def test_other_fingerprint_dimensions_forward_and_backward(nafp, emb_sz):
         err = np.abs(g.cpu().numpy() - wg).max() / (np.abs(wg).max() + 1e-12)
         assert err < 2e-3, (i, err)
     assert m_fp.variable_lengths()[64] == w['div.w1'].size // emb_sz
+
+
+def test_two_second_segments_forward_and_backward(nafp):
+    """input (256, 63, 1) (2-s segments: the shape behind the reference's `Total params: 19,224,576`,
+    nnfp.py:262-271): odd extents exercise the asymmetric SAME padding and the parity classes of the
+    transposed conv with an odd number of positions."""
+    from oracle import nnfp as o_nnfp
+    B, shape = 2, (256, 63, 1)
+    rng = np.random.default_rng(63)
+    feat = (-rng.uniform(0, 1.2, size=(B,) + shape)).astype(np.float32)
+    w = o_nnfp.init_weights(seed=6, input_shape=shape, randomize_affine=True)
+    d_emb = rng.normal(size=(B, 128)).astype(np.float32)
+    m_fp = nafp.FingerPrinter(input_shape=shape, seed=0)
+    assert sum(v.numel() for v in m_fp.trainable_variables) == 19224576
+    m_fp.set_weights(_inputs.weight_list(w))
+    emb = m_fp.forward_train(torch.from_numpy(feat).cuda())
+    grads = m_fp.backward(torch.from_numpy(d_emb).cuda())
+    tf = torch_ref.TorchFingerprinter(w, input_shape=shape, dtype=torch.float64, requires_grad=True)
+    e = tf(torch.tensor(feat, dtype=torch.float64))
+    (e * torch.tensor(d_emb, dtype=torch.float64)).sum().backward()
+    assert np.abs(emb.cpu().numpy() - e.detach().numpy()).max() < 2e-5
+    for i, (g, p) in enumerate(zip(grads, tf.params)):
+        wg = p.grad.numpy()
+        assert np.abs(g.cpu().numpy() - wg).max() / (np.abs(wg).max() + 1e-12) < 2e-3, i
