@@ -6,8 +6,9 @@ Mirrors `FingerPrinter` / `get_fingerprinter` of the reference
 `front_strides`, `emb_sz`, `norm`, `use_L2layer`, `trainable`,
 `trainable_variables` (used at trainer.py:42,47-48,73-75,87-88).
 
-Parameters are torch CUDA tensors in the keras variable shapes and order
-(include/nafp.h, "Parameter tensors"); they are pushed to the library (which
+Parameters are torch CUDA tensors in the keras variable SHAPES, listed in the library's own fixed order
+(include/nafp.h, "Parameter tensors": per conv kernel, bias, LN gamma, LN beta; the order of keras'
+`trainable_variables` is not relied upon anywhere -- checkpoints are keyed by name, `tensor_names()`); they are pushed to the library (which
 re-packs them for its kernels) lazily, whenever they were replaced or marked
 dirty.  No CPU path.
 """

@@ -40,23 +40,30 @@ def build_fp(cfg):
 
 
 def load_checkpoint(checkpoint_root_dir, checkpoint_name, checkpoint_index, m_fp, optimizer=None):
-    """generate.py:26-52: latest index when none is given; FileNotFoundError if absent."""
+    """generate.py:26-52: latest index when none is given; FileNotFoundError if absent.  `ckpt-N.pt` (this
+    build) or `ckpt-N.npz` (weights converted from a TensorFlow checkpoint of the reference by
+    tools/convert_tf_checkpoint.py); the .pt wins when both exist."""
     checkpoint_dir = checkpoint_root_dir + f'/{checkpoint_name}/'
     if checkpoint_index is None:
         print("\x1b[1;32mArgument 'checkpoint_index' was not specified.\x1b[0m")
         print('\x1b[1;32mSearching for the latest checkpoint...\x1b[0m')
-        idx = [int(m.group(1)) for f in glob.glob(checkpoint_dir + 'ckpt-*.pt')
-               for m in [re.search(r'ckpt-(\d+)\.pt$', f)] if m]
+        idx = [int(m.group(1)) for f in glob.glob(checkpoint_dir + 'ckpt-*')
+               for m in [re.search(r'ckpt-(\d+)\.(pt|npz)$', f)] if m]
         if not idx:
             raise FileNotFoundError(f'Cannot find checkpoint in {checkpoint_dir}')
         checkpoint_index = max(idx)
     fpath = checkpoint_dir + 'ckpt-' + str(checkpoint_index) + '.pt'
-    if not os.path.exists(fpath):
+    if os.path.exists(fpath):
+        ck = torch.load(fpath, map_location='cpu', weights_only=True)
+        m_fp.load_state_dict(ck['model'] if 'model' in ck else ck)
+        if optimizer is not None and 'optimizer' in ck:
+            optimizer.load_state_dict(ck['optimizer'], m_fp.trainable_variables)
+    elif os.path.exists(fpath[:-3] + '.npz'):
+        fpath = fpath[:-3] + '.npz'
+        with np.load(fpath) as z:
+            m_fp.load_state_dict({k: z[k] for k in z.files})
+    else:
         raise FileNotFoundError(f'Cannot find checkpoint {fpath}')
-    ck = torch.load(fpath, map_location='cpu', weights_only=True)
-    m_fp.load_state_dict(ck['model'] if 'model' in ck else ck)
-    if optimizer is not None and 'optimizer' in ck:
-        optimizer.load_state_dict(ck['optimizer'], m_fp.trainable_variables)
     print(f'---Restored from {fpath}---')
     return int(checkpoint_index)
 

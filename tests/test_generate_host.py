@@ -107,6 +107,10 @@ def test_checkpoint_discovery_and_errors(tmp_path):
     assert g.load_checkpoint(root, 'exp', '3', m) == 3
     with pytest.raises(FileNotFoundError):
         g.load_checkpoint(root, 'exp', 5, m)
+    # weights converted from a TensorFlow checkpoint of the reference arrive as ckpt-N.npz (tools/convert_tf_checkpoint.py)
+    np.savez(root + 'exp/ckpt-20.npz', w=np.full(2, 7.0, np.float32))
+    assert g.load_checkpoint(root, 'exp', None, m) == 20 and np.array_equal(m.sd['w'], np.full(2, 7.0, np.float32))
+    assert g.load_checkpoint(root, 'exp', 12, m) == 12 and torch.equal(m.sd['w'], torch.ones(2))
 
 
 def test_config_surface_matches_reference_keys():
