@@ -298,6 +298,16 @@ int nafp_search_seq_scores(const float* query, const float* index, int64_t n_ind
                            const int32_t* task_q0, const int32_t* task_len, int64_t n_tasks,
                            const int32_t* cand, int n_slots, float* out_scores, void* stream);
 
+/* In-training mini search test (model/utils/mini_search_subroutines.py): pairwise_distances_for_eval (:28-93;
+ * mode 0 = squared L2 clipped at 0 for 'argmin', 1 = dot product for 'argmax'; any dim) into out_scores
+ * (n_query, n_db); then, per sequence length `scope`, the rank of the ground-truth start id
+ * (t + gt_id_offset) among all candidate starts under the eye(scope) diagonal sum (conv_eye_func :96-119 and
+ * the argsort / np.where of mini_search_eval :180-205): out_rank (n_query - scope + 1) int32. */
+int nafp_minisearch_scores(const float* query, const float* db, int64_t n_query, int64_t n_db, int dim, int mode,
+                           float* out_scores, void* stream);
+int nafp_minisearch_ranks(const float* scores, int64_t n_query, int64_t n_db, int scope, int mode, int gt_id_offset,
+                          int32_t* out_rank, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

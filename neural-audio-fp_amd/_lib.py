@@ -69,6 +69,8 @@ PROTOTYPES = {
                                     c_void_p, c_i64, c_void_p]),
     'nafp_search_seq_scores': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_int,
                                        c_void_p, c_void_p]),
+    'nafp_minisearch_scores': (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_int, c_int, c_void_p, c_void_p]),
+    'nafp_minisearch_ranks': (c_int, [c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_void_p, c_void_p]),
     'nafp_lamb_step': (c_int, [c_void_p, c_int, c_float, c_float, c_float, c_float, c_float, c_i64,
                                c_void_p, c_i64, c_void_p]),
 }

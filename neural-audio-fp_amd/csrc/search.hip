@@ -318,3 +318,87 @@ extern "C" int nafp_search_seq_scores(const float* query, const float* index, in
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }
+
+// ---- in-training mini search (model/utils/mini_search_subroutines.py:28-220) ------------------------------
+namespace nafp {
+
+// scores[q, x] = max(|q|^2 + |x|^2 - 2 q.x, 0)  (mode 0)  or  q.x  (mode 1); any dim (1024 for the un-projected
+// features f(.), 128 for the fingerprints).  32 x 32 output tile per workgroup, operands staged through LDS.
+__global__ __launch_bounds__(256) void pairwise_scores_kernel(const float* __restrict__ Q, const float* __restrict__ X,
+                                                              float* __restrict__ out, int nQ, int nD, int D, int mode) {
+    __shared__ float sq[32][33], sx[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+    const int q0 = blockIdx.y * 32, x0 = blockIdx.x * 32;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, qq[4] = {0.f, 0.f, 0.f, 0.f}, xx = 0.f;
+    for (int k0 = 0; k0 < D; k0 += 32) {
+        for (int r = ty; r < 32; r += 8) {
+            sq[r][tx] = (q0 + r < nQ && k0 + tx < D) ? Q[(int64_t)(q0 + r) * D + k0 + tx] : 0.f;
+            sx[r][tx] = (x0 + r < nD && k0 + tx < D) ? X[(int64_t)(x0 + r) * D + k0 + tx] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            const float xv = sx[tx][k];
+            xx = fmaf(xv, xv, xx);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float qv = sq[ty + 8 * j][k]; acc[j] = fmaf(qv, xv, acc[j]); qq[j] = fmaf(qv, qv, qq[j]); }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = q0 + ty + 8 * j, x = x0 + tx;
+        if (q < nQ && x < nD) out[(int64_t)q * nD + x] = mode == 1 ? acc[j] : fmaxf(qq[j] + xx - 2.f * acc[j], 0.f);
+    }
+}
+
+// rank[t] = number of candidate starts c whose length-s diagonal sum beats the ground truth's (conv_eye_func +
+// argsort + np.where(sorted == gt)): smaller sum wins in mode 0, larger in mode 1; equal sums: smaller id first.
+__global__ __launch_bounds__(256) void diag_rank_kernel(const float* __restrict__ scores, int* __restrict__ rank, int nQ, int nD,
+                                                        int s, int mode, int gt_offset) {
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int n_c = nD - s + 1, gt = t + gt_offset;
+    __shared__ float ref;
+    __shared__ int cnt[4];
+    if (tid == 0) {
+        float r = 0.f;
+        for (int i = 0; i < s; ++i) r += scores[(int64_t)(t + i) * nD + gt + i];
+        ref = r;
+    }
+    __syncthreads();
+    const float r = ref;
+    int mine = 0;
+    for (int c = tid; c < n_c; c += 256) {
+        float v = 0.f;
+        for (int i = 0; i < s; ++i) v += scores[(int64_t)(t + i) * nD + c + i];
+        const bool better = mode == 1 ? (v > r || (v == r && c > gt)) : (v < r || (v == r && c < gt));   // argsort order incl. the reversal
+        mine += better ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((tid & 63) == 0) cnt[tid >> 6] = mine;
+    __syncthreads();
+    if (tid == 0) rank[t] = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+}
+
+}  // namespace nafp
+
+extern "C" int nafp_minisearch_scores(const float* query, const float* db, int64_t n_query, int64_t n_db, int dim, int mode,
+                                      float* out_scores, void* stream) {
+    if (!query || !db || !out_scores || n_query <= 0 || n_db <= 0 || dim <= 0) return NAFP_ERR_INVALID_ARG;
+    if ((mode != 0 && mode != 1) || n_query > (1 << 20) || n_db > (1 << 20)) return NAFP_ERR_UNSUPPORTED;
+    pairwise_scores_kernel<<<dim3((unsigned)((n_db + 31) / 32), (unsigned)((n_query + 31) / 32)), 256, 0, (hipStream_t)stream>>>(
+        query, db, out_scores, (int)n_query, (int)n_db, dim, mode);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}
+
+extern "C" int nafp_minisearch_ranks(const float* scores, int64_t n_query, int64_t n_db, int scope, int mode, int gt_id_offset,
+                                     int32_t* out_rank, void* stream) {
+    if (!scores || !out_rank || scope <= 0 || n_query < scope || n_db < scope) return NAFP_ERR_INVALID_ARG;
+    if (mode != 0 && mode != 1) return NAFP_ERR_UNSUPPORTED;
+    const int n_t = (int)(n_query - scope + 1);
+    if (gt_id_offset < 0 || n_t - 1 + gt_id_offset > n_db - scope) return NAFP_ERR_INVALID_ARG;
+    diag_rank_kernel<<<n_t, 256, 0, (hipStream_t)stream>>>(scores, out_rank, (int)n_query, (int)n_db, scope, mode, gt_id_offset);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}

@@ -18,7 +18,8 @@ and the replicas stay bit-identical.
 The training set comes from `Dataset(cfg).get_train_ds()` (model/dataset.py, utils/dataloader_keras.py:
 PCM resident in HBM, time-domain augmentation in one kernel) unless the caller passes its own
 iterable of (Xa, Xp) batches; the validation loss (trainer.py:200-213) is printed per epoch when the
-validation directory exists.  What is NOT here: TensorBoard and the mini-search validation.
+validation directory exists, followed by the mini search test (trainer.py:226-230) when TRAIN.MINI_TEST_IN_TRAIN
+is set.  What is NOT here: TensorBoard.
 """
 import torch
 
@@ -262,6 +263,9 @@ def trainer(cfg, checkpoint_name, train_batches=None, steps_per_epoch=None, max_
             if vn:
                 msg += f', val_loss:{vt / vn:.4f}'
         print(msg)
+        if val_ds is not None and cfg['TRAIN'].get('MINI_TEST_IN_TRAIN') and val_ds.n_pos_per_anchor == 1:
+            from .utils.mini_search_subroutines import mini_search_validation          # trainer.py:226-230
+            mini_search_validation(val_ds, m_pre, m_fp)
         if dist is None or dist.get_rank() == 0:
             _gen.save_checkpoint(ck_root, checkpoint_name, ep, m_fp, extra={'optimizer': opt.state_dict(m_fp.trainable_variables)})
     return history
