@@ -78,6 +78,25 @@ def save_checkpoint(checkpoint_root_dir, checkpoint_name, checkpoint_index, m_fp
     return d + f'ckpt-{int(checkpoint_index)}.pt'
 
 
+def prune_checkpoints(checkpoint_root_dir, checkpoint_name, max_to_keep=3, keep_every_n_hours=None):
+    """What tf.train.CheckpointManager(max_to_keep=3, keep_checkpoint_every_n_hours=N) does for the reference
+    (experiment_helper.py:100-107): the 3 newest checkpoints stay; an older one is deleted unless at least N hours lie
+    between it and the previously preserved one (file modification times)."""
+    d = checkpoint_root_dir + f'/{checkpoint_name}/'
+    found = sorted((int(m.group(1)), f) for f in glob.glob(d + 'ckpt-*.pt') for m in [re.search(r'ckpt-(\d+)\.pt$', f)] if m)
+    old = found[:-max_to_keep] if max_to_keep else []
+    last_kept = None
+    removed = []
+    for _, f in old:
+        t = os.path.getmtime(f)
+        if keep_every_n_hours and (last_kept is None or t - last_kept >= 3600.0 * keep_every_n_hours):
+            last_kept = t
+            continue
+        os.remove(f)
+        removed.append(f)
+    return removed
+
+
 def prevent_overwrite(key, target_path):
     """generate.py:55-58."""
     if (key == 'dummy_db') & os.path.exists(target_path):

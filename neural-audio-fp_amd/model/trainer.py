@@ -223,7 +223,9 @@ def trainer(cfg, checkpoint_name, train_batches=None, steps_per_epoch=None, max_
     m_pre, m_specaug, m_fp, opt, loss_obj, bucket = setup(cfg, max_epoch * steps_per_epoch)
     ck_root = cfg['DIR']['LOG_ROOT_DIR'] + 'checkpoint/'
     start = 1
-    try:                                            # resume from the latest checkpoint (experiment_helper.py:125-136)
+    # resume after the latest checkpoint (experiment_helper.py:125-136; the reference re-enters the epoch whose
+    # number equals the latest checkpoint index, i.e. repeats one epoch on every restart -- not mirrored)
+    try:
         start = _gen.load_checkpoint(ck_root, checkpoint_name, None, m_fp, optimizer=opt) + 1
     except FileNotFoundError:
         pass
@@ -268,4 +270,5 @@ def trainer(cfg, checkpoint_name, train_batches=None, steps_per_epoch=None, max_
             mini_search_validation(val_ds, m_pre, m_fp)
         if dist is None or dist.get_rank() == 0:
             _gen.save_checkpoint(ck_root, checkpoint_name, ep, m_fp, extra={'optimizer': opt.state_dict(m_fp.trainable_variables)})
+            _gen.prune_checkpoints(ck_root, checkpoint_name, 3, cfg['TRAIN'].get('CHECKPOINT_KEEP_N_HOUR'))
     return history

@@ -107,6 +107,17 @@ def test_checkpoint_discovery_and_errors(tmp_path):
     assert g.load_checkpoint(root, 'exp', '3', m) == 3
     with pytest.raises(FileNotFoundError):
         g.load_checkpoint(root, 'exp', 5, m)
+    # retention like tf.train.CheckpointManager(max_to_keep=3, keep_checkpoint_every_n_hours=N)
+    for i in (1, 2, 4, 5):
+        g.save_checkpoint(root, 'keep', i, Fake())
+    now = os.path.getmtime(root + 'keep/ckpt-5.pt')
+    for i, age_h in ((1, 30), (2, 29.5), (4, 3)):
+        os.utime(root + f'keep/ckpt-{i}.pt', (now - 3600 * age_h, now - 3600 * age_h))
+    g.save_checkpoint(root, 'keep', 6, Fake()); g.save_checkpoint(root, 'keep', 7, Fake())
+    removed = g.prune_checkpoints(root, 'keep', 3, keep_every_n_hours=1)
+    assert [os.path.basename(f) for f in removed] == ['ckpt-2.pt']          # 1 preserved (first), 2 too close to it, 4 is 26 h later
+    assert sorted(os.listdir(root + 'keep')) == ['ckpt-1.pt', 'ckpt-4.pt', 'ckpt-5.pt', 'ckpt-6.pt', 'ckpt-7.pt']
+    assert len(g.prune_checkpoints(root, 'keep', 3, keep_every_n_hours=None)) == 2
     # weights converted from a TensorFlow checkpoint of the reference arrive as ckpt-N.npz (tools/convert_tf_checkpoint.py)
     np.savez(root + 'exp/ckpt-20.npz', w=np.full(2, 7.0, np.float32))
     assert g.load_checkpoint(root, 'exp', None, m) == 20 and np.array_equal(m.sd['w'], np.full(2, 7.0, np.float32))
