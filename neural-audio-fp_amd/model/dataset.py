@@ -7,7 +7,7 @@ Mirrors the parts of the reference's `Dataset` (model/dataset.py:10-323) that
 `NotImplementedError` / `ValueError` behaviour.  `get_train_ds` / `get_val_ds`
 (dataset.py:118-186) return the device-side `genUnbalSequence`
 (utils/dataloader_keras.py: PCM resident in HBM, augmentation in one kernel).
-'unseen_syn' (real-time query synthesis for the test set) raises NotImplementedError.
+'unseen_syn' synthesises the test queries from the DB with the same loader (replicas only).
 """
 import glob
 
@@ -34,7 +34,8 @@ class Dataset:
         self.tr_batch_sz, self.tr_n_anchor = cfg['BSZ']['TR_BATCH_SZ'], cfg['BSZ']['TR_N_ANCHOR']
         self.val_batch_sz, self.val_n_anchor = cfg['BSZ']['VAL_BATCH_SZ'], cfg['BSZ']['VAL_N_ANCHOR']
         aug = cfg['TD_AUG']
-        self.tr_snr, self.val_snr = aug['TR_SNR'], aug['VAL_SNR']
+        self.tr_snr, self.val_snr, self.ts_snr = aug['TR_SNR'], aug['VAL_SNR'], aug['TS_SNR']
+        self.ts_use_bg_aug, self.ts_use_ir_aug = aug['TS_BG_AUG'], aug['TS_IR_AUG']
         self.tr_use_bg_aug, self.val_use_bg_aug = aug['TR_BG_AUG'], aug['VAL_BG_AUG']
         self.tr_use_ir_aug, self.val_use_ir_aug = aug['TR_IR_AUG'], aug['VAL_IR_AUG']
         self.tr_use_speech_aug, self.val_use_speech_aug = aug['TR_SPEECH_AUG'], aug['VAL_SPEECH_AUG']
@@ -46,7 +47,10 @@ class Dataset:
         self.val_ir_fps = g(self.ir_root_dir, 'tr') if self.val_use_ir_aug else None
         self.tr_speech_fps = g(self.speech_root_dir, 'train') if self.tr_use_speech_aug else None
         self.val_speech_fps = g(self.speech_root_dir, 'dev') if self.val_use_speech_aug else None
+        self.ts_bg_fps = g(self.bg_root_dir, 'ts') if self.ts_use_bg_aug else None
+        self.ts_ir_fps = g(self.ir_root_dir, 'ts') if self.ts_use_ir_aug else None
         self.tr_source_fps = self.val_source_fps = None
+        self.ts_query_db_unseen_fps = None
 
     def _source(self, fps):
         return SegmentSource(fps, self.ts_batch_sz, self.dur, self.hop, self.fs)
@@ -99,8 +103,15 @@ class Dataset:
             self.ts_db_icassp_fps = sorted(glob.glob(root + 'db/**/*.wav', recursive=True))
             return self._source(self.ts_query_icassp_fps), self._source(self.ts_db_icassp_fps)
         elif self.datasel_test_query_db == 'unseen_syn':
-            raise NotImplementedError("'unseen_syn' synthesises queries with host-side augmentation; "
-                                      "outside the built path")
+            # dataset.py:266-304: the queries are synthesised from the DB on the fly (test split of bg / ir)
+            self.ts_query_db_unseen_fps = sorted(glob.glob(self.source_root_dir + 'val-query-db-500-30s/' + 'db/**/*.wav',
+                                                           recursive=True))
+            ds_query = genUnbalSequence(
+                self.ts_query_db_unseen_fps, self.ts_batch_sz * 2, self.ts_batch_sz, self.dur, self.hop, self.fs, shuffle=False,
+                random_offset_anchor=False, bg_mix_parameter=[self.ts_use_bg_aug, self.ts_bg_fps, self.ts_snr],
+                ir_mix_parameter=[self.ts_use_ir_aug, self.ts_ir_fps], speech_mix_parameter=[False],
+                reduce_batch_first_half=True, drop_the_last_non_full_batch=False)
+            return ds_query, self._source(self.ts_query_db_unseen_fps)
         else:
             raise NotImplementedError(self.datasel_test_query_db)
 

@@ -141,6 +141,8 @@ def shard_rows(n_items, group, rank, world):
 
 def write_fingerprints(source, embed_fn, arr, group, rank=0, world=1, launch_rows=None):
     """Fill arr[rows of this rank] = embed_fn(int16 chunk (n,1,T), group) in row order."""
+    if hasattr(source, 'plan'):                      # a device-side augmenting sequence ('unseen_syn' queries)
+        return _write_from_sequence(source, embed_fn, arr, rank, world)
     r0, r1 = shard_rows(source.n_samples, group, rank, world)
     k = max(1, -(-LAUNCH_SEGMENTS // group))
     launch_rows = launch_rows or k * group
@@ -168,6 +170,18 @@ def write_fingerprints(source, embed_fn, arr, group, rank=0, world=1, launch_row
             drain(depth - 1)
     drain(0)
     return r0, r1
+
+
+def _write_from_sequence(seq, embed_fn, arr, rank=0, world=1):
+    """Rows of a `genUnbalSequence` built with reduce_batch_first_half=True: batch i holds the synthesised replicas of
+    rows [i*n_anchor, (i+1)*n_anchor); one batch = one max-normalisation group, like generate.py:176-181 feeds m_pre."""
+    n_b = len(seq)
+    b0, b1 = (n_b * rank) // world, (n_b * (rank + 1)) // world
+    for i in range(b0, b1):
+        X, _ = seq[i]
+        emb = embed_fn.embed_device(X)
+        arr[i * seq.n_anchor:i * seq.n_anchor + len(X), :] = emb.cpu().numpy()
+    return b0 * seq.n_anchor, min(b1 * seq.n_anchor, seq.n_samples)
 
 
 def _prefetch(gen, ahead):
@@ -242,6 +256,11 @@ class StreamedEmbedder:
             ev.record()
         return _Pending(out, ev)
 
+
+    def embed_device(self, X):
+        """(n,1,T) CUDA batch -> fingerprints; the batch is one max-normalisation group."""
+        self.m_fp.trainable = False
+        return self.m_fp(self.m_pre(X, group_size=len(X)))
 
     # ---- window path: the next launch's PCM is read straight into this slot's pinned arena ----
     def alloc(self, n_samples):

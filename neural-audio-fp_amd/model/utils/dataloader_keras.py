@@ -20,8 +20,7 @@ What is different, on purpose:
     batch draws from Generator([seed, epoch, batch index]), vectorised over the batch);
   * `randint(low, high)` with low >= high (single-segment files) raises in the reference; here it
     yields `low`.
-Unsupported (NotImplementedError): experimental_mode, reduce_batch_first_half, amp_mode other than
-'normal', seg_mode other than 'all'.
+Unsupported (NotImplementedError): experimental_mode, amp_mode other than 'normal', seg_mode other than 'all'.
 """
 import numpy as np
 import torch
@@ -137,8 +136,9 @@ class genUnbalSequence:
                  bg_mix_parameter=[False], ir_mix_parameter=[False], speech_mix_parameter=[False], reduce_items_p=0,
                  reduce_batch_first_half=False, experimental_mode=False, drop_the_last_non_full_batch=True,
                  seed=0, device=None, resident=True):
-        if experimental_mode or reduce_batch_first_half:
-            raise NotImplementedError('experimental_mode / reduce_batch_first_half')
+        if experimental_mode:
+            raise NotImplementedError('experimental_mode')
+        self.reduce_batch_first_half = reduce_batch_first_half
         if amp_mode != 'normal':
             raise NotImplementedError(f'amp_mode={amp_mode}')
         if seg_mode != 'all':
@@ -308,5 +308,7 @@ class genUnbalSequence:
             raise IndexError(idx)
         rows = self.plan(idx)
         nA = min(self.n_anchor, self.n_samples - idx * self.n_anchor)
+        if self.reduce_batch_first_half:           # synthesized queries only (dataloader_keras.py:308-309): the anchors are not built
+            return self.run(rows[nA:]), []
         out = self.run(rows)
         return out[:nA], out[nA:]

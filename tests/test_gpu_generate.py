@@ -183,3 +183,38 @@ def test_window_ingest_is_bit_identical_to_row_ingest(nafp, cfg, tmp_path):
         outs.append(arr)
     assert np.abs(outs[0]).sum() > 0
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_generate_with_synthesised_queries(nafp, cfg, tmp_path):
+    """DATA_SEL.TEST_QUERY_DB = 'unseen_syn': query.mm holds fingerprints of on-the-fly augmented replicas of the DB
+    segments (bg mix + IR + offset), row-aligned with db.mm; most of them retrieve their own DB row."""
+    from neural_audio_fp_amd.model import generate as g
+    from neural_audio_fp_amd.eval.eval_faiss import FlatL2Index
+    rng = np.random.default_rng(77)
+    t = np.arange(100000) / 8000.0
+    base = str(tmp_path) + '/ds/'
+    os.makedirs(base + 'music/val-query-db-500-30s/db/x'); os.makedirs(base + 'aug/bg/ts'); os.makedirs(base + 'aug/ir/ts')
+    for i in range(3):
+        x = rng.integers(-800, 800, size=100000) + sum(4000 * np.sin(2 * np.pi * f * t + p) for f, p in zip(rng.uniform(300, 3500, 4), rng.uniform(0, 6, 4)))
+        _write_wav(base + f'music/val-query-db-500-30s/db/x/{i}.wav', x)
+    _write_wav(base + 'aug/bg/ts/0.wav', rng.integers(-1500, 1500, size=50000))
+    _write_wav(base + 'aug/ir/ts/0.wav', 15000 * np.exp(-np.arange(400) / 30.0) * rng.normal(size=400))
+    c = copy.deepcopy(cfg)
+    c['DIR'].update({'SOURCE_ROOT_DIR': base + 'music/', 'BG_ROOT_DIR': base + 'aug/bg/', 'IR_ROOT_DIR': base + 'aug/ir/',
+                     'LOG_ROOT_DIR': str(tmp_path) + '/logs/', 'OUTPUT_ROOT_DIR': str(tmp_path) + '/logs/emb/'})
+    c['DATA_SEL']['TEST_QUERY_DB'] = 'unseen_syn'
+    c['TD_AUG']['TS_SNR'] = [10, 15]
+    c['BSZ']['TS_BATCH_SZ'] = 20
+    m_fp = nafp.get_fingerprinter(c)
+    g.save_checkpoint(c['DIR']['LOG_ROOT_DIR'] + 'checkpoint/', 'syn', 1, m_fp)
+    g.generate_fingerprint(c, 'syn', None, None, None, True)
+    out = c['DIR']['OUTPUT_ROOT_DIR'] + '/syn/1/'
+    n = 3 * 24                                                # 12.5-s clips: 24 segments each
+    assert tuple(np.load(out + 'query_shape.npy')) == tuple(np.load(out + 'db_shape.npy')) == (n, 128)
+    q = np.asarray(np.memmap(out + 'query.mm', dtype='float32', mode='r', shape=(n, 128)))
+    d = np.asarray(np.memmap(out + 'db.mm', dtype='float32', mode='r', shape=(n, 128)))
+    assert np.allclose(np.linalg.norm(q, axis=1), 1, atol=1e-4) and not np.allclose(q, d, atol=1e-3)
+    idx = FlatL2Index(128); idx.add(d)
+    hit = idx.search(q, 3)[1]
+    # random-weight network, augmented + shifted queries of stationary tones: the right CLIP is found (its segments look alike)
+    assert (hit[:, 0] // 24 == np.arange(n) // 24).mean() > 0.8

@@ -117,3 +117,30 @@ def test_validation_sequence_is_deterministic_and_unshuffled(corpus):
         p = corpus['ev'][0][:-4] + '_16k.wav'
         _write_wav(p, np.zeros(100), fs=16000)
         genUnbalSequence([p])
+
+
+def test_unseen_syn_query_sequence(corpus, tmp_path):
+    """Dataset.get_test_query_db_ds('unseen_syn') (dataset.py:266-304): queries = replicas only of the DB segments,
+    test split of bg / ir, one batch = TS_BATCH_SZ rows, nothing dropped."""
+    import os, shutil, yaml
+    from neural_audio_fp_amd.model.dataset import Dataset
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, 'config', 'default.yaml')))
+    base = str(tmp_path) + '/'
+    for sub, files in (('music/val-query-db-500-30s/db/a', corpus['ev'][:2]), ('aug/bg/ts', corpus['bg']), ('aug/ir/ts', corpus['ir'])):
+        os.makedirs(base + sub, exist_ok=True)
+        for f in files:
+            shutil.copy(f, base + sub)
+    cfg['DIR'].update({'SOURCE_ROOT_DIR': base + 'music/', 'BG_ROOT_DIR': base + 'aug/bg/', 'IR_ROOT_DIR': base + 'aug/ir/'})
+    cfg['DATA_SEL']['TEST_QUERY_DB'] = 'unseen_syn'
+    cfg['BSZ']['TS_BATCH_SZ'] = 50
+    q, db = Dataset(cfg).get_test_query_db_ds()
+    n = sum(len(A.segment_offsets(k)) for k in (240000, 100000))
+    assert q.n_samples == db.n_samples == n and q.n_anchor == 50 and q.n_pos_per_anchor == 1 and q.reduce_batch_first_half
+    assert len(q) == -(-n // 50) and not q.shuffle
+    rows = q.plan(len(q) - 1)                                  # the ragged last batch
+    n_last = n - 50 * (len(q) - 1)
+    assert len(rows) == 2 * n_last and (rows['mix'][n_last:] == 1).all() and (rows['ir_off'][n_last:] >= 0).all()
+    # replica i shadows DB row i within +-offset_margin (no anchor offset: random_offset_anchor=False)
+    d = rows['ev_off'][n_last:] - rows['ev_off'][:n_last]
+    assert np.abs(d).max() <= 1600
