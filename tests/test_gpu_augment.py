@@ -91,3 +91,29 @@ def test_special_rows(nafp, corpus):
     assert np.abs(got - want).max() < 2e-5
     assert np.abs(got[2]).max() == 0.0                        # circular convolution with a silent IR is silence
     assert abs(np.abs(got[0]).max() - 1.0) < 1e-6 and abs(np.abs(got[4]).max() - 1.0) < 1e-6
+
+
+def test_dataset2wav_writes_one_augmented_clip_per_source(nafp, cfg, tmp_path):
+    import copy, importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('dataset2wav', os.path.join(root, 'tools', 'dataset2wav.py'))
+    d2w = importlib.util.module_from_spec(spec); spec.loader.exec_module(d2w)
+    rng = np.random.default_rng(5)
+    base = str(tmp_path) + '/'
+    t = np.arange(48000) / 8000.0
+    for i in range(2):
+        os.makedirs(base + 'music/q/db/x', exist_ok=True)
+        _write_wav(base + f'music/q/db/x/{i}.wav', (rng.integers(-500, 500, size=48000) + 8000 * np.sin(2 * np.pi * (400 + 300 * i) * t)).astype(int))
+    os.makedirs(base + 'bg/ts'); os.makedirs(base + 'ir/ts')
+    _write_wav(base + 'bg/ts/0.wav', rng.integers(-3000, 3000, size=30000))
+    _write_wav(base + 'ir/ts/0.wav', (15000 * np.exp(-np.arange(300) / 25.0) * rng.normal(size=300)).astype(int))
+    c = copy.deepcopy(cfg)
+    c['DIR'].update({'SOURCE_ROOT_DIR': base + 'music/', 'BG_ROOT_DIR': base + 'bg/', 'IR_ROOT_DIR': base + 'ir/'})
+    files = d2w.synthesize(c, 'q/db', base + 'out', snr=(10, 10), interval=1, clip_sec=6)
+    assert [f.split('/')[-2:] for f in files] == [['x', '0.wav'], ['x', '1.wav']]
+    for f in files:
+        with wave.open(f) as w:
+            assert (w.getframerate(), w.getnchannels(), w.getsampwidth(), w.getnframes()) == (8000, 1, 2, 48000)
+            x = np.frombuffer(w.readframes(48000), dtype='<i2').astype(np.float64) / 32767
+        pieces = np.abs(x.reshape(6, 8000)).max(1)
+        assert np.all(pieces > 0.99) and np.all(pieces <= 1.0)     # every 1-s piece was max-normalised after the IR
