@@ -7,7 +7,7 @@
 // One 256-thread workgroup per segment.  The zero-padded segment sits in LDS once
 // (every sample is reused by four overlapping frames).  Two real frames are packed
 // into one complex 1024-point FFT (frame t -> re, frame t+1 -> im); each of the
-// 4 waves runs one such FFT per round as a radix-4 Stockham autosort in LDS
+// 4 waves runs one such FFT per round as an in-place radix-4 decimation-in-frequency FFT in LDS
 // (5 passes), un-packs the two spectra, and the 256 threads then apply the mel
 // bank as a <=8-tap gather from the LDS-resident magnitudes (941 non-zeros in
 // total: never a dense 513x256 GEMM).  The (n_mels, 32) tile is staged in LDS and
@@ -24,8 +24,10 @@ constexpr int HOP = 256;
 constexpr int NBIN = NFFT / 2 + 1;          // 513
 constexpr int MAX_TAPS = 8;
 constexpr int MAX_SEG = 1 << 22;             // LDS use no longer depends on the segment length
-constexpr int TILE_LD = 36;                 // LDS leading dimension of the (n_mels, <=32) tile chunk
-constexpr int SIG_CHUNK = 31 * HOP + NFFT;  // 8960 samples feed 32 consecutive frames
+constexpr int CHUNK_FRAMES = 16;             // frames per LDS-resident chunk
+constexpr int TILE_LD = 20;                 // LDS leading dimension of the (n_mels, <=16) tile chunk
+constexpr int SIG_CHUNK = (CHUNK_FRAMES - 1) * HOP + NFFT;  // 4864 samples feed 16 consecutive frames
+constexpr int N_TW = 768;                   // twiddles used by the radix-4 passes (index < 3 * 256)
 
 }  // namespace nafp
 
@@ -83,33 +85,38 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
-// One radix-4 Stockham pass over a 1024-point complex sequence held in LDS
-// (src -> dst), executed by one wave: 256 butterflies, 4 per lane.
-template <int P>
-__device__ __forceinline__ void stockham_pass(const float2* __restrict__ src, float2* __restrict__ dst,
-                                              const float2* __restrict__ tw, int lane) {
-    constexpr int T = NFFT / 4;
+// One radix-4 decimation-in-frequency pass, IN PLACE, over a 1024-point complex sequence held in LDS, executed by
+// one wave: 256 butterflies of span S, 4 per lane.  After the five passes (S = 256, 64, 16, 4, 1) X[k] sits at the
+// base-4 digit reversal of k (rev4 below).  In place = one 8 KB buffer per wave instead of a ping-pong pair: that is
+// what lets two workgroups share a CU.
+template <int S>
+__device__ __forceinline__ void dif_pass(float2* __restrict__ x, const float2* __restrict__ tw, int lane) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-        const int i = it * 64 + lane;
-        const int k = i & (P - 1);
-        const int j = ((i - k) << 2) + k;
-        float2 u0 = src[i], u1 = src[i + T], u2 = src[i + 2 * T], u3 = src[i + 3 * T];
-        if (P > 1) {
-            const int m = k * (256 / P);
-            u1 = cmul(u1, tw[m]);
-            u2 = cmul(u2, tw[2 * m]);
-            u3 = cmul(u3, tw[3 * m]);
+        const int b = it * 64 + lane;
+        const int off = b & (S - 1);
+        const int base = ((b - off) << 2) + off;
+        const float2 u0 = x[base], u1 = x[base + S], u2 = x[base + 2 * S], u3 = x[base + 3 * S];
+        const float2 t0 = make_float2(u0.x + u2.x, u0.y + u2.y);
+        const float2 t1 = make_float2(u0.x - u2.x, u0.y - u2.y);
+        const float2 t2 = make_float2(u1.x + u3.x, u1.y + u3.y);
+        const float2 t3 = make_float2(u1.y - u3.y, -(u1.x - u3.x));   // (u1-u3) * (-i)
+        float2 y1 = make_float2(t1.x + t3.x, t1.y + t3.y);
+        float2 y2 = make_float2(t0.x - t2.x, t0.y - t2.y);
+        float2 y3 = make_float2(t1.x - t3.x, t1.y - t3.y);
+        if (S > 1) {
+            const int m = off * (256 / S);
+            y1 = cmul(y1, tw[m]); y2 = cmul(y2, tw[2 * m]); y3 = cmul(y3, tw[3 * m]);
         }
-        const float2 v0 = make_float2(u0.x + u2.x, u0.y + u2.y);
-        const float2 v1 = make_float2(u0.x - u2.x, u0.y - u2.y);
-        const float2 v2 = make_float2(u1.x + u3.x, u1.y + u3.y);
-        const float2 v3 = make_float2(u1.y - u3.y, -(u1.x - u3.x));   // (u1-u3) * (-i)
-        dst[j] = make_float2(v0.x + v2.x, v0.y + v2.y);
-        dst[j + P] = make_float2(v1.x + v3.x, v1.y + v3.y);
-        dst[j + 2 * P] = make_float2(v0.x - v2.x, v0.y - v2.y);
-        dst[j + 3 * P] = make_float2(v1.x - v3.x, v1.y - v3.y);
+        x[base] = make_float2(t0.x + t2.x, t0.y + t2.y);
+        x[base + S] = y1; x[base + 2 * S] = y2; x[base + 3 * S] = y3;
     }
+}
+
+// position of X[k] after the in-place passes: the five base-4 digits of k reversed
+__device__ __forceinline__ int rev4(int k) {
+    const unsigned r = __brev((unsigned)k) >> 22;                   // 10-bit reversal
+    return (int)(((r & 0x155u) << 1) | ((r >> 1) & 0x155u));        // swap the bits of every pair
 }
 
 // order this wave's LDS writes before its later LDS reads (no workgroup barrier)
@@ -130,12 +137,13 @@ __global__ void melspec_init_stats(float* group_stat, int n_groups) {
     }
 }
 
-// LDS carve (floats):
-//   sig  [SIG_CHUNK]                  zero-padded samples of the current 32-frame chunk
-//   fftX [4][2048]  fftY [4][2048]    per-wave ping-pong complex buffers
-//   tile [n_mels][TILE_LD]            log-mel tile (<=32 frames per chunk)
+// LDS carve (80,896 B, so that TWO workgroups share a CU):
+//   sig  [SIG_CHUNK]          zero-padded samples of the current 16-frame chunk (19 KB)
+//   fft  [4][1024] float2     one in-place buffer per wave (32 KB); re-used for the two magnitude spectra
+//   tile [n_mels][TILE_LD]    log-mel tile of the chunk (20 KB)
+//   stw  [768] float2         twiddles exp(-2 pi i n / 1024), n < 768 (6 KB)
 template <typename TIn>
-__global__ __launch_bounds__(256) void melspec_kernel(
+__global__ __launch_bounds__(256, 2) void melspec_kernel(
         const TIn* __restrict__ audio, const int64_t* __restrict__ seg_offset, const int* __restrict__ seg_valid,
         float* __restrict__ feat, float* __restrict__ group_stat,
         const float2* __restrict__ tw, const float* __restrict__ window,
@@ -144,15 +152,11 @@ __global__ __launch_bounds__(256) void melspec_kernel(
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t seg = blockIdx.x;
-    constexpr int sig_alloc = SIG_CHUNK;                   // samples spanned by 32 frames: 31*256 + 1024
     float* sig = smem;
-    float2* fftX = (float2*)(smem + sig_alloc) + wave * NFFT;
-    float2* fftY = (float2*)(smem + sig_alloc + 4 * 2 * NFFT) + wave * NFFT;
-    float* tile = smem + sig_alloc + 8 * 2 * NFFT;
-    // twiddles and window in LDS: the FFT passes then touch no global memory at all
+    float2* fft = (float2*)(smem + SIG_CHUNK) + wave * NFFT;
+    float* tile = smem + SIG_CHUNK + 4 * 2 * NFFT;
     float2* stw = (float2*)(tile + n_mels * TILE_LD);
-    float* swin = (float*)(stw + NFFT);
-    for (int i = tid; i < NFFT; i += 256) { stw[i] = tw[i]; swin[i] = window[i]; }
+    for (int i = tid; i < N_TW; i += 256) stw[i] = tw[i];
 
     // rows of a (n_seg, seg_len) array, or -- window mode -- segment `seg` starts at sample
     // seg_offset[seg] of one PCM arena and has seg_valid[seg] real samples (the rest is the zero
@@ -170,23 +174,28 @@ __global__ __launch_bounds__(256) void melspec_kernel(
 #pragma unroll
         for (int j = 0; j < MAX_TAPS; ++j) mw[j] = mel_w[tid * MAX_TAPS + j];
     }
+    // the window values of this lane's 16 points of pass 0 (n = it*64 + lane + q*256): registers, read once
+    float wreg[4][4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wreg[it][q] = window[it * 64 + lane + q * 256];
     __syncthreads();
 
     float lmax = -INFINITY, lmin = INFINITY;
     const int n_pairs = (n_frames + 1) / 2;
     float* out_seg = feat + seg * (int64_t)n_mels * n_frames;
 
-    for (int chunk0 = 0; chunk0 < n_frames; chunk0 += 32) {          // 32-frame tile chunks
-        const int chunk_frames = min(32, n_frames - chunk0);
+    for (int chunk0 = 0; chunk0 < n_frames; chunk0 += CHUNK_FRAMES) {
+        const int chunk_frames = min(CHUNK_FRAMES, n_frames - chunk0);
         // ---- zero-padded samples of this chunk into LDS (melspectrogram.py:59-65): padded index
         // chunk0*256 + i  <->  sample index chunk0*256 + i - 512
         __syncthreads();
         {
-            // all loads of the chunk are issued before the first LDS write (35 dependent load -> store round
-            // trips per thread otherwise): 4 samples per lane and step, 9 steps.  Vector loads need the
-            // segment start 4-sample aligned (always true for rows of a (n_seg, seg_len) array with seg_len % 4 == 0;
-            // window mode checks the offset).
-            constexpr int STEPS = (SIG_CHUNK / 4 + 255) / 256;            // 9
+            // all loads of the chunk are issued before the first LDS write: 4 samples per lane and step.
+            // Vector loads need the segment start 4-sample aligned (always true for rows of a (n_seg, seg_len)
+            // array with seg_len % 4 == 0; window mode checks the offset).
+            constexpr int STEPS = (SIG_CHUNK / 4 + 255) / 256;            // 5
             const int s_base = chunk0 * HOP - NFFT / 2;                    // multiple of 4
             const bool vec_ok = ((uintptr_t)a % (4 * sizeof(TIn))) == 0;
             float4 v[STEPS];
@@ -219,12 +228,12 @@ __global__ __launch_bounds__(256) void melspec_kernel(
             }
         }
         __syncthreads();
-        for (int round = 0; round < 4; ++round) {                      // 4 waves x 2 frames
+        for (int round = 0; round < CHUNK_FRAMES / 8; ++round) {        // 4 waves x 2 frames per round
             const int pair = chunk0 / 2 + round * 4 + wave;
             const int f0 = 2 * pair, f1 = 2 * pair + 1;
             const bool live = pair < n_pairs && f0 < chunk0 + chunk_frames;
             if (live) {
-                // pass 1 reads the windowed frames straight from `sig`: z = w*(x_f0 + i x_f1)
+                // pass 0 (S = 256) reads the windowed frames straight from `sig`: z = w*(x_f0 + i x_f1)
                 const float* s0 = sig + (f0 - chunk0) * HOP;
                 const bool has1 = f1 < n_frames;
                 const float* s1 = sig + ((has1 ? f1 : f0) - chunk0) * HOP;
@@ -235,42 +244,55 @@ __global__ __launch_bounds__(256) void melspec_kernel(
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int n = i + q * 256;
-                        const float w = swin[n];
+                        const float w = wreg[it][q];
                         u[q] = make_float2(w * s0[n], has1 ? w * s1[n] : 0.f);
                     }
-                    const float2 v0 = make_float2(u[0].x + u[2].x, u[0].y + u[2].y);
-                    const float2 v1 = make_float2(u[0].x - u[2].x, u[0].y - u[2].y);
-                    const float2 v2 = make_float2(u[1].x + u[3].x, u[1].y + u[3].y);
-                    const float2 v3 = make_float2(u[1].y - u[3].y, -(u[1].x - u[3].x));
-                    const int j = i << 2;
-                    fftX[j] = make_float2(v0.x + v2.x, v0.y + v2.y);
-                    fftX[j + 1] = make_float2(v1.x + v3.x, v1.y + v3.y);
-                    fftX[j + 2] = make_float2(v0.x - v2.x, v0.y - v2.y);
-                    fftX[j + 3] = make_float2(v1.x - v3.x, v1.y - v3.y);
+                    const float2 t0 = make_float2(u[0].x + u[2].x, u[0].y + u[2].y);
+                    const float2 t1 = make_float2(u[0].x - u[2].x, u[0].y - u[2].y);
+                    const float2 t2 = make_float2(u[1].x + u[3].x, u[1].y + u[3].y);
+                    const float2 t3 = make_float2(u[1].y - u[3].y, -(u[1].x - u[3].x));
+                    fft[i] = make_float2(t0.x + t2.x, t0.y + t2.y);
+                    fft[i + 256] = cmul(make_float2(t1.x + t3.x, t1.y + t3.y), stw[i]);
+                    fft[i + 512] = cmul(make_float2(t0.x - t2.x, t0.y - t2.y), stw[2 * i]);
+                    fft[i + 768] = cmul(make_float2(t1.x - t3.x, t1.y - t3.y), stw[3 * i]);
                 }
             }
-            // the five passes of a frame pair touch only this wave's two buffers: wave-level ordering is enough
+            // the passes of a frame pair touch only this wave's buffer: wave-level ordering is enough
             // (LDS operations of one wave execute in order), so the four waves are not forced into lockstep
             NAFP_WAVE_SYNC();
-            if (live) stockham_pass<4>(fftX, fftY, stw, lane);
+            if (live) dif_pass<64>(fft, stw, lane);
             NAFP_WAVE_SYNC();
-            if (live) stockham_pass<16>(fftY, fftX, stw, lane);
+            if (live) dif_pass<16>(fft, stw, lane);
             NAFP_WAVE_SYNC();
-            if (live) stockham_pass<64>(fftX, fftY, stw, lane);
+            if (live) dif_pass<4>(fft, stw, lane);
             NAFP_WAVE_SYNC();
-            if (live) stockham_pass<256>(fftY, fftX, stw, lane);
+            if (live) dif_pass<1>(fft, stw, lane);
             NAFP_WAVE_SYNC();
             if (live) {
-                // un-pack: X0[k] = (Z[k]+conj Z[N-k])/2, X1[k] = (Z[k]-conj Z[N-k])/(2i); keep |.|
-                float* mag0 = (float*)fftY;            // [0..512]
+                // un-pack: X0[k] = (Z[k]+conj Z[N-k])/2, X1[k] = (Z[k]-conj Z[N-k])/(2i); keep |.|.
+                // Z[k] lives at rev4(k); everything is read into registers first, then the two magnitude
+                // spectra overwrite the buffer (floats [0..512] and [520..1032]).
+                float m0[9], m1[9];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const int k = lane + 64 * j;
+                    m0[j] = 0.f; m1[j] = 0.f;
+                    if (k < NBIN) {
+                        const float2 z = fft[rev4(k)];
+                        const float2 zc = fft[rev4((NFFT - k) & (NFFT - 1))];
+                        const float ar = 0.5f * (z.x + zc.x), ai = 0.5f * (z.y - zc.y);
+                        const float br = 0.5f * (z.y + zc.y), bi = -0.5f * (z.x - zc.x);
+                        m0[j] = sqrtf(ar * ar + ai * ai);            // kapre Magnitude = tf.abs
+                        m1[j] = sqrtf(br * br + bi * bi);
+                    }
+                }
+                NAFP_WAVE_SYNC();
+                float* mag0 = (float*)fft;             // [0..512]
                 float* mag1 = mag0 + 520;              // [0..512]
-                for (int k = lane; k < NBIN; k += 64) {
-                    const float2 z = fftX[k];
-                    const float2 zc = fftX[(NFFT - k) & (NFFT - 1)];
-                    const float ar = 0.5f * (z.x + zc.x), ai = 0.5f * (z.y - zc.y);
-                    const float br = 0.5f * (z.y + zc.y), bi = -0.5f * (z.x - zc.x);
-                    mag0[k] = sqrtf(ar * ar + ai * ai);            // kapre Magnitude = tf.abs
-                    mag1[k] = sqrtf(br * br + bi * bi);
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const int k = lane + 64 * j;
+                    if (k < NBIN) { mag0[k] = m0[j]; mag1[k] = m1[j]; }
                 }
             }
             __syncthreads();
@@ -279,7 +301,7 @@ __global__ __launch_bounds__(256) void melspec_kernel(
 #pragma unroll
                 for (int wv = 0; wv < 4; ++wv) {
                     const int p = chunk0 / 2 + round * 4 + wv;
-                    const float* mg = (const float*)((float2*)(smem + sig_alloc + 4 * 2 * NFFT) + wv * NFFT);
+                    const float* mg = (const float*)((float2*)(smem + SIG_CHUNK) + wv * NFFT);
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int f = 2 * p + h;
@@ -300,9 +322,9 @@ __global__ __launch_bounds__(256) void melspec_kernel(
             __syncthreads();
         }
         // ---- tile chunk out: (n_mels, chunk_frames) -> feat[seg][m][chunk0 + t] ----
-        if (chunk_frames == 32 && (n_frames & 3) == 0) {
-            for (int idx = tid; idx < n_mels * 8; idx += 256) {
-                const int m = idx >> 3, q = idx & 7;
+        if (chunk_frames == CHUNK_FRAMES && (n_frames & 3) == 0) {
+            for (int idx = tid; idx < n_mels * (CHUNK_FRAMES / 4); idx += 256) {
+                const int m = idx / (CHUNK_FRAMES / 4), q = idx % (CHUNK_FRAMES / 4);
                 const float4 v = *(const float4*)(tile + m * TILE_LD + 4 * q);
                 *(float4*)(out_seg + (int64_t)m * n_frames + chunk0 + 4 * q) = v;
             }
@@ -364,7 +386,7 @@ static int melspec_forward(nafp_melspec* p, const TIn* audio, int64_t n_seg, int
     const int n_groups = (int)((n_seg + group_size - 1) / group_size);
     melspec_init_stats<<<(n_groups + 255) / 256, 256, 0, st>>>(group_stat, n_groups);
     NAFP_LAUNCH_CHECK();
-    const size_t lds = (size_t)(SIG_CHUNK + 8 * 2 * NFFT + p->n_mels * TILE_LD + 3 * NFFT) * sizeof(float);
+    const size_t lds = (size_t)(SIG_CHUNK + 4 * 2 * NFFT + p->n_mels * TILE_LD + 2 * N_TW) * sizeof(float);
     melspec_kernel<TIn><<<dim3((unsigned)n_seg), 256, lds, st>>>(
         audio, seg_offset, seg_valid, feat, group_stat, p->d_twiddle, p->d_window, p->d_mel_start, p->d_mel_w,
         p->seg_len, p->n_frames, p->n_mels, group_size);
@@ -433,8 +455,8 @@ extern "C" int nafp_melspec_create(nafp_melspec** plan, int fs, int seg_len, int
     if ((e = hipMemcpy(p->d_window, win.data(), sizeof(float) * NFFT, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(p->d_mel_start, start.data(), sizeof(int) * n_mels, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(p->d_mel_w, w.data(), sizeof(float) * n_mels * MAX_TAPS, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
-    // the kernel needs > 64 KiB of dynamic LDS
-    const int lds = (SIG_CHUNK + 8 * 2 * NFFT + n_mels * TILE_LD + 3 * NFFT) * (int)sizeof(float);
+    // the kernel needs > 64 KiB of dynamic LDS (80,896 B: two workgroups per CU)
+    const int lds = (SIG_CHUNK + 4 * 2 * NFFT + n_mels * TILE_LD + 2 * N_TW) * (int)sizeof(float);
     if ((e = hipFuncSetAttribute((const void*)melspec_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return fail(e);
     if ((e = hipFuncSetAttribute((const void*)melspec_kernel<int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return fail(e);
     *plan = p;
