@@ -157,6 +157,16 @@ int nafp_encoder_backward(nafp_encoder* enc, const float* feat, const float* d_e
                           void* workspace, int64_t workspace_bytes, float* const* grads_host_array,
                           int l2norm, void* stream);
 
+/* Overlap of the data-parallel gradient reduction with the backward pass.  The backward pass finishes the
+ * parameter gradients last layer first; it records one event per GROUP of tensors, in completion order:
+ *   group 0 = tensors 48..67 (convs 12-15 and the divide-and-encode tensors: 65 % of all parameters),
+ *   group 1 = 32..47, group 2 = 16..31, group 3 = 0..15.
+ * nafp_encoder_grad_group_wait makes `stream` (the communication stream) wait, on the device, until group
+ * `group` of the most recent nafp_encoder_backward call is complete; the host does not block. */
+#define NAFP_GRAD_GROUPS 4
+int nafp_encoder_grad_group_range(const nafp_encoder* enc, int group, int* first_tensor, int* last_tensor);
+int nafp_encoder_grad_group_wait(nafp_encoder* enc, int group, void* stream);
+
 /* Execution options of an encoder handle (results are identical either way).
  *   NAFP_OPT_FUSE_CONV0  0 (default): b0.conv1x3 writes its activation, b0.conv3x1 reads it back.
  *                        1: only conv0's LayerNorm statistics are computed up front and conv1
@@ -167,6 +177,10 @@ int nafp_encoder_set_option(nafp_encoder* enc, int option, int value);
 /* m_fp.div_enc(x) alone (nnfp.py:141-156; called separately at trainer.py:73-76). */
 int nafp_encoder_div_enc(nafp_encoder* enc, const float* flat, int64_t n_seg,
                          float* out_emb, int l2norm, void* stream);
+
+/* tf.math.l2_normalize(x, axis=1) of a (n_rows, dim) array: x * rsqrt(max(sum x^2, 1e-12)), as test_step
+ * applies it to front_conv's and div_enc's outputs (trainer.py:74, 76).  out may alias x. */
+int nafp_l2_normalize_rows(const float* x, int64_t n_rows, int dim, float* out, void* stream);
 
 /* ------------------------------------------------------------------------
  * NT-Xent loss (model/fp/NTxent_loss_single_gpu.py:52-82; sharded form
@@ -186,7 +200,7 @@ int64_t nafp_ntxent_workspace_bytes(int64_t n_local, int64_t n_global);
  *   d_org_all/d_rep_all optional (n_global, d): gradient of (loss_sum/n_global)
  *             w.r.t. the global arrays contributed by this rank's rows AND
  *             columns restricted to local rows (sum over ranks = full gradient);
- *             NULL to skip.  d must be 128. */
+ *             NULL to skip.  d (MODEL.EMB_SZ, nnfp.py:250) is 64, 128 or 256. */
 int nafp_ntxent_forward(const float* emb_org_local, const float* emb_rep_local,
                         const float* emb_org_all, const float* emb_rep_all,
                         int64_t n_local, int64_t n_global, int64_t rank_offset, int d,
@@ -208,6 +222,16 @@ typedef struct { int f0, f1, t0, t1; } nafp_rect;
 int nafp_specaug_apply(float* feat, int64_t n_seg, int F, int T, const nafp_rect* rects_host,
                        int n_rects, const unsigned char* active, float fill_value, void* stream);
 
+/* The same with the fill value read from device memory (hole_fill = 'min' fills with reduce_mean(x),
+ * ncutout_tarray.py:203-204: nafp_specaug_mean leaves that mean on the device, no host round trip). */
+int nafp_specaug_apply_fill_dev(float* feat, int64_t n_seg, int F, int T, const nafp_rect* rects_host,
+                                int n_rects, const unsigned char* active, const float* fill_value_dev,
+                                void* stream);
+/* mean_out[0] = mean of the n floats of feat (16-byte aligned), summed in double in a fixed order. */
+int64_t nafp_specaug_mean_workspace_bytes(void);
+int nafp_specaug_mean(const float* feat, int64_t n, float* mean_out, void* workspace, int64_t workspace_bytes,
+                      void* stream);
+
 /* ------------------------------------------------------------------------
  * Optimizer steps of the train step (model/trainer.py:47-48, 119-140)
  * ---------------------------------------------------------------------- */
@@ -223,6 +247,10 @@ typedef struct {
 
 /* tf.keras.experimental.CosineDecay(lr0, decay_steps, alpha) at `step` (trainer.py:119-124). */
 float nafp_cosine_decay_lr_host(float lr0, int64_t step, int64_t decay_steps, float alpha);
+/* tf.keras.experimental.CosineDecayRestarts(lr0, first_decay_steps, t_mul, m_mul, alpha) at `step`
+ * (LR_SCHEDULE 'COS-RESTART', trainer.py:125-131). */
+float nafp_cosine_decay_restarts_lr_host(float lr0, int64_t step, int64_t first_decay_steps, float t_mul,
+                                         float m_mul, float alpha);
 
 /* tf.keras.optimizers.Adam.apply_gradients (trainer.py:138): step is 1-based (iterations + 1);
  * keras defaults beta1 0.9, beta2 0.999, eps 1e-7. */
@@ -238,7 +266,8 @@ int nafp_lamb_step(const nafp_opt_tensor* tensors_host, int n, float lr, float b
 
 /* Online triplet loss of the now-playing baseline: OnlineTripletLoss.compute_loss with use_anc_as_pos = True
  * (model/fp/online_triplet_loss.py:199-239; masks :98-121; distances :185-196).  mode 0 = 'semi-hard'
- * (training, trainer.py:160-164), 1 = 'all' (validation, :165-169).  n_pos = n_anchor * n_pos_per_anchor,
+ * (training, trainer.py:160-164), 1 = 'all' (validation, :165-169), 2 = 'all-balanced' (:215-222), 3 = 'hardest'
+ * (:223-227, with the reference's min over the MASKED matrix, i.e. hardest negative = 0).  n_pos = n_anchor * n_pos_per_anchor,
  * replicas in anchor order.  loss_out (1); pairwise_dist (n_anchor, n_pos + n_anchor) or NULL; d_anchor /
  * d_pos: gradients of the loss (both or neither).  All device pointers. */
 int64_t nafp_triplet_workspace_bytes(int64_t n_anchor, int64_t n_pos);

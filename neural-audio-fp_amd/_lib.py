@@ -50,12 +50,19 @@ PROTOTYPES = {
     'nafp_encoder_forward_train': (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p]),
     'nafp_encoder_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64,
                                       ctypes.POINTER(c_void_p), c_int, c_void_p]),
+    'nafp_encoder_grad_group_range': (c_int, [c_void_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    'nafp_encoder_grad_group_wait': (c_int, [c_void_p, c_int, c_void_p]),
     'nafp_encoder_div_enc': (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_int, c_void_p]),
     'nafp_ntxent_workspace_bytes': (c_i64, [c_i64, c_i64]),
     'nafp_ntxent_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int,
                                     c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     'nafp_specaug_apply': (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_int, c_void_p, c_float, c_void_p]),
+    'nafp_specaug_apply_fill_dev': (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'nafp_specaug_mean_workspace_bytes': (c_i64, []),
+    'nafp_specaug_mean': (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p]),
+    'nafp_l2_normalize_rows': (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     'nafp_cosine_decay_lr_host': (c_float, [c_float, c_i64, c_i64, c_float]),
+    'nafp_cosine_decay_restarts_lr_host': (c_float, [c_float, c_i64, c_i64, c_float, c_float, c_float]),
     'nafp_adam_step': (c_int, [c_void_p, c_int, c_float, c_float, c_float, c_float, c_i64, c_void_p]),
     'nafp_lamb_workspace_bytes': (c_i64, [c_void_p, c_int]),
     'nafp_triplet_workspace_bytes': (c_i64, [c_i64, c_i64]),

@@ -85,7 +85,15 @@ struct nafp_encoder {
     // optional per-kernel event timing (nafp_encoder_profile_*)
     std::vector<hipEvent_t> prof_events;  // (max_forwards, 18)
     int prof_max = 0, prof_count = 0;
+    // nafp_encoder_backward records one event per gradient group (layers complete last to first), so that a
+    // communication stream can start reducing a group while the rest of the backward pass still runs
+    hipEvent_t grad_events[NAFP_GRAD_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
+    bool grad_events_valid = false;
 };
+
+// gradient group k = parameter tensors [kGroupFirst[k], kGroupLast[k]] in COMPLETION order of the backward pass
+static const int kGroupFirst[NAFP_GRAD_GROUPS] = {48, 32, 16, 0};
+static const int kGroupLast[NAFP_GRAD_GROUPS] = {67, 47, 31, 15};
 
 static void profile_free(nafp_encoder* e) {
     for (auto ev : e->prof_events) (void)hipEventDestroy(ev);
@@ -191,6 +199,7 @@ extern "C" int nafp_encoder_destroy(nafp_encoder* e) {
     if (!e) return NAFP_OK;
     if (e->d_blob) (void)hipFree(e->d_blob);
     profile_free(e);
+    for (auto& ev : e->grad_events) if (ev) (void)hipEventDestroy(ev);
     delete e;
     return NAFP_OK;
 }
@@ -477,6 +486,9 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
         i = k + 1;
     }
     NAFP_HIP_CHECK(hipMemsetAsync(L.zero_begin, 0, L.zero_bytes, st));
+    for (auto& ev : e->grad_events)
+        if (!ev) NAFP_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    e->grad_events_valid = false;
     int rc = launch_stats_to_mr(L.stats, L.mr, e->d_inv_n, B, 16, st);
     if (rc != NAFP_OK) return rc;
     // tail: d_emb -> r * dxhat of the last conv + divide-and-encode gradients
@@ -511,6 +523,9 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
         rc = launch_conv_gemm(a, B, g, st);
         if (rc != NAFP_OK) return rc;
         std::swap(cur, other);
+        // layers j .. 15 (and the divide-and-encode tensors) are final from here on
+        for (int k = 0; k < NAFP_GRAD_GROUPS - 1; ++k)
+            if (4 * j == kGroupFirst[k]) NAFP_HIP_CHECK(hipEventRecord(e->grad_events[k], st));
     }
     {
         const ConvGeom& g = e->geom[0];
@@ -520,5 +535,20 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
         rc = launch_conv0_bwd(feat, cur, grads[0], nullptr, B, g, st);
         if (rc != NAFP_OK) return rc;
     }
+    NAFP_HIP_CHECK(hipEventRecord(e->grad_events[NAFP_GRAD_GROUPS - 1], st));
+    e->grad_events_valid = true;
+    return NAFP_OK;
+}
+
+extern "C" int nafp_encoder_grad_group_range(const nafp_encoder* e, int group, int* first_tensor, int* last_tensor) {
+    if (!e || group < 0 || group >= NAFP_GRAD_GROUPS || !first_tensor || !last_tensor) return NAFP_ERR_INVALID_ARG;
+    *first_tensor = kGroupFirst[group]; *last_tensor = kGroupLast[group];
+    return NAFP_OK;
+}
+
+extern "C" int nafp_encoder_grad_group_wait(nafp_encoder* e, int group, void* stream) {
+    if (!e || group < 0 || group >= NAFP_GRAD_GROUPS) return NAFP_ERR_INVALID_ARG;
+    if (!e->grad_events_valid) return NAFP_ERR_INVALID_ARG;          // no backward pass has been enqueued
+    NAFP_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, e->grad_events[group], 0));
     return NAFP_OK;
 }

@@ -24,8 +24,9 @@ namespace nafp {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int ND = 128;
-
+// Embedding width ND (MODEL.EMB_SZ, nnfp.py:250): 64, 128 or 256.  Lane half h multiplies
+// k in [ND/2 * h, ND/2 * h + ND/2).
+template <int ND>
 __global__ __launch_bounds__(256) void ntxent_fwd_kernel(
         const float* __restrict__ org_l, const float* __restrict__ rep_l,
         const float* __restrict__ org_all, const float* __restrict__ rep_all,
@@ -42,11 +43,12 @@ __global__ __launch_bounds__(256) void ntxent_fwd_kernel(
     const int self_col = r_is_b ? n_global + gi : gi;
     const int pos_col = r_is_b ? gi : n_global + gi;
 
-    float rf[64];                                           // R[r][64h .. 64h+63]
+    constexpr int HK = ND / 2, NV = ND / 8;                // k per lane half; float4 loads per lane
+    float rf[HK];                                           // R[r][HK*h .. HK*h+HK-1]
     {
-        const float* src = rvalid ? ((r_is_b ? rep_l : org_l) + (int64_t)ri * ND + 64 * h) : nullptr;
+        const float* src = rvalid ? ((r_is_b ? rep_l : org_l) + (int64_t)ri * ND + HK * h) : nullptr;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
+        for (int v = 0; v < NV; ++v) {
             float4 t = rvalid ? *(const float4*)(src + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
             rf[4 * v] = t.x; rf[4 * v + 1] = t.y; rf[4 * v + 2] = t.z; rf[4 * v + 3] = t.w;
         }
@@ -57,12 +59,12 @@ __global__ __launch_bounds__(256) void ntxent_fwd_kernel(
         const int c = t * 32 + rl;                          // column this lane feeds into the A operand
         const bool cvalid = c < n_cols;
         const float* csrc = nullptr;
-        if (cvalid) csrc = (c >= n_global ? rep_all + (int64_t)(c - n_global) * ND : org_all + (int64_t)c * ND) + 64 * h;
+        if (cvalid) csrc = (c >= n_global ? rep_all + (int64_t)(c - n_global) * ND : org_all + (int64_t)c * ND) + HK * h;
         f32x16 acc;
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
+        for (int v = 0; v < NV; ++v) {
             const float4 cv = cvalid ? *(const float4*)(csrc + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cv.x, rf[4 * v], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cv.y, rf[4 * v + 1], acc, 0, 0, 0);
@@ -139,13 +141,13 @@ __global__ __launch_bounds__(256) void ntxent_fwd_kernel(
 // k = i_h(t) = (t&3) + 8(t>>2) + 4h, which is exactly register t of lane half h.
 // Every output row is produced by one workgroup in a fixed order: deterministic, no atomics.
 // ---------------------------------------------------------------------------------------
-template <bool COL>
+template <int ND, bool COL>
 __global__ __launch_bounds__(256) void ntxent_bwd_kernel(
         const float* __restrict__ org_l, const float* __restrict__ rep_l,
         const float* __restrict__ org_all, const float* __restrict__ rep_all,
         const float* __restrict__ row_lse, int n_local, int n_global, int rank_offset,
         float tau, float scale,                 // scale = 1 / (tau * n_global)
-        float* __restrict__ part,               // [4 waves][n_owner][128] partial sums over this wave's tiles
+        float* __restrict__ part,               // [4 waves][n_owner][ND] partial sums over this wave's tiles
         int n_owner_pad) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, jl = lane & 31;
@@ -153,14 +155,15 @@ __global__ __launch_bounds__(256) void ntxent_bwd_kernel(
     const int n_owner = COL ? n_cols : n_rows, n_other = COL ? n_rows : n_cols;
     const int o = blockIdx.x * 32 + jl;                     // my owner index
     const bool ovalid = o < n_owner;
-    // owner vector fragment (64 values: features 64h .. 64h+63), like `rf` in the forward kernel
+    // owner vector fragment (HK values: features HK*h .. HK*h+HK-1), like `rf` in the forward kernel
+    constexpr int HK = ND / 2, NV = ND / 8, NB = ND / 32;
     auto row_ptr = [&](int r) { return r >= n_local ? rep_l + (int64_t)(r - n_local) * ND : org_l + (int64_t)r * ND; };
     auto col_ptr = [&](int c) { return c >= n_global ? rep_all + (int64_t)(c - n_global) * ND : org_all + (int64_t)c * ND; };
-    float of[64];
+    float of[HK];
     {
-        const float* src = ovalid ? (COL ? col_ptr(o) : row_ptr(o)) + 64 * h : nullptr;
+        const float* src = ovalid ? (COL ? col_ptr(o) : row_ptr(o)) + HK * h : nullptr;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
+        for (int v = 0; v < NV; ++v) {
             const float4 t = ovalid ? *(const float4*)(src + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
             of[4 * v] = t.x; of[4 * v + 1] = t.y; of[4 * v + 2] = t.z; of[4 * v + 3] = t.w;
         }
@@ -173,9 +176,9 @@ __global__ __launch_bounds__(256) void ntxent_bwd_kernel(
         o_self = is_b ? n_global + gi : gi; o_pos = is_b ? gi : n_global + gi;
         o_lse = row_lse[o];
     }
-    f32x16 out[4];
+    f32x16 out[NB];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int q = 0; q < 16; ++q) out[nb][q] = 0.f;
 
@@ -183,12 +186,12 @@ __global__ __launch_bounds__(256) void ntxent_bwd_kernel(
     for (int t = wave; t < n_tiles; t += 4) {
         const int ti = t * 32 + jl;                          // tile member this lane feeds (A operand)
         const bool tvalid = ti < n_other;
-        const float* tsrc = tvalid ? (COL ? row_ptr(ti) : col_ptr(ti)) + 64 * h : nullptr;
+        const float* tsrc = tvalid ? (COL ? row_ptr(ti) : col_ptr(ti)) + HK * h : nullptr;
         f32x16 acc;
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
+        for (int v = 0; v < NV; ++v) {
             const float4 cv = tvalid ? *(const float4*)(tsrc + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cv.x, of[4 * v], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cv.y, of[4 * v + 1], acc, 0, 0, 0);
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(256) void ntxent_bwd_kernel(
             const bool iv = i < n_other;
             const float* trow = iv ? (COL ? row_ptr(i) : col_ptr(i)) : nullptr;
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
+            for (int nb = 0; nb < NB; ++nb) {
                 const float tv = iv ? trow[nb * 32 + jl] : 0.f;
                 out[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(tv, acc[q], out[nb], 0, 0, 0);
             }
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(256) void ntxent_bwd_kernel(
     if (ovalid) {
         float* dst = part + ((int64_t)wave * n_owner_pad + o) * ND;
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 *(float4*)(dst + nb * 32 + 8 * g + 4 * h) =
@@ -243,9 +246,9 @@ __global__ __launch_bounds__(256) void ntxent_bwd_kernel(
 
 // d_all[c] = sum_w partC[w][c] (+ sum_w partR[w][local row of c]); fixed order.
 __global__ void ntxent_bwd_combine_kernel(const float* __restrict__ partC, const float* __restrict__ partR,
-                                          int n_local, int n_global, int rank_offset, int padC, int padR,
+                                          int n_local, int n_global, int rank_offset, int padC, int padR, int ND,
                                           float* __restrict__ d_org_all, float* __restrict__ d_rep_all) {
-    const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;     // float4 index over (2*n_global, 32)
+    const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;     // float4 index over (2*n_global, ND/4)
     const int64_t total = (int64_t)2 * n_global * (ND / 4);
     if (idx >= total) return;
     const int c = (int)(idx / (ND / 4)), f4 = (int)(idx % (ND / 4));
@@ -284,10 +287,48 @@ using namespace nafp;
 
 extern "C" int64_t nafp_ntxent_workspace_bytes(int64_t n_local, int64_t n_global) {
     if (n_local < 0 || n_global < n_local) return -1;
-    // row_loss + row_lse, then the backward partials: [4][2*n_local padded][128] + [4][2*n_global padded][128]
+    // row_loss + row_lse, then the backward partials: [4][2*n_local padded][d] + [4][2*n_global padded][d], d <= 256
     const int64_t padR = (2 * n_local + 31) / 32 * 32, padC = (2 * n_global + 31) / 32 * 32;
-    return (int64_t)sizeof(float) * (2 * (2 * n_local) + 64 + 4 * (padR + padC) * ND) + 256;
+    return (int64_t)sizeof(float) * (2 * (2 * n_local) + 64 + 4 * (padR + padC) * 256) + 256;
 }
+
+namespace {
+template <int ND>
+int ntxent_launch(const float* emb_org_local, const float* emb_rep_local, const float* emb_org_all,
+                  const float* emb_rep_all, int64_t n_local, int64_t n_global, int64_t rank_offset, float tau,
+                  float* loss_sum, float* sim_mtx, float* d_org_all, float* d_rep_all, void* workspace,
+                  hipStream_t st) {
+    float* row_loss = (float*)workspace;
+    float* row_lse = row_loss + 2 * n_local;
+    const int n_rows = (int)(2 * n_local);
+    ntxent_fwd_kernel<ND><<<(n_rows + 31) / 32, 256, 0, st>>>(
+        emb_org_local, emb_rep_local, emb_org_all, emb_rep_all, (int)n_local, (int)n_global,
+        (int)rank_offset, tau, row_loss, row_lse, sim_mtx);
+    NAFP_LAUNCH_CHECK();
+    ntxent_sum_kernel<<<1, 256, 0, st>>>(row_loss, n_rows, loss_sum);
+    NAFP_LAUNCH_CHECK();
+    if (d_org_all) {
+        const int padR = (n_rows + 31) / 32 * 32, padC = (int)((2 * n_global + 31) / 32 * 32);
+        float* partR = row_lse + 2 * n_local + 64;
+        partR = (float*)(((uintptr_t)partR + 15) & ~(uintptr_t)15);
+        float* partC = partR + (int64_t)4 * padR * ND;
+        const float scale = 1.0f / (tau * (float)n_global);
+        ntxent_bwd_kernel<ND, false><<<padR / 32, 256, 0, st>>>(emb_org_local, emb_rep_local, emb_org_all, emb_rep_all,
+                                                               row_lse, (int)n_local, (int)n_global, (int)rank_offset,
+                                                               tau, scale, partR, padR);
+        NAFP_LAUNCH_CHECK();
+        ntxent_bwd_kernel<ND, true><<<padC / 32, 256, 0, st>>>(emb_org_local, emb_rep_local, emb_org_all, emb_rep_all,
+                                                              row_lse, (int)n_local, (int)n_global, (int)rank_offset,
+                                                              tau, scale, partC, padC);
+        NAFP_LAUNCH_CHECK();
+        const int64_t total = (int64_t)2 * n_global * (ND / 4);
+        ntxent_bwd_combine_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
+            partC, partR, (int)n_local, (int)n_global, (int)rank_offset, padC, padR, ND, d_org_all, d_rep_all);
+        NAFP_LAUNCH_CHECK();
+    }
+    return NAFP_OK;
+}
+}  // namespace
 
 extern "C" int nafp_ntxent_forward(const float* emb_org_local, const float* emb_rep_local,
                                    const float* emb_org_all, const float* emb_rep_all,
@@ -300,37 +341,14 @@ extern "C" int nafp_ntxent_forward(const float* emb_org_local, const float* emb_
     if (n_local <= 0 || n_global < n_local || rank_offset < 0 || rank_offset + n_local > n_global ||
         !(tau > 0.f) || n_global > (1 << 29))
         return NAFP_ERR_INVALID_ARG;
-    if (d != ND) return NAFP_ERR_UNSUPPORTED;
+    if (d != 64 && d != 128 && d != 256) return NAFP_ERR_UNSUPPORTED;
     if ((d_org_all == nullptr) != (d_rep_all == nullptr)) return NAFP_ERR_INVALID_ARG;
     if (workspace_bytes < nafp_ntxent_workspace_bytes(n_local, n_global)) return NAFP_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    float* row_loss = (float*)workspace;
-    float* row_lse = row_loss + 2 * n_local;
-    const int n_rows = (int)(2 * n_local);
-    ntxent_fwd_kernel<<<(n_rows + 31) / 32, 256, 0, st>>>(
-        emb_org_local, emb_rep_local, emb_org_all, emb_rep_all, (int)n_local, (int)n_global,
-        (int)rank_offset, tau, row_loss, row_lse, sim_mtx);
-    NAFP_LAUNCH_CHECK();
-    ntxent_sum_kernel<<<1, 256, 0, st>>>(row_loss, n_rows, loss_sum);
-    NAFP_LAUNCH_CHECK();
-    if (d_org_all) {
-        const int padR = (n_rows + 31) / 32 * 32, padC = (int)((2 * n_global + 31) / 32 * 32);
-        float* partR = row_lse + 2 * n_local + 64 - ((2 * n_local) % 4 ? 0 : 0);
-        partR = (float*)(((uintptr_t)partR + 15) & ~(uintptr_t)15);
-        float* partC = partR + (int64_t)4 * padR * ND;
-        const float scale = 1.0f / (tau * (float)n_global);
-        ntxent_bwd_kernel<false><<<padR / 32, 256, 0, st>>>(emb_org_local, emb_rep_local, emb_org_all, emb_rep_all,
-                                                           row_lse, (int)n_local, (int)n_global, (int)rank_offset,
-                                                           tau, scale, partR, padR);
-        NAFP_LAUNCH_CHECK();
-        ntxent_bwd_kernel<true><<<padC / 32, 256, 0, st>>>(emb_org_local, emb_rep_local, emb_org_all, emb_rep_all,
-                                                          row_lse, (int)n_local, (int)n_global, (int)rank_offset,
-                                                          tau, scale, partC, padC);
-        NAFP_LAUNCH_CHECK();
-        const int64_t total = (int64_t)2 * n_global * (ND / 4);
-        ntxent_bwd_combine_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
-            partC, partR, (int)n_local, (int)n_global, (int)rank_offset, padC, padR, d_org_all, d_rep_all);
-        NAFP_LAUNCH_CHECK();
-    }
-    return NAFP_OK;
+#define NAFP_NTXENT_ARGS emb_org_local, emb_rep_local, emb_org_all, emb_rep_all, n_local, n_global, rank_offset, tau, \
+                         loss_sum, sim_mtx, d_org_all, d_rep_all, workspace, st
+    if (d == 64) return ntxent_launch<64>(NAFP_NTXENT_ARGS);
+    if (d == 256) return ntxent_launch<256>(NAFP_NTXENT_ARGS);
+    return ntxent_launch<128>(NAFP_NTXENT_ARGS);
+#undef NAFP_NTXENT_ARGS
 }

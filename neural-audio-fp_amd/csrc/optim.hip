@@ -121,6 +121,24 @@ extern "C" float nafp_cosine_decay_lr_host(float lr0, int64_t step, int64_t deca
     return (float)((double)lr0 * ((1.0 - (double)alpha) * c + (double)alpha));
 }
 
+extern "C" float nafp_cosine_decay_restarts_lr_host(float lr0, int64_t step, int64_t first_decay_steps, float t_mul,
+                                                     float m_mul, float alpha) {
+    // tf.keras.experimental.CosineDecayRestarts (SGDR; trainer.py:125-131 passes first_decay_steps = 0.1 * total
+    // steps and alpha = 2e-6, t_mul / m_mul at their defaults 2 / 1)
+    if (first_decay_steps <= 0) return lr0;
+    double f = (double)step / (double)first_decay_steps, i_restart;
+    if (t_mul != 1.0f) {
+        i_restart = floor(log(1.0 - f * (1.0 - (double)t_mul)) / log((double)t_mul));
+        const double sum_r = (1.0 - pow((double)t_mul, i_restart)) / (1.0 - (double)t_mul);
+        f = (f - sum_r) / pow((double)t_mul, i_restart);
+    } else {
+        i_restart = floor(f);
+        f -= i_restart;
+    }
+    const double c = 0.5 * pow((double)m_mul, i_restart) * (1.0 + cos(M_PI * f));
+    return (float)((double)lr0 * ((1.0 - (double)alpha) * c + (double)alpha));
+}
+
 extern "C" int nafp_adam_step(const nafp_opt_tensor* tensors_host, int n, float lr, float beta1, float beta2,
                               float eps, int64_t step, void* stream) {
     if (!tensors_host || n <= 0 || step < 1) return NAFP_ERR_INVALID_ARG;

@@ -16,7 +16,8 @@ struct RectTable { int f0[MAX_RECTS], f1[MAX_RECTS], t0[MAX_RECTS], t1[MAX_RECTS
 
 __global__ __launch_bounds__(256) void specaug_kernel(float* __restrict__ x, int64_t n_vec4, int F, int T,
                                                       const RectTable r, const unsigned char* __restrict__ active,
-                                                      float fill) {
+                                                      float fill, const float* __restrict__ fill_dev) {
+    if (fill_dev) fill = *fill_dev;
     const int per_seg4 = F * T / 4;
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n_vec4; i += (int64_t)gridDim.x * 256) {
         const int64_t b = i / per_seg4;
@@ -39,12 +40,66 @@ __global__ __launch_bounds__(256) void specaug_kernel(float* __restrict__ x, int
     }
 }
 
+// mean of n floats into *out, deterministic: 256 partial sums (double) in a fixed order, then one workgroup.
+__global__ __launch_bounds__(256) void mean_partial_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ part) {
+    double acc = 0.0;
+    const int64_t n4 = n / 4;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = ((const float4*)x)[i];
+        acc += (double)((v.x + v.y) + (v.z + v.w));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) acc += (double)x[4 * n4 + threadIdx.x];
+    acc = wave_sum(acc);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void mean_final_kernel(const double* __restrict__ part, int n_part, int64_t n,
+                                                         float* __restrict__ out) {
+    double acc = threadIdx.x < n_part ? part[threadIdx.x] : 0.0;
+    acc = wave_sum(acc);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)n);
+}
+
 }  // namespace nafp
 
 using namespace nafp;
 
+static int specaug_launch(float* feat, int64_t n_seg, int F, int T, const nafp_rect* rects_host, int n_rects,
+                          const unsigned char* active, float fill_value, const float* fill_dev, void* stream);
+
+extern "C" int64_t nafp_specaug_mean_workspace_bytes(void) { return 256 * (int64_t)sizeof(double) + 256; }
+
+extern "C" int nafp_specaug_mean(const float* feat, int64_t n, float* mean_out, void* workspace, int64_t workspace_bytes,
+                                 void* stream) {
+    if (!feat || !mean_out || !workspace || n <= 0 || ((uintptr_t)feat & 15)) return NAFP_ERR_INVALID_ARG;
+    if (workspace_bytes < nafp_specaug_mean_workspace_bytes()) return NAFP_ERR_WORKSPACE;
+    double* part = (double*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    mean_partial_kernel<<<256, 256, 0, (hipStream_t)stream>>>(feat, n, part);
+    NAFP_LAUNCH_CHECK();
+    mean_final_kernel<<<1, 256, 0, (hipStream_t)stream>>>(part, 256, n, mean_out);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}
+
+extern "C" int nafp_specaug_apply_fill_dev(float* feat, int64_t n_seg, int F, int T, const nafp_rect* rects_host,
+                                           int n_rects, const unsigned char* active, const float* fill_value_dev,
+                                           void* stream) {
+    if (!fill_value_dev) return NAFP_ERR_INVALID_ARG;
+    return specaug_launch(feat, n_seg, F, T, rects_host, n_rects, active, 0.f, fill_value_dev, stream);
+}
+
 extern "C" int nafp_specaug_apply(float* feat, int64_t n_seg, int F, int T, const nafp_rect* rects_host,
                                   int n_rects, const unsigned char* active, float fill_value, void* stream) {
+    return specaug_launch(feat, n_seg, F, T, rects_host, n_rects, active, fill_value, nullptr, stream);
+}
+
+static int specaug_launch(float* feat, int64_t n_seg, int F, int T, const nafp_rect* rects_host, int n_rects,
+                          const unsigned char* active, float fill_value, const float* fill_dev, void* stream) {
     if (!feat || n_seg < 0 || F <= 0 || T <= 0 || n_rects < 0 || (n_rects > 0 && !rects_host))
         return NAFP_ERR_INVALID_ARG;
     if (n_rects > MAX_RECTS || (T % 4) != 0) return NAFP_ERR_UNSUPPORTED;
@@ -55,7 +110,7 @@ extern "C" int nafp_specaug_apply(float* feat, int64_t n_seg, int F, int T, cons
     }
     const int64_t n_vec4 = n_seg * F * T / 4;
     const int blocks = (int)std::min<int64_t>((n_vec4 + 255) / 256, 2048);
-    specaug_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(feat, n_vec4, F, T, r, active, fill_value);
+    specaug_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(feat, n_vec4, F, T, r, active, fill_value, fill_dev);
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }

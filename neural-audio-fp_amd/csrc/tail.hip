@@ -115,6 +115,19 @@ int launch_tail(const TailArgs& a, int64_t B, hipStream_t st) {
     return NAFP_OK;
 }
 
+// tf.math.l2_normalize(x, axis=1) of a (n_rows, dim) array (trainer.py:74, 76): one wave per row.
+__global__ __launch_bounds__(256) void l2_normalize_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                int64_t n_rows, int dim) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const float* src = x + row * dim;
+    float ss = 0.f;
+    for (int c = lane; c < dim; c += 64) ss = fmaf(src[c], src[c], ss);
+    const float inv = rsqrtf(fmaxf(wave_sum(ss), 1e-12f));
+    for (int c = lane; c < dim; c += 64) y[row * dim + c] = src[c] * inv;
+}
+
 // (Q,S,32) -> (S,32,Q); (Q,32) -> (32,Q) for b1 and w2.
 __global__ void pack_div_kernel(const float* __restrict__ w1, const float* __restrict__ b1,
                                 const float* __restrict__ w2, float* __restrict__ w1p,
@@ -139,3 +152,11 @@ int launch_pack_div(const float* w1, const float* b1, const float* w2, float* w1
 }
 
 }  // namespace nafp
+
+extern "C" int nafp_l2_normalize_rows(const float* x, int64_t n_rows, int dim, float* out, void* stream) {
+    if (!x || !out || n_rows < 0 || dim <= 0) return NAFP_ERR_INVALID_ARG;
+    if (n_rows == 0) return NAFP_OK;
+    nafp::l2_normalize_rows_kernel<<<(unsigned)((n_rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(x, out, n_rows, dim);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}

@@ -39,6 +39,52 @@ __global__ __launch_bounds__(256) void triplet_rows_kernel(const float* __restri
     if (mode == 0) {
         for (int k = 0; k < npa; ++k) { const float v = drow[a * npa + k]; if (v > hard) { hard = v; hard_m = a * npa + k; } }
     }
+    if (mode >= 2) {
+        // 'all-balanced' (mode 2, online_triplet_loss.py:215-222): max(mean_pos d - mean_neg d + margin, 0) per anchor;
+        // 'hardest' (mode 3, :223-227): max(max_pos d - min(d * an_mask) + margin, 0) per anchor.  The reference takes
+        // the min over the MASKED matrix, whose entries at the anchor's own replicas and at the anchor itself are 0
+        // (and every distance is > 0), so its "hardest negative" is always 0: mirrored as written.
+        // Both reduce to one term per anchor, averaged over the anchors.
+        float sp = 0.f, sn = 0.f, mx = 0.f;
+        for (int m = tid; m < M; m += 256) {
+            const bool is_pos = m >= a * npa && m < (a + 1) * npa;
+            const bool is_neg = !is_pos && m != nP + a;
+            const float dd = drow[m];
+            if (is_pos) { sp += dd; mx = fmaxf(mx, dd); }
+            if (is_neg) sn += dd;
+        }
+        sp = wave_sum(sp); sn = wave_sum(sn);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if ((tid & 63) == 0) { red[tid >> 6] = sp; red[4 + (tid >> 6)] = sn; }
+        __syncthreads();
+        sp = (red[0] + red[1]) + (red[2] + red[3]); sn = (red[4] + red[5]) + (red[6] + red[7]);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const int n_an = M - npa - 1;
+        const float inv_a = 1.f / (float)nA;
+        const float t = mode == 2 ? sp / (float)npa - sn / (float)n_an + margin : mx - 0.f + margin;
+        const bool active = t > 0.f;
+        // hardest positive = FIRST maximum along the row (the sub-gradient tf.reduce_max / torch.max hand out)
+        int hard_m = a * npa;
+        for (int k = 0; k < npa; ++k) if (drow[a * npa + k] == mx) { hard_m = a * npa + k; break; }
+        for (int m = tid; m < M; m += 256) {
+            const bool is_pos = m >= a * npa && m < (a + 1) * npa;
+            const bool is_neg = !is_pos && m != nP + a;
+            const float dd = drow[m];
+            float dterm_dd = 0.f;
+            if (active) {
+                if (mode == 2) dterm_dd = is_pos ? 1.f / (float)npa : (is_neg ? -1.f / (float)n_an : 0.f);
+                else dterm_dd = m == hard_m ? 1.f : 0.f;
+            }
+            const float d2pos = dd * dd - TRIPLET_EPS > 0.f ? 1.f : 0.f;
+            coef[(int64_t)a * M + m] = inv_a * dterm_dd * (-d2pos / dd);
+        }
+        if (tid == 0 && active) atomicAdd(loss_sum, t * inv_a);
+        return;
+    }
     const float inv = 1.f / ((float)nA * (float)M);
     float lsum = 0.f, n_active = 0.f;
     for (int m = tid; m < M; m += 256) {
@@ -74,7 +120,7 @@ __global__ __launch_bounds__(256) void triplet_rows_kernel(const float* __restri
 }
 
 // out[r, :] = sum_m C[r, m] * cols[m, :]   (r over nR rows; cols = [pos ; anc])
-__global__ __launch_bounds__(128) void triplet_grad_anchor_kernel(const float* __restrict__ coef, const float* __restrict__ anc,
+__global__ __launch_bounds__(256) void triplet_grad_anchor_kernel(const float* __restrict__ coef, const float* __restrict__ anc,
                                                                   const float* __restrict__ pos, float* __restrict__ d_anc,
                                                                   int nA, int npa, int D) {
     const int a = blockIdx.x, c = threadIdx.x, nP = nA * npa, M = nP + nA;
@@ -91,7 +137,7 @@ __global__ __launch_bounds__(128) void triplet_grad_anchor_kernel(const float* _
     d_anc[(int64_t)a * D + c] = s;
 }
 
-__global__ __launch_bounds__(128) void triplet_grad_pos_kernel(const float* __restrict__ coef, const float* __restrict__ anc,
+__global__ __launch_bounds__(256) void triplet_grad_pos_kernel(const float* __restrict__ coef, const float* __restrict__ anc,
                                                                float* __restrict__ d_pos, int nA, int npa, int D) {
     const int m = blockIdx.x, c = threadIdx.x, M = nA * npa + nA;
     if (c >= D) return;
@@ -116,8 +162,9 @@ extern "C" int nafp_triplet_forward(const float* emb_anchor, const float* emb_po
                                     int mode, float margin, float* loss_out, float* pairwise_dist, float* d_anchor,
                                     float* d_pos, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!emb_anchor || !emb_pos || !loss_out || !workspace || n_anchor <= 0 || n_pos <= 0 || dim <= 0) return NAFP_ERR_INVALID_ARG;
-    if (n_pos % n_anchor != 0 || dim % 4 != 0 || dim > 128 || (mode != 0 && mode != 1) || n_anchor + n_pos > 8192)
+    if (n_pos % n_anchor != 0 || dim % 4 != 0 || dim > 256 || mode < 0 || mode > 3 || n_anchor + n_pos > 8192)
         return NAFP_ERR_UNSUPPORTED;
+    if (mode == 2 && n_anchor == 1) return NAFP_ERR_UNSUPPORTED;      // no negatives: the reference divides 0 by 0
     if (workspace_bytes < nafp_triplet_workspace_bytes(n_anchor, n_pos)) return NAFP_ERR_WORKSPACE;
     if ((d_anchor == nullptr) != (d_pos == nullptr)) return NAFP_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -128,9 +175,9 @@ extern "C" int nafp_triplet_forward(const float* emb_anchor, const float* emb_po
     triplet_rows_kernel<<<nA, 256, lds, st>>>(emb_anchor, emb_pos, pairwise_dist, coef, loss_out, nA, npa, dim, mode, margin);
     NAFP_LAUNCH_CHECK();
     if (d_anchor) {
-        triplet_grad_anchor_kernel<<<nA, 128, 0, st>>>(coef, emb_anchor, emb_pos, d_anchor, nA, npa, dim);
+        triplet_grad_anchor_kernel<<<nA, 256, 0, st>>>(coef, emb_anchor, emb_pos, d_anchor, nA, npa, dim);
         NAFP_LAUNCH_CHECK();
-        triplet_grad_pos_kernel<<<(unsigned)n_pos, 128, 0, st>>>(coef, emb_anchor, d_pos, nA, npa, dim);
+        triplet_grad_pos_kernel<<<(unsigned)n_pos, 256, 0, st>>>(coef, emb_anchor, d_pos, nA, npa, dim);
         NAFP_LAUNCH_CHECK();
     }
     return NAFP_OK;

@@ -55,8 +55,9 @@ class Dataset:
     def _source(self, fps):
         return SegmentSource(fps, self.ts_batch_sz, self.dur, self.hop, self.fs)
 
-    def get_train_ds(self, reduce_items_p=0, n_anchor=None, bsz=None, seed=0):
-        """dataset.py:128-153.  n_anchor / bsz: this rank's share of the global batch (data parallel)."""
+    def get_train_ds(self, reduce_items_p=0, n_anchor=None, bsz=None, seed=0, shard=(0, 1)):
+        """dataset.py:128-153.  shard = (rank, world): this rank's rows of each GLOBAL batch (data parallel; the
+        permutation and the draws are those of the single-process run, see genUnbalSequence)."""
         if self.datasel_train == '10k_icassp':
             _prefix = 'train-10k-30s/'
         else:
@@ -68,7 +69,7 @@ class Dataset:
             bg_mix_parameter=[self.tr_use_bg_aug, self.tr_bg_fps, self.tr_snr],
             ir_mix_parameter=[self.tr_use_ir_aug, self.tr_ir_fps],
             speech_mix_parameter=[self.tr_use_speech_aug, self.tr_speech_fps, self.tr_snr],
-            reduce_items_p=reduce_items_p, seed=seed)
+            reduce_items_p=reduce_items_p, seed=seed, shard=shard)
 
     def get_val_ds(self, max_song=500):
         """dataset.py:156-186."""

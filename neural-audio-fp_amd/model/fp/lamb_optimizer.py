@@ -4,7 +4,8 @@ Mirrors what the reference's train step uses (model/trainer.py:119-140):
   * `LAMB(learning_rate=...)` of model/fp/lamb_optimizer.py:20-158 (defaults beta 0.9/0.999,
     epsilon 1e-6, weight_decay_rate 1e-6, decay + layer adaptation on every variable);
   * `Adam(learning_rate=...)` = tf.keras.optimizers.Adam (epsilon 1e-7);
-  * `CosineDecay(initial_learning_rate, decay_steps, alpha)`.
+  * `CosineDecay(initial_learning_rate, decay_steps, alpha)`, `CosineDecayRestarts(initial_learning_rate,
+    first_decay_steps, t_mul, m_mul, alpha)`.
 `apply_gradients(zip(grads, variables))` updates the torch CUDA tensors in place; `iterations`
 counts steps like keras.  `var_lens` maps a tensor to the length of one keras variable inside
 it: the fingerprinter stacks its 128x4 divide-and-encode variables into 4 tensors, and LAMB's
@@ -26,6 +27,19 @@ class CosineDecay:
     def __call__(self, step):
         return float(self._lib.nafp_cosine_decay_lr_host(self.initial_learning_rate, int(step), self.decay_steps,
                                                          self.alpha))
+
+
+class CosineDecayRestarts:
+    """tf.keras.experimental.CosineDecayRestarts (trainer.py:125-131)."""
+
+    def __init__(self, initial_learning_rate, first_decay_steps, t_mul=2.0, m_mul=1.0, alpha=0.0):
+        self.initial_learning_rate, self.first_decay_steps = float(initial_learning_rate), int(first_decay_steps)
+        self.t_mul, self.m_mul, self.alpha = float(t_mul), float(m_mul), float(alpha)
+        self._lib = _lib.load()
+
+    def __call__(self, step):
+        return float(self._lib.nafp_cosine_decay_restarts_lr_host(self.initial_learning_rate, int(step), self.first_decay_steps,
+                                                                  self.t_mul, self.m_mul, self.alpha))
 
 
 class _MultiTensorOptimizer:

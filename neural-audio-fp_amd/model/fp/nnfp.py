@@ -68,6 +68,7 @@ class FingerPrinter:
         self._names = tensor_names()
         self._vars = self._init_variables(seed)
         self._dirty = True
+        self._weights_event, self._weights_stream, self._use_events = None, None, {}
         self._ws = {}          # one workspace per HIP stream: batches may be pipelined across streams
 
     # ---- parameters -------------------------------------------------------
@@ -128,13 +129,41 @@ class FingerPrinter:
         self.load_state_dict({n: a for n, a in zip(self._names, arrays)})
 
     def _sync(self):
+        """Push replaced / modified variables to the library, ordered against every stream that uses
+        the handle: the re-pack (copy, pack, G/Hb launches) writes the handle's shared packed-weight
+        blob, so (i) it first waits for the forwards still running on OTHER streams, and (ii) every later
+        forward waits for its completion event before it reads the blob (`_wait_weights`)."""
         if not self._dirty:
+            self._wait_weights()
             return
+        cur = torch.cuda.current_stream(self.device)
+        for key, ev in list(self._use_events.items()):
+            if key != cur.cuda_stream:
+                cur.wait_event(ev)
         arr = (ctypes.c_void_p * len(self._vars))(*[v.data_ptr() for v in self._vars])
         with torch.cuda.device(self.device):
             _lib.check(self._lib.nafp_encoder_set_weights(self._h, arr, _lib.current_stream()),
                        'encoder_set_weights')
+            self._weights_event = torch.cuda.Event()
+            self._weights_event.record(cur)
+        self._weights_stream = cur.cuda_stream
+        self._use_events = {}
         self._dirty = False
+
+    def _wait_weights(self):
+        ev = self._weights_event
+        if ev is not None:
+            cur = torch.cuda.current_stream(self.device)
+            if cur.cuda_stream != self._weights_stream:
+                cur.wait_event(ev)
+
+    def _mark_use(self):
+        """Record that the current stream has read the packed weights up to here (see `_sync`)."""
+        cur = torch.cuda.current_stream(self.device)
+        ev = self._use_events.get(cur.cuda_stream)
+        if ev is None:
+            ev = self._use_events[cur.cuda_stream] = torch.cuda.Event()
+        ev.record(cur)
 
     def __del__(self):
         h = getattr(self, '_h', None)
@@ -172,6 +201,7 @@ class FingerPrinter:
                                                       _lib.ptr(flat), _lib.ptr(emb),
                                                       int(bool(self.use_L2layer)), _lib.current_stream()),
                        'encoder_forward')
+            self._mark_use()
         return flat, emb
 
     # ---- training: forward that keeps activations + backward (trainer.py:41-47) ----------
@@ -188,6 +218,7 @@ class FingerPrinter:
             _lib.check(self._lib.nafp_encoder_forward_train(self._h, _lib.ptr(feat), B, _lib.ptr(self._train_ws), need,
                                                             _lib.ptr(emb), int(bool(self.use_L2layer)),
                                                             _lib.current_stream()), 'encoder_forward_train')
+            self._mark_use()
         self._train_feat = feat
         return emb
 
@@ -206,7 +237,24 @@ class FingerPrinter:
                                                        _lib.ptr(self._train_ws), need, arr,
                                                        int(bool(self.use_L2layer)), _lib.current_stream()),
                        'encoder_backward')
+            self._mark_use()
         return self._grads
+
+    def grad_groups(self):
+        """[(first_tensor, last_tensor)] of the library's gradient groups, in completion order of `backward`."""
+        out = []
+        a, b = ctypes.c_int(), ctypes.c_int()
+        k = 0
+        while self._lib.nafp_encoder_grad_group_range(self._h, k, ctypes.byref(a), ctypes.byref(b)) == 0:
+            out.append((a.value, b.value))
+            k += 1
+        return out
+
+    def grad_group_wait(self, group):
+        """The CURRENT stream waits (on the device) until gradient group `group` of the last `backward` is complete."""
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.nafp_encoder_grad_group_wait(self._h, int(group), _lib.current_stream()),
+                       'encoder_grad_group_wait')
 
     def set_option(self, option, value):
         """Execution options of the library handle (include/nafp.h NAFP_OPT_*); results do not change."""
@@ -238,6 +286,16 @@ class FingerPrinter:
         with torch.cuda.device(x.device):
             _lib.check(self._lib.nafp_encoder_div_enc(self._h, _lib.ptr(x), x.shape[0], _lib.ptr(out), 0,
                                                       _lib.current_stream()), 'encoder_div_enc')
+            self._mark_use()
+        return out
+
+    def l2_normalize(self, x):
+        """tf.math.l2_normalize(x, axis=1) (nnfp.py:229; trainer.py:74, 76)."""
+        x = _lib.require_cuda(torch.as_tensor(x), 'x').float().contiguous()
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(self._lib.nafp_l2_normalize_rows(_lib.ptr(x), x.shape[0], x.shape[1], _lib.ptr(out),
+                                                        _lib.current_stream()), 'l2_normalize_rows')
         return out
 
     def __call__(self, inputs):

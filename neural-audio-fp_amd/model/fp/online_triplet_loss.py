@@ -2,8 +2,9 @@
 
 Mirrors `OnlineTripletLoss` (model/fp/online_triplet_loss.py:34-244): constructor arguments, the
 `(loss, pairwise_dist, num_active_triplets)` return of `compute_loss(emb_anchor, emb_pos)`, modes
-'semi-hard' (training) and 'all' (validation) as trainer.py:160-169 uses them, use_anc_as_pos=True.
-'all-balanced' / 'hardest' / squared distances / use_anc_as_pos=False raise NotImplementedError.
+'semi-hard' (training) and 'all' (validation) as trainer.py:160-169 uses them, plus 'all-balanced' and 'hardest'
+(online_triplet_loss.py:215-227; 'hardest' keeps the reference's min over the MASKED distance matrix, i.e. a
+hardest-negative distance of 0), use_anc_as_pos=True.  Squared distances / use_anc_as_pos=False raise NotImplementedError.
 `num_active_triplets` is, as in the reference, the count of positive entries of the SCALAR loss (0 or 1,
 online_triplet_loss.py:238).  `loss_and_grad` returns the gradients the tape would derive.
 """
@@ -12,11 +13,14 @@ import torch
 from ... import _lib
 
 
+_MODES = {'semi-hard': 0, 'all': 1, 'all-balanced': 2, 'hardest': 3}
+
+
 class OnlineTripletLoss:
     def __init__(self, bsz=int(), n_anchor=int(), n_pos_per_anchor=int(), use_anc_as_pos=True, mode='semi-hard', margin=.5):
         if not use_anc_as_pos:
             raise NotImplementedError('use_anc_as_pos=False')
-        if mode not in ('semi-hard', 'all'):
+        if mode not in _MODES:
             raise NotImplementedError(mode)
         self.bsz, self.n_anchor = bsz, n_anchor
         self.n_pos_per_anchor = n_pos_per_anchor if n_pos_per_anchor else int((bsz - n_anchor) / n_anchor)
@@ -39,7 +43,7 @@ class OnlineTripletLoss:
         need = int(self._lib.nafp_triplet_workspace_bytes(nA, nP))
         ws = torch.empty((need,), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(self._lib.nafp_triplet_forward(_lib.ptr(a), _lib.ptr(p), nA, nP, d, 0 if self.mode == 'semi-hard' else 1,
+            _lib.check(self._lib.nafp_triplet_forward(_lib.ptr(a), _lib.ptr(p), nA, nP, d, _MODES[self.mode],
                                                       float(self.margin), _lib.ptr(loss), _lib.ptr(dist), _lib.ptr(da), _lib.ptr(dp),
                                                       _lib.ptr(ws), need, _lib.current_stream()), 'triplet_forward')
         return loss[0], dist, da, dp

@@ -66,14 +66,30 @@ class SpecAugChainer:
         self._lib = _lib.load()
 
     def apply_rects(self, x, rects, active=None, fill=0.0):
-        """In place: holes of `rects` -> fill for the active samples.  x: (B,F,T,1) CUDA float32."""
+        """In place: holes of `rects` -> fill for the active samples.  x: (B,F,T,1) CUDA float32.
+        `fill`: a number, or a 1-element CUDA tensor (read on the device: no host round trip)."""
         _lib.require_cuda(x, 'x')
         B, F, T = x.shape[0], x.shape[1], x.shape[2]
         arr = (_lib.Rect * len(rects))(*[_lib.Rect(*r) for r in rects])
         with torch.cuda.device(x.device):
-            _lib.check(self._lib.nafp_specaug_apply(_lib.ptr(x), B, F, T, arr, len(rects), _lib.ptr(active),
-                                                    float(fill), _lib.current_stream()), 'specaug_apply')
+            if torch.is_tensor(fill):
+                _lib.check(self._lib.nafp_specaug_apply_fill_dev(_lib.ptr(x), B, F, T, arr, len(rects), _lib.ptr(active),
+                                                                 _lib.ptr(_lib.require_cuda(fill, 'fill')),
+                                                                 _lib.current_stream()), 'specaug_apply_fill_dev')
+            else:
+                _lib.check(self._lib.nafp_specaug_apply(_lib.ptr(x), B, F, T, arr, len(rects), _lib.ptr(active),
+                                                        float(fill), _lib.current_stream()), 'specaug_apply')
         return x
+
+    def mean_dev(self, x):
+        """reduce_mean(x) as a 1-element CUDA tensor (the 'min' hole filler, ncutout_tarray.py:203-204)."""
+        out = torch.empty((1,), dtype=torch.float32, device=x.device)
+        need = int(self._lib.nafp_specaug_mean_workspace_bytes())
+        ws = torch.empty((need,), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(self._lib.nafp_specaug_mean(_lib.ptr(x), x.numel(), _lib.ptr(out), _lib.ptr(ws), need,
+                                                   _lib.current_stream()), 'specaug_mean')
+        return out
 
     def __call__(self, x):
         if self.bypass:
@@ -87,7 +103,7 @@ class SpecAugChainer:
             active = None
             if prob < 1.0:      # per-sample activation (ncutout_tarray.py:259)
                 active = torch.from_numpy((self.rng.random(B) < prob).astype(np.uint8)).to(x.device)
-            fill = float(x.mean()) if self.hole_fill == 'min' else 0.0        # 'min' fills with reduce_mean: :203-204
+            fill = self.mean_dev(x) if self.hole_fill == 'min' else 0.0       # 'min' fills with reduce_mean: :203-204
             self.apply_rects(x, rects, active, fill)
         return x
 

@@ -97,12 +97,22 @@ def prune_checkpoints(checkpoint_root_dir, checkpoint_name, max_to_keep=3, keep_
     return removed
 
 
+def overwrite_refused(key, target_path):
+    """The question of generate.py:55-58, answered without exiting.  No terminal on stdin (batch job, torchrun): the
+    prompt cannot be answered; the file is then overwritten, with a notice."""
+    if (key == 'dummy_db') & os.path.exists(target_path):
+        if not sys.stdin or not sys.stdin.isatty():
+            print(f'{target_path} exists; stdin is not a terminal: overwriting.')
+            return False
+        answer = input(f'{target_path} exists. Will you overwrite (y/N)?')
+        return answer.lower() not in ['y', 'yes']
+    return False
+
+
 def prevent_overwrite(key, target_path):
     """generate.py:55-58."""
-    if (key == 'dummy_db') & os.path.exists(target_path):
-        answer = input(f'{target_path} exists. Will you overwrite (y/N)?')
-        if answer.lower() not in ['y', 'yes']:
-            sys.exit()
+    if overwrite_refused(key, target_path):
+        sys.exit()
 
 
 def get_data_source(cfg, source_root_dir, skip_dummy):
@@ -319,8 +329,14 @@ def generate_fingerprint(cfg, checkpoint_name, checkpoint_index, source_root_dir
     else:
         output_root_dir = cfg['DIR']['OUTPUT_ROOT_DIR'] + f'/{checkpoint_name}/{checkpoint_index}/'
     os.makedirs(output_root_dir, exist_ok=True)
-    if not skip_dummy and rank == 0:
-        prevent_overwrite('dummy_db', f'{output_root_dir}/dummy_db.mm')
+    if not skip_dummy:
+        # rank 0 asks; every rank learns the answer, so that all of them leave together (a lone sys.exit on
+        # rank 0 would strand the others in the barrier below)
+        refused = [overwrite_refused('dummy_db', f'{output_root_dir}/dummy_db.mm') if rank == 0 else False]
+        if dist:
+            dist.broadcast_object_list(refused, src=0)
+        if refused[0]:
+            sys.exit()
 
     embed = StreamedEmbedder(m_pre, m_fp)
 

@@ -11,9 +11,12 @@ Data parallel (one process per GPU, torch.distributed over RCCL): every rank hol
 and their replicas; the L2-normalised embeddings are all-gathered before the loss
 (NTxent_loss_tpu.py:57-87, 110-126), each rank scores its local rows against all columns, the
 gradient w.r.t. the gathered embeddings is summed over ranks (what TF's all_reduce-in-the-forward
-yields in its backward) and each rank back-propagates its slice; parameter gradients are then
-all-reduced (sum) in one flat buffer, so every rank applies the gradient of the GLOBAL mean loss
-and the replicas stay bit-identical.
+yields in its backward) by a reduce-scatter, so each rank receives just its slice and back-propagates
+it; parameter gradients live in one flat buffer that is all-reduced (sum) in NAFP_GRAD_GROUPS pieces on a
+communication stream, each piece as soon as the backward pass has finished its layers (layers complete
+last to first; the first piece -- convs 12-15, 65 % of the parameters -- is ready after a few per cent of
+the backward pass), so every rank applies the gradient of the GLOBAL mean loss and the replicas stay
+bit-identical.
 
 The training set comes from `Dataset(cfg).get_train_ds()` (model/dataset.py, utils/dataloader_keras.py:
 PCM resident in HBM, time-domain augmentation in one kernel) unless the caller passes its own
@@ -27,7 +30,7 @@ from .fp.melspec.melspectrogram import get_melspec_layer
 from .fp.nnfp import get_fingerprinter
 from .fp.NTxent_loss_single_gpu import NTxentLoss, _ntxent_call
 from .fp.online_triplet_loss import OnlineTripletLoss
-from .fp.lamb_optimizer import LAMB, Adam, CosineDecay
+from .fp.lamb_optimizer import LAMB, Adam, CosineDecay, CosineDecayRestarts
 from .fp.specaug_chain.specaug_chain import get_specaug_chain_layer
 from . import generate as _gen
 
@@ -49,17 +52,53 @@ def _dist():
 
 
 class GradientBucket:
-    """All parameter gradients as views into ONE flat buffer: a single all-reduce per step
-    (67.8 MB for the 1-s model) instead of 68."""
+    """All parameter gradients as views into ONE flat buffer (67.8 MB for the 1-s model), reduced in
+    NAFP_GRAD_GROUPS contiguous pieces instead of 68 tensors: `pieces[k]` = the slice of gradient group k
+    of the library (include/nafp.h: groups in completion order of the backward pass)."""
 
     def __init__(self, m_fp):
         vs = m_fp.trainable_variables
         self.flat = torch.zeros(sum(v.numel() for v in vs), dtype=torch.float32, device=vs[0].device)
-        self.views, o = [], 0
+        self.views, offs, o = [], [], 0
         for v in vs:
             self.views.append(self.flat[o:o + v.numel()].view_as(v))
+            offs.append(o)
             o += v.numel()
+        offs.append(o)
         m_fp._grads = self.views          # FingerPrinter.backward writes straight into the views
+        self.m_fp = m_fp
+        self.pieces = [self.flat[offs[a]:offs[b + 1]] for a, b in m_fp.grad_groups()]
+        self.comm_stream = None
+        self.timings = None               # optional: {'allreduce_ms': [...]} filled when `timed` is set
+        self.timed = False
+        self._ev = None
+
+    def all_reduce(self, dist):
+        """Sum the gradients over the ranks, overlapped with the backward pass still running on the current
+        stream: piece k is reduced on the communication stream as soon as the library's event for group k has
+        fired.  Returns after making the current stream wait for all pieces (no host block)."""
+        cur = torch.cuda.current_stream(self.flat.device)
+        if self.comm_stream is None:
+            self.comm_stream = torch.cuda.Stream(device=self.flat.device)
+        cs = self.comm_stream
+        evs = []
+        with torch.cuda.stream(cs):
+            for k, piece in enumerate(self.pieces):
+                self.m_fp.grad_group_wait(k)               # device-side wait of `cs` on the backward pass
+                if self.timed:
+                    e0 = torch.cuda.Event(enable_timing=True); e0.record(cs)
+                dist.all_reduce(piece)
+                if self.timed:
+                    e1 = torch.cuda.Event(enable_timing=True); e1.record(cs)
+                    evs.append((e0, e1))
+        cur.wait_stream(cs)
+        self._ev = evs or None
+
+    def read_timings(self):
+        """ms of each piece's all-reduce of the last `all_reduce` call (after a device synchronisation)."""
+        if not self._ev:
+            return None
+        return [a.elapsed_time(b) for a, b in self._ev]
 
 
 def train_step(X, m_pre, m_specaug, m_fp, loss_obj, opt, bucket=None):
@@ -75,8 +114,10 @@ def train_step(X, m_pre, m_specaug, m_fp, loss_obj, opt, bucket=None):
     dist = _dist()
     if dist is None:
         loss, d_a, d_b = loss_obj.loss_and_grad(ha, hb)
+        d_emb = torch.cat([d_a, d_b], dim=0)
     else:
-        # 2 small collectives: all-gather of [ha; hb], then ONE all-reduce of [d/d a_all; d/d b_all; loss]
+        # 2 small collectives: all-gather of [ha; hb], then ONE reduce-scatter of [d/d a; d/d b; loss] laid out
+        # per destination rank (every rank needs only the gradient of its own rows, NTxent_loss_tpu.py:57-87)
         world, rank = dist.get_world_size(), dist.get_rank()
         d = emb.shape[1]
         gathered = torch.empty((world * 2 * n_anchors, d), dtype=emb.dtype, device=emb.device)
@@ -86,19 +127,34 @@ def train_step(X, m_pre, m_specaug, m_fp, loss_obj, opt, bucket=None):
         n_g = world * n_anchors
         loss_sum, _, d_a_all, d_b_all = _ntxent_call(loss_obj._lib, ha, hb, a_all, b_all, rank * n_anchors,
                                                      loss_obj.tau, False, True)
-        red = torch.cat([d_a_all.view(-1), d_b_all.view(-1), loss_sum / n_g])
-        dist.all_reduce(red)
-        loss = red[-1]
-        sl = slice(rank * n_anchors, (rank + 1) * n_anchors)
-        d_a, d_b = red[:n_g * d].view(n_g, d)[sl], red[n_g * d:2 * n_g * d].view(n_g, d)[sl]
-    grads = m_fp.backward(torch.cat([d_a, d_b], dim=0))
+        chunk = 2 * n_anchors * d
+        send = torch.empty((world, chunk + 4), dtype=torch.float32, device=emb.device)
+        send[:, :n_anchors * d] = d_a_all.view(world, n_anchors * d)
+        send[:, n_anchors * d:chunk] = d_b_all.view(world, n_anchors * d)
+        send[:, chunk:] = loss_sum / n_g                 # every destination receives the sum of the local losses
+        recv = torch.empty((chunk + 4,), dtype=torch.float32, device=emb.device)
+        _reduce_scatter(dist, recv, send)
+        loss = recv[chunk]
+        d_emb = recv[:chunk].view(2 * n_anchors, d)
+    grads = m_fp.backward(d_emb)
     if dist is not None:
         if bucket is None:
             raise ValueError('data-parallel train_step needs a GradientBucket')
-        dist.all_reduce(bucket.flat)
+        bucket.all_reduce(dist)
     opt.apply_gradients(zip(grads, m_fp.trainable_variables), var_lens=m_fp.variable_lengths())
     m_fp.mark_dirty()
     return loss, None
+
+
+def _reduce_scatter(dist, recv, send):
+    """recv = sum over ranks of send[rank] (reduce_scatter_tensor over RCCL; a backend without it -- some gloo
+    builds, CPU tests only -- falls back to an all-reduce and a slice)."""
+    try:
+        dist.reduce_scatter_tensor(recv, send.view(-1))
+    except (RuntimeError, NotImplementedError):
+        full = send.clone()
+        dist.all_reduce(full)
+        recv.copy_(full[dist.get_rank()])
 
 
 def val_step(X, m_pre, m_fp, loss_obj):
@@ -117,8 +173,8 @@ def test_step(X, m_pre, m_fp):
     X = torch.cat([torch.as_tensor(x) for x in X], dim=0)
     m_fp.trainable = False
     emb_f = m_fp.front_conv(m_pre(X))
-    emb_f_postL2 = torch.nn.functional.normalize(emb_f, dim=1, eps=1e-6)
-    emb_gf = torch.nn.functional.normalize(m_fp.div_enc(emb_f), dim=1, eps=1e-6)
+    emb_f_postL2 = m_fp.l2_normalize(emb_f)
+    emb_gf = m_fp.l2_normalize(m_fp.div_enc(emb_f))
     return emb_f, emb_f_postL2, emb_gf
 
 
@@ -128,7 +184,10 @@ def make_optimizer(cfg, total_nsteps):
     if sched == 'COS':
         lr = CosineDecay(float(cfg['TRAIN']['LR']), total_nsteps, alpha=1e-06)
     elif sched == 'COS-RESTART':
-        raise NotImplementedError('CosineDecayRestarts')
+        # trainer.py:125-131.  The reference also passes `num_periods=0.5`, which tf.keras' CosineDecayRestarts
+        # does not accept (its constructor raises TypeError there); the schedule below is the one its other
+        # arguments describe (t_mul / m_mul at the keras defaults).
+        lr = CosineDecayRestarts(float(cfg['TRAIN']['LR']), int(total_nsteps * 0.1), alpha=2e-06)
     else:
         lr = float(cfg['TRAIN']['LR'])
     name = cfg['TRAIN']['OPTIMIZER'].upper()
@@ -199,7 +258,7 @@ def sync_replicas(m_fp):
 def trainer(cfg, checkpoint_name, train_batches=None, steps_per_epoch=None, max_epoch=None):
     """trainer.py:111-230.  `train_batches`: optional callable epoch -> iterable of (Xa, Xp) CUDA (or host)
     batches of shape (n, 1, T); default = the reference's training set (cfg DIR / DATA_SEL / TD_AUG) through the
-    device-side loader (every rank draws its own share of each global batch)."""
+    device-side loader (all ranks share one permutation; rank r keeps rows r*n_a/world ... of each global batch)."""
     own_dataset = train_batches is None
     if train_batches is None:
         # the reference's loader (trainer.py:113, 181-197): anchors + augmented replicas, assembled on the device
@@ -207,19 +266,23 @@ def trainer(cfg, checkpoint_name, train_batches=None, steps_per_epoch=None, max_
         dist = _dist()
         world = dist.get_world_size() if dist is not None else 1
         rank = dist.get_rank() if dist is not None else 0
-        ds = Dataset(cfg).get_train_ds(cfg['DATA_SEL']['REDUCE_ITEMS_P'], n_anchor=cfg['BSZ']['TR_N_ANCHOR'] // world,
-                                       bsz=cfg['BSZ']['TR_BATCH_SZ'] // world, seed=1000 + rank)
+        # ONE permutation and one set of draws shared by all ranks (same seed); rank r takes its rows of each
+        # global batch, so an epoch is n_samples / TR_N_ANCHOR steps whatever the world size
+        ds = Dataset(cfg).get_train_ds(cfg['DATA_SEL']['REDUCE_ITEMS_P'], seed=1000, shard=(rank, world))
         if ds.n_pos_per_anchor != 1 and cfg['LOSS']['LOSS_MODE'].upper() == 'NTXENT':
             raise NotImplementedError('NT-Xent trains with one replica per anchor (TR_BATCH_SZ = 2 * TR_N_ANCHOR)')
 
         def train_batches(ep, ds=ds):
+            # epoch `ep` (1-based) always sees the same permutation and draws, also after a restart: the loader
+            # state is a function of (seed, epoch), rebuilt here rather than stored in the checkpoint
+            ds.set_epoch(ep - 1)
             for i in range(len(ds)):
                 yield ds[i]
-            ds.on_epoch_end()
         steps_per_epoch = steps_per_epoch or len(ds)
     max_epoch = max_epoch or cfg['TRAIN']['MAX_EPOCH']
     if steps_per_epoch is None:
-        steps_per_epoch = len(train_batches(1))
+        raise ValueError('steps_per_epoch is required when train_batches is supplied (the LR schedule needs the '
+                         'total number of steps)')
     m_pre, m_specaug, m_fp, opt, loss_obj, bucket = setup(cfg, max_epoch * steps_per_epoch)
     ck_root = cfg['DIR']['LOG_ROOT_DIR'] + 'checkpoint/'
     start = 1
@@ -248,11 +311,12 @@ def trainer(cfg, checkpoint_name, train_batches=None, steps_per_epoch=None, max_
             loss_obj_val = OnlineTripletLoss(bsz=cfg['BSZ']['VAL_BATCH_SZ'], n_anchor=cfg['BSZ']['VAL_N_ANCHOR'], mode='all', margin=0.)
     history = []
     for ep in range(start, max_epoch + 1):
-        tot, n = 0.0, 0
+        tot, n = None, 0
         for X in train_batches(ep):
             loss, _ = train_step(X, m_pre, m_specaug, m_fp, loss_obj, opt, bucket)
-            tot += float(loss); n += 1
-        history.append(tot / max(n, 1))
+            tot = loss.detach().clone() if tot is None else tot + loss       # stays on the device: one read per epoch
+            n += 1
+        history.append(float(tot) / max(n, 1) if n else 0.0)
         msg = f'epoch {ep}: tr_loss:{history[-1]:.4f}'
         if val_ds is not None:
             vt, vn = 0.0, 0

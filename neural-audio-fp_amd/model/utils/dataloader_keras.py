@@ -135,7 +135,7 @@ class genUnbalSequence:
                  seg_mode='all', amp_mode='normal', random_offset_anchor=False, offset_margin_hop_rate=0.4,
                  bg_mix_parameter=[False], ir_mix_parameter=[False], speech_mix_parameter=[False], reduce_items_p=0,
                  reduce_batch_first_half=False, experimental_mode=False, drop_the_last_non_full_batch=True,
-                 seed=0, device=None, resident=True):
+                 seed=0, device=None, resident=True, shard=(0, 1)):
         if experimental_mode:
             raise NotImplementedError('experimental_mode')
         self.reduce_batch_first_half = reduce_batch_first_half
@@ -197,12 +197,19 @@ class genUnbalSequence:
             self.index_ir = self.rng.permutation(self.n_ir_samples) if shuffle else np.arange(self.n_ir_samples)
         self.reduce_items_p = reduce_items_p
         assert reduce_items_p <= 100
+        # data parallel: bsz / n_anchor are the GLOBAL batch, every rank builds the SAME permutation and the
+        # same draws (same seed) and keeps rows [rank * n_anchor/world, (rank+1) * n_anchor/world) of each batch
+        # with their replicas, so that len(ds), the epoch and the batches equal the single-process run
+        self.rank, self.world = int(shard[0]), int(shard[1])
+        if not 0 <= self.rank < self.world or n_anchor % self.world:
+            raise ValueError(f'shard={shard}: n_anchor={n_anchor} must split evenly over the ranks')
         self.arena = PcmArena(stores)
         self.device = device
         self._pcm = None
         self._lib = None
         if not resident:
             raise NotImplementedError('streaming (non-resident) PCM arena')
+        self.set_epoch(0)
 
     def __len__(self):
         """dataloader_keras.py:187-195."""
@@ -212,15 +219,21 @@ class genUnbalSequence:
 
     def on_epoch_end(self):
         """dataloader_keras.py:198-222."""
-        self.epoch += 1
+        self.set_epoch(self.epoch + 1)
+
+    def set_epoch(self, epoch):
+        """Permutations of epoch `epoch` (0-based): a function of (seed, epoch) only, so a restarted run that
+        resumes at epoch e continues with the permutations and draws the uninterrupted run would have used."""
+        self.epoch = int(epoch)
         if self.shuffle:
-            self.index_event = self.rng.permutation(self.n_samples)
+            rng = np.random.default_rng([self.seed, 0x5eed, self.epoch])
+            self.index_event = rng.permutation(self.n_samples)
             if self.bg_mix:
-                self.index_bg = self.rng.permutation(self.n_bg_samples)
+                self.index_bg = rng.permutation(self.n_bg_samples)
             if self.ir_mix:
-                self.index_ir = self.rng.permutation(self.n_ir_samples)
+                self.index_ir = rng.permutation(self.n_ir_samples)
             if self.speech_mix:
-                self.index_speech = self.rng.permutation(self.n_speech_samples)
+                self.index_speech = rng.permutation(self.n_speech_samples)
 
     # ---- the batch as a table of windows (host only; unit-testable without a GPU) -----------
     def plan(self, idx):
@@ -284,7 +297,16 @@ class genUnbalSequence:
                 fi = self.fns_ir_seg_list[self.index_ir[sel % self.n_ir_samples] % self.n_ir_samples][:, 0]
                 rows['ir_off'][rep] = self.ir.start[fi]
                 rows['ir_len'][rep] = np.minimum(np.minimum(self.ir.n_frames[fi], MAX_IR_LENGTH), T)
+        if self.world > 1:
+            # this rank's anchors of the global batch and their replicas (a ragged last batch splits as evenly
+            # as its anchors allow)
+            a0, a1 = (nA * self.rank) // self.world, (nA * (self.rank + 1)) // self.world
+            rows = np.concatenate([rows[a0:a1], rows[nA + a0 * npa:nA + a1 * npa]])
         return rows
+
+    def n_local_anchors(self, idx):
+        nA = min(self.n_anchor, self.n_samples - idx * self.n_anchor)
+        return (nA * (self.rank + 1)) // self.world - (nA * self.rank) // self.world
 
     # ---- device ---------------------------------------------------------------------------
     def _resident(self):
@@ -307,7 +329,7 @@ class genUnbalSequence:
         if idx < 0 or idx >= len(self):
             raise IndexError(idx)
         rows = self.plan(idx)
-        nA = min(self.n_anchor, self.n_samples - idx * self.n_anchor)
+        nA = self.n_local_anchors(idx)
         if self.reduce_batch_first_half:           # synthesized queries only (dataloader_keras.py:308-309): the anchors are not built
             return self.run(rows[nA:]), []
         out = self.run(rows)

@@ -7,6 +7,7 @@ trainer's choices at model/trainer.py:119-140.  Third-party semantics restated:
     m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; w -= lr_t * m / (sqrt(v) + eps); eps = 1e-7;
     t = iterations + 1.
   * tf.keras.experimental.CosineDecay(lr0, S, alpha): lr0*((1-alpha)*0.5*(1+cos(pi*min(s,S)/S))+alpha).
+  * tf.keras.experimental.CosineDecayRestarts: period k has length S*t_mul^k and amplitude m_mul^k.
 """
 import numpy as np
 
@@ -14,6 +15,19 @@ import numpy as np
 def cosine_decay(lr0, step, decay_steps, alpha=1e-6):
     s = min(step, decay_steps) / decay_steps
     return lr0 * ((1 - alpha) * 0.5 * (1 + np.cos(np.pi * s)) + alpha)
+
+
+def cosine_decay_restarts(lr0, step, first_decay_steps, t_mul=2.0, m_mul=1.0, alpha=0.0):
+    """tf.keras.experimental.CosineDecayRestarts.__call__ (SGDR, Loshchilov & Hutter 2017), used by the reference
+    for LR_SCHEDULE 'COS-RESTART' (model/trainer.py:125-131: first_decay_steps = int(0.1 * total), alpha 2e-6)."""
+    f = step / first_decay_steps
+    if t_mul == 1.0:
+        i = np.floor(f)
+        f = f - i
+    else:
+        i = np.floor(np.log(1.0 - f * (1.0 - t_mul)) / np.log(t_mul))
+        f = (f - (1.0 - t_mul ** i) / (1.0 - t_mul)) / t_mul ** i
+    return lr0 * ((1 - alpha) * 0.5 * m_mul ** i * (1 + np.cos(np.pi * f)) + alpha)
 
 
 def adam_step(w, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-7, dtype=np.float64):

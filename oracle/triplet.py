@@ -3,8 +3,12 @@
 
 Follows model/fp/online_triplet_loss.py:34-244: masks `_get_anchor_positive_mask_v2` /
 `_get_anchor_negative_mask_v2` (:98-121), `_pairwise_distances_v2_fast` (:185-196: d = sqrt(2(1-a.p)
-* [2(1-a.p) > 0] + 1e-9)), and `compute_loss` modes 'semi-hard' (training) and 'all' (validation)
-(:199-239), with use_anc_as_pos=True (the positives matrix is [emb_pos ; emb_anchor])."""
+* [2(1-a.p) > 0] + 1e-9)), and `compute_loss` (:199-239) in all four modes -- 'semi-hard' (training), 'all'
+(validation), 'all-balanced', 'hardest' -- with use_anc_as_pos=True (the positives matrix is [emb_pos ; emb_anchor]).
+
+'hardest' is restated AS WRITTEN: `tf.reduce_min(pairwise_dist * self.an_mask, axis=1)` (:225) runs over the masked
+matrix, whose entries at the anchor's replicas and at the anchor itself are 0 while every distance is > 0, so the
+reference's hardest-negative distance is identically 0."""
 import numpy as np
 
 EPS = 1e-9
@@ -37,6 +41,12 @@ def compute_loss(emb_anc, emb_pos, mode='semi-hard', margin=0.5):
     elif mode == 'semi-hard':
         hardest = ap_d.max(axis=1, keepdims=True) * np.ones((1, d.shape[1]))
         loss = np.maximum((hardest - d + margin) * an, 0.).mean()
+    elif mode == 'all-balanced':                                            # :215-222
+        ap_m = ap_d.sum(axis=1) / ap.sum(axis=1)
+        an_m = (d * an).sum(axis=1) / an.sum(axis=1)
+        loss = np.maximum(ap_m - an_m + margin, 0.).mean()
+    elif mode == 'hardest':                                                 # :223-227
+        loss = np.maximum(ap_d.max(axis=1) - (d * an).min(axis=1) + margin, 0.).mean()
     else:
         raise NotImplementedError(mode)
     return loss, d, float(loss > 0)
@@ -52,5 +62,9 @@ def torch_loss(emb_anc, emb_pos, mode='semi-hard', margin=0.5):
     d = torch.sqrt(d * (d > 0) + EPS)
     if mode == 'all':
         return torch.clamp(d * ap - d * an + margin, min=0.).mean()
+    if mode == 'all-balanced':
+        return torch.clamp((d * ap).sum(1) / ap.sum(1) - (d * an).sum(1) / an.sum(1) + margin, min=0.).mean()
+    if mode == 'hardest':
+        return torch.clamp((d * ap).max(dim=1).values - (d * an).min(dim=1).values + margin, min=0.).mean()
     hardest = (d * ap).max(dim=1, keepdim=True).values
     return torch.clamp((hardest - d + margin) * an, min=0.).mean()

@@ -16,6 +16,28 @@ def test_cosine_decay_endpoints_and_host_entry(nafp):
         assert np.isclose(lib.nafp_cosine_decay_lr_host(1e-4, s, 1000, 1e-6), o_opt.cosine_decay(1e-4, s, 1000), rtol=1e-6)
 
 
+def test_cosine_decay_restarts_vs_torch_warm_restarts_and_host_entry(nafp):
+    """LR_SCHEDULE 'COS-RESTART' (trainer.py:125-131): the oracle's CosineDecayRestarts against torch's
+    CosineAnnealingWarmRestarts (T_0 = first_decay_steps, T_mult = t_mul, eta_min = alpha * lr0) and the library."""
+    lib = nafp._lib.load()
+    lr0, first, alpha = 1e-4, 50, 2e-6
+    w = torch.zeros(1, requires_grad=True)
+    opt = torch.optim.SGD([w], lr=lr0)
+    sch = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, T_0=first, T_mult=2, eta_min=alpha * lr0)
+    for s in range(0, 400):
+        want = opt.param_groups[0]['lr']
+        got = o_opt.cosine_decay_restarts(lr0, s, first, 2.0, 1.0, alpha)
+        assert np.isclose(got, want, rtol=1e-9, atol=1e-16), (s, got, want)
+        assert np.isclose(lib.nafp_cosine_decay_restarts_lr_host(lr0, s, first, 2.0, 1.0, alpha), want, rtol=2e-6)
+        opt.step(); sch.step()
+    # restarts at 50, 150, 350: back to lr0
+    for s in (0, 50, 150, 350):
+        assert np.isclose(o_opt.cosine_decay_restarts(lr0, s, first, 2.0, 1.0, alpha), lr0)
+    # t_mul = 1: plain periodic; m_mul scales every period
+    assert np.isclose(o_opt.cosine_decay_restarts(1.0, 75, 50, 1.0, 0.5, 0.0), 0.5 * 0.5 * (1 + np.cos(np.pi * 0.5)))
+    assert np.isclose(lib.nafp_cosine_decay_restarts_lr_host(1.0, 75, 50, 1.0, 0.5, 0.0), 0.25, rtol=1e-6)
+
+
 def test_adam_matches_torch_with_rescaled_epsilon():
     # torch: w -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps_t); keras puts eps outside the bias
     # correction, i.e. eps_t = eps_keras / sqrt(1-b2^t).  One step at a time with that eps.

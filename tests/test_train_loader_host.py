@@ -144,3 +144,41 @@ def test_unseen_syn_query_sequence(corpus, tmp_path):
     # replica i shadows DB row i within +-offset_margin (no anchor offset: random_offset_anchor=False)
     d = rows['ev_off'][n_last:] - rows['ev_off'][:n_last]
     assert np.abs(d).max() <= 1600
+
+
+def test_sharded_plan_is_the_rank_slice_of_the_global_batch(corpus):
+    """Data parallel: one permutation and one set of draws for all ranks; rank r keeps anchors
+    [r*n/world, (r+1)*n/world) of each global batch with their replicas, so that len(ds), the epoch and the union of
+    the ranks' rows equal the single-process loader."""
+    from neural_audio_fp_amd.model.utils.dataloader_keras import genUnbalSequence
+    kw = dict(bsz=24, n_anchor=8, shuffle=True, random_offset_anchor=True, bg_mix_parameter=[True, corpus['bg'], (0, 10)],
+              ir_mix_parameter=[True, corpus['ir']], seed=5)
+    full = genUnbalSequence(corpus['ev'], **kw)
+    parts = [genUnbalSequence(corpus['ev'], shard=(r, 4), **kw) for r in range(4)]
+    assert all(len(p) == len(full) and p.n_samples == full.n_samples for p in parts)
+    for ep in (0, 1):
+        for ds in [full] + parts:
+            ds.set_epoch(ep)
+        for idx in (0, len(full) - 1):
+            g = full.plan(idx)
+            nA, npa = 8, 2
+            for r, p in enumerate(parts):
+                rows = p.plan(idx)
+                assert p.n_local_anchors(idx) == 2 and len(rows) == 2 + 4
+                assert rows[:2].tobytes() == g[2 * r:2 * r + 2].tobytes()
+                assert rows[2:].tobytes() == g[nA + 2 * r * npa:nA + (2 * r + 2) * npa].tobytes()
+    with pytest.raises(ValueError):
+        genUnbalSequence(corpus['ev'], shard=(0, 3), **kw)             # 8 anchors do not split over 3 ranks
+
+
+def test_epoch_state_is_a_function_of_seed_and_epoch(corpus):
+    """Resume: epoch e of a restarted run uses the permutations and draws of the uninterrupted run."""
+    from neural_audio_fp_amd.model.utils.dataloader_keras import genUnbalSequence
+    kw = dict(bsz=8, n_anchor=4, shuffle=True, random_offset_anchor=True, seed=9)
+    a, b = genUnbalSequence(corpus['ev'], **kw), genUnbalSequence(corpus['ev'], **kw)
+    a.on_epoch_end(); a.on_epoch_end()                                 # ran epochs 0 and 1, now in epoch 2
+    b.set_epoch(2)                                                      # restarted straight into epoch 2
+    assert a.epoch == b.epoch == 2 and np.array_equal(a.index_event, b.index_event)
+    assert a.plan(1).tobytes() == b.plan(1).tobytes()
+    b.set_epoch(0)
+    assert not np.array_equal(a.index_event, b.index_event)
