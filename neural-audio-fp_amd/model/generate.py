@@ -194,6 +194,44 @@ def _write_from_sequence(seq, embed_fn, arr, rank=0, world=1):
     return b0 * seq.n_anchor, min(b1 * seq.n_anchor, seq.n_samples)
 
 
+def write_fingerprints_from_device_rows(row_fn, n_items, m_pre, m_fp, arr, group, rank=0, world=1, launch_groups=5,
+                                        n_streams=N_STREAMS):
+    """Fill arr[rows of this rank] from a DEVICE-side source: row_fn(row0, n) -> (n, 1, T) CUDA batch of rows
+    [row0, row0 + n) (audio synthesised or already resident in HBM -- the full-scale stand-in of SURVEY.md 8d
+    config 5, where no 443 GB dataset exists).  Same sharding (`shard_rows`, whole max-normalisation groups), same
+    launch pipelining (round-robin over `n_streams` HIP streams, pinned download buffers) and same row placement as
+    `write_fingerprints`.  Returns the row range written."""
+    r0, r1 = shard_rows(n_items, group, rank, world)
+    launch = launch_groups * group
+    streams = [torch.cuda.Stream() for _ in range(n_streams)]
+    host = [torch.empty((launch, m_fp.emb_sz), dtype=torch.float32).pin_memory() for _ in range(n_streams)]
+    pend = [None] * n_streams
+
+    def drain(s):
+        if pend[s] is not None:
+            ev, a, n = pend[s]
+            ev.synchronize()
+            arr[a:a + n, :] = host[s][:n].numpy()
+            pend[s] = None
+
+    m_fp.trainable = False
+    m_fp._sync()
+    torch.cuda.current_stream().synchronize()
+    for k, a in enumerate(range(r0, r1, launch)):
+        s = k % n_streams
+        drain(s)
+        n = min(launch, r1 - a)
+        with torch.cuda.stream(streams[s]):
+            emb = m_fp(m_pre(row_fn(a, n), group_size=group))
+            host[s][:n].copy_(emb, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        pend[s] = (ev, a, n)
+    for s in range(n_streams):
+        drain(s)
+    return r0, r1
+
+
 def _prefetch(gen, ahead):
     """Run generator `gen` on a reader thread, at most `ahead` items ahead of the consumer."""
     import queue

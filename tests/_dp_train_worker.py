@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_train_dp.py: one rank of a 2-process data-parallel train step.
+"""Worker of tests/test_gpu_train_dp.py: one rank of a 2- or 4-process data-parallel train step.
 Both ranks share cuda:0 and talk over gloo (the GPU box has one GPU; on a node the same code
 runs one rank per GPU over RCCL).  Usage: python -m torch.distributed.run ... _dp_train_worker.py OUT_DIR"""
 import os
@@ -27,6 +27,7 @@ class Identity:
 
 
 def main(out_dir, n=4):
+    n = int(n)
     dist.init_process_group('gloo')
     rank = dist.get_rank()
     torch.cuda.set_device(0)
@@ -54,4 +55,4 @@ def main(out_dir, n=4):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1])
+    main(*sys.argv[1:3])

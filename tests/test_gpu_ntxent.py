@@ -102,3 +102,82 @@ def test_ntxent_sharded_gradients_sum_to_full(nafp):
     scale = max(np.abs(wa).max(), np.abs(wb).max())
     assert np.abs(tot_a.cpu().numpy() - wa).max() < 2e-4 * scale + 1e-6
     assert np.abs(tot_b.cpu().numpy() - wb).max() < 2e-4 * scale + 1e-6
+
+
+# ---- BASELINE.json configs[2] (N = 640) and configs[3] (N = 2560, sharded 320 x 2560) at size -----------------------
+def _hard(n, seed, d=128):
+    return __import__('_inputs').unit_pairs(n, seed=seed, d=d, noise=1.5)
+
+
+@pytest.mark.parametrize('n', [640, 2560])
+def test_ntxent_at_baseline_sizes_loss_sim_and_gradient(nafp, n):
+    """NTxent_loss_single_gpu.py:52-82 at the anchor counts of BSZ 1280 and BSZ 5120: loss, the (N, 2N-1) sim_mtx
+    and both gradients vs the float64 oracle."""
+    a, b = _hard(n, 7000 + n)
+    obj = nafp.NTxentLoss(n_org=n, n_rep=n, tau=0.05)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    loss, sim, _ = obj.compute_loss(ta, tb)
+    wl, wsim, _ = o_nt.compute_loss(a, b, tau=0.05)
+    assert abs(float(loss) - wl) < 1e-4 * max(1.0, abs(wl))
+    assert sim.shape == (n, 2 * n - 1) and np.abs(sim.cpu().numpy() - wsim).max() < 1e-4
+    l2, da, db = obj.loss_and_grad(ta, tb)
+    wa, wb = o_nt.grad_embeddings(a, b, tau=0.05)
+    scale = max(np.abs(wa).max(), np.abs(wb).max())
+    assert abs(float(l2) - wl) < 1e-4 * max(1.0, abs(wl))
+    assert np.abs(da.cpu().numpy() - wa).max() < 2e-4 * scale + 1e-6
+    assert np.abs(db.cpu().numpy() - wb).max() < 2e-4 * scale + 1e-6
+
+
+def test_ntxent_sharded_320_of_2560_ranks_0_and_7(nafp):
+    """configs[3]: global batch 5120 over 8 ranks = 320 local anchors against 2560 gathered columns.  Per-rank loss
+    rows vs NTxent_loss_tpu.py:90-137 (`replica_loss_fn`) for the first and the last rank; the gradient w.r.t. the
+    gathered arrays, summed over all 8 ranks, vs the analytic gradient of the single-device loss."""
+    from neural_audio_fp_amd import _lib
+    from neural_audio_fp_amd.model.fp.NTxent_loss_single_gpu import _ntxent_call
+    lib = _lib.load()
+    R, n_a = 8, 320
+    a, b = _hard(R * n_a, 99)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    tot_a, tot_b, total = torch.zeros_like(ta), torch.zeros_like(tb), 0.0
+    for r in range(R):
+        sl = slice(r * n_a, (r + 1) * n_a)
+        loss_sum, _, da, db = _ntxent_call(lib, ta[sl].contiguous(), tb[sl].contiguous(), ta, tb, r * n_a, 0.05, False, True)
+        tot_a += da; tot_b += db; total += float(loss_sum)
+        if r in (0, R - 1):
+            want = o_nt.replica_loss_fn(np.concatenate([a[sl], b[sl]]), a, b, r, 0.05)
+            assert abs(float(loss_sum) - want.sum()) < 1e-4 * max(1.0, abs(want.sum()))
+    wl = o_nt.compute_loss(a, b, 0.05)[0]
+    assert abs(total / (R * n_a) - wl) < 1e-4 * max(1.0, abs(wl))
+    wa, wb = o_nt.grad_embeddings(a, b, 0.05)
+    scale = max(np.abs(wa).max(), np.abs(wb).max())
+    assert np.abs(tot_a.cpu().numpy() - wa).max() < 2e-4 * scale + 1e-6
+    assert np.abs(tot_b.cpu().numpy() - wb).max() < 2e-4 * scale + 1e-6
+
+
+@pytest.mark.parametrize('d', [64, 256])
+@pytest.mark.parametrize('n', [5, 97, 320])
+def test_ntxent_other_embedding_widths(nafp, n, d):
+    """MODEL.EMB_SZ 64 / 256 (nnfp.py:250): loss, sim_mtx, gradients, and one sharded rank."""
+    from neural_audio_fp_amd import _lib
+    from neural_audio_fp_amd.model.fp.NTxent_loss_single_gpu import _ntxent_call
+    a, b = _hard(n, 31 * n + d, d=d)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    obj = nafp.NTxentLoss(n_org=n, n_rep=n, tau=0.05)
+    loss, sim, _ = obj.compute_loss(ta, tb)
+    wl, wsim, _ = o_nt.compute_loss(a, b, tau=0.05)
+    assert abs(float(loss) - wl) < 1e-4 * max(1.0, abs(wl)) and np.abs(sim.cpu().numpy() - wsim).max() < 1e-4
+    _, da, db = obj.loss_and_grad(ta, tb)
+    wa, wb = o_nt.grad_embeddings(a, b, tau=0.05)
+    scale = max(np.abs(wa).max(), np.abs(wb).max())
+    assert np.abs(da.cpu().numpy() - wa).max() < 2e-4 * scale + 1e-6
+    assert np.abs(db.cpu().numpy() - wb).max() < 2e-4 * scale + 1e-6
+    if n == 97:                      # ragged split: rank 1 of 2 holds rows [48, 97)
+        lo = 48
+        ls, _, _, _ = _ntxent_call(_lib.load(), ta[lo:].contiguous(), tb[lo:].contiguous(), ta, tb, lo, 0.05, False, False)
+        # replica_loss_fn needs equal shards; take the rows of the single-device loss instead
+        a64, b64 = a.astype(np.float64), b.astype(np.float64)
+        la = np.concatenate([a64 @ b64.T, a64 @ a64.T], 1) / 0.05; lb = np.concatenate([b64 @ a64.T, b64 @ b64.T], 1) / 0.05
+        idx = np.arange(n)
+        la[idx, n + idx] = -np.inf; lb[idx, n + idx] = -np.inf
+        rows = (o_nt._lse(la) - la[idx, idx]) + (o_nt._lse(lb) - lb[idx, idx])
+        assert abs(float(ls) - rows[lo:].sum()) < 1e-4 * max(1.0, abs(rows[lo:].sum()))

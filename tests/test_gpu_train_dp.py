@@ -16,31 +16,36 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_rank_step_equals_single_process_step(nafp, tmp_path):
+@pytest.mark.parametrize('world,n', [(2, 4), (4, 2)])
+def test_multi_rank_step_equals_single_process_step(nafp, tmp_path, world, n):
+    """`world` ranks x n anchors each: all-gather of the embeddings, reduce-scatter of d(emb), the flat gradient
+    buffer all-reduced in NAFP_GRAD_GROUPS pieces on the communication stream behind the library's gradient-group
+    events (trainer.GradientBucket.all_reduce)."""
     from neural_audio_fp_amd.model import trainer as T
     from neural_audio_fp_amd.model.fp.lamb_optimizer import LAMB
-    n = 4
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
-    port = 29600 + (os.getpid() % 300)
-    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+    port = 29600 + (os.getpid() % 300) + world
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
                         '--master-addr', '127.0.0.1', '--master-port', str(port),
-                        os.path.join(ROOT, 'tests', '_dp_train_worker.py'), str(tmp_path)],
-                       env=env, capture_output=True, text=True, timeout=600)
+                        os.path.join(ROOT, 'tests', '_dp_train_worker.py'), str(tmp_path), str(n)],
+                       env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    r0 = torch.load(tmp_path / 'rank0.pt', weights_only=True)
-    r1 = torch.load(tmp_path / 'rank1.pt', weights_only=True)
-    assert r0['losses'] == r1['losses']
-    assert torch.equal(r0['grad0'], r1['grad0'])
-    for a, b in zip(r0['params'], r1['params']):
-        assert torch.equal(a, b)
-    # single process on the concatenated batch: anchors of rank 0 then rank 1, replicas likewise
-    (fa0, fp0), (fa1, fp1) = W.features(0, n), W.features(1, n)
-    X = (torch.from_numpy(np.concatenate([fa0, fa1])).cuda(), torch.from_numpy(np.concatenate([fp0, fp1])).cuda())
+    rs = [torch.load(tmp_path / f'rank{k}.pt', weights_only=True) for k in range(world)]
+    r0 = rs[0]
+    for rk in rs[1:]:
+        assert r0['losses'] == rk['losses']
+        assert torch.equal(r0['grad0'], rk['grad0'])
+        for a, b in zip(r0['params'], rk['params']):
+            assert torch.equal(a, b)
+    # single process on the concatenated batch: anchors of rank 0, 1, ... then the replicas likewise
+    feats = [W.features(k, n) for k in range(world)]
+    X = (torch.from_numpy(np.concatenate([f[0] for f in feats])).cuda(),
+         torch.from_numpy(np.concatenate([f[1] for f in feats])).cuda())
     m_fp = nafp.FingerPrinter(seed=0)
     m_fp.set_weights(_inputs.weight_list(_inputs.weights(seed=31)))
     bucket = T.GradientBucket(m_fp)
     opt = LAMB(learning_rate=1e-3)
-    loss_obj = nafp.NTxentLoss(n_org=2 * n, n_rep=2 * n, tau=0.05)
+    loss_obj = nafp.NTxentLoss(n_org=world * n, n_rep=world * n, tau=0.05)
     loss, _ = T.train_step(X, W.Identity(), W.Identity(), m_fp, loss_obj, opt, bucket)
     assert abs(float(loss) - r0['losses'][0]) < 1e-5 * max(1.0, abs(float(loss)))
     g1 = bucket.flat.cpu()
@@ -53,3 +58,29 @@ def test_two_rank_step_equals_single_process_step(nafp, tmp_path):
     loss2, _ = T.train_step(X, W.Identity(), W.Identity(), m_fp, loss_obj, opt, bucket)
     assert abs(float(loss2) - r0['losses'][1]) < 1e-3 * max(1.0, abs(float(loss2)))
     assert float(loss2) < float(loss)
+
+
+def test_weights_marked_dirty_then_four_streams(nafp):
+    """the re-pack of the weights (nafp_encoder_set_weights: copies, packs, G/Hb launches into the handle's
+    shared blob) is enqueued on ONE stream; forwards issued right afterwards on other streams must wait for it, and a
+    later re-pack must wait for the forwards still reading the old blob."""
+    rng = np.random.default_rng(3)
+    feat = torch.from_numpy((-rng.uniform(0, 1.2, size=(4, 640, 256, 32, 1))).astype(np.float32)).cuda()
+    m_fp = nafp.FingerPrinter(seed=1)
+    w_a, w_b = _inputs.weight_list(_inputs.weights(seed=5)), _inputs.weight_list(_inputs.weights(seed=6))
+    want = {}
+    for tag, w in (('a', w_a), ('b', w_b)):
+        m_fp.set_weights(w)
+        want[tag] = [m_fp(feat[k]).clone() for k in range(4)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    for rep in range(6):
+        tag, w = ('a', w_a) if rep % 2 == 0 else ('b', w_b)
+        m_fp.set_weights(w)                      # dirty: the next forward re-packs on ITS stream
+        outs = []
+        for k in range(4):
+            with torch.cuda.stream(streams[(k + rep) % 4]):
+                outs.append(m_fp(feat[k]))
+        torch.cuda.synchronize()
+        for k in range(4):
+            assert float((outs[k] - want[tag][k]).abs().max()) < 1e-6, (rep, k)
