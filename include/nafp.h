@@ -75,17 +75,26 @@ int nafp_melspec_n_mels(const nafp_melspec* plan);
  *   group_size the reference subtracts the max over the WHOLE device batch
  *              (melspectrogram.py:108); consecutive runs of group_size segments
  *              (last ragged) form one such batch.  <= 0 means one group.
- *   segment_norm  FEAT == 'melspec_maxnorm' (melspectrogram.py:110-111)
+ *   segment_norm  bit 0: FEAT == 'melspec_maxnorm' (melspectrogram.py:110-111);
+ *              bit 1 (NAFP_MELSPEC_DEFER): stop before melspectrogram.py:108 -- feat is the raw log10 mel and
+ *              group_stat the (max, min) per group; nafp_encoder_forward_raw finishes the layer inside its first
+ *              conv (one kernel and one round trip of the feature tensor through HBM fewer; same result)
  *   feat       out, (n_seg, n_mels, n_frames) float32 == the reference's
  *              (B, n_mels, n_frames, 1)
  *   group_stat scratch, 2*ceil(n_seg/group_size) floats (raw max / min per group)
  */
+#define NAFP_MELSPEC_DEFER 2
 int nafp_melspec_forward_f32(nafp_melspec* plan, const float* audio, int64_t n_seg,
                              int group_size, int segment_norm, float* feat,
                              float* group_stat, void* stream);
 int nafp_melspec_forward_i16(nafp_melspec* plan, const int16_t* audio, int64_t n_seg,
                              int group_size, int segment_norm, float* feat,
                              float* group_stat, void* stream);
+
+/* Finish a deferred call in place: feat <- max(feat - group max, -80) [, segment normalisation]
+ * (melspectrogram.py:108-111), for consumers other than nafp_encoder_forward_raw. */
+int nafp_melspec_finish(nafp_melspec* plan, float* feat, const float* group_stat, int64_t n_seg, int group_size,
+                        int segment_norm, void* stream);
 
 /* The same layer fed by WINDOWS of one int16 PCM arena instead of a materialised (n_seg, seg_len)
  * array: segment i starts at sample seg_offset[i] of `pcm` and has seg_valid[i] (<= seg_len) real
@@ -133,6 +142,14 @@ int64_t nafp_encoder_workspace_bytes(const nafp_encoder* enc, int64_t n_seg);
 int nafp_encoder_forward(nafp_encoder* enc, const float* feat, int64_t n_seg,
                          void* workspace, int64_t workspace_bytes,
                          float* out_flat, float* out_emb, int l2norm, void* stream);
+
+/* m_fp(m_pre(X)) with the tail of the log-mel layer (x - reduce_max(x), clamp at -80, optional segment
+ * normalisation: melspectrogram.py:108-111) applied by the first conv as it loads: raw_feat / group_stat are what
+ * nafp_melspec_forward_* leave with NAFP_MELSPEC_DEFER, group_size the same grouping.  Bit-identical to
+ * nafp_encoder_forward on the finished features. */
+int nafp_encoder_forward_raw(nafp_encoder* enc, const float* raw_feat, const float* group_stat, int group_size,
+                             int segment_norm, int64_t n_seg, void* workspace, int64_t workspace_bytes,
+                             float* out_flat, float* out_emb, int l2norm, void* stream);
 
 /* Per-kernel timing of nafp_encoder_forward with HIP events recorded on the
  * caller's stream (bench.py's roofline leg).  enable(max_forwards > 0) allocates a

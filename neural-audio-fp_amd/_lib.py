@@ -31,6 +31,7 @@ PROTOTYPES = {
     'nafp_melspec_n_mels': (c_int, [c_void_p]),
     'nafp_melspec_forward_f32': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'nafp_melspec_forward_i16': (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'nafp_melspec_finish': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p]),
     'nafp_melspec_forward_windows_i16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p,
                                                  c_void_p, c_void_p]),
     'nafp_encoder_create': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int]),
@@ -42,6 +43,8 @@ PROTOTYPES = {
     'nafp_encoder_set_weights': (c_int, [c_void_p, ctypes.POINTER(c_void_p), c_void_p]),
     'nafp_encoder_workspace_bytes': (c_i64, [c_void_p, c_i64]),
     'nafp_encoder_forward': (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_int, c_void_p]),
+    'nafp_encoder_forward_raw': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_i64, c_void_p, c_i64, c_void_p, c_void_p,
+                                         c_int, c_void_p]),
     'nafp_encoder_profile_enable': (c_int, [c_void_p, c_int]),
     'nafp_encoder_profile_count': (c_int, [c_void_p]),
     'nafp_encoder_profile_read': (c_int, [c_void_p, c_int, c_void_p]),

@@ -290,9 +290,28 @@ extern "C" int64_t nafp_encoder_workspace_bytes(const nafp_encoder* e, int64_t n
     return stats + a + b + align_up(slab * (int64_t)sizeof(float), 256) + 256;
 }
 
+static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float* gstat, int group_size, int segment_norm,
+                                int64_t n_seg, void* workspace, int64_t workspace_bytes, float* out_flat,
+                                float* out_emb, int l2norm, void* stream);
+
 extern "C" int nafp_encoder_forward(nafp_encoder* e, const float* feat, int64_t n_seg,
                                     void* workspace, int64_t workspace_bytes,
                                     float* out_flat, float* out_emb, int l2norm, void* stream) {
+    return encoder_forward_impl(e, feat, nullptr, 0, 0, n_seg, workspace, workspace_bytes, out_flat, out_emb, l2norm, stream);
+}
+
+extern "C" int nafp_encoder_forward_raw(nafp_encoder* e, const float* raw_feat, const float* group_stat, int group_size,
+                                        int segment_norm, int64_t n_seg, void* workspace, int64_t workspace_bytes,
+                                        float* out_flat, float* out_emb, int l2norm, void* stream) {
+    if (!group_stat) return NAFP_ERR_INVALID_ARG;
+    if (group_size <= 0 || group_size > n_seg) group_size = (int)std::min<int64_t>(n_seg, INT32_MAX);   // as the front end
+    return encoder_forward_impl(e, raw_feat, group_stat, group_size, segment_norm & 1, n_seg, workspace, workspace_bytes,
+                                out_flat, out_emb, l2norm, stream);
+}
+
+static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float* gstat, int group_size, int segment_norm,
+                                int64_t n_seg, void* workspace, int64_t workspace_bytes, float* out_flat,
+                                float* out_emb, int l2norm, void* stream) {
     if (!e || !feat || !workspace || n_seg < 0) return NAFP_ERR_INVALID_ARG;
     if (!e->has_weights) return NAFP_ERR_NO_WEIGHTS;
     if (n_seg == 0) return NAFP_OK;
@@ -316,8 +335,10 @@ extern "C" int nafp_encoder_forward(nafp_encoder* e, const float* feat, int64_t 
     // computed here and conv1 re-generates z0 tiles in-kernel from the log-mel features
     // (NAFP_FUSE0=0 selects the materialised path).
     const bool fuse0 = e->opt_fuse_conv0 && e->geom[1].axis == 1 && e->geom[1].Cin % 16 == 0;
+    if (fuse0 && gstat) return NAFP_ERR_UNSUPPORTED;          // the in-kernel conv0 generator reads finished features
     int rc = fuse0 ? launch_conv0_stats(feat, e->d_w[0], e->d_bias[0], stats, n_seg, e->geom[0], st)
-                   : launch_conv0(feat, e->d_w[0], e->d_bias[0], e->d_gamma[0], bufA, nullptr, stats, n_seg, e->geom[0], st);
+                   : launch_conv0(feat, e->d_w[0], e->d_bias[0], e->d_gamma[0], bufA, nullptr, stats, n_seg, e->geom[0], st,
+                                  gstat, group_size, segment_norm);
     if (rc != NAFP_OK) return rc;
     if (ev) NAFP_HIP_CHECK(hipEventRecord(ev[1], st));
     float* cur = bufA;

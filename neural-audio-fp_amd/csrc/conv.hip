@@ -44,10 +44,33 @@ template <bool STORE, int ROWS0>
 __global__ __launch_bounds__(256) void conv0_kernel(
         const float* __restrict__ feat, const float* __restrict__ w3, const float* __restrict__ bias,
         const float* __restrict__ gamma, float* __restrict__ y, float* __restrict__ v_out,
-        double* __restrict__ stats, int F, int Tin, int Tout, int Cout, int stride, int pad) {
+        double* __restrict__ stats, int F, int Tin, int Tout, int Cout, int stride, int pad,
+        const float* __restrict__ gstat, int group_size, int segment_norm) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int blocks_per_sample = (F + ROWS0 - 1) / ROWS0;
     const int64_t b = blockIdx.x / blocks_per_sample;
+    // gstat != null: `feat` is the RAW log-mel of the front end (melspec.hip with NAFP_MELSPEC_DEFER) and the
+    // batch-max subtraction, clamp and optional segment normalisation (melspectrogram.py:108-111) happen here, on
+    // load -- the same float operations in the same order as melspec_finalize_kernel, so the result is bit-identical
+    // and the log-mel tensor crosses HBM once less in each direction.
+    float gmax = 0.f, nh = 0.f, nd = 1.f;
+    if (gstat) {
+        const int64_t g = group_size > 0 ? b / group_size : 0;
+        gmax = gstat[2 * g];
+        if (segment_norm) {
+            const float mn = fmaxf(gstat[2 * g + 1] - gmax, -80.f);
+            nh = mn / 2.f; nd = fabsf(nh + 1e-10f);
+        }
+    }
+    auto ld = [&](const float* xr, int t) -> float {
+        if (t < 0 || t >= Tin) return 0.f;                 // conv zero padding (of the NORMALISED features)
+        float v = xr[t];
+        if (gstat) {
+            v = fmaxf(v - gmax, -80.f);
+            if (segment_norm) v = (v - nh) / nd;
+        }
+        return v;
+    };
     const int f0 = (blockIdx.x % blocks_per_sample) * ROWS0;
     const int cgroups = Cout / 4;                   // float4 groups per position
     const int pos_per_iter = 256 / cgroups;         // positions covered per iteration (8 for Cout=128)
@@ -66,9 +89,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(
         const int r = p / Tout, to = p % Tout;
         const int t0 = to * stride - pad;
         const float* xr = xin + r * Tin;
-        const float x0 = (t0 >= 0 && t0 < Tin) ? xr[t0] : 0.f;
-        const float x1 = (t0 + 1 >= 0 && t0 + 1 < Tin) ? xr[t0 + 1] : 0.f;
-        const float x2 = (t0 + 2 >= 0 && t0 + 2 < Tin) ? xr[t0 + 2] : 0.f;
+        const float x0 = ld(xr, t0), x1 = ld(xr, t0 + 1), x2 = ld(xr, t0 + 2);
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         if (STORE) g = *(const float4*)(gin + (int64_t)p * Cout + 4 * cg);
         float4 v;
@@ -94,11 +115,13 @@ __global__ __launch_bounds__(256) void conv0_kernel(
 }
 
 int launch_conv0(const float* feat, const float* w3, const float* bias, const float* gamma, float* y,
-                 float* v_out, double* stats, int64_t B, const ConvGeom& g, hipStream_t st) {
+                 float* v_out, double* stats, int64_t B, const ConvGeom& g, hipStream_t st, const float* gstat,
+                 int group_size, int segment_norm) {
     if (g.Cin != 1 || g.axis != 0 || (g.Cout % 4) != 0 || 256 % (g.Cout / 4) != 0) return NAFP_ERR_UNSUPPORTED;
     const int64_t blocks = B * ((g.Fin + ROWS0 - 1) / ROWS0);
     conv0_kernel<true, ROWS0><<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, gamma, y, v_out, stats, g.Fin,
-                                                                      g.Tin, g.Tout, g.Cout, g.stride, g.pad);
+                                                                      g.Tin, g.Tout, g.Cout, g.stride, g.pad, gstat,
+                                                                      group_size, segment_norm);
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }
@@ -109,7 +132,7 @@ int launch_conv0_stats(const float* feat, const float* w3, const float* bias, do
     constexpr int R = 32;
     const int64_t blocks = B * ((g.Fin + R - 1) / R);
     conv0_kernel<false, R><<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, nullptr, nullptr, nullptr, stats,
-                                                                   g.Fin, g.Tin, g.Tout, g.Cout, g.stride, g.pad);
+                                                                   g.Fin, g.Tin, g.Tout, g.Cout, g.stride, g.pad, nullptr, 0, 0);
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }

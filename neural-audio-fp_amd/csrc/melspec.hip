@@ -391,6 +391,8 @@ static int melspec_forward(nafp_melspec* p, const TIn* audio, int64_t n_seg, int
         audio, seg_offset, seg_valid, feat, group_stat, p->d_twiddle, p->d_window, p->d_mel_start, p->d_mel_w,
         p->seg_len, p->n_frames, p->n_mels, group_size);
     NAFP_LAUNCH_CHECK();
+    if (segment_norm & NAFP_MELSPEC_DEFER) return NAFP_OK;   // raw log-mel + group_stat: the consumer finishes
+    segment_norm &= 1;
     const int per_seg = p->n_mels * p->n_frames;     // multiple of 4 (n_mels % 64 == 0)
     const int64_t n_vec4 = n_seg * per_seg / 4;
     const int blocks = (int)std::min<int64_t>((n_vec4 + 255) / 256, 2048);
@@ -485,6 +487,20 @@ extern "C" int nafp_melspec_forward_i16(nafp_melspec* plan, const int16_t* audio
                                         int group_size, int segment_norm, float* feat,
                                         float* group_stat, void* stream) {
     return melspec_forward<int16_t>(plan, audio, n_seg, group_size, segment_norm, feat, group_stat, stream);
+}
+
+extern "C" int nafp_melspec_finish(nafp_melspec* p, float* feat, const float* group_stat, int64_t n_seg, int group_size,
+                                   int segment_norm, void* stream) {
+    if (!p || !feat || !group_stat || n_seg < 0) return NAFP_ERR_INVALID_ARG;
+    if (n_seg == 0) return NAFP_OK;
+    if (group_size <= 0 || group_size > n_seg) group_size = (int)std::min<int64_t>(n_seg, INT32_MAX);
+    const int per_seg = p->n_mels * p->n_frames;
+    const int64_t n_vec4 = n_seg * per_seg / 4;
+    const int blocks = (int)std::min<int64_t>((n_vec4 + 255) / 256, 2048);
+    melspec_finalize_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(feat, group_stat, n_vec4, per_seg / 4, group_size,
+                                                                     segment_norm & 1);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
 }
 
 extern "C" int nafp_melspec_forward_windows_i16(nafp_melspec* plan, const int16_t* pcm, const int64_t* seg_offset,

@@ -86,8 +86,11 @@ __device__ __forceinline__ void atomic_min_float(float* addr, float v) {
 
 // conv0: (B,F,T) x kernel(3,Cout) -> z0 = gamma0 . ELU(conv + bias), (B,F,Tout,Cout),
 // + per-sample sum/sumsq of the ELU output.
+// gstat != nullptr: `feat` is the raw log-mel and (max, min) per group of `group_size` samples; the batch-max
+// subtraction / clamp / segment normalisation of melspectrogram.py:108-111 is applied on load.
 int launch_conv0(const float* feat, const float* w3, const float* bias, const float* gamma, float* y,
-                 float* v_out, double* stats, int64_t B, const ConvGeom& g, hipStream_t st);
+                 float* v_out, double* stats, int64_t B, const ConvGeom& g, hipStream_t st,
+                 const float* gstat = nullptr, int group_size = 0, int segment_norm = 0);
 
 // implicit-GEMM conv (see conv.hip for the LayerNorm folding).
 struct ConvGemmArgs {

@@ -19,6 +19,26 @@ import torch
 from .... import _lib
 
 
+class DeferredFeatures:
+    """What `Melspec_layer(x, defer=True)` returns: the raw log10-mel tensor plus the per-group (max, min), i.e. the
+    layer stopped before `x - reduce_max(x)` (melspectrogram.py:108).  `m_fp(deferred)` finishes the layer inside its
+    first conv (nafp_encoder_forward_raw): same fingerprints, one kernel and one round trip of the feature tensor
+    through HBM fewer.  `.finish()` materialises the ordinary (B, n_mels, n_frames, 1) tensor."""
+
+    def __init__(self, layer, raw, gstat, group_size, segment_norm):
+        self.layer, self.raw, self.gstat = layer, raw, gstat
+        self.group_size, self.segment_norm = int(group_size), bool(segment_norm)
+        self.shape, self.device = raw.shape, raw.device
+
+    def finish(self):
+        out = self.raw.clone()
+        lay = self.layer
+        with torch.cuda.device(out.device):
+            _lib.check(lay._lib.nafp_melspec_finish(lay._h, _lib.ptr(out), _lib.ptr(self.gstat), out.shape[0], self.group_size,
+                                                    int(self.segment_norm), _lib.current_stream()), 'melspec_finish')
+        return out
+
+
 class Melspec_layer:
     def __init__(self, input_shape=(1, 8000), segment_norm=False, n_fft=1024, stft_hop=256,
                  n_mels=256, fs=8000, dur=1., f_min=300., f_max=4000., amin=1e-10,
@@ -51,7 +71,8 @@ class Melspec_layer:
             self._lib.nafp_melspec_destroy(h)
             self._h = None
 
-    def __call__(self, x, group_size=None):
+    def __call__(self, x, group_size=None, defer=False):
+        """`defer=True`: return `DeferredFeatures` (raw log-mel + group statistics) for `m_fp` to finish."""
         x = torch.as_tensor(x)
         if not x.is_cuda:
             x = x.cuda()
@@ -67,13 +88,14 @@ class Melspec_layer:
         feat = torch.empty((B, self.n_mels, self.n_frames, 1), dtype=torch.float32, device=x.device)
         gstat = torch.empty((2 * max(n_groups, 1),), dtype=torch.float32, device=x.device)
         fn = self._lib.nafp_melspec_forward_i16 if x.dtype == torch.int16 else self._lib.nafp_melspec_forward_f32
+        flags = int(bool(self.segment_norm)) | (2 if defer else 0)            # NAFP_MELSPEC_DEFER
         with torch.cuda.device(x.device):
-            _lib.check(fn(self._h, _lib.ptr(x), B, g, int(bool(self.segment_norm)), _lib.ptr(feat),
+            _lib.check(fn(self._h, _lib.ptr(x), B, g, flags, _lib.ptr(feat),
                           _lib.ptr(gstat), _lib.current_stream()), 'melspec_forward')
-        return feat
+        return DeferredFeatures(self, feat, gstat, g, self.segment_norm) if defer else feat
 
 
-    def forward_windows(self, pcm, seg_offset, seg_valid, group_size=None):
+    def forward_windows(self, pcm, seg_offset, seg_valid, group_size=None, defer=False):
         """Same output as __call__ on the materialised segments: segment i = pcm[seg_offset[i] :
         seg_offset[i] + seg_len] with samples >= seg_valid[i] read as zero.  pcm int16 (n,),
         seg_offset int64 (B,), seg_valid int32 (B,), all CUDA."""
@@ -89,11 +111,12 @@ class Melspec_layer:
         n_groups = 1 if g <= 0 else (B + g - 1) // g
         feat = torch.empty((B, self.n_mels, self.n_frames, 1), dtype=torch.float32, device=pcm.device)
         gstat = torch.empty((2 * max(n_groups, 1),), dtype=torch.float32, device=pcm.device)
+        flags = int(bool(self.segment_norm)) | (2 if defer else 0)
         with torch.cuda.device(pcm.device):
             _lib.check(self._lib.nafp_melspec_forward_windows_i16(
-                self._h, _lib.ptr(pcm), _lib.ptr(seg_offset), _lib.ptr(seg_valid), B, g, int(bool(self.segment_norm)),
+                self._h, _lib.ptr(pcm), _lib.ptr(seg_offset), _lib.ptr(seg_valid), B, g, flags,
                 _lib.ptr(feat), _lib.ptr(gstat), _lib.current_stream()), 'melspec_forward_windows')
-        return feat
+        return DeferredFeatures(self, feat, gstat, g, self.segment_norm) if defer else feat
 
 
 def get_melspec_layer(cfg, trainable=False):

@@ -14,6 +14,7 @@ dirty.  No CPU path.
 """
 import ctypes
 import math
+import os
 
 import torch
 
@@ -69,6 +70,7 @@ class FingerPrinter:
         self._vars = self._init_variables(seed)
         self._dirty = True
         self._weights_event, self._weights_stream, self._use_events = None, None, {}
+        self._fuse0 = os.environ.get('NAFP_FUSE0', '') == '1'          # NAFP_OPT_FUSE_CONV0 (the library reads the same variable)
         self._ws = {}          # one workspace per HIP stream: batches may be pipelined across streams
 
     # ---- parameters -------------------------------------------------------
@@ -190,6 +192,12 @@ class FingerPrinter:
         return ws, need
 
     def _forward(self, feat, want_flat, want_emb):
+        deferred = None
+        if hasattr(feat, 'raw') and hasattr(feat, 'gstat'):        # melspectrogram.DeferredFeatures
+            if self._fuse0:
+                feat = feat.finish()
+            else:
+                deferred, feat = feat, feat.raw
         feat = self._prep(feat, self.input_shape)
         self._sync()
         B = feat.shape[0]
@@ -197,10 +205,17 @@ class FingerPrinter:
         emb = torch.empty((B, self.emb_sz), dtype=torch.float32, device=feat.device) if want_emb else None
         ws, need = self._workspace(B)
         with torch.cuda.device(feat.device):
-            _lib.check(self._lib.nafp_encoder_forward(self._h, _lib.ptr(feat), B, _lib.ptr(ws), need,
-                                                      _lib.ptr(flat), _lib.ptr(emb),
-                                                      int(bool(self.use_L2layer)), _lib.current_stream()),
-                       'encoder_forward')
+            if deferred is not None:
+                _lib.check(self._lib.nafp_encoder_forward_raw(self._h, _lib.ptr(feat), _lib.ptr(deferred.gstat),
+                                                              deferred.group_size, int(deferred.segment_norm), B,
+                                                              _lib.ptr(ws), need, _lib.ptr(flat), _lib.ptr(emb),
+                                                              int(bool(self.use_L2layer)), _lib.current_stream()),
+                           'encoder_forward_raw')
+            else:
+                _lib.check(self._lib.nafp_encoder_forward(self._h, _lib.ptr(feat), B, _lib.ptr(ws), need,
+                                                          _lib.ptr(flat), _lib.ptr(emb),
+                                                          int(bool(self.use_L2layer)), _lib.current_stream()),
+                           'encoder_forward')
             self._mark_use()
         return flat, emb
 
@@ -258,6 +273,8 @@ class FingerPrinter:
 
     def set_option(self, option, value):
         """Execution options of the library handle (include/nafp.h NAFP_OPT_*); results do not change."""
+        if int(option) == 1:
+            self._fuse0 = bool(value)
         _lib.check(self._lib.nafp_encoder_set_option(self._h, int(option), int(value)), 'encoder_set_option')
 
     # ---- per-kernel HIP-event timing (bench.py roofline leg) ----------------

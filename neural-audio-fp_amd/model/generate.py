@@ -135,9 +135,9 @@ def get_data_source(cfg, source_root_dir, skip_dummy):
 
 
 def test_step(X, m_pre, m_fp, group_size=None):
-    """generate.py:83-88: m_fp(m_pre(X))."""
+    """generate.py:83-88: m_fp(m_pre(X)) (the layer's max subtraction is finished inside the encoder's first conv)."""
     m_fp.trainable = False
-    return m_fp(m_pre(X, group_size=group_size))
+    return m_fp(m_pre(X, group_size=group_size, defer=True))
 
 
 def shard_rows(n_items, group, rank, world):
@@ -222,7 +222,7 @@ def write_fingerprints_from_device_rows(row_fn, n_items, m_pre, m_fp, arr, group
         drain(s)
         n = min(launch, r1 - a)
         with torch.cuda.stream(streams[s]):
-            emb = m_fp(m_pre(row_fn(a, n), group_size=group))
+            emb = m_fp(m_pre(row_fn(a, n), group_size=group, defer=True))
             host[s][:n].copy_(emb, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
@@ -308,7 +308,7 @@ class StreamedEmbedder:
     def embed_device(self, X):
         """(n,1,T) CUDA batch -> fingerprints; the batch is one max-normalisation group."""
         self.m_fp.trainable = False
-        return self.m_fp(self.m_pre(X, group_size=len(X)))
+        return self.m_fp(self.m_pre(X, group_size=len(X), defer=True))
 
     # ---- window path: the next launch's PCM is read straight into this slot's pinned arena ----
     def alloc(self, n_samples):
@@ -336,7 +336,8 @@ class StreamedEmbedder:
             pcm = pcm_host[:max(used, 1)].cuda(non_blocking=True)
             d_idx = idx[:, :n].cuda(non_blocking=True)
             self.m_fp.trainable = False
-            feat = self.m_pre.forward_windows(pcm, d_idx[0].contiguous(), d_idx[1].to(torch.int32), group_size=group)
+            feat = self.m_pre.forward_windows(pcm, d_idx[0].contiguous(), d_idx[1].to(torch.int32), group_size=group,
+                                              defer=True)
             emb = self.m_fp(feat)
             out = self.h_out[k][:n]
             out.copy_(emb, non_blocking=True)

@@ -122,3 +122,28 @@ def test_melspec_two_second_segments(nafp, cfg):
     want = o_mel.melspec_layer(x, dtype=np.float64)
     assert got.shape == want.shape == (3, 256, 63, 1)
     assert np.abs(got - want).max() < 2e-5
+
+
+@pytest.mark.parametrize('feat_kind', ['melspec', 'melspec_maxnorm'])
+def test_deferred_log_mel_tail_is_bit_identical(nafp, cfg, feat_kind):
+    """`x - reduce_max(x)`, the clamp and the optional segment normalisation
+    (melspectrogram.py:108-111) applied by conv0 as it loads (nafp_encoder_forward_raw) instead of by a separate pass
+    over the feature tensor: same float operations in the same order -> the fingerprints must not move by one bit."""
+    import copy
+    c = copy.deepcopy(cfg); c['MODEL']['FEAT'] = feat_kind
+    m_pre = nafp.get_melspec_layer(c)
+    m_fp = nafp.FingerPrinter(seed=3)
+    x = torch.from_numpy(_audio(253, seed=77)).cuda()
+    xi = (x * 32768.0).clamp(-32768, 32767).to(torch.int16)
+    for inp in (x, xi):
+        for g in (None, 125, 7):
+            ref_feat = m_pre(inp, group_size=g)
+            d = m_pre(inp, group_size=g, defer=True)
+            assert torch.equal(d.finish(), ref_feat)
+            ref = m_fp(ref_feat)
+            got = m_fp(d)
+            # the per-sample LayerNorm statistics are double atomics whose order varies run to run: 1e-6, like
+            # two runs of the same path (test_batch_independence_and_ragged_sizes)
+            assert float((got - ref).abs().max()) < 1e-6
+            flat_ref, flat = m_fp.front_conv(ref_feat), m_fp.front_conv(d)
+            assert float((flat - flat_ref).abs().max()) < 1e-5
