@@ -290,11 +290,12 @@ def main():
         conv0_ms = sum(p[0] for p in prof) / len(prof)
         tail_ms = sum(p[16] for p in prof) / len(prof)
         value = world * BSZ * args.steps / el
-        traffic, traffic_src = None, None
+        traffic, traffic_src, fe_traffic = None, None, None
         tp = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tp):          # PMC passes cannot run inside this process: profiles/ holds them
             tj = json.load(open(tp))
             traffic = tj.get('per_launch_bytes')
+            fe_traffic = (tj.get('frontend') or {}).get('bytes_per_launch')
             traffic_src = f"profiles/traffic.json ({tj.get('tag')}: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
         out = {
             'metric': 'fingerprint generation throughput (1-s segments/s)',
@@ -319,8 +320,12 @@ def main():
             'stage_ms_per_step': {'melspec(2 kernels)': round(mel_ms, 4), 'conv0': round(conv0_ms, 4),
                                   'conv_gemm x15': round(gemm_ms, 4), 'tail': round(tail_ms, 4),
                                   'per_conv': [round(sum(p[k] for p in prof) / len(prof), 4) for k in range(17)]},
-            'frontend_hbm': {'algorithmic_bytes_per_segment': 32000 + 32768,
-                             'GB/s': round(BSZ * (32000 + 32768) / (mel_ms * 1e-3) / 1e9, 2)},
+            'frontend_hbm': {'bound': 'hbm', 'kernel': 'melspec_kernel (STFT + mel + log; the max subtraction is applied by conv0 on load)',
+                             'algorithmic_bytes_per_segment': 32000 + 32768,
+                             'achieved': round(BSZ * (32000 + 32768) / (mel_ms * 1e-3) / 1e9, 2), 'peak': 8000.0, 'unit': 'GB/s',
+                             'frac': round(BSZ * (32000 + 32768) / (mel_ms * 1e-3) / 1e9 / 8000.0, 4),
+                             'traffic': fe_traffic, 'traffic_unit': 'bytes/launch (640 segments)',
+                             'traffic_ratio_to_algorithmic': round(fe_traffic / (BSZ * (32000 + 32768)), 3) if fe_traffic else None},
         }
         out['config']['streams'] = n_str
         if pipelined:

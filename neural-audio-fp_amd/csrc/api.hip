@@ -415,7 +415,7 @@ struct TrainLayout {
     // zeroed together at the start of the backward pass: per-layer LN sums, S1/S2 of every layer
     char* zero_begin; int64_t zero_bytes;
     double* lnsum[16]; float* S1[16]; float* S2[16];
-    float* z[16]; float* v[16];
+    float* z[16]; float* v[16];          // z = gamma . ELU(t) (operand of the next conv), v = the pre-activation t
     float* slab; int64_t slab_floats;
     float* dA; float* dB; float* dy;
     int64_t bytes;
@@ -528,7 +528,7 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
         const int P = g.Fout * g.Tout;
         const float* mr_j = L.mr + 2 * B * j; const float* mr_p = L.mr + 2 * B * (j - 1);
         rc = launch_ln_bwd(cur, L.v[j], e->d_gamma[j], mr_j, mr_p, L.lnsum[j], L.sc, grads[4 * j + 2], grads[4 * j + 3],
-                           grads[4 * j + 1], L.S1[j], L.S2[j], B, P, g.Cout, st);
+                           grads[4 * j + 1], L.S1[j], L.S2[j], B, P, g.Cout, st, j == 15, e->d_G[j], e->d_Hb[j], L.lnsum[j - 1]);
         if (rc != NAFP_OK) return rc;
         // dW_j = wgrad(z_{j-1}, r dt) + wgrad(gamma_{j-1}, sum_b c_b dt) + wgrad(beta_{j-1}, sum_b dt)
         rc = launch_wgrad(L.z[j - 1], cur, grads[4 * j], B, g, st);
@@ -551,7 +551,7 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
     {
         const ConvGeom& g = e->geom[0];
         rc = launch_ln_bwd(cur, L.v[0], e->d_gamma[0], L.mr, nullptr, L.lnsum[0], L.sc, grads[2], grads[3], grads[1],
-                           nullptr, nullptr, B, g.Fout * g.Tout, g.Cout, st);
+                           nullptr, nullptr, B, g.Fout * g.Tout, g.Cout, st, false, nullptr, nullptr, nullptr);
         if (rc != NAFP_OK) return rc;
         rc = launch_conv0_bwd(feat, cur, grads[0], nullptr, B, g, st);
         if (rc != NAFP_OK) return rc;

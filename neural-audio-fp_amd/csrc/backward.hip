@@ -4,11 +4,19 @@
 // Per conv layer j the forward graph is  t = conv_j(xhat_{j-1}) + bias,  v = ELU(t),
 // xt = (v - mu_b) r_b,  xhat_j = xt*gamma_j + beta_j  (LayerNorm over (F,T,C) per sample).
 // Given dxh = dL/dxhat_j the kernels here produce
-//   ln_bwd_reduce   s1_b = sum g, s2_b = sum g*xt            (g = dxh*gamma)
-//   ln_bwd_fused    dt = r_b (g - s1/n - xt*s2/n) * ELU'(v); dts = r_{j-1,b} * dt [in place];
+//   ln_bwd_reduce   s1_b = sum g, s2_b = sum g*xt            (g = dxh*gamma)  -- TOP layer only, see below
+//   ln_bwd_fused    dt = r_b (g - s1/n - xt*s2/n) * ELU'(t); dts = r_{j-1,b} * dt [in place];
 //                   dgamma = sum_b dxh*xt, dbeta = sum_b dxh, dbias = sum dt,
 //                   S1 = sum_b c_{j-1,b} dt, S2 = sum_b dt   (c = -mu r of the layer below)
 //                   (one pass: 2 reads + 1 write of the activation-sized arrays)
+//                   + the (s1, s2) of the layer BELOW, without touching that layer's arrays: the gradient that
+//                   layer j-1 will receive is D'_{j-1} = conv_j^T(dts_j), and for any image u
+//                       sum_x D'_{j-1}(x) u(x) = sum_y dts_j(y) conv_j(u)(y)           (adjoint of the conv)
+//                   so  s1_{j-1} = sum D' gamma_{j-1}        = sum_y dts_j(y) G_j(y)            (G_j = conv_j(gamma_{j-1}))
+//                       s2_{j-1} = sum D' (xhat_{j-1} - beta) = sum_y dts_j(y) (t_j(y) - Hb_j(y))  (t_j = conv_j(xhat_{j-1}) + bias,
+//                                                                                               Hb_j = conv_j(beta_{j-1}) + bias)
+//                   with G_j, Hb_j the positional tensors of the forward pass and t_j the stored pre-activation.
+//                   This replaces a separate reduction pass (2 reads of activation-sized arrays per layer).
 //   wgrad           dW_j[tap,c,n] += sum_{b,pos} X[b, in(pos,tap), c] * D[b,pos,n]   (fp32 MFMA)
 // and the transposed conv (dgrad) comes from conv_gemm in DGRAD mode.  With the LayerNorm fold
 // of the forward pass, xhat_{j-1} = r z + c gamma + beta, so
@@ -36,16 +44,17 @@ __global__ void stats_to_mr_kernel(const double* __restrict__ stats, float* __re
 }
 
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(
-        const float* __restrict__ dxh, const float* __restrict__ v, const float* __restrict__ gamma,
+        const float* __restrict__ dxh, const float* __restrict__ tpre, const float* __restrict__ gamma,
         const float* __restrict__ mr, double* __restrict__ lnsum, int64_t n) {
     const int64_t b = blockIdx.y;
     const float mean = mr[2 * b], rstd = mr[2 * b + 1];
     const float4* d4 = (const float4*)(dxh + b * n);
-    const float4* v4 = (const float4*)(v + b * n);
+    const float4* v4 = (const float4*)(tpre + b * n);
     const float4* g4 = (const float4*)gamma;
     float s1 = 0.f, s2 = 0.f;
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n / 4; i += (int64_t)gridDim.x * 256) {
-        const float4 d = d4[i], vv = v4[i], gg = g4[i];
+        const float4 d = d4[i], tq = v4[i], gg = g4[i];
+        const float4 vv = make_float4(elu1(tq.x), elu1(tq.y), elu1(tq.z), elu1(tq.w));
         const float g0 = d.x * gg.x, g1 = d.y * gg.y, g2 = d.z * gg.z, g3 = d.w * gg.w;
         s1 += (g0 + g1) + (g2 + g3);
         s2 += g0 * ((vv.x - mean) * rstd) + g1 * ((vv.y - mean) * rstd) + g2 * ((vv.z - mean) * rstd) +
@@ -90,35 +99,61 @@ __global__ void ln_bwd_scalars_kernel(const float* __restrict__ mr, const double
 // Thread <-> one float4 of the (P, C) plane, loop over a chunk of the batch (blockIdx.y): every
 // per-element sum over b stays in registers and meets the other chunks through one atomic each.
 __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
-        float* __restrict__ d, const float* __restrict__ v, const float* __restrict__ gamma,
+        float* __restrict__ d, const float* __restrict__ tpre, const float* __restrict__ gamma,
         const float* __restrict__ sc, float* __restrict__ dgamma, float* __restrict__ dbeta,
-        float* __restrict__ dbias, float* __restrict__ S1, float* __restrict__ S2, int64_t n, int64_t B, int C) {
+        float* __restrict__ dbias, float* __restrict__ S1, float* __restrict__ S2, int64_t n, int64_t B, int C,
+        const float* __restrict__ Gj, const float* __restrict__ Hbj, double* __restrict__ lnsum_below) {
+    extern __shared__ float s_q[];                                 // [per][2]: (s1, s2) of the layer below, this block's share
     const int64_t i = blockIdx.x * 256ll + threadIdx.x;
     const bool live = i < n / 4;
     const int64_t ii = live ? i : 0;
     const int64_t per = (B + gridDim.y - 1) / gridDim.y;
     const int64_t b0 = blockIdx.y * per, b1 = std::min<int64_t>(B, b0 + per);
     const float4 gg = ((const float4*)gamma)[ii];
+    float4 Gq = make_float4(0.f, 0.f, 0.f, 0.f), Hq = Gq;
+    if (lnsum_below) {
+        Gq = ((const float4*)Gj)[ii]; Hq = ((const float4*)Hbj)[ii];
+        for (int64_t k = threadIdx.x; k < 2 * per; k += 256) s_q[k] = 0.f;
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
     float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag, a1 = ag, a2 = ag;
 #pragma unroll 2
     for (int64_t b = b0; b < b1; ++b) {
         const float4 s0 = *(const float4*)(sc + 8 * b), s1 = *(const float4*)(sc + 8 * b + 4);
         const float mean = s0.x, rstd = s0.y, m1 = s0.z, m2 = s0.w, inv_r = s1.x, rprev = s1.y, cprev = s1.z;
         float4* dp = (float4*)(d + b * n) + ii;
-        const float4 dd = *dp, vv = ((const float4*)(v + b * n))[ii];
+        const float4 dd = *dp, tt = ((const float4*)(tpre + b * n))[ii];
         float4 o;
+        float q1 = 0.f, q2 = 0.f;
 #define NAFP_LN_ONE(c_)                                                                     \
         {                                                                                   \
-            const float xt = (vv.c_ - mean) * rstd;                                         \
-            const float dt = (dd.c_ * gg.c_ - m1 - xt * m2) * (vv.c_ > 0.f ? 1.f : vv.c_ + 1.f);   /* ELU'(t) = v + 1, t <= 0 */ \
+            const float vv_l = elu1(tt.c_);                                                 \
+            const float xt = (vv_l - mean) * rstd;                                          \
+            const float dt = (dd.c_ * gg.c_ - m1 - xt * m2) * (vv_l > 0.f ? 1.f : vv_l + 1.f);   /* ELU'(t) = v + 1, t <= 0 */ \
             const float du = dd.c_ * inv_r;                                                 \
             ag.c_ = fmaf(du, xt, ag.c_); ab.c_ += du;                                       \
             o.c_ = dt * rprev;                                                              \
             a1.c_ = fmaf(cprev, o.c_, a1.c_); a2.c_ += dt;                                  \
+            q1 = fmaf(o.c_, Gq.c_, q1); q2 = fmaf(o.c_, tt.c_ - Hq.c_, q2);                 \
         }
         NAFP_LN_ONE(x) NAFP_LN_ONE(y) NAFP_LN_ONE(z) NAFP_LN_ONE(w)
 #undef NAFP_LN_ONE
         if (live) *dp = o;
+        if (lnsum_below) {
+            // wave sums of (q1, q2) in 7 shuffles: fold the halves, then q1 lives in lanes 0..31 and q2 in 32..63
+            if (!live) { q1 = 0.f; q2 = 0.f; }
+            q1 += __shfl_xor(q1, 32, 64); q2 += __shfl_xor(q2, 32, 64);
+            float x = lane < 32 ? q1 : q2;
+#pragma unroll
+            for (int o2 = 16; o2 > 0; o2 >>= 1) x += __shfl_xor(x, o2, 64);
+            if ((lane & 31) == 0) atomicAdd(s_q + 2 * (b - b0) + (lane >> 5), x);
+        }
+    }
+    if (lnsum_below) {
+        __syncthreads();
+        for (int64_t k = threadIdx.x; k < 2 * (b1 - b0); k += 256)
+            atomicAdd(lnsum_below + 2 * b0 + k, (double)s_q[k]);
     }
     if (live) {
         float* g = dgamma + 4 * i; float* bt = dbeta + 4 * i;
@@ -508,21 +543,28 @@ int launch_stats_to_mr(const double* stats, float* mr, const double* inv_n_dev, 
     return NAFP_OK;
 }
 
-int launch_ln_bwd(float* d, const float* v, const float* gamma, const float* mr, const float* mr_prev,
+int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* mr, const float* mr_prev,
                   double* lnsum, float* sc, float* dgamma, float* dbeta, float* dbias, float* S1, float* S2,
-                  int64_t B, int P, int C, hipStream_t st) {
+                  int64_t B, int P, int C, hipStream_t st, bool reduce_here, const float* Gj, const float* Hbj,
+                  double* lnsum_below) {
     const int64_t n = (int64_t)P * C;
     if (C % 4 != 0 || (256 % (C / 4) != 0 && (C / 4) % 256 != 0) || n % 1024 != 0 || 1024 % C != 0) return NAFP_ERR_UNSUPPORTED;
-    const int chunks = (int)std::min<int64_t>(std::max<int64_t>(1, n / 4 / 2048), 64);
-    ln_bwd_reduce_kernel<<<dim3(chunks, (unsigned)B), 256, 0, st>>>(d, v, gamma, mr, lnsum, n);
-    NAFP_LAUNCH_CHECK();
+    if (reduce_here) {
+        // top layer: its gradient comes from the divide-and-encode tail, not from a transposed conv
+        const int chunks = (int)std::min<int64_t>(std::max<int64_t>(1, n / 4 / 2048), 64);
+        ln_bwd_reduce_kernel<<<dim3(chunks, (unsigned)B), 256, 0, st>>>(d, tpre, gamma, mr, lnsum, n);
+        NAFP_LAUNCH_CHECK();
+    }
     ln_bwd_scalars_kernel<<<(unsigned)((B + 255) / 256), 256, 0, st>>>(mr, lnsum, mr_prev, sc, B, 1.0 / (double)n);
     NAFP_LAUNCH_CHECK();
     // batch chunks: every chunk ends in 5 atomics per element (~33 G atomics/s measured), which is what a
     // small layer pays for; 256..1024 workgroups keep the streaming layers at HBM speed
     const int64_t bx = n / 1024;
-    const int by = (int)std::min<int64_t>(B, std::min<int64_t>(64, std::max<int64_t>(4, 256 / bx)));
-    ln_bwd_fused_kernel<<<dim3((unsigned)bx, by), 256, 0, st>>>(d, v, gamma, sc, dgamma, dbeta, dbias, S1, S2, n, B, C);
+    int by = (int)std::min<int64_t>(B, std::min<int64_t>(64, std::max<int64_t>(4, 256 / bx)));
+    while (lnsum_below && (B + by - 1) / by * 8 > 32768 && by < B) by *= 2;      // LDS share of the sums below: 8 B per sample
+    const size_t lds = lnsum_below ? (size_t)((B + by - 1) / by) * 2 * sizeof(float) : 0;
+    ln_bwd_fused_kernel<<<dim3((unsigned)bx, by), 256, lds, st>>>(d, tpre, gamma, sc, dgamma, dbeta, dbias, S1, S2, n, B, C,
+                                                                Gj, Hbj, lnsum_below);
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }

@@ -92,16 +92,17 @@ __global__ __launch_bounds__(256) void conv0_kernel(
         const float x0 = ld(xr, t0), x1 = ld(xr, t0 + 1), x2 = ld(xr, t0 + 2);
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         if (STORE) g = *(const float4*)(gin + (int64_t)p * Cout + 4 * cg);
-        float4 v;
-        v.x = elu1(fmaf(x2, w2.x, fmaf(x1, w1.x, fmaf(x0, w0.x, bb.x))));
-        v.y = elu1(fmaf(x2, w2.y, fmaf(x1, w1.y, fmaf(x0, w0.y, bb.y))));
-        v.z = elu1(fmaf(x2, w2.z, fmaf(x1, w1.z, fmaf(x0, w0.z, bb.z))));
-        v.w = elu1(fmaf(x2, w2.w, fmaf(x1, w1.w, fmaf(x0, w0.w, bb.w))));
+        float4 tq, v;
+        tq.x = fmaf(x2, w2.x, fmaf(x1, w1.x, fmaf(x0, w0.x, bb.x)));
+        tq.y = fmaf(x2, w2.y, fmaf(x1, w1.y, fmaf(x0, w0.y, bb.y)));
+        tq.z = fmaf(x2, w2.z, fmaf(x1, w1.z, fmaf(x0, w0.z, bb.z)));
+        tq.w = fmaf(x2, w2.w, fmaf(x1, w1.w, fmaf(x0, w0.w, bb.w)));
+        v.x = elu1(tq.x); v.y = elu1(tq.y); v.z = elu1(tq.z); v.w = elu1(tq.w);
         s += (v.x + v.y) + (v.z + v.w);
         q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         if (STORE) {
             *(float4*)(yout + (int64_t)p * Cout + 4 * cg) = make_float4(v.x * g.x, v.y * g.y, v.z * g.z, v.w * g.w);
-            if (v_out) *(float4*)(v_out + (yout - y) + (int64_t)p * Cout + 4 * cg) = v;
+            if (v_out) *(float4*)(v_out + (yout - y) + (int64_t)p * Cout + 4 * cg) = tq;   // training keeps the pre-activation
         }
     }
     double ds = wave_sum((double)s), dq = wave_sum((double)q);
@@ -617,11 +618,12 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
                 float rs = 0.f, rq = 0.f;
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
-                    float v = elu1(fmaf(rb, acc[mi][ni][r], fmaf(cb, Gv[mi][rg][ni], Hv[mi][rg][ni])));
+                    const float tpre = fmaf(rb, acc[mi][ni][r], fmaf(cb, Gv[mi][rg][ni], Hv[mi][rg][ni]));
+                    float v = elu1(tpre);
                     v = valid ? v : 0.f;
                     if (valid) {
                         yrow[q * ystep + ni * 32] = v * gv[mi][rg][ni];
-                        if (p.v_out) p.v_out[(yrow - p.y) + q * ystep + ni * 32] = v;
+                        if (p.v_out) p.v_out[(yrow - p.y) + q * ystep + ni * 32] = tpre;    // training keeps the pre-activation
                     }
                     rs += v; rq += v * v;
                 }
@@ -714,15 +716,16 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(
         const float4 g4 = *(const float4*)(G + (int64_t)pos * Cout + n);
         const float4 h4 = *(const float4*)(Hb + (int64_t)pos * Cout + n);
         const float4 go = *(const float4*)(gamma_out + (int64_t)pos * Cout + n);
-        float4 v;
-        v.x = elu1(fmaf(rb, acc.x, fmaf(cb, g4.x, h4.x)));
-        v.y = elu1(fmaf(rb, acc.y, fmaf(cb, g4.y, h4.y)));
-        v.z = elu1(fmaf(rb, acc.z, fmaf(cb, g4.z, h4.z)));
-        v.w = elu1(fmaf(rb, acc.w, fmaf(cb, g4.w, h4.w)));
+        float4 tq, v;
+        tq.x = fmaf(rb, acc.x, fmaf(cb, g4.x, h4.x));
+        tq.y = fmaf(rb, acc.y, fmaf(cb, g4.y, h4.y));
+        tq.z = fmaf(rb, acc.z, fmaf(cb, g4.z, h4.z));
+        tq.w = fmaf(rb, acc.w, fmaf(cb, g4.w, h4.w));
+        v.x = elu1(tq.x); v.y = elu1(tq.y); v.z = elu1(tq.z); v.w = elu1(tq.w);
         s += (v.x + v.y) + (v.z + v.w);
         q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         *(float4*)(y + row * Cout + n) = make_float4(v.x * go.x, v.y * go.y, v.z * go.z, v.w * go.w);
-        if (v_out) *(float4*)(v_out + row * Cout + n) = v;
+        if (v_out) *(float4*)(v_out + row * Cout + n) = tq;
     }
     const double ds = wave_sum((double)s), dq = wave_sum((double)q);
     __shared__ double red[8];

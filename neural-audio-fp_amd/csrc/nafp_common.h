@@ -103,7 +103,7 @@ struct ConvGemmArgs {
     const double* stats_in;  // (B,2): sum, sumsq of the previous conv's ELU output   FULL
     double* stats_out;       // (B,2), must be zero on entry                          FULL
     float* y;                // (B,Fout,Tout,Cout): z = gamma_out . v (FULL) or acc + bias (PLAIN)
-    float* v_out;            // optional (FULL): v itself, kept for the backward pass
+    float* v_out;            // optional (FULL): the pre-activation t (v = ELU(t)), kept for the backward pass
     bool plain;
     bool dgrad;              // PLAIN only: y (B,Fin,Tin,Cin) = transposed conv of x = dT (B,Fout,Tout,Cout) with wp = (Cin, 3*Cout)
     float* slab;             // split-K partial sums workspace (or nullptr: never split)
@@ -149,9 +149,13 @@ int launch_tail_bwd(const TailBwdArgs& a, int64_t B, hipStream_t st);
 int launch_stats_to_mr(const double* stats, float* mr, const double* inv_n_dev, int64_t B, int n_layers, hipStream_t st);
 // LayerNorm + ELU backward of one layer (backward.hip): d = r_j * dL/dxhat_j -> dts = r_{j-1} * dL/dt_j in place;
 // dgamma/dbeta/dbias/S1/S2 accumulate (zeroed by the caller, like lnsum); sc = (B, 8) scratch.
-int launch_ln_bwd(float* d, const float* v, const float* gamma, const float* mr, const float* mr_prev,
+// tpre = the layer's stored PRE-activation t (v = ELU(t) is recomputed).  reduce_here: compute this layer's (s1, s2)
+// from d by a reduction pass (top layer); otherwise lnsum already holds them.  Gj / Hbj / lnsum_below (all or none):
+// also accumulate the (s1, s2) of the layer below through the adjoint identity (see backward.hip).
+int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* mr, const float* mr_prev,
                   double* lnsum, float* sc, float* dgamma, float* dbeta, float* dbias, float* S1, float* S2,
-                  int64_t B, int P, int C, hipStream_t st);
+                  int64_t B, int P, int C, hipStream_t st, bool reduce_here, const float* Gj, const float* Hbj,
+                  double* lnsum_below);
 // dW (keras (3,Cin,Cout), accumulated) += sum_rows X[b, in(pos,tap), :] (x) D[b,pos,:]
 int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const ConvGeom& g, hipStream_t st);
 int launch_conv0_bwd(const float* feat, const float* dt, float* dW0, float* dbias0, int64_t B, const ConvGeom& g,

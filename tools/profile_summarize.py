@@ -92,7 +92,34 @@ alg_bytes_per_launch = alg / 15
 traffic = None
 if fetch_bytes_per_launch and write_bytes_per_launch:
     traffic = fetch_bytes_per_launch + write_bytes_per_launch
+
+
+def kernel_traffic(name_part):
+    """(fetch bytes x2-corrected, write bytes, mean duration us, launches) per launch of the kernels matching name_part."""
+    fs = [(v, d) for k, lst in fetch.items() if name_part in k for (g, v, d) in lst]
+    ws = [(v, d) for k, lst in write.items() if name_part in k for (g, v, d) in lst]
+    if not fs or not ws:
+        return None
+    return {'fetch_bytes_x2_corrected': 2.0 * 1024 * sum(v for v, _ in fs) / len(fs),
+            'write_bytes': 1024 * sum(v for v, _ in ws) / len(ws),
+            'mean_us_under_pmc': sum(d for _, d in fs + ws) / len(fs + ws) / 1e3, 'launches': len(fs)}
+
+
+# front end (north star: "rocprof HBM GB/s on the STFT/mel path") and the Cin = 1 conv, per launch of 640 segments
+front = {}
+for key, part in (('melspec_kernel', 'melspec_kernel'), ('melspec_finalize_kernel', 'melspec_finalize'), ('conv0_kernel', 'conv0_kernel')):
+    kt = kernel_traffic(part)
+    if kt:
+        kt['bytes_per_segment'] = (kt['fetch_bytes_x2_corrected'] + kt['write_bytes']) / BSZ
+        front[key] = kt
+fe_total = sum(front[k]['fetch_bytes_x2_corrected'] + front[k]['write_bytes'] for k in front if k.startswith('melspec'))
 json.dump({'tag': tag, 'kernel': 'conv_gemm_k16s3', 'per_launch_bytes': traffic,
+           'frontend': {'kernels': front, 'bytes_per_launch': fe_total, 'bytes_per_segment': fe_total / BSZ,
+                        'algorithmic_bytes_per_segment': 32000 + 32768,
+                        'ratio_to_algorithmic': fe_total / BSZ / (32000 + 32768) if fe_total else None,
+                        'note': 'f32 audio in (32,000 B) + log-mel out (32,768 B) per segment; the kernels of the front end '
+                                'that ran in the profiled bench (melspec_kernel, plus melspec_finalize_kernel when the '
+                                'log-mel tail is not deferred into conv0)'},
            'fetch_bytes_x2_corrected': fetch_bytes_per_launch, 'write_bytes': write_bytes_per_launch,
            'algorithmic_activation_bytes_per_launch': alg_bytes_per_launch,
            'launches_averaged': {'fetch': f_n, 'write': w_n},
@@ -134,6 +161,15 @@ with open(os.path.join(dst, f'{tag}_summary.md'), 'w') as f:
         f.write(f'* WRITE_SIZE: {write_bytes_per_launch / 1e6:.1f} MB per launch (mean of {w_n})\n')
         f.write(f'* total {traffic / 1e6:.1f} MB per launch vs {alg_bytes_per_launch / 1e6:.1f} MB algorithmic '
                 f'activation bytes (each z tensor read once + written once; weights/G/Hb/gamma not counted)\n\n')
+    if front:
+        f.write('## HBM traffic of the front end and of the Cin = 1 conv (same PMC passes, per launch of 640 segments)\n\n')
+        f.write('| kernel | FETCH x2 MB | WRITE MB | bytes / segment | us (under PMC) | GB/s |\n|---|---|---|---|---|---|\n')
+        for k, kt in front.items():
+            tot = kt['fetch_bytes_x2_corrected'] + kt['write_bytes']
+            f.write(f'| `{k}` | {kt["fetch_bytes_x2_corrected"] / 1e6:.2f} | {kt["write_bytes"] / 1e6:.2f} | '
+                    f'{kt["bytes_per_segment"]:.0f} | {kt["mean_us_under_pmc"]:.1f} | {tot / kt["mean_us_under_pmc"] / 1e3:.0f} |\n')
+        f.write(f'\nFront end (STFT/mel path) total: {fe_total / BSZ:.0f} B per segment vs 64,768 B algorithmic '
+                f'(32,000 B f32 audio + 32,768 B log-mel) = {fe_total / BSZ / 64768:.2f}x.\n\n')
     f.write('## SQ counters per GEMM-conv shape (grid threads -> mean over launches)\n\n')
     f.write('| grid threads | dur us | clock GHz | MFMA busy % | wave occupancy/CU | WAIT_ANY % | WAIT_INST % | LDS bank conflicts |\n|---|---|---|---|---|---|---|---|\n')
     for g in sorted(agg, reverse=True):
