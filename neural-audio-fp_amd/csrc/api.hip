@@ -249,8 +249,13 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
     add_copy(t[67], e->d_b2, e->emb_sz);
     multi_copy_kernel<<<dim3(32, ct.count), 256, 0, st>>>(ct);
     NAFP_LAUNCH_CHECK();
-    for (int j = 1; j < 16; ++j) {
-        int rc = launch_pack_conv_weight(t[4 * j], e->d_w[j], e->geom[j].Cin, e->geom[j].Cout, st);
+    {
+        PackTable pt; pt.count = 0;
+        for (int j = 1; j < 16; ++j) {
+            pt.k3[pt.count] = t[4 * j]; pt.wp[pt.count] = e->d_w[j]; pt.wd[pt.count] = e->d_wd[j];
+            pt.cin[pt.count] = e->geom[j].Cin; pt.cout[pt.count] = e->geom[j].Cout; ++pt.count;
+        }
+        int rc = launch_multi_pack(pt, st);
         if (rc != NAFP_OK) return rc;
     }
     // positional epilogue terms of conv j: G = conv_j(gamma_{j-1}), Hb = conv_j(beta_{j-1}) + bias_j:
@@ -268,10 +273,6 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
     }
     add_bias_kernel<<<dim3(32, bt.count), 256, 0, st>>>(bt);
     NAFP_LAUNCH_CHECK();
-    for (int j = 1; j < 16; ++j) {
-        int rcd = launch_pack_dgrad_weight(t[4 * j], e->d_wd[j], e->geom[j].Cin, e->geom[j].Cout, st);
-        if (rcd != NAFP_OK) return rcd;
-    }
     int rc = launch_pack_div(t[64], t[65], t[66], e->d_w1p, e->d_b1p, e->d_w2p, e->emb_sz, e->S, st);
     if (rc != NAFP_OK) return rc;
     e->has_weights = true;

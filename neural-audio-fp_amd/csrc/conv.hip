@@ -40,73 +40,94 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int ROWS0 = 4;
 
 // STORE = false: statistics only (the activation is re-generated inside conv1, see FUSE0).
+//
+// The input rows of the workgroup (ROWS0 x Tin floats) are staged in LDS once -- the deferred tail of the log-mel
+// layer is applied there, once per input element -- and a thread then works on batches of NP positions: all gamma
+// loads of a batch are issued before the first store.  (The straightforward loop -- load, compute, store per position
+// -- made every iteration wait for its own loads behind the previous iteration's store: 3.9 TB/s; see DESIGN.md.)
 template <bool STORE, int ROWS0>
 __global__ __launch_bounds__(256) void conv0_kernel(
         const float* __restrict__ feat, const float* __restrict__ w3, const float* __restrict__ bias,
         const float* __restrict__ gamma, float* __restrict__ y, float* __restrict__ v_out,
         double* __restrict__ stats, int F, int Tin, int Tout, int Cout, int stride, int pad,
         const float* __restrict__ gstat, int group_size, int segment_norm) {
+    constexpr int NP = 8;                           // positions per thread and batch
+    __shared__ float s_x[ROWS0 * 64 + 8];           // rows of the input, Tin <= 64, with one zero in front (index -1)
+    __shared__ double red[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int blocks_per_sample = (F + ROWS0 - 1) / ROWS0;
     const int64_t b = blockIdx.x / blocks_per_sample;
-    // gstat != null: `feat` is the RAW log-mel of the front end (melspec.hip with NAFP_MELSPEC_DEFER) and the
-    // batch-max subtraction, clamp and optional segment normalisation (melspectrogram.py:108-111) happen here, on
-    // load -- the same float operations in the same order as melspec_finalize_kernel, so the result is bit-identical
-    // and the log-mel tensor crosses HBM once less in each direction.
-    float gmax = 0.f, nh = 0.f, nd = 1.f;
-    if (gstat) {
-        const int64_t g = group_size > 0 ? b / group_size : 0;
-        gmax = gstat[2 * g];
-        if (segment_norm) {
-            const float mn = fmaxf(gstat[2 * g + 1] - gmax, -80.f);
-            nh = mn / 2.f; nd = fabsf(nh + 1e-10f);
-        }
-    }
-    auto ld = [&](const float* xr, int t) -> float {
-        if (t < 0 || t >= Tin) return 0.f;                 // conv zero padding (of the NORMALISED features)
-        float v = xr[t];
-        if (gstat) {
-            v = fmaxf(v - gmax, -80.f);
-            if (segment_norm) v = (v - nh) / nd;
-        }
-        return v;
-    };
     const int f0 = (blockIdx.x % blocks_per_sample) * ROWS0;
     const int cgroups = Cout / 4;                   // float4 groups per position
     const int pos_per_iter = 256 / cgroups;         // positions covered per iteration (8 for Cout=128)
     const int cg = tid % cgroups, pslot = tid / cgroups;
+    const int rows = min(ROWS0, F - f0);
+    const int npos = rows * Tout;
+    // gstat != null: `feat` is the RAW log-mel of the front end (melspec.hip with NAFP_MELSPEC_DEFER) and the
+    // batch-max subtraction, clamp and optional segment normalisation (melspectrogram.py:108-111) happen here, on
+    // load -- the same float operations in the same order as melspec_finalize_kernel, so the result is bit-identical
+    // and the log-mel tensor crosses HBM once less in each direction.
+    {
+        float gmax = 0.f, nh = 0.f, nd = 1.f;
+        if (gstat) {
+            const int64_t g = group_size > 0 ? b / group_size : 0;
+            gmax = gstat[2 * g];
+            if (segment_norm) {
+                const float mn = fmaxf(gstat[2 * g + 1] - gmax, -80.f);
+                nh = mn / 2.f; nd = fabsf(nh + 1e-10f);
+            }
+        }
+        const float* xin = feat + (b * F + f0) * (int64_t)Tin;
+        for (int i = tid; i < rows * Tin; i += 256) {
+            float v = xin[i];
+            if (gstat) {
+                v = fmaxf(v - gmax, -80.f);
+                if (segment_norm) v = (v - nh) / nd;
+            }
+            s_x[(i / Tin) * 64 + (i % Tin)] = v;
+        }
+    }
     const float4 w0 = *(const float4*)(w3 + 0 * Cout + 4 * cg);
     const float4 w1 = *(const float4*)(w3 + 1 * Cout + 4 * cg);
     const float4 w2 = *(const float4*)(w3 + 2 * Cout + 4 * cg);
     const float4 bb = *(const float4*)(bias + 4 * cg);
-    const int rows = min(ROWS0, F - f0);
-    const int npos = rows * Tout;
-    const float* xin = feat + (b * F + f0) * (int64_t)Tin;
     float* yout = STORE ? y + ((b * F + f0) * (int64_t)Tout) * Cout : nullptr;
     const float* gin = STORE ? gamma + ((int64_t)f0 * Tout) * Cout : nullptr;
+    __syncthreads();
     float s = 0.f, q = 0.f;
-    for (int p = pslot; p < npos; p += pos_per_iter) {
-        const int r = p / Tout, to = p % Tout;
-        const int t0 = to * stride - pad;
-        const float* xr = xin + r * Tin;
-        const float x0 = ld(xr, t0), x1 = ld(xr, t0 + 1), x2 = ld(xr, t0 + 2);
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (STORE) g = *(const float4*)(gin + (int64_t)p * Cout + 4 * cg);
-        float4 tq, v;
-        tq.x = fmaf(x2, w2.x, fmaf(x1, w1.x, fmaf(x0, w0.x, bb.x)));
-        tq.y = fmaf(x2, w2.y, fmaf(x1, w1.y, fmaf(x0, w0.y, bb.y)));
-        tq.z = fmaf(x2, w2.z, fmaf(x1, w1.z, fmaf(x0, w0.z, bb.z)));
-        tq.w = fmaf(x2, w2.w, fmaf(x1, w1.w, fmaf(x0, w0.w, bb.w)));
-        v.x = elu1(tq.x); v.y = elu1(tq.y); v.z = elu1(tq.z); v.w = elu1(tq.w);
-        s += (v.x + v.y) + (v.z + v.w);
-        q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-        if (STORE) {
-            *(float4*)(yout + (int64_t)p * Cout + 4 * cg) = make_float4(v.x * g.x, v.y * g.y, v.z * g.z, v.w * g.w);
-            if (v_out) *(float4*)(v_out + (yout - y) + (int64_t)p * Cout + 4 * cg) = tq;   // training keeps the pre-activation
+    for (int p0 = pslot; p0 < npos; p0 += NP * pos_per_iter) {
+        float4 g[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int p = p0 + i * pos_per_iter;
+            g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (STORE && p < npos) g[i] = *(const float4*)(gin + (int64_t)p * Cout + 4 * cg);
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int p = p0 + i * pos_per_iter;
+            if (p >= npos) continue;
+            const int r = p / Tout, to = p - r * Tout;
+            const int t0 = to * stride - pad;
+            const float* xr = s_x + r * 64;
+            const float x0 = (t0 >= 0 && t0 < Tin) ? xr[t0] : 0.f;          // conv zero padding (of the NORMALISED features)
+            const float x1 = (t0 + 1 >= 0 && t0 + 1 < Tin) ? xr[t0 + 1] : 0.f;
+            const float x2 = (t0 + 2 >= 0 && t0 + 2 < Tin) ? xr[t0 + 2] : 0.f;
+            float4 tq, v;
+            tq.x = fmaf(x2, w2.x, fmaf(x1, w1.x, fmaf(x0, w0.x, bb.x)));
+            tq.y = fmaf(x2, w2.y, fmaf(x1, w1.y, fmaf(x0, w0.y, bb.y)));
+            tq.z = fmaf(x2, w2.z, fmaf(x1, w1.z, fmaf(x0, w0.z, bb.z)));
+            tq.w = fmaf(x2, w2.w, fmaf(x1, w1.w, fmaf(x0, w0.w, bb.w)));
+            v.x = elu1(tq.x); v.y = elu1(tq.y); v.z = elu1(tq.z); v.w = elu1(tq.w);
+            s += (v.x + v.y) + (v.z + v.w);
+            q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            if (STORE) {
+                *(float4*)(yout + (int64_t)p * Cout + 4 * cg) = make_float4(v.x * g[i].x, v.y * g[i].y, v.z * g[i].z, v.w * g[i].w);
+                if (v_out) *(float4*)(v_out + (yout - y) + (int64_t)p * Cout + 4 * cg) = tq;   // training keeps the pre-activation
+            }
         }
     }
     double ds = wave_sum((double)s), dq = wave_sum((double)q);
-    __shared__ double red[8];
     if (lane == 0) { red[wave] = ds; red[4 + wave] = dq; }
     __syncthreads();
     if (tid == 0) {
@@ -118,7 +139,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(
 int launch_conv0(const float* feat, const float* w3, const float* bias, const float* gamma, float* y,
                  float* v_out, double* stats, int64_t B, const ConvGeom& g, hipStream_t st, const float* gstat,
                  int group_size, int segment_norm) {
-    if (g.Cin != 1 || g.axis != 0 || (g.Cout % 4) != 0 || 256 % (g.Cout / 4) != 0) return NAFP_ERR_UNSUPPORTED;
+    if (g.Cin != 1 || g.axis != 0 || (g.Cout % 4) != 0 || 256 % (g.Cout / 4) != 0 || g.Tin > 64) return NAFP_ERR_UNSUPPORTED;
     const int64_t blocks = B * ((g.Fin + ROWS0 - 1) / ROWS0);
     conv0_kernel<true, ROWS0><<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, gamma, y, v_out, stats, g.Fin,
                                                                       g.Tin, g.Tout, g.Cout, g.stride, g.pad, gstat,
@@ -129,7 +150,7 @@ int launch_conv0(const float* feat, const float* w3, const float* bias, const fl
 
 int launch_conv0_stats(const float* feat, const float* w3, const float* bias, double* stats, int64_t B,
                        const ConvGeom& g, hipStream_t st) {
-    if (g.Cin != 1 || g.axis != 0 || (g.Cout % 4) != 0 || 256 % (g.Cout / 4) != 0) return NAFP_ERR_UNSUPPORTED;
+    if (g.Cin != 1 || g.axis != 0 || (g.Cout % 4) != 0 || 256 % (g.Cout / 4) != 0 || g.Tin > 64) return NAFP_ERR_UNSUPPORTED;
     constexpr int R = 32;
     const int64_t blocks = B * ((g.Fin + R - 1) / R);
     conv0_kernel<false, R><<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, nullptr, nullptr, nullptr, stats,
@@ -594,6 +615,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
             const int pofs = (pos < p.P ? pos : 0) * p.Cout + n_base;
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
+                if (p.abl & 32) {               // ablation: no positional operand loads
+                    Gv[mi][rg][ni] = 0.5f; Hv[mi][rg][ni] = 0.25f; gv[mi][rg][ni] = 1.5f;
+                    continue;
+                }
                 Gv[mi][rg][ni] = p.G[pofs + ni * 32];
                 Hv[mi][rg][ni] = p.Hb[pofs + ni * 32];
                 gv[mi][rg][ni] = p.gamma_out[pofs + ni * 32];
@@ -619,9 +644,9 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
                     const float tpre = fmaf(rb, acc[mi][ni][r], fmaf(cb, Gv[mi][rg][ni], Hv[mi][rg][ni]));
-                    float v = elu1(tpre);
+                    float v = (p.abl & 128) ? tpre : elu1(tpre);          // ablation 128: no exp
                     v = valid ? v : 0.f;
-                    if (valid) {
+                    if (valid && !((p.abl & 64) && v != 12345.678f)) {   // ablation 64: no stores
                         yrow[q * ystep + ni * 32] = v * gv[mi][rg][ni];
                         if (p.v_out) p.v_out[(yrow - p.y) + q * ystep + ni * 32] = tpre;    // training keeps the pre-activation
                     }
@@ -635,6 +660,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
                 }
             }
         }
+    }
+    if (p.abl & 16) {         // ablation: no statistics reduction (keep the sums alive)
+        if (s4[0] + s4[1] + s4[2] + s4[3] + q4[0] + q4[1] + q4[2] + q4[3] == 12345.678f) p.y[tid] = 1.f;
+        return;
     }
     if (fast_stats) {
         // ST == 4: the tile's 4 samples are the 4 register slots (r & 3)
@@ -916,6 +945,44 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ k3, float* __r
     __syncthreads();
     for (int r = ty; r < 32; r += 8)
         if (n0 + r < Cout && k0 + tx < K) wp[(int64_t)(n0 + r) * K + k0 + tx] = t[tx][r];
+}
+
+// All convs' weight re-layouts of one set_weights call in ONE launch (training re-packs after every optimizer
+// step): entry e, blockIdx.y = e; forward operand (Cout, 3*Cin) by 32 x 32 LDS transposes and -- training only --
+// the transposed-conv operand (Cin, 3*Cout): Wd[c][k*Cout + n] = W[k][c][n].
+__global__ __launch_bounds__(256) void multi_pack_kernel(const PackTable t) {
+    __shared__ float tile[32][33];
+    const int e = blockIdx.y;
+    const float* __restrict__ k3 = t.k3[e];
+    float* __restrict__ wp = t.wp[e]; float* __restrict__ wd = t.wd[e];
+    const int Cin = t.cin[e], Cout = t.cout[e], K = 3 * Cin;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int tiles_k = (K + 31) / 32, tiles_n = (Cout + 31) / 32;
+    for (int tl = blockIdx.x; tl < tiles_k * tiles_n; tl += gridDim.x) {
+        const int k0 = (tl % tiles_k) * 32, n0 = (tl / tiles_k) * 32;
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8)
+            if (k0 + r < K && n0 + tx < Cout) tile[r][tx] = k3[(int64_t)(k0 + r) * Cout + n0 + tx];
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8)
+            if (n0 + r < Cout && k0 + tx < K) wp[(int64_t)(n0 + r) * K + k0 + tx] = tile[tx][r];
+    }
+    if (wd) {
+        const int64_t total = (int64_t)3 * Cin * Cout;
+        for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+            const int n = (int)(i % Cout);
+            const int64_t r = i / Cout;
+            const int c = (int)(r % Cin), k = (int)(r / Cin);
+            wd[((int64_t)c * 3 + k) * Cout + n] = k3[i];
+        }
+    }
+}
+
+int launch_multi_pack(const PackTable& t, hipStream_t st) {
+    if (t.count <= 0) return NAFP_OK;
+    multi_pack_kernel<<<dim3(96, t.count), 256, 0, st>>>(t);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
 }
 
 int launch_pack_conv_weight(const float* k3, float* wp, int Cin, int Cout, hipStream_t st) {
