@@ -101,9 +101,10 @@ class GradientBucket:
         return [a.elapsed_time(b) for a, b in self._ev]
 
 
-def train_step(X, m_pre, m_specaug, m_fp, loss_obj, opt, bucket=None):
+def train_step(X, m_pre, m_specaug, m_fp, loss_obj, opt, bucket=None, timers=None):
     """trainer.py:33-50.  Returns (loss, None): loss is the GLOBAL batch loss (identical on every
-    rank).  `bucket` (GradientBucket) is required for data-parallel runs."""
+    rank).  `bucket` (GradientBucket) is required for data-parallel runs.  `timers` (a list, bench.py): receives
+    (name, start_event, end_event) of the two embedding collectives; the gradient pieces are timed by the bucket."""
     Xa, Xp = X
     n_anchors = len(Xa)
     X = torch.cat([torch.as_tensor(Xa), torch.as_tensor(Xp)], dim=0)
@@ -121,21 +122,17 @@ def train_step(X, m_pre, m_specaug, m_fp, loss_obj, opt, bucket=None):
         world, rank = dist.get_world_size(), dist.get_rank()
         d = emb.shape[1]
         gathered = torch.empty((world * 2 * n_anchors, d), dtype=emb.dtype, device=emb.device)
+        t0 = _mark(timers)
         dist.all_gather_into_tensor(gathered, emb.contiguous())
+        _mark(timers, 'all_gather(emb)', t0)
         g4 = gathered.view(world, 2, n_anchors, d)
         a_all, b_all = g4[:, 0].reshape(-1, d), g4[:, 1].reshape(-1, d)
         n_g = world * n_anchors
         loss_sum, _, d_a_all, d_b_all = _ntxent_call(loss_obj._lib, ha, hb, a_all, b_all, rank * n_anchors,
                                                      loss_obj.tau, False, True)
-        chunk = 2 * n_anchors * d
-        send = torch.empty((world, chunk + 4), dtype=torch.float32, device=emb.device)
-        send[:, :n_anchors * d] = d_a_all.view(world, n_anchors * d)
-        send[:, n_anchors * d:chunk] = d_b_all.view(world, n_anchors * d)
-        send[:, chunk:] = loss_sum / n_g                 # every destination receives the sum of the local losses
-        recv = torch.empty((chunk + 4,), dtype=torch.float32, device=emb.device)
-        _reduce_scatter(dist, recv, send)
-        loss = recv[chunk]
-        d_emb = recv[:chunk].view(2 * n_anchors, d)
+        t0 = _mark(timers)
+        loss, d_emb = scatter_embedding_gradients(dist, loss_sum / n_g, d_a_all, d_b_all, n_anchors)
+        _mark(timers, 'reduce_scatter(d emb)', t0)
     grads = m_fp.backward(d_emb)
     if dist is not None:
         if bucket is None:
@@ -144,6 +141,33 @@ def train_step(X, m_pre, m_specaug, m_fp, loss_obj, opt, bucket=None):
     opt.apply_gradients(zip(grads, m_fp.trainable_variables), var_lens=m_fp.variable_lengths())
     m_fp.mark_dirty()
     return loss, None
+
+
+def _mark(timers, name=None, start=None):
+    if timers is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    if name is not None:
+        timers.append((name, start, e))
+    return e
+
+
+def scatter_embedding_gradients(dist, loss_local, d_a_all, d_b_all, n_anchors):
+    """The backward of the embedding all-gather.  Every rank holds its contribution to the gradient w.r.t. ALL gathered
+    embeddings (d_a_all, d_b_all: (world * n_anchors, d)) and its share `loss_local` of the global loss; it needs the sum
+    over ranks of only ITS rows.  ONE reduce-scatter of [d/d a | d/d b | loss] laid out per destination rank; the loss
+    rides in a 4-float tail of every chunk, so each rank also receives the global loss.
+    Returns (loss, d_emb (2 * n_anchors, d) = [d/d a_local ; d/d b_local])."""
+    world, d = dist.get_world_size(), d_a_all.shape[1]
+    chunk = 2 * n_anchors * d
+    send = torch.empty((world, chunk + 4), dtype=torch.float32, device=d_a_all.device)
+    send[:, :n_anchors * d] = d_a_all.reshape(world, n_anchors * d)
+    send[:, n_anchors * d:chunk] = d_b_all.reshape(world, n_anchors * d)
+    send[:, chunk:] = loss_local
+    recv = torch.empty((chunk + 4,), dtype=torch.float32, device=d_a_all.device)
+    _reduce_scatter(dist, recv, send)
+    return recv[chunk], recv[:chunk].view(2 * n_anchors, d)
 
 
 def _reduce_scatter(dist, recv, send):

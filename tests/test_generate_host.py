@@ -156,3 +156,32 @@ def test_bench_flop_model_matches_survey():
     import bench
     m = bench.conv_effective_macs()
     assert sum(m) == 278888448 and m[0] == 1540096 and 2 * (sum(m) + 36864) == 557850624
+
+
+def _scatter_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from neural_audio_fp_amd.model import trainer as T
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    n_a, d = 3, 8
+    g = torch.Generator().manual_seed(100 + rank)
+    d_a, d_b = torch.randn((world * n_a, d), generator=g), torch.randn((world * n_a, d), generator=g)
+    loss, d_emb = T.scatter_embedding_gradients(dist, torch.tensor(0.5 + rank), d_a, d_b, n_a)
+    torch.save({'loss': float(loss), 'd_emb': d_emb.clone(), 'd_a': d_a, 'd_b': d_b}, os.path.join(out_dir, f'r{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_gloo_reduce_scatter_of_embedding_gradients(tmp_path, world):
+    """The exchange step of the data-parallel train step (NTxent_loss_tpu.py:57-87 backward): each rank gets
+    the rank-summed gradient of ITS rows and the global loss from one reduce-scatter."""
+    import torch.multiprocessing as mp
+    port = 29100 + (os.getpid() % 400) + world
+    mp.spawn(_scatter_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rs = [torch.load(tmp_path / f'r{k}.pt', weights_only=True) for k in range(world)]
+    tot_a, tot_b = sum(r['d_a'] for r in rs), sum(r['d_b'] for r in rs)
+    for k, r in enumerate(rs):
+        assert abs(r['loss'] - sum(0.5 + j for j in range(world))) < 1e-6
+        want = torch.cat([tot_a[3 * k:3 * k + 3], tot_b[3 * k:3 * k + 3]])
+        assert torch.allclose(r['d_emb'], want, atol=1e-6)

@@ -38,3 +38,27 @@ def test_bench_line_contract():
     assert cb['kind'] == 'port' and cb['unit'] == 'segments/s' and cb['value'] > 0 and cb['cores'] >= 1
     tr = d['train']
     assert tr['global_batch'] == 256 and tr['unit'] == 'steps/s' and tr['value'] > 0 and tr['scaling'] == 'strong'
+
+
+def test_bench_two_ranks_on_one_gpu_prints_train_with_collective_timings():
+    """The N > 1 path the driver launches (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`),
+    here with 2 ranks sharing cuda:0 over gloo (NAFP_BENCH_BACKEND / NAFP_BENCH_ONE_GPU: RCCL refuses two ranks per
+    GPU): ONE JSON line from rank 0, whole-job value, and the `train` object with per-collective timings."""
+    env = dict(os.environ, NAFP_BENCH_BACKEND='gloo', NAFP_BENCH_ONE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    port = 29800 + (os.getpid() % 100)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
+                        '--gpus', '2', '--steps', '3', '--warmup', '1', '--train-steps', '2', '--train-bsz', '128'],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and 'cpu_baseline' not in d
+    assert abs(d['value'] - 2 * 640 * 3 / (d['ms_per_step'] * 3 / 1e3)) < 1e-3 * d['value']           # whole-job throughput
+    tr = d['train']
+    assert tr['n_gpus'] == 2 and tr['global_batch'] == 128 and tr['per_gpu_batch'] == 64 and tr['scaling'] == 'strong'
+    c = tr['collectives']
+    assert c['all_gather(emb)_ms'] > 0 and c['reduce_scatter(d emb)_ms'] > 0
+    assert len(c['all_reduce(grad pieces)_ms']) == 4 and all(x > 0 for x in c['all_reduce(grad pieces)_ms'])
+    assert abs(sum(c['grad_piece_MB']) - 67.76) < 0.1
