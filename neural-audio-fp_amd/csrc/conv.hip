@@ -187,7 +187,7 @@ int launch_conv0_stats(const float* feat, const float* w3, const float* bias, do
 //   MFMAs of step s.  Taps that hit only zero padding for every row of the tile
 //   are skipped.
 // ============================================================================
-constexpr int BM = 128, BN = 128;
+constexpr int BN = 128;          // BM (tile rows) is a template parameter: 128 (4 waves) or 256 (8 waves)
 
 struct ConvKernelParams {
     const float* x;           // (B, Fin, Tin, Cin)
@@ -302,14 +302,21 @@ __device__ __forceinline__ int tile_pos(const ConvKernelParams& p, int idx) {
     return (2 * e + 1 - p.perm_c0) * p.Tout + (j - e * p.Tout);
 }
 
-template <int BK, int NSTAGE, bool FUSE0>
+template <int BM, int BK, int NSTAGE, bool FUSE0>
 __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
-    static_assert(!FUSE0 || BK == 16, "the in-kernel conv0 generator is written for BK = 16");
+    static_assert(!FUSE0 || (BK == 16 && BM == 128), "the in-kernel conv0 generator is written for BK = 16, BM = 128");
+    static_assert(BM == 128 || BM == 256, "tile rows");
+    constexpr int NT = 2 * BM;                     // threads: BM / 32 waves as (BM/64) x 2, each wave 64 x 64
+    constexpr int NW = BM / 32;
     constexpr int CH = BK / 4;                     // 16-B chunks per row
     constexpr int RPI = 64 / CH;                   // rows covered by one DMA wave-instruction
-    constexpr int NI = 32 / RPI;                   // DMA instructions per wave per operand per step
-    constexpr int TILE = BM * BK;                  // floats per operand tile
-    constexpr int STAGE = 2 * TILE;                // A | B
+    constexpr int NI = 32 / RPI;                   // A: DMA instructions per wave per step (every wave stages 32 rows of A)
+    constexpr int BROWS = BN / NW;                 // B: rows staged per wave (32 or 16)
+    constexpr int NIB = BROWS / RPI;               // B: DMA instructions per wave per step
+    static_assert(NIB >= 1, "B rows per wave");
+    constexpr int TILE = BM * BK;                  // floats of the A tile
+    constexpr int TILEB = BN * BK;                 // floats of the B tile
+    constexpr int STAGE = TILE + TILEB;            // A | B
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // [stage 0: A | B] ... [stage NSTAGE-1] [sRB[128]] [sCB[128]] [sPos[32]] [FUSE0: conv0 w (3,Cin) | bias (Cin)]
     float* sRB = smem + NSTAGE * STAGE;
@@ -318,7 +325,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     float* sW0 = sCB + BM + 32;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 1, wn = wave & 1;       // wm < BM / 64
     const int sg = blockIdx.x % p.n_sg, pb = blockIdx.x / p.n_sg;
     const int tile_n0 = blockIdx.y * BN;
     const int K = 3 * p.Cin;
@@ -339,7 +346,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         }
         sRB[tid] = r; sCB[tid] = c;
     }
-    if (tid >= 128 && tid < 128 + p.PT) sPos[tid - 128] = tile_pos(p, pb * p.PT + tid - 128);
+    if (tid >= NT - 32 && tid < NT - 32 + p.PT) sPos[tid - (NT - 32)] = tile_pos(p, pb * p.PT + tid - (NT - 32));
 
     // ---- DMA geometry.  Wave w stages rows [32w, 32w+32) of A and of B; instruction q
     // covers rows 32w + q*RPI + lane/CH, physical chunk pc = lane % CH, which must hold
@@ -347,7 +354,14 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     constexpr unsigned OOB = 0x80000000u;
     unsigned voffA[NI];           // byte offset of tap 0 from the tile's first sample
     unsigned vmaskA[NI];          // bit t: tap t reads real data (else zero padding -> OOB lane)
-    unsigned voffB[NI];
+    unsigned voffB[NIB];
+#pragma unroll
+    for (int q = 0; q < NIB; ++q) {
+        const int lr = wave * BROWS + q * RPI + lane / CH;
+        const int pc = lane % CH;
+        const int swz = BK == 32 ? ((lr >> 1) & 7) : ((lr >> 2) & 3);
+        voffB[q] = (unsigned)((tile_n0 + lr) * K + (pc ^ swz) * 4) * 4u;
+    }
 #pragma unroll
     for (int q = 0; q < NI; ++q) {
         const int lr = wave * 32 + q * RPI + lane / CH;
@@ -362,7 +376,6 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
             voffA[q] = (unsigned)(sl * (int)p.sample_in + rg.inner + lc * 4) * 4u;   // may wrap for an invalid tap: masked
             vmaskA[q] = rg.mask;
         }
-        voffB[q] = (unsigned)((tile_n0 + lr) * K + lc * 4) * 4u;
     }
     // ---- FUSE0 generator geometry: thread t builds row t>>1, channels 8*(t&1)..+8 of every
     // K-step of the A tile: z0[b, f, t, c] = gamma0[f,t,c] * ELU(bias0[c] + sum_k w0[k,c] feat[b, f, t*s0 - p0 + k])
@@ -372,7 +385,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     const int g_row = tid >> 1, g_ch = (tid & 1) * 8;
     const int g_swz = (g_row >> 2) & 3;
     if (FUSE0) {
-        for (int i = tid; i < 4 * p.Cin; i += 256) sW0[i] = i < 3 * p.Cin ? p.f0_w[i] : p.f0_bias[i - 3 * p.Cin];
+        for (int i = tid; i < 4 * p.Cin; i += NT) sW0[i] = i < 3 * p.Cin ? p.f0_w[i] : p.f0_bias[i - 3 * p.Cin];
 #pragma unroll
         for (int t = 0; t < 3; ++t) { x0[t][0] = 0.f; x0[t][1] = 0.f; x0[t][2] = 0.f; }
         const int pos = pb * p.PT + (g_row >> p.log2ST);
@@ -405,7 +418,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     {
         unsigned m = 0;
 #pragma unroll
-        for (int hrow = 0; hrow < 2; ++hrow) {
+        for (int hrow = 0; hrow < BM / 64; ++hrow) {
             const int lr = lane + 64 * hrow;
             const int pos = tile_pos(p, pb * p.PT + (lr >> p.log2ST));
             if (pos < p.P && (lr & ST1) < nb) m |= row_geom(p, pos).mask;
@@ -428,6 +441,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     const u32x4 rsA = make_rsrc(p.x + (int64_t)b0 * p.sample_in, (unsigned)nb * (unsigned)p.sample_in * 4u);
     const u32x4 rsB = make_rsrc(p.wp, p.wp_bytes);
     const unsigned lds0 = (unsigned)(unsigned long long)(lds_ptr_t)smem + (unsigned)(wave * 32 * BK * 4);
+    const unsigned ldsB0 = (unsigned)(unsigned long long)(lds_ptr_t)smem + (unsigned)((TILE + wave * BROWS * BK) * 4);
 
     // Issue the DMA of K-step s_ into ring slot slot_ (wave-uniform LDS bases).
 #define NAFP_DMA_STEP(s_, slot_)                                                              \
@@ -436,12 +450,13 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         const int tap_l = (int)((tap_pack >> (2 * tsel_l)) & 3u);                              \
         const int c0_l = ((s_) - tsel_l * cpt) * BK;                                           \
         const unsigned la_l = lds0 + (unsigned)((slot_) * STAGE * 4);                          \
+        const unsigned lb_l = ldsB0 + (unsigned)((slot_) * STAGE * 4);                         \
         const unsigned tapb_l = (unsigned)(tap_l * p.tap_stride) * 4u;                         \
         _Pragma("unroll") for (int q = 0; q < NI; ++q) {                                       \
             const unsigned va = ((vmaskA[q] >> tap_l) & 1u) ? voffA[q] + tapb_l : OOB;         \
             if (!FUSE0) lds_dma16(la_l + q * RPI * BK * 4, va, rsA, (unsigned)(c0_l * 4));     \
-            lds_dma16(la_l + (TILE + q * RPI * BK) * 4, voffB[q], rsB,                          \
-                      (unsigned)((tap_l * p.Cin + c0_l) * 4));                                 \
+            if (q < NIB) lds_dma16(lb_l + q * RPI * BK * 4, voffB[q], rsB,                      \
+                                   (unsigned)((tap_l * p.Cin + c0_l) * 4));                    \
         }                                                                                      \
     }
     // FUSE0: gamma0 of my 8 channels of K-step s_ (issued early), then build + store the A rows.
@@ -495,7 +510,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     // operand read addresses (floats): row*BK + ((lc ^ swz(row)) * 4), lc = 2*kk + (lane>>5)
     const int rl = lane & 31, hh = lane >> 5;
     const int rswz = BK == 32 ? ((rl >> 1) & 7) : ((rl >> 2) & 3);     // wm*64, 32*mi do not change swz
-    const int aoff = (wm * 64 + rl) * BK, boff = TILE + (wn * 64 + rl) * BK;
+    const int aoff = (wm * 64 + rl) * BK, boff = TILE + (wn * 64 + rl) * BK;     // (NIB <= NI: the B pieces ride in the A loop)
     int slot = 0;
     if (p.abl & 8) {          // ablation: prologue + pipeline fill only (wait for the prefilled stages, then leave)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -509,7 +524,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         // wait for the gamma0 loads has already retired every older DMA.)
         if (FUSE0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else if (NSTAGE == 2 || s + NSTAGE - 2 >= n_steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" :: "i"((NSTAGE - 2) * 2 * NI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "i"((NSTAGE - 2) * (NI + NIB)) : "memory");
         __builtin_amdgcn_s_barrier();
         const bool has_next = s + NSTAGE - 1 < n_steps && !(p.abl & 1);
         int nslot = slot + NSTAGE - 1; if (nslot >= NSTAGE) nslot -= NSTAGE;
@@ -598,34 +613,33 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
     float* rowS = smem;                 // [BM] (LDS tiles are free again: last loop barrier passed)
     float* rowQ = smem + BM;
-    const bool fast_stats = p.ST == 4;
+    const bool fast_stats = p.ST == 4 || p.ST == 8;
     if (!fast_stats) {
-        if (tid < BM) { rowS[tid] = 0.f; rowQ[tid] = 0.f; }
+        if (tid < BM) { rowS[tid] = 0.f; rowQ[tid] = 0.f; }           // NT >= BM
         __syncthreads();
     }
     // All position-indexed operands first (48 independent loads in flight together),
     // then the arithmetic: issuing them group by group exposed one L2 round trip per group.
-    float Gv[2][4][2], Hv[2][4][2], gv[2][4][2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const int grp = wm * 16 + mi * 8 + 2 * rg + (lane >> 5);      // = lr >> 2
-            const int pos = pb * p.PT + (grp >> (p.log2ST - 2));
-            const int pofs = (pos < p.P ? pos : 0) * p.Cout + n_base;
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                if (p.abl & 32) {               // ablation: no positional operand loads
-                    Gv[mi][rg][ni] = 0.5f; Hv[mi][rg][ni] = 0.25f; gv[mi][rg][ni] = 1.5f;
-                    continue;
-                }
-                Gv[mi][rg][ni] = p.G[pofs + ni * 32];
-                Hv[mi][rg][ni] = p.Hb[pofs + ni * 32];
-                gv[mi][rg][ni] = p.gamma_out[pofs + ni * 32];
-            }
-        }
+    // (BM = 256 runs at 128 VGPRs: there the operands are fetched per 32-row block, 24 at a time.)
+    constexpr int MIL = BM == 256 ? 1 : 2;            // 32-row blocks whose operands are resident at once
+    float Gv[MIL][4][2], Hv[MIL][4][2], gv[MIL][4][2];
+#define NAFP_EPI_LOAD(mi_, slot_)                                                              \
+    _Pragma("unroll") for (int rg = 0; rg < 4; ++rg) {                                         \
+        const int grp_l = wm * 16 + (mi_) * 8 + 2 * rg + (lane >> 5);                          \
+        const int pos_l = pb * p.PT + (grp_l >> (p.log2ST - 2));                               \
+        const int pofs_l = (pos_l < p.P ? pos_l : 0) * p.Cout + n_base;                        \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                     \
+            if (p.abl & 32) { Gv[slot_][rg][ni] = 0.5f; Hv[slot_][rg][ni] = 0.25f; gv[slot_][rg][ni] = 1.5f; continue; } \
+            Gv[slot_][rg][ni] = p.G[pofs_l + ni * 32];                                         \
+            Hv[slot_][rg][ni] = p.Hb[pofs_l + ni * 32];                                        \
+            gv[slot_][rg][ni] = p.gamma_out[pofs_l + ni * 32];                                 \
+        }                                                                                      \
+    }
+    if (MIL == 2) { NAFP_EPI_LOAD(0, 0) NAFP_EPI_LOAD(1, MIL - 1) }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
+        const int ms = MIL == 2 ? mi : 0;
+        if (MIL == 1) { NAFP_EPI_LOAD(mi, 0) }
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             const int grp = wm * 16 + mi * 8 + 2 * rg + (lane >> 5);      // = lr >> 2
@@ -643,11 +657,11 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
                 float rs = 0.f, rq = 0.f;
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
-                    const float tpre = fmaf(rb, acc[mi][ni][r], fmaf(cb, Gv[mi][rg][ni], Hv[mi][rg][ni]));
+                    const float tpre = fmaf(rb, acc[mi][ni][r], fmaf(cb, Gv[ms][rg][ni], Hv[ms][rg][ni]));
                     float v = (p.abl & 128) ? tpre : elu1(tpre);          // ablation 128: no exp
                     v = valid ? v : 0.f;
                     if (valid && !((p.abl & 64) && v != 12345.678f)) {   // ablation 64: no stores
-                        yrow[q * ystep + ni * 32] = v * gv[mi][rg][ni];
+                        yrow[q * ystep + ni * 32] = v * gv[ms][rg][ni];
                         if (p.v_out) p.v_out[(yrow - p.y) + q * ystep + ni * 32] = tpre;    // training keeps the pre-activation
                     }
                     rs += v; rq += v * v;
@@ -666,20 +680,29 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         return;
     }
     if (fast_stats) {
-        // ST == 4: the tile's 4 samples are the 4 register slots (r & 3)
-        double* red = (double*)smem;        // [4 waves][8]
+        // ST == 4: the tile's 4 samples are the 4 register slots (r & 3) of every lane.
+        // ST == 8: lanes 0..31 hold samples 0..3, lanes 32..63 samples 4..7 (grp & 1 == lane >> 5 for every block).
+        double* red = (double*)smem;        // [NW waves][half][sum | sumsq][4]
+        const bool two = p.ST == 8;
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const double ds = wave_sum((double)s4[q]), dq = wave_sum((double)q4[q]);
-            if (lane == 0) { red[wave * 8 + q] = ds; red[wave * 8 + 4 + q] = dq; }
+            double ds = (double)s4[q], dq = (double)q4[q];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { ds += __shfl_xor(ds, o, 64); dq += __shfl_xor(dq, o, 64); }
+            if (!two) { ds += __shfl_xor(ds, 32, 64); dq += __shfl_xor(dq, 32, 64); }
+            if ((lane & 31) == 0 && (two || lane == 0)) {
+                red[wave * 16 + (lane >> 5) * 8 + q] = ds; red[wave * 16 + (lane >> 5) * 8 + 4 + q] = dq;
+            }
         }
         __syncthreads();
-        if (tid < 8) {
-            const int q = tid & 3, which = tid >> 2;
-            const int b = sg * 4 + q;
+        if (tid < 2 * p.ST) {
+            const int which = tid / p.ST, sl = tid - which * p.ST;
+            const int b = sg * p.ST + sl;
             if (b < p.B) {
-                const double t = red[tid] + red[8 + tid] + red[16 + tid] + red[24 + tid];
+                double t = 0.0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) t += red[w * 16 + (sl >> 2) * 8 + which * 4 + (sl & 3)];
                 atomicAdd(p.stats_out + 2 * (int64_t)b + which, t);
             }
         }
@@ -698,21 +721,24 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
 }
 
 // One __global__ per staging variant (launch bounds are not template-dependent).
-#define NAFP_GEMM_KERNEL(name_, BK_, NSTAGE_, MINW_, FUSE0_)                                \
-    __global__ __launch_bounds__(256, MINW_) void name_(const ConvKernelParams p) {          \
-        conv_gemm_body<BK_, NSTAGE_, FUSE0_>(p);                                             \
+#define NAFP_GEMM_KERNEL(name_, BM_, BK_, NSTAGE_, MINW_, FUSE0_)                            \
+    __global__ __launch_bounds__(2 * BM_, MINW_) void name_(const ConvKernelParams p) {       \
+        conv_gemm_body<BM_, BK_, NSTAGE_, FUSE0_>(p);                                         \
     }
 // BK = 16, 3 stages, 3 workgroups/CU.  The other staging points were built and measured on the MI355X
 // (segments/s at BSZ 640, same run): k16s3 148.2 k | k32s2 (2 WG/CU) 143.6 k | k16s2 (4 WG/CU) 142.7 k |
 // k16s4 (2 WG/CU) 140.9 k | k32s3 (1 WG/CU) 116.4 k; they are not compiled any more.
-NAFP_GEMM_KERNEL(conv_gemm_k16s3, 16, 3, 3, false)
-NAFP_GEMM_KERNEL(conv_gemm_k16s3_fuse0, 16, 3, 3, true)    // conv1 with conv0 generated in-kernel
+NAFP_GEMM_KERNEL(conv_gemm_k16s3, 128, 16, 3, 3, false)
+NAFP_GEMM_KERNEL(conv_gemm_k16s3_fuse0, 128, 16, 3, 3, true)    // conv1 with conv0 generated in-kernel
+// 256 x 128 tile, 8 waves (4 x 2), 72 KB ring -> 2 workgroups = 16 waves per CU (4 per SIMD): the weight tile is staged
+// once per 256 rows instead of once per 128, and a workgroup's fixed costs (geometry, pipeline fill) cover twice the output
+NAFP_GEMM_KERNEL(conv_gemm_m256k16s3, 256, 16, 3, 4, false)
 
 template <typename KernelT>
-static int launch_variant(KernelT kernel, int BK, int NSTAGE, const ConvKernelParams& p, dim3 grid, hipStream_t st) {
-    const int lds = (NSTAGE * 2 * BM * BK + 2 * BM + 32 + (p.f0_feat ? 4 * p.Cin : 0)) * (int)sizeof(float);
+static int launch_variant(KernelT kernel, int BM, int BK, int NSTAGE, const ConvKernelParams& p, dim3 grid, hipStream_t st) {
+    const int lds = (NSTAGE * (BM + BN) * BK + 2 * BM + 32 + (p.f0_feat ? 4 * p.Cin : 0)) * (int)sizeof(float);
     NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    kernel<<<grid, 256, lds, st>>>(p);
+    kernel<<<grid, 2 * BM, lds, st>>>(p);
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }
@@ -829,15 +855,27 @@ static int tile_pt(int P) {
     return pt;
 }
 
+// Tile height of a launch: 256 rows (8 waves, 2 workgroups per CU) when the launch has enough 128-row tiles to fill the
+// chip several times over with the larger tile as well -- those launches are never split along K; 128 rows otherwise.
+// NAFP_BM256 = minimum number of 128-row tiles (0 = never).
+static int pick_bm(int64_t B, int P, int Cout) {
+    static const int64_t thr = []() { const char* e = getenv("NAFP_BM256"); return e ? atoll(e) : (int64_t)0; }();
+    if (thr <= 0) return 128;
+    const int pt = tile_pt(P), ST = 128 / pt;
+    const int64_t n_tiles = ((B + ST - 1) / ST) * ((P + pt - 1) / pt) * (Cout / BN);
+    return n_tiles >= thr ? 256 : 128;
+}
+
 int64_t conv_gemm_slab_floats(int64_t B, const ConvGeom& g, bool with_dgrad) {
     const int P = g.Fout * g.Tout;
+    const int BM = pick_bm(B, P, g.Cout);
     const int pt = tile_pt(P), ST = BM / pt;
     const int64_t n_tiles = ((B + ST - 1) / ST) * ((P + pt - 1) / pt) * (g.Cout / BN);
-    const int S = choose_split(n_tiles, live_k_steps(g), B * P * g.Cout);
+    const int S = BM == 256 ? 1 : choose_split(n_tiles, live_k_steps(g), B * P * g.Cout);
     int64_t need = S > 1 ? (int64_t)S * B * P * g.Cout : 0;
-    if (with_dgrad && g.Cin % BN == 0) {
+    if (with_dgrad && g.Cin % BN == 0 && pick_bm(B, g.Fin * g.Tin, g.Cin) == 128) {
         const int Pd = g.Fin * g.Tin;
-        const int ptd = tile_pt(Pd), STd = BM / ptd;
+        const int ptd = tile_pt(Pd), STd = 128 / ptd;
         const int64_t tiles_d = ((B + STd - 1) / STd) * ((Pd + ptd - 1) / ptd) * (g.Cin / BN);
         const int Sd = choose_split(tiles_d, dgrad_k_steps(g), B * Pd * g.Cin);
         if (Sd > 1) need = std::max(need, (int64_t)Sd * B * Pd * g.Cin);
@@ -853,6 +891,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     p.Fin = g.Fin; p.Tin = g.Tin; p.Cin = g.Cin; p.Tout = g.Tout; p.Cout = g.Cout;
     p.axis = g.axis; p.stride = g.stride; p.pad = g.pad;
     p.B = (int)B; p.P = g.Fout * g.Tout;
+    int BM = a.f0_feat ? 128 : pick_bm(B, a.dgrad ? g.Fin * g.Tin : p.P, a.dgrad ? g.Cin : g.Cout);
     int pt = tile_pt(p.P);
     p.PT = pt; p.ST = BM / pt;
     p.log2ST = 0;
@@ -899,7 +938,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     const int64_t n_tiles = (int64_t)p.n_sg * n_pb * (p.Cout / BN);
     int S = 1;
     const int64_t out_floats = B * p.P * p.Cout;
-    if (a.slab && !a.f0_feat) {
+    if (a.slab && !a.f0_feat && BM == 128) {
         S = choose_split(n_tiles, k_steps, out_floats);
         if ((int64_t)S * out_floats > a.slab_floats) S = 1;
     }
@@ -915,9 +954,10 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
             return NAFP_ERR_UNSUPPORTED;
         p.f0_feat = a.f0_feat; p.f0_w = a.f0_w; p.f0_bias = a.f0_bias; p.f0_gamma = a.f0_gamma;
         p.f0_T = a.f0_geom->Tin; p.f0_stride = a.f0_geom->stride; p.f0_pad = a.f0_geom->pad;
-        return launch_variant(conv_gemm_k16s3_fuse0, 16, 3, p, grid, st);
+        return launch_variant(conv_gemm_k16s3_fuse0, 128, 16, 3, p, grid, st);
     }
-    rc = launch_variant(conv_gemm_k16s3, 16, 3, p, grid, st);
+    rc = BM == 256 ? launch_variant(conv_gemm_m256k16s3, 256, 16, 3, p, grid, st)
+                   : launch_variant(conv_gemm_k16s3, 128, 16, 3, p, grid, st);
     if (rc != NAFP_OK || S == 1) return rc;
     if (a.plain) {
         const int64_t n4 = out_floats / 4;
