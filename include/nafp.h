@@ -49,6 +49,9 @@ int nafp_abi_version(void);
 const char* nafp_status_string(int status);
 /* hipError_t (as int) of the most recent failing HIP call on this thread. */
 int nafp_last_hip_error(void);
+/* CRC-32C (Castagnoli) of n host bytes, continuing from `crc` (0 to start): the checksum TensorFlow's TensorBundle
+ * stores per tensor and per index block; used by the reader of the reference's checkpoints (model/generate.py:26-52). */
+uint32_t nafp_crc32c_host(const void* data_host, int64_t n, uint32_t crc);
 
 /* ------------------------------------------------------------------------
  * Front end: Melspec_layer (model/fp/melspec/melspectrogram.py:10-112)

@@ -24,6 +24,7 @@ PROTOTYPES = {
     'nafp_abi_version': (c_int, []),
     'nafp_status_string': (ctypes.c_char_p, [c_int]),
     'nafp_last_hip_error': (c_int, []),
+    'nafp_crc32c_host': (ctypes.c_uint32, [c_void_p, c_i64, ctypes.c_uint32]),
     'nafp_mel_filterbank_host': (c_int, [c_int, c_int, c_int, c_float, c_float, c_void_p]),
     'nafp_melspec_create': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_float, c_float]),
     'nafp_melspec_destroy': (c_int, [c_void_p]),

@@ -123,6 +123,35 @@ extern "C" const char* nafp_status_string(int status) {
 
 extern "C" int nafp_last_hip_error(void) { return g_last_hip_error; }
 
+// CRC-32C (Castagnoli, reflected 0x82F63B78), slicing-by-8, host only: checksums of TensorFlow checkpoint files
+// (model/utils/tf_checkpoint.py).  crc = running value (0 to start).
+extern "C" uint32_t nafp_crc32c_host(const void* data, int64_t n, uint32_t crc) {
+    static uint32_t T[8][256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0x82F63B78u & (0u - (c & 1u)));
+            T[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xffu];
+        init = true;
+    }
+    const unsigned char* p = (const unsigned char*)data;
+    uint32_t c = ~crc;
+    while (n > 0 && ((uintptr_t)p & 7)) { c = (c >> 8) ^ T[0][(c ^ *p++) & 0xffu]; --n; }
+    while (n >= 8) {
+        uint64_t w; memcpy(&w, p, 8);
+        w ^= c;
+        c = T[7][w & 0xff] ^ T[6][(w >> 8) & 0xff] ^ T[5][(w >> 16) & 0xff] ^ T[4][(w >> 24) & 0xff] ^
+            T[3][(w >> 32) & 0xff] ^ T[2][(w >> 40) & 0xff] ^ T[1][(w >> 48) & 0xff] ^ T[0][(w >> 56) & 0xff];
+        p += 8; n -= 8;
+    }
+    while (n-- > 0) c = (c >> 8) ^ T[0][(c ^ *p++) & 0xffu];
+    return ~c;
+}
+
 extern "C" int nafp_encoder_create(nafp_encoder** out, int in_f, int in_t, int emb_sz) {
     if (!out || in_f <= 0 || in_t <= 0 || emb_sz <= 0) return NAFP_ERR_INVALID_ARG;
     nafp_encoder* e = new nafp_encoder();

@@ -218,6 +218,7 @@ struct WgradParams {
     int B, P, Tout, Fin, Tin, Cin, Cout, axis, stride, pad;
     long long sample_in;
     int rows_per_wg;
+    int tap_pack, n_live;          // live taps, 2 bits each: taps that read real data for at least one output position
 };
 
 __global__ __launch_bounds__(256, 3) void wgrad_kernel(const WgradParams p) {
@@ -229,7 +230,9 @@ __global__ __launch_bounds__(256, 3) void wgrad_kernel(const WgradParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wave >> 1, wn = wave & 1;
     const int ctiles = p.Cin / 128;
-    const int tap = blockIdx.z / ctiles, c0 = (blockIdx.z % ctiles) * 128, n0 = blockIdx.y * 128;
+    // blockIdx.z enumerates (live tap, c-tile): a tap that only ever sees zero padding (b5-b7 at the 1-s input) has a
+    // zero gradient, which the zeroed dW already holds
+    const int tap = (p.tap_pack >> (2 * (blockIdx.z / ctiles))) & 3, c0 = (blockIdx.z % ctiles) * 128, n0 = blockIdx.y * 128;
     const long long M = (long long)p.B * p.P;
     const long long m0 = (long long)blockIdx.x * p.rows_per_wg;
     const long long m_end = std::min<long long>(M, m0 + p.rows_per_wg);
@@ -329,7 +332,16 @@ int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const Con
     p.Fin = g.Fin; p.Tin = g.Tin; p.Cin = g.Cin; p.Cout = g.Cout; p.axis = g.axis; p.stride = g.stride; p.pad = g.pad;
     p.sample_in = (long long)g.Fin * g.Tin * g.Cin;
     const long long M = (long long)B * p.P;
-    const int col_tiles = (g.Cout / 128) * (3 * g.Cin / 128);
+    p.tap_pack = 0; p.n_live = 0;
+    {
+        const int n_in = g.axis == 0 ? g.Tin : g.Fin, n_out = g.axis == 0 ? g.Tout : g.Fout;
+        for (int t = 0; t < 3; ++t) {
+            bool live = false;
+            for (int o = 0; o < n_out && !live; ++o) { const int i = o * g.stride - g.pad + t; live = i >= 0 && i < n_in; }
+            if (live) { p.tap_pack |= t << (2 * p.n_live); ++p.n_live; }
+        }
+    }
+    const int col_tiles = (g.Cout / 128) * (p.n_live * g.Cin / 128);
     // one resident round: 256 CUs x 3 workgroups (each workgroup ends in 16 K atomics, so fewer is better;
     // measured at B = 1280: 768 / 1536 / 3072 / 6144 workgroups -> backward 22.3 / 22.5 / 22.9 / 24.3 ms)
     long long chunks = std::max<long long>(1, 768 / col_tiles);
@@ -345,7 +357,7 @@ int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const Con
         NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr = true;
     }
-    wgrad_kernel<<<dim3(gx, g.Cout / 128, 3 * g.Cin / 128), 256, lds, st>>>(p);
+    wgrad_kernel<<<dim3(gx, g.Cout / 128, p.n_live * g.Cin / 128), 256, lds, st>>>(p);
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }

@@ -857,9 +857,11 @@ static int tile_pt(int P) {
 
 // Tile height of a launch: 256 rows (8 waves, 2 workgroups per CU) when the launch has enough 128-row tiles to fill the
 // chip several times over with the larger tile as well -- those launches are never split along K; 128 rows otherwise.
-// NAFP_BM256 = minimum number of 128-row tiles (0 = never).
+// NAFP_BM256 = minimum number of 128-row tiles (0 = never; default 2000).  Measured at B = 640, same box, ms per launch
+// for convs 1-5 with thresholds 0 / 2000 / 1000: 1.185 0.605 0.316 0.315 0.289 / 1.160 0.591 0.306 0.306 0.293 /
+// 1.166 0.592 0.307 0.306 0.334 -- conv5 has 1280 tiles of 128 rows = 640 of 256: 1.25 rounds of 512 slots.
 static int pick_bm(int64_t B, int P, int Cout) {
-    static const int64_t thr = []() { const char* e = getenv("NAFP_BM256"); return e ? atoll(e) : (int64_t)0; }();
+    static const int64_t thr = []() { const char* e = getenv("NAFP_BM256"); return e ? atoll(e) : (int64_t)2000; }();
     if (thr <= 0) return 128;
     const int pt = tile_pt(P), ST = 128 / pt;
     const int64_t n_tiles = ((B + ST - 1) / ST) * ((P + pt - 1) / pt) * (Cout / BN);

@@ -40,15 +40,16 @@ def build_fp(cfg):
 
 
 def load_checkpoint(checkpoint_root_dir, checkpoint_name, checkpoint_index, m_fp, optimizer=None):
-    """generate.py:26-52: latest index when none is given; FileNotFoundError if absent.  `ckpt-N.pt` (this
-    build) or `ckpt-N.npz` (weights converted from a TensorFlow checkpoint of the reference by
-    tools/convert_tf_checkpoint.py); the .pt wins when both exist."""
+    """generate.py:26-52: latest index when none is given; FileNotFoundError if absent.  In order of preference:
+    `ckpt-N.pt` (this build); `ckpt-N.npz` (weights converted inside the reference's TensorFlow environment by
+    tools/convert_tf_checkpoint.py); `ckpt-N.index` + `ckpt-N.data-00000-of-00001` = a checkpoint WRITTEN BY THE
+    REFERENCE itself, read directly (utils/tf_checkpoint.py: every checksum of the format verified; see its caveat)."""
     checkpoint_dir = checkpoint_root_dir + f'/{checkpoint_name}/'
     if checkpoint_index is None:
         print("\x1b[1;32mArgument 'checkpoint_index' was not specified.\x1b[0m")
         print('\x1b[1;32mSearching for the latest checkpoint...\x1b[0m')
         idx = [int(m.group(1)) for f in glob.glob(checkpoint_dir + 'ckpt-*')
-               for m in [re.search(r'ckpt-(\d+)\.(pt|npz)$', f)] if m]
+               for m in [re.search(r'ckpt-(\d+)\.(pt|npz|index)$', f)] if m]
         if not idx:
             raise FileNotFoundError(f'Cannot find checkpoint in {checkpoint_dir}')
         checkpoint_index = max(idx)
@@ -62,6 +63,13 @@ def load_checkpoint(checkpoint_root_dir, checkpoint_name, checkpoint_index, m_fp
         fpath = fpath[:-3] + '.npz'
         with np.load(fpath) as z:
             m_fp.load_state_dict({k: z[k] for k in z.files})
+    elif os.path.exists(fpath[:-3] + '.index'):
+        from .utils import tf_checkpoint as tfc
+        from .fp.nnfp import tensor_names
+        fpath = fpath[:-3]
+        m_fp.load_state_dict(tfc.state_dict_from_tf_checkpoint(fpath, tensor_names(), [tuple(v.shape) for v in m_fp.trainable_variables],
+                                                               m_fp.emb_sz))
+        fpath += '.index'
     else:
         raise FileNotFoundError(f'Cannot find checkpoint {fpath}')
     print(f'---Restored from {fpath}---')

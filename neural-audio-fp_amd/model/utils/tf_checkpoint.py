@@ -213,7 +213,8 @@ _FWD = {0: 'conv2d_1x3', 1: 'BN_1x3', 2: 'conv2d_3x1', 3: 'BN_3x1'}      # ConvL
 def state_dict_from_tf_checkpoint(prefix, names, shapes, emb_sz):
     """The encoder's state dict (keys `names`, shapes `shapes`: nnfp.tensor_names() / library order) from the reference's
     checkpoint `prefix` = .../ckpt-<N>.  Raises if any variable is missing, duplicated or mis-shaped."""
-    tensors = read_bundle(prefix, want=lambda n: n.startswith('model/') and n.endswith(SUFFIX))
+    # optimizer slots hang off the variables they belong to (`<variable>/.OPTIMIZER_SLOT/optimizer/{m,v}/...`): not weights
+    tensors = read_bundle(prefix, want=lambda n: n.startswith('model/') and n.endswith(SUFFIX) and '/.OPTIMIZER_SLOT/' not in n)
     got, div = {}, {}
     for name, arr in tensors.items():
         m = _CONV.match(name)
