@@ -80,6 +80,8 @@ struct nafp_encoder {
     // conv1 1.17 ms materialised vs 0.17 ms (statistics pass) + 1.38 ms fused: the ELU evaluation is
     // VALU-bound, so re-generating z0 in conv1 costs what the store saved.
     bool opt_fuse_conv0 = []() { const char* v = getenv("NAFP_FUSE0"); return v && v[0] == '1'; }();
+    // NAFP_OPT_FUSED_LN_BWD (default NAFP_DGRAD_LN env, else 1)
+    int opt_fused_ln_bwd = []() { const char* v = getenv("NAFP_DGRAD_LN"); return v ? atoi(v) : 1; }();
     // per-segment workspace layout (floats)
     int64_t bufA_per_seg = 0, bufB_per_seg = 0;
     // optional per-kernel event timing (nafp_encoder_profile_*)
@@ -237,6 +239,9 @@ extern "C" int nafp_encoder_set_option(nafp_encoder* e, int option, int value) {
     if (!e) return NAFP_ERR_INVALID_ARG;
     switch (option) {
         case NAFP_OPT_FUSE_CONV0: e->opt_fuse_conv0 = value != 0; return NAFP_OK;
+        case NAFP_OPT_FUSED_LN_BWD:
+            if (value < 0 || value > 2) return NAFP_ERR_INVALID_ARG;
+            e->opt_fused_ln_bwd = value; return NAFP_OK;
         default: return NAFP_ERR_INVALID_ARG;
     }
 }
@@ -553,13 +558,16 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
     if (rc != NAFP_OK) return rc;
     // `cur` holds r_j * dL/dxhat_j on entry of iteration j and r_{j-1} * dL/dt_j (dts) after launch_ln_bwd
     float* cur = L.dA; float* other = L.dB;
+    bool ln_done = false;       // `cur` already holds dts_j (the LayerNorm backward of layer j ran inside dgrad_{j+1})
     for (int j = 15; j >= 1; --j) {
         const ConvGeom& g = e->geom[j];
         const int P = g.Fout * g.Tout;
         const float* mr_j = L.mr + 2 * B * j; const float* mr_p = L.mr + 2 * B * (j - 1);
-        rc = launch_ln_bwd(cur, L.v[j], e->d_gamma[j], mr_j, mr_p, L.lnsum[j], L.sc, grads[4 * j + 2], grads[4 * j + 3],
-                           grads[4 * j + 1], L.S1[j], L.S2[j], B, P, g.Cout, st, j == 15, e->d_G[j], e->d_Hb[j], L.lnsum[j - 1]);
-        if (rc != NAFP_OK) return rc;
+        if (!ln_done) {
+            rc = launch_ln_bwd(cur, L.v[j], e->d_gamma[j], mr_j, mr_p, L.lnsum[j], L.sc, grads[4 * j + 2], grads[4 * j + 3],
+                               grads[4 * j + 1], L.S1[j], L.S2[j], B, P, g.Cout, st, j == 15, e->d_G[j], e->d_Hb[j], L.lnsum[j - 1]);
+            if (rc != NAFP_OK) return rc;
+        }
         // dW_j = wgrad(z_{j-1}, r dt) + wgrad(gamma_{j-1}, sum_b c_b dt) + wgrad(beta_{j-1}, sum_b dt)
         rc = launch_wgrad(L.z[j - 1], cur, grads[4 * j], B, g, st);
         if (rc != NAFP_OK) return rc;
@@ -567,22 +575,40 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
         if (rc != NAFP_OK) return rc;
         rc = launch_wgrad(e->d_beta[j - 1], L.S2[j], grads[4 * j], 1, g, st);
         if (rc != NAFP_OK) return rc;
-        // r_{j-1} * dxhat_{j-1} = transposed conv of dts_j
-        ConvGemmArgs a{};
-        a.x = cur; a.wp = e->d_wd[j]; a.y = other; a.plain = true; a.dgrad = true;
-        a.slab = L.slab_floats ? L.slab : nullptr; a.slab_floats = L.slab_floats;
-        rc = launch_conv_gemm(a, B, g, st);
-        if (rc != NAFP_OK) return rc;
+        ln_done = dgrad_ln_eligible(B, g, e->opt_fused_ln_bwd);
+        if (ln_done) {
+            // transposed conv of dts_j with the LayerNorm + ELU backward of layer j-1 in its epilogue: `other` <- dts_{j-1}
+            const ConvGeom& gp = e->geom[j - 1];
+            const int64_t n_prev = (int64_t)gp.Fout * gp.Tout * gp.Cout;
+            rc = launch_ln_bwd_scalars(mr_p, L.lnsum[j - 1], j >= 2 ? L.mr + 2 * B * (j - 2) : nullptr, L.sc, B, n_prev, st);
+            if (rc != NAFP_OK) return rc;
+            DgradLnArgs d{};
+            d.dts_in = cur; d.wd = e->d_wd[j]; d.t = L.v[j - 1]; d.gamma = e->d_gamma[j - 1]; d.sc = L.sc; d.dts_out = other;
+            d.dgamma = grads[4 * (j - 1) + 2]; d.dbeta = grads[4 * (j - 1) + 3]; d.dbias = grads[4 * (j - 1) + 1];
+            if (j >= 2) { d.G = e->d_G[j - 1]; d.Hb = e->d_Hb[j - 1]; d.S1 = L.S1[j - 1]; d.S2 = L.S2[j - 1]; d.lnsum_below = L.lnsum[j - 2]; }
+            rc = launch_dgrad_ln(d, B, g, st);
+            if (rc != NAFP_OK) return rc;
+        } else {
+            // r_{j-1} * dxhat_{j-1} = transposed conv of dts_j
+            ConvGemmArgs a{};
+            a.x = cur; a.wp = e->d_wd[j]; a.y = other; a.plain = true; a.dgrad = true;
+            a.slab = L.slab_floats ? L.slab : nullptr; a.slab_floats = L.slab_floats;
+            rc = launch_conv_gemm(a, B, g, st);
+            if (rc != NAFP_OK) return rc;
+        }
         std::swap(cur, other);
-        // layers j .. 15 (and the divide-and-encode tensors) are final from here on
+        // layers j .. 15 (and the divide-and-encode tensors) are final from here on (when the LayerNorm backward of layer
+        // j-1 ran fused, its dgamma / dbeta / dbias are final too: they belong to the next group or are simply early)
         for (int k = 0; k < NAFP_GRAD_GROUPS - 1; ++k)
             if (4 * j == kGroupFirst[k]) NAFP_HIP_CHECK(hipEventRecord(e->grad_events[k], st));
     }
     {
         const ConvGeom& g = e->geom[0];
-        rc = launch_ln_bwd(cur, L.v[0], e->d_gamma[0], L.mr, nullptr, L.lnsum[0], L.sc, grads[2], grads[3], grads[1],
-                           nullptr, nullptr, B, g.Fout * g.Tout, g.Cout, st, false, nullptr, nullptr, nullptr);
-        if (rc != NAFP_OK) return rc;
+        if (!ln_done) {
+            rc = launch_ln_bwd(cur, L.v[0], e->d_gamma[0], L.mr, nullptr, L.lnsum[0], L.sc, grads[2], grads[3], grads[1],
+                               nullptr, nullptr, B, g.Fout * g.Tout, g.Cout, st, false, nullptr, nullptr, nullptr);
+            if (rc != NAFP_OK) return rc;
+        }
         rc = launch_conv0_bwd(feat, cur, grads[0], nullptr, B, g, st);
         if (rc != NAFP_OK) return rc;
     }

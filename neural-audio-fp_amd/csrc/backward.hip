@@ -581,6 +581,12 @@ int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* 
     return NAFP_OK;
 }
 
+int launch_ln_bwd_scalars(const float* mr, const double* lnsum, const float* mr_prev, float* sc, int64_t B, int64_t n, hipStream_t st) {
+    ln_bwd_scalars_kernel<<<(unsigned)((B + 255) / 256), 256, 0, st>>>(mr, lnsum, mr_prev, sc, B, 1.0 / (double)n);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}
+
 int launch_conv0_bwd(const float* feat, const float* dt, float* dW0, float* dbias0, int64_t B, const ConvGeom& g,
                      hipStream_t st) {
     if (g.Cin != 1 || g.axis != 0 || (g.Cout % 4) != 0 || 256 % (g.Cout / 4) != 0) return NAFP_ERR_UNSUPPORTED;

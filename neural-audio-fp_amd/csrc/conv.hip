@@ -975,6 +975,320 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
 }
 
 // ============================================================================
+// Transposed conv FUSED with the LayerNorm + ELU backward of the layer it feeds (training, big layers).
+//
+// The plain chain per layer is: dgrad_j writes D'_{j-1} = conv_j^T(dts_j)  ->  ln_bwd_fused(j-1) reads D'_{j-1} and
+// t_{j-1}, writes dts_{j-1}: the gradient crosses HBM twice for nothing.  The per-sample sums (s1, s2) that the
+// LayerNorm backward needs are known BEFORE this launch (adjoint identity, backward.hip), so the whole element-wise part
+// can run in the epilogue of the transposed conv, on the accumulators: read t_{j-1}, write dts_{j-1}.
+// What remains are the sums over the BATCH per element (dgamma, dbeta, S1, S2; dbias).  To make those cheap a tile is
+// ONE position x 128 samples (so every row of a tile adds into the same (position, channel) slots) and a workgroup walks
+// over the sample groups of its position, keeping the five sums per owned column in registers: one set of atomics per
+// workgroup, not per tile.  All rows of a tile share their source geometry and live taps (a stride-2 position is of one
+// parity class by construction).  The per-sample sums of the layer below (adjoint identity again) are row sums: lanes of
+// a row meet through 5 shuffles and one LDS atomic.
+//   grid = (positions x chunks of sample groups, C / 128); 256 threads = 2 x 2 waves of 64 x 64, BK = 16, 3-stage ring.
+// ============================================================================
+// Sum over each 32-lane half of a wave with DPP row shifts (VALU only, no LDS crossbar): afterwards lane 31 holds the sum
+// of lanes 0..31 and lane 63 the sum of lanes 32..63.
+__device__ __forceinline__ float half_wave_sum_dpp(float x) {
+    int v = __builtin_bit_cast(int, x);
+#define NAFP_DPP_ADD(ctrl_, rmask_)                                                                       \
+    v = __builtin_bit_cast(int, __builtin_bit_cast(float, v) +                                            \
+                                    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, v, ctrl_, rmask_, 0xf, true)));
+    NAFP_DPP_ADD(0x111, 0xf)      // row_shr:1
+    NAFP_DPP_ADD(0x112, 0xf)      // row_shr:2
+    NAFP_DPP_ADD(0x114, 0xf)      // row_shr:4
+    NAFP_DPP_ADD(0x118, 0xf)      // row_shr:8   -> lane 15 of every 16-lane row holds the row's sum
+    NAFP_DPP_ADD(0x142, 0xa)      // row_bcast:15 into rows 1 and 3: lanes 31 and 63 hold the half sums
+#undef NAFP_DPP_ADD
+    return __builtin_bit_cast(float, v);
+}
+
+struct DgradLnParams {
+    ConvKernelParams c;            // the transposed conv (dgrad = 1): x = dts_j, wp = Wd_j, P / Tout / ... of its OUTPUT rows
+    const float* t;                // (B, P, C)  pre-activation of layer j-1
+    const float* gamma;            // (P, C)     LN scale of layer j-1
+    const float* G; const float* Hb;   // (P, C) positional tensors of layer j-1 (sums of layer j-2), or null
+    const float* sc;               // (B, 8)     per-sample scalars of layer j-1 (ln_bwd_scalars_kernel)
+    float* dts;                    // (B, P, C)  out
+    float* dgamma; float* dbeta; float* dbias;
+    float* S1; float* S2;          // or null
+    double* lnsum_below;           // (B, 2) or null
+    int n_groups, groups_per_wg, n_chunks;
+};
+
+__global__ __launch_bounds__(256, 3) void dgrad_ln_kernel(const DgradLnParams q) {
+    constexpr int BM = 128, BK = 16, NSTAGE = 3, CH = 4, RPI = 16, NI = 2;
+    constexpr int TILE = BM * BK, STAGE = 2 * TILE;
+    constexpr unsigned OOB = 0x80000000u;
+    const ConvKernelParams& p = q.c;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // [3 stages: A | B] [sSc[128][8]] [sRow[128][2]] [sCol[5][128]] [sDummy[64]]
+    float* sSc = smem + NSTAGE * STAGE;
+    float* sRow = sSc + BM * 8;
+    float* sCol = sRow + BM * 2;
+    float* sDummy = sCol + 5 * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int chunk = blockIdx.x % q.n_chunks;
+    const int pos = tile_pos(p, blockIdx.x / q.n_chunks);
+    const int tile_n0 = blockIdx.y * BN;
+    const int K = 3 * p.Cin;
+    const int C = p.Cout;                              // channels of the layer whose LayerNorm backward runs here
+    const RowGeom rg = row_geom(p, pos);               // one position per workgroup: shared by every row
+    unsigned tap_pack = 0; int n_live = 0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        if (rg.mask & (1u << t)) { tap_pack |= (unsigned)t << (2 * n_live); ++n_live; }
+    const int cpt = p.Cin / BK, n_steps = n_live * cpt;
+
+    unsigned voffA[NI], voffB[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int lr = wave * 32 + i * RPI + lane / CH;
+        const int lc = (lane % CH) ^ ((lr >> 2) & 3);
+        voffA[i] = (unsigned)(lr * (int)p.sample_in + rg.inner + lc * 4) * 4u;      // row lr = sample b0 + lr
+        voffB[i] = (unsigned)((tile_n0 + lr) * K + lc * 4) * 4u;
+    }
+    const u32x4 rsB = make_rsrc(p.wp, p.wp_bytes);
+    const unsigned lds0 = (unsigned)(unsigned long long)(lds_ptr_t)smem + (unsigned)(wave * 32 * BK * 4);
+    const int rl = lane & 31, hh = lane >> 5;
+    const int rswz = (rl >> 2) & 3;
+    const int aoff = (wm * 64 + rl) * BK, boff = TILE + (wn * 64 + rl) * BK;
+    const int ncol = lane & 31;
+    const int n_base = tile_n0 + wn * 64 + ncol;
+    // positional operands of this lane's two columns
+    float gam[2], Gq[2], Hq[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int o = pos * C + n_base + ni * 32;
+        gam[ni] = q.gamma[o];
+        Gq[ni] = q.lnsum_below ? q.G[o] : 0.f;
+        Hq[ni] = q.lnsum_below ? q.Hb[o] : 0.f;
+    }
+    float ag[2] = {0.f, 0.f}, ab[2] = {0.f, 0.f}, a1[2] = {0.f, 0.f}, a2[2] = {0.f, 0.f};
+
+    const int g_begin = chunk * q.groups_per_wg, g_end = min(q.n_groups, g_begin + q.groups_per_wg);
+    for (int grp = g_begin; grp < g_end; ++grp) {
+        const int b0 = grp * BM;
+        const int nb = min(BM, p.B - b0);
+        // per-sample scalars of this group, zeroed row sums (visible after the first K-step barrier)
+        {
+            const int r = tid >> 1, h = tid & 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < nb) v = *(const float4*)(q.sc + 8 * (int64_t)(b0 + r) + 4 * h);
+            *(float4*)(sSc + 8 * r + 4 * h) = v;
+            sRow[tid] = 0.f;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // landed before this wave reaches the first barrier
+        }
+        const u32x4 rsA = make_rsrc(p.x + (int64_t)b0 * p.sample_in, (unsigned)nb * (unsigned)p.sample_in * 4u);
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+#define NAFP_DL_DMA(s_, slot_)                                                                 \
+        {                                                                                      \
+            const int tsel_l = (s_) / cpt;                                                     \
+            const int tap_l = (int)((tap_pack >> (2 * tsel_l)) & 3u);                          \
+            const int c0_l = ((s_) - tsel_l * cpt) * BK;                                       \
+            const unsigned la_l = lds0 + (unsigned)((slot_) * STAGE * 4);                      \
+            const unsigned tapb_l = (unsigned)(tap_l * p.tap_stride) * 4u;                     \
+            _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                   \
+                const int lr_l = wave * 32 + i * RPI + lane / CH;                              \
+                lds_dma16(la_l + i * RPI * BK * 4, lr_l < nb ? voffA[i] + tapb_l : OOB, rsA, (unsigned)(c0_l * 4)); \
+                lds_dma16(la_l + (TILE + i * RPI * BK) * 4, voffB[i], rsB, (unsigned)((tap_l * p.Cin + c0_l) * 4)); \
+            }                                                                                  \
+        }
+#pragma unroll
+        for (int s = 0; s < NSTAGE - 1; ++s)
+            if (s < n_steps) NAFP_DL_DMA(s, s)
+        int slot = 0;
+        for (int s = 0; s < n_steps; ++s) {
+            if (s + NSTAGE - 2 >= n_steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "i"((NSTAGE - 2) * 2 * NI) : "memory");
+            __builtin_amdgcn_s_barrier();
+            int nslot = slot + NSTAGE - 1; if (nslot >= NSTAGE) nslot -= NSTAGE;
+            const float* St = smem + slot * STAGE;
+            float4 a0[2], b0v[2];
+            {
+                const int pc4 = ((0 + hh) ^ rswz) * 4;
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) a0[mi] = *(const float4*)(St + aoff + mi * 32 * BK + pc4);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) b0v[ni] = *(const float4*)(St + boff + ni * 32 * BK + pc4);
+            }
+            if (s + NSTAGE - 1 < n_steps) NAFP_DL_DMA(s + NSTAGE - 1, nslot)
+#pragma unroll
+            for (int kk = 0; kk < BK / 8; ++kk) {
+                const int pc4 = ((2 * kk + hh) ^ rswz) * 4;
+                float4 a[2], b[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) a[mi] = kk == 0 ? a0[mi] : *(const float4*)(St + aoff + mi * 32 * BK + pc4);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) b[ni] = kk == 0 ? b0v[ni] : *(const float4*)(St + boff + ni * 32 * BK + pc4);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].x, b[ni].x, acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].y, b[ni].y, acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].z, b[ni].z, acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, b[ni].w, acc[mi][ni], 0, 0, 0);
+                    }
+            }
+            if (++slot == NSTAGE) slot = 0;
+        }
+#undef NAFP_DL_DMA
+        if (n_steps == 0) __syncthreads();             // (a position no tap reaches: D' = 0; still publish sSc / sRow)
+        // ---- epilogue: LayerNorm + ELU backward of layer j-1 on the accumulators (D' = acc) ----
+        // row = (r & 3) + 8 (r >> 2) + 4 hh inside each 32-row block = sample b0 + row.  t and dts go through buffer
+        // descriptors re-based on the group's first sample: the lane part of the address is ONE 32-bit register for
+        // the whole epilogue, the row part a running scalar, and rows beyond the batch are out of range (loads return
+        // 0, stores are dropped) -- no 64-bit address arithmetic, no predication.
+        {
+            int PC = p.P * C;
+            asm volatile("" : "+s"(PC));                   // keep the per-row scalars inside the loop (they were hoisted -> spills)
+            const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(q.t) + (int64_t)b0 * PC, 0, (int)((unsigned)nb * (unsigned)PC * 4u), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(
+                q.dts + (int64_t)b0 * PC, 0, (int)((unsigned)nb * (unsigned)PC * 4u), 0x00020000);
+            const int voff = ((wm * 64 + 4 * hh) * PC + pos * C + n_base) * 4;
+            const int row_bytes = PC * 4;
+            const float* sScL = sSc + 8 * (wm * 64 + 4 * hh);
+            float* sRowL = sRow + 2 * (wm * 64 + 4 * hh);
+            const int nbl = nb - (wm * 64 + 4 * hh);         // rows (r & 3) + 8 (r >> 2) + 32 mi < nbl are real samples
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {                      // 4 rows at a time: 8 loads in flight, then the arithmetic
+                    const int soff0 = (mi * 32 + 8 * rq) * row_bytes;
+                    float tv[4][2];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        tv[k][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsT, voff, soff0 + k * row_bytes, 0));
+                        tv[k][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsT, voff + 128, soff0 + k * row_bytes, 0));
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int r = 4 * rq + k;
+                        const int rl_ = mi * 32 + 8 * rq + k;          // row relative to this lane's first row
+                        const bool valid = rl_ < nbl;
+                        const float4 s0 = *(const float4*)(sScL + 8 * rl_), s1 = *(const float4*)(sScL + 8 * rl_ + 4);
+                        const float mean = s0.x, rstd = s0.y, m1 = s0.z, m2 = s0.w, inv_r = s1.x, rprev = s1.y, cprev = s1.z;
+                        float q1 = 0.f, q2 = 0.f;
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            const float tt = tv[k][ni], dd = acc[mi][ni][r];
+                            const float vv = elu1(tt);
+                            const float xt = (vv - mean) * rstd;
+                            float dt = (dd * gam[ni] - m1 - xt * m2) * (vv > 0.f ? 1.f : vv + 1.f);
+                            float du = dd * inv_r;
+                            if (!valid) { dt = 0.f; du = 0.f; }
+                            const float o = dt * rprev;
+                            ag[ni] = fmaf(du, xt, ag[ni]); ab[ni] += du;
+                            a1[ni] = fmaf(cprev, o, a1[ni]); a2[ni] += dt;
+                            // pin the four running sums here: otherwise the compiler sinks all 64 rows' updates below the
+                            // loop nest and spills their operands (xt, dt, the scalars) to scratch on the way
+                            asm volatile("" : "+v"(ag[ni]), "+v"(ab[ni]), "+v"(a1[ni]), "+v"(a2[ni]));
+                            q1 = fmaf(o, Gq[ni], q1); q2 = fmaf(o, tt - Hq[ni], q2);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, o), rsO, voff + 128 * ni, soff0 + k * row_bytes, 0);
+                        }
+                        // the 32 lanes of a half hold the 64 columns of this row: (q1, q2) meet in lanes 31 / 63.
+                        // Branch-free on purpose (the other lanes add into a scratch slot of their own; without a layer
+                        // below the sums are simply not read): with a branch per row the compiler postponed the batch
+                        // sums of all 64 rows to the end of the epilogue and spilled their operands.
+                        q1 = half_wave_sum_dpp(q1); q2 = half_wave_sum_dpp(q2);
+                        float* dstq = ncol == 31 ? sRowL + 2 * rl_ : sDummy + lane;
+                        atomicAdd(dstq, q1);
+                        atomicAdd(ncol == 31 ? dstq + 1 : dstq, q2);
+                    }
+                    // one 4-row block at a time: left to itself the scheduler hoists the operand reads of all 16
+                    // blocks to the top of the epilogue and spills the accumulators to make room
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        __syncthreads();                               // all reads of the ring / sSc and all sRow atomics are done
+        if (q.lnsum_below && tid < 2 * nb) atomicAdd(q.lnsum_below + 2 * (int64_t)b0 + tid, (double)sRow[tid]);
+        __syncthreads();                               // sRow / sSc are rewritten by the next group
+    }
+    // ---- the batch sums of this workgroup's (position, 128 columns): halves of a wave, then the two wm waves ----
+    for (int i = tid; i < 5 * BN; i += 256) sCol[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        float v0 = ag[ni] + __shfl_xor(ag[ni], 32, 64), v1 = ab[ni] + __shfl_xor(ab[ni], 32, 64);
+        float v2 = a1[ni] + __shfl_xor(a1[ni], 32, 64), v3 = a2[ni] + __shfl_xor(a2[ni], 32, 64);
+        if (hh == 0) {
+            const int cidx = wn * 64 + ni * 32 + ncol;
+            atomicAdd(sCol + 0 * BN + cidx, v0); atomicAdd(sCol + 1 * BN + cidx, v1);
+            atomicAdd(sCol + 2 * BN + cidx, v2); atomicAdd(sCol + 3 * BN + cidx, v3);
+        }
+    }
+    __syncthreads();
+    if (tid < BN) {
+        const int o = pos * C + tile_n0 + tid;
+        atomicAdd(q.dgamma + o, sCol[0 * BN + tid]);
+        atomicAdd(q.dbeta + o, sCol[1 * BN + tid]);
+        if (q.S1) { atomicAdd(q.S1 + o, sCol[2 * BN + tid]); atomicAdd(q.S2 + o, sCol[3 * BN + tid]); }
+        atomicAdd(q.dbias + tile_n0 + tid, sCol[3 * BN + tid]);
+    }
+}
+
+// Whether the transposed conv of layer geometry `g` at batch B takes the fused path (layer j-1 = the conv's input).
+bool dgrad_ln_eligible(int64_t B, const ConvGeom& g, int mode) {
+    if (mode == 0 || g.Cin % BN != 0 || g.Cout % 16 != 0) return false;
+    if ((int64_t)BN * g.Fout * g.Tout * g.Cout * 4 >= ((int64_t)1 << 31)) return false;      // A descriptor of 128 samples
+    if (mode == 2) return true;
+    // the big layers only: that is where the LayerNorm backward is HBM traffic; small ones keep their launch count down
+    return B >= 64 && (int64_t)g.Fin * g.Tin * g.Cin >= 32768;
+}
+
+int launch_dgrad_ln(const DgradLnArgs& a, int64_t B, const ConvGeom& g, hipStream_t st) {
+    if (!dgrad_ln_eligible(B, g, 2)) return NAFP_ERR_UNSUPPORTED;
+    DgradLnParams q;
+    ConvKernelParams& p = q.c;
+    p.x = a.dts_in; p.wp = a.wd; p.G = nullptr; p.Hb = nullptr; p.gamma_out = nullptr; p.bias = nullptr;
+    p.stats_in = nullptr; p.stats_out = nullptr; p.y = nullptr; p.v_out = nullptr;
+    // rows = input positions of the conv; source = dT (B, Fout, Tout, Cout); weights (Cin, 3*Cout): as launch_conv_gemm's dgrad
+    p.axis = g.axis; p.stride = g.stride; p.pad = g.pad;
+    p.dgrad = 1;
+    p.Fin = g.Fout; p.Tin = g.Tout; p.Cin = g.Cout; p.Cout = g.Cin; p.Tout = g.Tin;
+    p.B = (int)B; p.P = g.Fin * g.Tin;
+    p.PT = 1; p.ST = BN; p.log2ST = 7;
+    p.n_sg = (int)((B + 127) / 128);
+    p.sample_in = (int64_t)g.Fout * g.Tout * g.Cout;
+    const int S = g.axis == 0 ? g.Cout : g.Tout * g.Cout;
+    p.tap_stride = -(S / g.stride);
+    p.inv_n_in = 1.0; p.mode = 1; p.n_split = 1; p.abl = 0;
+    p.perm_on = 0; p.perm_n0 = 0; p.perm_c0 = 0;        // one position per workgroup: no class ordering needed
+    p.wp_bytes = (unsigned)((int64_t)g.Cout * 3 * g.Cin * 4);
+    p.f0_feat = nullptr; p.f0_w = nullptr; p.f0_bias = nullptr; p.f0_gamma = nullptr; p.f0_T = 0; p.f0_stride = 1; p.f0_pad = 0;
+    q.t = a.t; q.gamma = a.gamma; q.G = a.G; q.Hb = a.Hb; q.sc = a.sc; q.dts = a.dts_out;
+    q.dgamma = a.dgamma; q.dbeta = a.dbeta; q.dbias = a.dbias; q.S1 = a.S1; q.S2 = a.S2; q.lnsum_below = a.lnsum_below;
+    q.n_groups = p.n_sg;
+    // enough workgroups for two full rounds of 768 resident ones; a workgroup's atomics amortise over its sample groups
+    const int64_t base = (int64_t)p.P * (g.Cin / BN);
+    int chunks = (int)std::min<int64_t>(q.n_groups, std::max<int64_t>(1, (1536 + base - 1) / base));
+    q.groups_per_wg = (q.n_groups + chunks - 1) / chunks;
+    q.n_chunks = (q.n_groups + q.groups_per_wg - 1) / q.groups_per_wg;
+    const int lds = (3 * 2 * 128 * 16 + 128 * 8 + 128 * 2 + 5 * BN + 64) * (int)sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)dgrad_ln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
+    }
+    dgrad_ln_kernel<<<dim3((unsigned)((int64_t)p.P * q.n_chunks), (unsigned)(g.Cin / BN)), 256, lds, st>>>(q);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}
+
+// ============================================================================
 // weight packing: keras kernel (3, Cin, Cout) -> Wp (Cout, 3*Cin), k contiguous,
 // so that B-operand tiles load exactly like A-operand tiles.
 // ============================================================================

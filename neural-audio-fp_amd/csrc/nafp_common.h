@@ -119,6 +119,19 @@ int launch_conv0_stats(const float* feat, const float* w3, const float* bias, do
 int64_t conv_gemm_slab_floats(int64_t B, const ConvGeom& g, bool with_dgrad = false);   // workspace the split-K policy wants
 int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStream_t st);
 
+// Transposed conv of layer j fused with the LayerNorm + ELU backward of layer j-1 (conv.hip, dgrad_ln_kernel): reads
+// dts_j, t_{j-1} and the per-sample scalars of layer j-1, writes dts_{j-1} and accumulates dgamma / dbeta / dbias / S1 /
+// S2 of layer j-1 and (G, Hb, lnsum_below given) the LayerNorm sums of layer j-2.
+struct DgradLnArgs {
+    const float* dts_in; const float* wd;
+    const float* t; const float* gamma; const float* G; const float* Hb; const float* sc;
+    float* dts_out; float* dgamma; float* dbeta; float* dbias; float* S1; float* S2; double* lnsum_below;
+};
+bool dgrad_ln_eligible(int64_t B, const ConvGeom& g, int mode);      // mode: 0 never, 1 big layers at B >= 64, 2 wherever the geometry permits
+int launch_dgrad_ln(const DgradLnArgs& a, int64_t B, const ConvGeom& g, hipStream_t st);
+// per-sample scalar records (B, 8) of one layer's LayerNorm backward (see backward.hip)
+int launch_ln_bwd_scalars(const float* mr, const double* lnsum, const float* mr_prev, float* sc, int64_t B, int64_t n, hipStream_t st);
+
 // tail: LN of the last conv + flatten + divide-and-encode + optional L2 norm.
 struct TailArgs {
     const float* x;          // (B, D): z = gamma . v of the last conv, or already-normalised flat

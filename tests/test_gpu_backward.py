@@ -17,13 +17,18 @@ def _reference(feat, w, d_emb):
     return emb.detach().numpy(), [p.grad.numpy() for p in tf.params]
 
 
+@pytest.mark.parametrize('fused_ln', [1, 0, 2])
 @pytest.mark.parametrize('B', [2, 5])
-def test_encoder_backward_matches_autograd(nafp, B):
+def test_encoder_backward_matches_autograd(nafp, B, fused_ln):
+    """fused_ln = NAFP_OPT_FUSED_LN_BWD: 2 runs the LayerNorm backward of every eligible layer inside the transposed
+    conv that produces its gradient (dgrad_ln_kernel: one position x 128 samples per tile, here mostly empty rows),
+    0 never, 1 the default policy (at this batch size: never)."""
     rng = np.random.default_rng(20 + B)
     feat = (-rng.uniform(0, 1.2, size=(B, 256, 32, 1))).astype(np.float32)
     w = _inputs.weights(seed=12)
     d_emb = rng.normal(size=(B, 128)).astype(np.float32)
     m_fp = nafp.FingerPrinter(seed=0)
+    m_fp.set_option(2, fused_ln)
     m_fp.set_weights(_inputs.weight_list(w))
     emb = m_fp.forward_train(torch.from_numpy(feat).cuda())
     grads = m_fp.backward(torch.from_numpy(d_emb).cuda())
@@ -113,3 +118,25 @@ def test_two_second_segments_forward_and_backward(nafp):
     for i, (g, p) in enumerate(zip(grads, tf.params)):
         wg = p.grad.numpy()
         assert np.abs(g.cpu().numpy() - wg).max() / (np.abs(wg).max() + 1e-12) < 2e-3, i
+
+
+@pytest.mark.parametrize('B', [64, 130, 257])
+def test_fused_ln_backward_equals_the_separate_pass(nafp, B):
+    """At batches where the default policy fuses (B >= 64; 130 and 257 leave ragged 128-sample groups): gradients with
+    NAFP_OPT_FUSED_LN_BWD = 1 and 2 against 0 (the separate LayerNorm-backward pass, itself held to float64 autograd
+    above).  Same arithmetic per element; the sums over samples and positions run in a different order."""
+    g = torch.Generator(device='cuda').manual_seed(B)
+    feat = -1.2 * torch.rand((B, 256, 32, 1), generator=g, device='cuda')
+    d_emb = torch.randn((B, 128), generator=g, device='cuda')
+    w = _inputs.weight_list(_inputs.weights(seed=14))
+    out = {}
+    for mode in (0, 1, 2):
+        m_fp = nafp.FingerPrinter(seed=0)
+        m_fp.set_option(2, mode)
+        m_fp.set_weights(w)
+        m_fp.forward_train(feat)
+        out[mode] = [t.clone() for t in m_fp.backward(d_emb)]
+    for mode in (1, 2):
+        for i, (a, b) in enumerate(zip(out[mode], out[0])):
+            scale = float(b.abs().max()) + 1e-20
+            assert float((a - b).abs().max()) / scale < 2e-4, (mode, i)
