@@ -193,8 +193,9 @@ int nafp_encoder_grad_group_wait(nafp_encoder* enc, int group, void* stream);
  *                           re-generates its input tiles in-kernel from the log-mel features.
  *   NAFP_OPT_FUSED_LN_BWD  training: the LayerNorm + ELU backward of a layer runs in the epilogue of the transposed conv
  *                        that produces its gradient (one read of the stored pre-activation, one write, instead of a
- *                        separate pass that re-reads and re-writes the gradient).  0: never; 1 (default): for the
- *                        layers of >= 32768 elements per sample at batches >= 64; 2: wherever the geometry permits. */
+ *                        separate pass that re-reads and re-writes the gradient).  0 (default): never -- measured slower
+ *                        than the separate pass; 1: for the layers of >= 32768 elements per sample at
+ *                        batches >= 64; 2: wherever the geometry permits. */
 #define NAFP_OPT_FUSE_CONV0 1
 #define NAFP_OPT_FUSED_LN_BWD 2
 int nafp_encoder_set_option(nafp_encoder* enc, int option, int value);

@@ -81,7 +81,10 @@ struct nafp_encoder {
     // VALU-bound, so re-generating z0 in conv1 costs what the store saved.
     bool opt_fuse_conv0 = []() { const char* v = getenv("NAFP_FUSE0"); return v && v[0] == '1'; }();
     // NAFP_OPT_FUSED_LN_BWD (default NAFP_DGRAD_LN env, else 1)
-    int opt_fused_ln_bwd = []() { const char* v = getenv("NAFP_DGRAD_LN"); return v ? atoi(v) : 1; }();
+    // Measured (B = 1280, same box, ms per backward pass): 20.9 with the separate LayerNorm-backward pass, 23.3 with the
+    // fused kernel: its one-position x 128-sample tiles read 128 different samples per K-step and its epilogue (row sums
+    // for the layer below, five running batch sums) outweighs the two passes it saves.  Kept as an option, off by default.
+    int opt_fused_ln_bwd = []() { const char* v = getenv("NAFP_DGRAD_LN"); return v ? atoi(v) : 0; }();
     // per-segment workspace layout (floats)
     int64_t bufA_per_seg = 0, bufB_per_seg = 0;
     // optional per-kernel event timing (nafp_encoder_profile_*)
@@ -477,7 +480,7 @@ TrainLayout train_layout(const nafp_encoder* e, int64_t B, void* ws) {
         const int64_t n = (int64_t)e->geom[j].Fout * e->geom[j].Tout * e->geom[j].Cout;
         max_n = std::max(max_n, n);
         L.z[j] = (float*)take((int64_t)sizeof(float) * n * B);
-        L.v[j] = (float*)take((int64_t)sizeof(float) * n * B);
+        L.v[j] = j == 0 ? nullptr : (float*)take((int64_t)sizeof(float) * n * B);     // layer 0: regenerated, not stored
     }
     L.slab_floats = 0;
     for (int j = 1; j < 16; ++j) L.slab_floats = std::max(L.slab_floats, conv_gemm_slab_floats(B, e->geom[j], true));
@@ -503,7 +506,8 @@ extern "C" int nafp_encoder_forward_train(nafp_encoder* e, const float* feat, in
     hipStream_t st = (hipStream_t)stream;
     TrainLayout L = train_layout(e, n_seg, workspace);
     NAFP_HIP_CHECK(hipMemsetAsync(L.stats, 0, sizeof(double) * 2 * 16 * n_seg, st));
-    int rc = launch_conv0(feat, e->d_w[0], e->d_bias[0], e->d_gamma[0], L.z[0], L.v[0], L.stats, n_seg, e->geom[0], st);
+    // (layer 0 keeps no pre-activation: the backward pass regenerates it from `feat`, 3 FMAs per element)
+    int rc = launch_conv0(feat, e->d_w[0], e->d_bias[0], e->d_gamma[0], L.z[0], nullptr, L.stats, n_seg, e->geom[0], st);
     if (rc != NAFP_OK) return rc;
     for (int j = 1; j < 16; ++j) {
         ConvGemmArgs a{};
@@ -575,7 +579,7 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
         if (rc != NAFP_OK) return rc;
         rc = launch_wgrad(e->d_beta[j - 1], L.S2[j], grads[4 * j], 1, g, st);
         if (rc != NAFP_OK) return rc;
-        ln_done = dgrad_ln_eligible(B, g, e->opt_fused_ln_bwd);
+        ln_done = j >= 2 && dgrad_ln_eligible(B, g, e->opt_fused_ln_bwd);   // (layer 0 keeps no pre-activation: see conv0 below)
         if (ln_done) {
             // transposed conv of dts_j with the LayerNorm + ELU backward of layer j-1 in its epilogue: `other` <- dts_{j-1}
             const ConvGeom& gp = e->geom[j - 1];
@@ -605,8 +609,9 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
     {
         const ConvGeom& g = e->geom[0];
         if (!ln_done) {
-            rc = launch_ln_bwd(cur, L.v[0], e->d_gamma[0], L.mr, nullptr, L.lnsum[0], L.sc, grads[2], grads[3], grads[1],
-                               nullptr, nullptr, B, g.Fout * g.Tout, g.Cout, st, false, nullptr, nullptr, nullptr);
+            rc = launch_ln_bwd(cur, nullptr, e->d_gamma[0], L.mr, nullptr, L.lnsum[0], L.sc, grads[2], grads[3], grads[1],
+                               nullptr, nullptr, B, g.Fout * g.Tout, g.Cout, st, false, nullptr, nullptr, nullptr,
+                               feat, e->d_w[0], e->d_bias[0], &g);
             if (rc != NAFP_OK) return rc;
         }
         rc = launch_conv0_bwd(feat, cur, grads[0], nullptr, B, g, st);

@@ -98,11 +98,17 @@ __global__ void ln_bwd_scalars_kernel(const float* __restrict__ mr, const double
 //   S1 += sum_b (-mu_{j-1,b}) dts = sum_b c_b dt,   S2 += sum_b dt.
 // Thread <-> one float4 of the (P, C) plane, loop over a chunk of the batch (blockIdx.y): every
 // per-element sum over b stays in registers and meets the other chunks through one atomic each.
+// CONV0: the layer is b0.conv1x3 (Cin = 1).  Its pre-activation is not stored by the forward pass -- 2 MB per segment
+// written and read back for 3 FMAs per element -- but regenerated here from the log-mel features:
+// t[b, f, to, c] = bias[c] + sum_k w[k, c] feat[b, f, to * stride - pad + k]   (the same fmaf chain as conv0_kernel).
+struct Conv0Regen { const float* feat; const float* w3; const float* bias; int F, Tin, Tout, stride, pad; };
+
+template <bool CONV0>
 __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
         float* __restrict__ d, const float* __restrict__ tpre, const float* __restrict__ gamma,
         const float* __restrict__ sc, float* __restrict__ dgamma, float* __restrict__ dbeta,
         float* __restrict__ dbias, float* __restrict__ S1, float* __restrict__ S2, int64_t n, int64_t B, int C,
-        const float* __restrict__ Gj, const float* __restrict__ Hbj, double* __restrict__ lnsum_below) {
+        const float* __restrict__ Gj, const float* __restrict__ Hbj, double* __restrict__ lnsum_below, const Conv0Regen c0) {
     extern __shared__ float s_q[];                                 // [per][2]: (s1, s2) of the layer below, this block's share
     const int64_t i = blockIdx.x * 256ll + threadIdx.x;
     const bool live = i < n / 4;
@@ -117,13 +123,37 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
+    // CONV0: this thread's position (f, to), its 4 channels' kernel taps and bias
+    float4 k0 = make_float4(0.f, 0.f, 0.f, 0.f), k1 = k0, k2 = k0, kb = k0;
+    int x_off = 0; bool x_ok[3] = {false, false, false};
+    if (CONV0) {
+        const int ch = (int)((4 * ii) % C), pp = (int)((4 * ii) / C);
+        const int f = pp / c0.Tout, to = pp - f * c0.Tout;
+        const int t0 = to * c0.stride - c0.pad;
+        k0 = *(const float4*)(c0.w3 + ch); k1 = *(const float4*)(c0.w3 + C + ch); k2 = *(const float4*)(c0.w3 + 2 * C + ch);
+        kb = *(const float4*)(c0.bias + ch);
+        x_off = f * c0.Tin + t0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) x_ok[k] = t0 + k >= 0 && t0 + k < c0.Tin;
+    }
     float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag, a1 = ag, a2 = ag;
 #pragma unroll 2
     for (int64_t b = b0; b < b1; ++b) {
         const float4 s0 = *(const float4*)(sc + 8 * b), s1 = *(const float4*)(sc + 8 * b + 4);
         const float mean = s0.x, rstd = s0.y, m1 = s0.z, m2 = s0.w, inv_r = s1.x, rprev = s1.y, cprev = s1.z;
         float4* dp = (float4*)(d + b * n) + ii;
-        const float4 dd = *dp, tt = ((const float4*)(tpre + b * n))[ii];
+        const float4 dd = *dp;
+        float4 tt;
+        if (CONV0) {
+            const float* xr = c0.feat + b * (int64_t)c0.F * c0.Tin + x_off;
+            const float x0 = x_ok[0] ? xr[0] : 0.f, x1 = x_ok[1] ? xr[1] : 0.f, x2 = x_ok[2] ? xr[2] : 0.f;
+            tt.x = fmaf(x2, k2.x, fmaf(x1, k1.x, fmaf(x0, k0.x, kb.x)));
+            tt.y = fmaf(x2, k2.y, fmaf(x1, k1.y, fmaf(x0, k0.y, kb.y)));
+            tt.z = fmaf(x2, k2.z, fmaf(x1, k1.z, fmaf(x0, k0.z, kb.z)));
+            tt.w = fmaf(x2, k2.w, fmaf(x1, k1.w, fmaf(x0, k0.w, kb.w)));
+        } else {
+            tt = ((const float4*)(tpre + b * n))[ii];
+        }
         float4 o;
         float q1 = 0.f, q2 = 0.f;
 #define NAFP_LN_ONE(c_)                                                                     \
@@ -558,7 +588,7 @@ int launch_stats_to_mr(const double* stats, float* mr, const double* inv_n_dev, 
 int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* mr, const float* mr_prev,
                   double* lnsum, float* sc, float* dgamma, float* dbeta, float* dbias, float* S1, float* S2,
                   int64_t B, int P, int C, hipStream_t st, bool reduce_here, const float* Gj, const float* Hbj,
-                  double* lnsum_below) {
+                  double* lnsum_below, const float* feat0, const float* w0, const float* bias0, const ConvGeom* g0) {
     const int64_t n = (int64_t)P * C;
     if (C % 4 != 0 || (256 % (C / 4) != 0 && (C / 4) % 256 != 0) || n % 1024 != 0 || 1024 % C != 0) return NAFP_ERR_UNSUPPORTED;
     if (reduce_here) {
@@ -575,8 +605,17 @@ int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* 
     int by = (int)std::min<int64_t>(B, std::min<int64_t>(64, std::max<int64_t>(4, 256 / bx)));
     while (lnsum_below && (B + by - 1) / by * 8 > 32768 && by < B) by *= 2;      // LDS share of the sums below: 8 B per sample
     const size_t lds = lnsum_below ? (size_t)((B + by - 1) / by) * 2 * sizeof(float) : 0;
-    ln_bwd_fused_kernel<<<dim3((unsigned)bx, by), 256, lds, st>>>(d, tpre, gamma, sc, dgamma, dbeta, dbias, S1, S2, n, B, C,
-                                                                Gj, Hbj, lnsum_below);
+    Conv0Regen c0{};
+    if (feat0) {
+        if (!g0 || g0->Cin != 1 || g0->axis != 0 || g0->Cout != C || g0->Fout * g0->Tout != P || reduce_here) return NAFP_ERR_INVALID_ARG;
+        c0.feat = feat0; c0.w3 = w0; c0.bias = bias0; c0.F = g0->Fin; c0.Tin = g0->Tin; c0.Tout = g0->Tout;
+        c0.stride = g0->stride; c0.pad = g0->pad;
+        ln_bwd_fused_kernel<true><<<dim3((unsigned)bx, by), 256, lds, st>>>(d, nullptr, gamma, sc, dgamma, dbeta, dbias, S1, S2, n, B,
+                                                                          C, Gj, Hbj, lnsum_below, c0);
+    } else {
+        ln_bwd_fused_kernel<false><<<dim3((unsigned)bx, by), 256, lds, st>>>(d, tpre, gamma, sc, dgamma, dbeta, dbias, S1, S2, n, B,
+                                                                           C, Gj, Hbj, lnsum_below, c0);
+    }
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }

@@ -168,7 +168,8 @@ int launch_stats_to_mr(const double* stats, float* mr, const double* inv_n_dev, 
 int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* mr, const float* mr_prev,
                   double* lnsum, float* sc, float* dgamma, float* dbeta, float* dbias, float* S1, float* S2,
                   int64_t B, int P, int C, hipStream_t st, bool reduce_here, const float* Gj, const float* Hbj,
-                  double* lnsum_below);
+                  double* lnsum_below, const float* feat0 = nullptr, const float* w0 = nullptr, const float* bias0 = nullptr,
+                  const ConvGeom* g0 = nullptr);      // feat0 (layer 0 only): regenerate the pre-activation instead of reading tpre
 // dW (keras (3,Cin,Cout), accumulated) += sum_rows X[b, in(pos,tap), :] (x) D[b,pos,:]
 int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const ConvGeom& g, hipStream_t st);
 int launch_conv0_bwd(const float* feat, const float* dt, float* dW0, float* dbias0, int64_t B, const ConvGeom& g,
