@@ -611,11 +611,12 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
         if (!ln_done) {
             rc = launch_ln_bwd(cur, nullptr, e->d_gamma[0], L.mr, nullptr, L.lnsum[0], L.sc, grads[2], grads[3], grads[1],
                                nullptr, nullptr, B, g.Fout * g.Tout, g.Cout, st, false, nullptr, nullptr, nullptr,
-                               feat, e->d_w[0], e->d_bias[0], &g);
+                               feat, e->d_w[0], e->d_bias[0], &g, grads[0]);     // ... and dW0 in the same pass
+            if (rc != NAFP_OK) return rc;
+        } else {
+            rc = launch_conv0_bwd(feat, cur, grads[0], nullptr, B, g, st);
             if (rc != NAFP_OK) return rc;
         }
-        rc = launch_conv0_bwd(feat, cur, grads[0], nullptr, B, g, st);
-        if (rc != NAFP_OK) return rc;
     }
     NAFP_HIP_CHECK(hipEventRecord(e->grad_events[NAFP_GRAD_GROUPS - 1], st));
     e->grad_events_valid = true;

@@ -101,7 +101,9 @@ __global__ void ln_bwd_scalars_kernel(const float* __restrict__ mr, const double
 // CONV0: the layer is b0.conv1x3 (Cin = 1).  Its pre-activation is not stored by the forward pass -- 2 MB per segment
 // written and read back for 3 FMAs per element -- but regenerated here from the log-mel features:
 // t[b, f, to, c] = bias[c] + sum_k w[k, c] feat[b, f, to * stride - pad + k]   (the same fmaf chain as conv0_kernel).
-struct Conv0Regen { const float* feat; const float* w3; const float* bias; int F, Tin, Tout, stride, pad; };
+// The same kernel then also forms conv0's weight gradient dW0[k, c] = sum feat[b, f, to*s - p + k] * dt[b, f, to, c] from
+// the dt it has just produced (it holds both factors), so the gradient of the first layer is not read a second time.
+struct Conv0Regen { const float* feat; const float* w3; const float* bias; float* dW0; int F, Tin, Tout, stride, pad; };
 
 template <bool CONV0>
 __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
@@ -137,6 +139,7 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
         for (int k = 0; k < 3; ++k) x_ok[k] = t0 + k >= 0 && t0 + k < c0.Tin;
     }
     float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag, a1 = ag, a2 = ag;
+    float4 gw0 = ag, gw1 = ag, gw2 = ag;                    // CONV0: dW0 taps 0..2 of this thread's 4 channels
 #pragma unroll 2
     for (int64_t b = b0; b < b1; ++b) {
         const float4 s0 = *(const float4*)(sc + 8 * b), s1 = *(const float4*)(sc + 8 * b + 4);
@@ -144,9 +147,10 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
         float4* dp = (float4*)(d + b * n) + ii;
         const float4 dd = *dp;
         float4 tt;
+        float x0 = 0.f, x1 = 0.f, x2 = 0.f;
         if (CONV0) {
             const float* xr = c0.feat + b * (int64_t)c0.F * c0.Tin + x_off;
-            const float x0 = x_ok[0] ? xr[0] : 0.f, x1 = x_ok[1] ? xr[1] : 0.f, x2 = x_ok[2] ? xr[2] : 0.f;
+            x0 = x_ok[0] ? xr[0] : 0.f; x1 = x_ok[1] ? xr[1] : 0.f; x2 = x_ok[2] ? xr[2] : 0.f;
             tt.x = fmaf(x2, k2.x, fmaf(x1, k1.x, fmaf(x0, k0.x, kb.x)));
             tt.y = fmaf(x2, k2.y, fmaf(x1, k1.y, fmaf(x0, k0.y, kb.y)));
             tt.z = fmaf(x2, k2.z, fmaf(x1, k1.z, fmaf(x0, k0.z, kb.z)));
@@ -169,7 +173,12 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
         }
         NAFP_LN_ONE(x) NAFP_LN_ONE(y) NAFP_LN_ONE(z) NAFP_LN_ONE(w)
 #undef NAFP_LN_ONE
-        if (live) *dp = o;
+        if (CONV0 && live) {                                   // o = dt here (no layer below: rprev = 1)
+            gw0.x = fmaf(x0, o.x, gw0.x); gw0.y = fmaf(x0, o.y, gw0.y); gw0.z = fmaf(x0, o.z, gw0.z); gw0.w = fmaf(x0, o.w, gw0.w);
+            gw1.x = fmaf(x1, o.x, gw1.x); gw1.y = fmaf(x1, o.y, gw1.y); gw1.z = fmaf(x1, o.z, gw1.z); gw1.w = fmaf(x1, o.w, gw1.w);
+            gw2.x = fmaf(x2, o.x, gw2.x); gw2.y = fmaf(x2, o.y, gw2.y); gw2.z = fmaf(x2, o.z, gw2.z); gw2.w = fmaf(x2, o.w, gw2.w);
+        }
+        if (live && !(CONV0 && c0.dW0)) *dp = o;               // (nothing reads dts_0 once dW0 is formed here)
         if (lnsum_below) {
             // wave sums of (q1, q2) in 7 shuffles: fold the halves, then q1 lives in lanes 0..31 and q2 in 32..63
             if (!live) { q1 = 0.f; q2 = 0.f; }
@@ -213,6 +222,24 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
         }
         float* o = dbias + 4 * threadIdx.x;                 // block start is a multiple of 1024 elements, C | 1024
         atomicAdd(o, t.x); atomicAdd(o + 1, t.y); atomicAdd(o + 2, t.z); atomicAdd(o + 3, t.w);
+    }
+    if (CONV0 && c0.dW0) {
+        // dW0[k][c]: the same reduction over the threads of a channel group, once per tap (C / 4 <= 256 here)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            __syncthreads();
+            red[threadIdx.x] = k == 0 ? gw0 : (k == 1 ? gw1 : gw2);
+            __syncthreads();
+            if ((int)threadIdx.x < cg) {
+                float4 t = red[threadIdx.x];
+                for (int r = threadIdx.x + cg; r < 256; r += cg) {
+                    const float4 u = red[r];
+                    t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+                }
+                float* o = c0.dW0 + k * C + 4 * threadIdx.x;
+                atomicAdd(o, t.x); atomicAdd(o + 1, t.y); atomicAdd(o + 2, t.z); atomicAdd(o + 3, t.w);
+            }
+        }
     }
 }
 
@@ -588,7 +615,7 @@ int launch_stats_to_mr(const double* stats, float* mr, const double* inv_n_dev, 
 int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* mr, const float* mr_prev,
                   double* lnsum, float* sc, float* dgamma, float* dbeta, float* dbias, float* S1, float* S2,
                   int64_t B, int P, int C, hipStream_t st, bool reduce_here, const float* Gj, const float* Hbj,
-                  double* lnsum_below, const float* feat0, const float* w0, const float* bias0, const ConvGeom* g0) {
+                  double* lnsum_below, const float* feat0, const float* w0, const float* bias0, const ConvGeom* g0, float* dW0) {
     const int64_t n = (int64_t)P * C;
     if (C % 4 != 0 || (256 % (C / 4) != 0 && (C / 4) % 256 != 0) || n % 1024 != 0 || 1024 % C != 0) return NAFP_ERR_UNSUPPORTED;
     if (reduce_here) {
@@ -608,7 +635,8 @@ int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* 
     Conv0Regen c0{};
     if (feat0) {
         if (!g0 || g0->Cin != 1 || g0->axis != 0 || g0->Cout != C || g0->Fout * g0->Tout != P || reduce_here) return NAFP_ERR_INVALID_ARG;
-        c0.feat = feat0; c0.w3 = w0; c0.bias = bias0; c0.F = g0->Fin; c0.Tin = g0->Tin; c0.Tout = g0->Tout;
+        if (dW0 && C / 4 > 256) return NAFP_ERR_UNSUPPORTED;
+        c0.feat = feat0; c0.w3 = w0; c0.bias = bias0; c0.dW0 = dW0; c0.F = g0->Fin; c0.Tin = g0->Tin; c0.Tout = g0->Tout;
         c0.stride = g0->stride; c0.pad = g0->pad;
         ln_bwd_fused_kernel<true><<<dim3((unsigned)bx, by), 256, lds, st>>>(d, nullptr, gamma, sc, dgamma, dbeta, dbias, S1, S2, n, B,
                                                                           C, Gj, Hbj, lnsum_below, c0);

@@ -169,7 +169,9 @@ int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* 
                   double* lnsum, float* sc, float* dgamma, float* dbeta, float* dbias, float* S1, float* S2,
                   int64_t B, int P, int C, hipStream_t st, bool reduce_here, const float* Gj, const float* Hbj,
                   double* lnsum_below, const float* feat0 = nullptr, const float* w0 = nullptr, const float* bias0 = nullptr,
-                  const ConvGeom* g0 = nullptr);      // feat0 (layer 0 only): regenerate the pre-activation instead of reading tpre
+                  const ConvGeom* g0 = nullptr, float* dW0 = nullptr);
+// feat0 (layer 0 only): regenerate the pre-activation instead of reading tpre; dW0: also accumulate conv0's weight gradient
+// (keras (1,3,1,C) layout) and leave `d` unwritten
 // dW (keras (3,Cin,Cout), accumulated) += sum_rows X[b, in(pos,tap), :] (x) D[b,pos,:]
 int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const ConvGeom& g, hipStream_t st);
 int launch_conv0_bwd(const float* feat, const float* dt, float* dW0, float* dbias0, int64_t B, const ConvGeom& g,
