@@ -186,7 +186,11 @@ __global__ __launch_bounds__(256, 2) void melspec_kernel(
     const int n_pairs = (n_frames + 1) / 2;
     float* out_seg = feat + seg * (int64_t)n_mels * n_frames;
 
-    for (int chunk0 = 0; chunk0 < n_frames; chunk0 += CHUNK_FRAMES) {
+    // one workgroup per (segment, 16-frame chunk): 640 segments are 1280 workgroups of half the length, which fill the
+    // 512 resident slots (2 per CU) in 2.5 rounds of half a segment instead of 2 rounds of a whole one (the second
+    // three quarters empty)
+    {
+        const int chunk0 = blockIdx.y * CHUNK_FRAMES;
         const int chunk_frames = min(CHUNK_FRAMES, n_frames - chunk0);
         // ---- zero-padded samples of this chunk into LDS (melspectrogram.py:59-65): padded index
         // chunk0*256 + i  <->  sample index chunk0*256 + i - 512
@@ -387,7 +391,7 @@ static int melspec_forward(nafp_melspec* p, const TIn* audio, int64_t n_seg, int
     melspec_init_stats<<<(n_groups + 255) / 256, 256, 0, st>>>(group_stat, n_groups);
     NAFP_LAUNCH_CHECK();
     const size_t lds = (size_t)(SIG_CHUNK + 4 * 2 * NFFT + p->n_mels * TILE_LD + 2 * N_TW) * sizeof(float);
-    melspec_kernel<TIn><<<dim3((unsigned)n_seg), 256, lds, st>>>(
+    melspec_kernel<TIn><<<dim3((unsigned)n_seg, (unsigned)((p->n_frames + CHUNK_FRAMES - 1) / CHUNK_FRAMES)), 256, lds, st>>>(
         audio, seg_offset, seg_valid, feat, group_stat, p->d_twiddle, p->d_window, p->d_mel_start, p->d_mel_w,
         p->seg_len, p->n_frames, p->n_mels, group_size);
     NAFP_LAUNCH_CHECK();
