@@ -302,20 +302,22 @@ __device__ __forceinline__ int tile_pos(const ConvKernelParams& p, int idx) {
     return (2 * e + 1 - p.perm_c0) * p.Tout + (j - e * p.Tout);
 }
 
-template <int BM, int BK, int NSTAGE, bool FUSE0>
+template <int BM, int BNT, int BK, int NSTAGE, bool FUSE0>
 __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     static_assert(!FUSE0 || (BK == 16 && BM == 128), "the in-kernel conv0 generator is written for BK = 16, BM = 128");
     static_assert(BM == 128 || BM == 256, "tile rows");
+    static_assert(BNT == 128 || (BNT == 64 && BM == 128 && !FUSE0), "tile columns");
+    constexpr int NIW = BNT / 64;                  // 32-column MFMA tiles per wave (a wave covers 64 rows x BNT / 2 columns)
     constexpr int NT = 2 * BM;                     // threads: BM / 32 waves as (BM/64) x 2, each wave 64 x 64
     constexpr int NW = BM / 32;
     constexpr int CH = BK / 4;                     // 16-B chunks per row
     constexpr int RPI = 64 / CH;                   // rows covered by one DMA wave-instruction
     constexpr int NI = 32 / RPI;                   // A: DMA instructions per wave per step (every wave stages 32 rows of A)
-    constexpr int BROWS = BN / NW;                 // B: rows staged per wave (32 or 16)
+    constexpr int BROWS = BNT / NW;                 // B: rows staged per wave (32 or 16)
     constexpr int NIB = BROWS / RPI;               // B: DMA instructions per wave per step
     static_assert(NIB >= 1, "B rows per wave");
     constexpr int TILE = BM * BK;                  // floats of the A tile
-    constexpr int TILEB = BN * BK;                 // floats of the B tile
+    constexpr int TILEB = BNT * BK;                 // floats of the B tile
     constexpr int STAGE = TILE + TILEB;            // A | B
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // [stage 0: A | B] ... [stage NSTAGE-1] [sRB[128]] [sCB[128]] [sPos[32]] [FUSE0: conv0 w (3,Cin) | bias (Cin)]
@@ -327,7 +329,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;       // wm < BM / 64
     const int sg = blockIdx.x % p.n_sg, pb = blockIdx.x / p.n_sg;
-    const int tile_n0 = blockIdx.y * BN;
+    const int tile_n0 = blockIdx.y * BNT;
     const int K = 3 * p.Cin;
     const int ST1 = p.ST - 1;
     const int b0 = sg * p.ST;                       // first sample of this tile
@@ -489,11 +491,11 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
             NAFP_GEN_ONE(4, gg1.x), NAFP_GEN_ONE(5, gg1.y), NAFP_GEN_ONE(6, gg1.z), NAFP_GEN_ONE(7, gg1.w)); \
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NIW];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NIW; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
@@ -510,7 +512,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     // operand read addresses (floats): row*BK + ((lc ^ swz(row)) * 4), lc = 2*kk + (lane>>5)
     const int rl = lane & 31, hh = lane >> 5;
     const int rswz = BK == 32 ? ((rl >> 1) & 7) : ((rl >> 2) & 3);     // wm*64, 32*mi do not change swz
-    const int aoff = (wm * 64 + rl) * BK, boff = TILE + (wn * 64 + rl) * BK;     // (NIB <= NI: the B pieces ride in the A loop)
+    const int aoff = (wm * 64 + rl) * BK, boff = TILE + (wn * (BNT / 2) + rl) * BK;     // (NIB <= NI: the B pieces ride in the A loop)
     int slot = 0;
     if (p.abl & 8) {          // ablation: prologue + pipeline fill only (wait for the prefilled stages, then leave)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -536,13 +538,13 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         }
         // the first operand fragments are requested BEFORE the next DMA is issued: the DMA issue
         // (descriptor moves, m0 writes) then runs under the LDS read latency instead of ahead of it
-        float4 a0[2], b0[2];
+        float4 a0[2], b0[NIW];
         {
             const int pc4 = ((0 + hh) ^ rswz) * 4;
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) a0[mi] = *(const float4*)(St + aoff + mi * 32 * BK + pc4);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) b0[ni] = *(const float4*)(St + boff + ni * 32 * BK + pc4);
+            for (int ni = 0; ni < NIW; ++ni) b0[ni] = *(const float4*)(St + boff + ni * 32 * BK + pc4);
         }
         if (has_next) {
             NAFP_DMA_STEP(s + NSTAGE - 1, nslot)
@@ -551,15 +553,15 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             const int pc4 = ((2 * kk + hh) ^ rswz) * 4;
-            float4 a[2], b[2];
+            float4 a[2], b[NIW];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) a[mi] = kk == 0 ? a0[mi] : *(const float4*)(St + aoff + mi * 32 * BK + pc4);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) b[ni] = kk == 0 ? b0[ni] : *(const float4*)(St + boff + ni * 32 * BK + pc4);
+            for (int ni = 0; ni < NIW; ++ni) b[ni] = kk == 0 ? b0[ni] : *(const float4*)(St + boff + ni * 32 * BK + pc4);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
+                for (int ni = 0; ni < NIW; ++ni) {
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].x, b[ni].x, acc[mi][ni], 0, 0, 0);
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].y, b[ni].y, acc[mi][ni], 0, 0, 0);
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].z, b[ni].z, acc[mi][ni], 0, 0, 0);
@@ -576,7 +578,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < NIW; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) t += acc[mi][ni][r];
         if (t == 12345.678f) p.y[tid] = t;
@@ -586,13 +588,13 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).
     // Row groups of 4 (r & 3) = 4 consecutive samples at one position.
     const int ncol = lane & 31;
-    const int n_base = tile_n0 + wn * 64 + ncol;
+    const int n_base = tile_n0 + wn * (BNT / 2) + ncol;
     const int g4 = p.ST >> 2;                         // sample quads per position
     if (p.mode != 0) {
         // PLAIN: y = acc (+ bias)
-        float bv[2];
+        float bv[NIW];
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) bv[ni] = p.bias ? p.bias[n_base + ni * 32] : 0.f;
+        for (int ni = 0; ni < NIW; ++ni) bv[ni] = p.bias ? p.bias[n_base + ni * 32] : 0.f;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -602,7 +604,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
                 const int b = sg * p.ST + (lr & ST1);
                 if (pos < p.P && b < p.B) {
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
+                    for (int ni = 0; ni < NIW; ++ni)
                         p.y[(((int64_t)blockIdx.z * p.B + b) * p.P + pos) * p.Cout + n_base + ni * 32] = acc[mi][ni][r] + bv[ni];
                 }
             }
@@ -622,13 +624,13 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     // then the arithmetic: issuing them group by group exposed one L2 round trip per group.
     // (BM = 256 runs at 128 VGPRs: there the operands are fetched per 32-row block, 24 at a time.)
     constexpr int MIL = BM == 256 ? 1 : 2;            // 32-row blocks whose operands are resident at once
-    float Gv[MIL][4][2], Hv[MIL][4][2], gv[MIL][4][2];
+    float Gv[MIL][4][NIW], Hv[MIL][4][NIW], gv[MIL][4][NIW];
 #define NAFP_EPI_LOAD(mi_, slot_)                                                              \
     _Pragma("unroll") for (int rg = 0; rg < 4; ++rg) {                                         \
         const int grp_l = wm * 16 + (mi_) * 8 + 2 * rg + (lane >> 5);                          \
         const int pos_l = pb * p.PT + (grp_l >> (p.log2ST - 2));                               \
         const int pofs_l = (pos_l < p.P ? pos_l : 0) * p.Cout + n_base;                        \
-        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                     \
+        _Pragma("unroll") for (int ni = 0; ni < NIW; ++ni) {                                   \
             if (p.abl & 32) { Gv[slot_][rg][ni] = 0.5f; Hv[slot_][rg][ni] = 0.25f; gv[slot_][rg][ni] = 1.5f; continue; } \
             Gv[slot_][rg][ni] = p.G[pofs_l + ni * 32];                                         \
             Hv[slot_][rg][ni] = p.Hb[pofs_l + ni * 32];                                        \
@@ -656,7 +658,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
                 const float rb = sRB[sl], cb = sCB[sl];
                 float rs = 0.f, rq = 0.f;
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
+                for (int ni = 0; ni < NIW; ++ni) {
                     const float tpre = fmaf(rb, acc[mi][ni][r], fmaf(cb, Gv[ms][rg][ni], Hv[ms][rg][ni]));
                     float v = (p.abl & 128) ? tpre : elu1(tpre);          // ablation 128: no exp
                     v = valid ? v : 0.f;
@@ -721,22 +723,25 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
 }
 
 // One __global__ per staging variant (launch bounds are not template-dependent).
-#define NAFP_GEMM_KERNEL(name_, BM_, BK_, NSTAGE_, MINW_, FUSE0_)                            \
+#define NAFP_GEMM_KERNEL(name_, BM_, BN_, BK_, NSTAGE_, MINW_, FUSE0_)                       \
     __global__ __launch_bounds__(2 * BM_, MINW_) void name_(const ConvKernelParams p) {       \
-        conv_gemm_body<BM_, BK_, NSTAGE_, FUSE0_>(p);                                         \
+        conv_gemm_body<BM_, BN_, BK_, NSTAGE_, FUSE0_>(p);                                    \
     }
 // BK = 16, 3 stages, 3 workgroups/CU.  The other staging points were built and measured on the MI355X
 // (segments/s at BSZ 640, same run): k16s3 148.2 k | k32s2 (2 WG/CU) 143.6 k | k16s2 (4 WG/CU) 142.7 k |
 // k16s4 (2 WG/CU) 140.9 k | k32s3 (1 WG/CU) 116.4 k; they are not compiled any more.
-NAFP_GEMM_KERNEL(conv_gemm_k16s3, 128, 16, 3, 3, false)
-NAFP_GEMM_KERNEL(conv_gemm_k16s3_fuse0, 128, 16, 3, 3, true)    // conv1 with conv0 generated in-kernel
+NAFP_GEMM_KERNEL(conv_gemm_k16s3, 128, 128, 16, 3, 3, false)
+NAFP_GEMM_KERNEL(conv_gemm_k16s3_fuse0, 128, 128, 16, 3, 3, true)    // conv1 with conv0 generated in-kernel
+// 128 x 64 tile (each wave 64 x 32), 36 KB ring -> 4 workgroups per CU: twice the workgroups of half the size for the
+// launches whose 128 x 128 tiling leaves the CUs unevenly loaded or forces a split along K (the mid and late convs)
+NAFP_GEMM_KERNEL(conv_gemm_n64k16s3, 128, 64, 16, 3, 4, false)
 // 256 x 128 tile, 8 waves (4 x 2), 72 KB ring -> 2 workgroups = 16 waves per CU (4 per SIMD): the weight tile is staged
 // once per 256 rows instead of once per 128, and a workgroup's fixed costs (geometry, pipeline fill) cover twice the output
-NAFP_GEMM_KERNEL(conv_gemm_m256k16s3, 256, 16, 3, 4, false)
+NAFP_GEMM_KERNEL(conv_gemm_m256k16s3, 256, 128, 16, 3, 4, false)
 
 template <typename KernelT>
-static int launch_variant(KernelT kernel, int BM, int BK, int NSTAGE, const ConvKernelParams& p, dim3 grid, hipStream_t st) {
-    const int lds = (NSTAGE * (BM + BN) * BK + 2 * BM + 32 + (p.f0_feat ? 4 * p.Cin : 0)) * (int)sizeof(float);
+static int launch_variant(KernelT kernel, int BM, int BNt, int BK, int NSTAGE, const ConvKernelParams& p, dim3 grid, hipStream_t st) {
+    const int lds = (NSTAGE * (BM + BNt) * BK + 2 * BM + 32 + (p.f0_feat ? 4 * p.Cin : 0)) * (int)sizeof(float);
     NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     kernel<<<grid, 2 * BM, lds, st>>>(p);
     NAFP_LAUNCH_CHECK();
@@ -806,7 +811,7 @@ static int live_k_steps(const ConvGeom& g) {
     return n_live * g.Cin / 16;
 }
 
-static int choose_split(int64_t n_tiles, int k_steps, int64_t out_floats) {
+static int choose_split(int64_t n_tiles, int k_steps, int64_t out_floats, double slots = 768.0) {
     // Score each split factor S by (how full the last round of workgroups is) x (share of a
     // workgroup's time spent in its K-loop rather than prologue/epilogue); 768 = 256 CUs x 3
     // resident workgroups.  Splitting costs a slab round trip, so it must win by a margin.
@@ -814,7 +819,7 @@ static int choose_split(int64_t n_tiles, int k_steps, int64_t out_floats) {
     if (force == 0) return 1;
     if (force > 0) return force;
     if (n_tiles >= 3072) return 1;
-    const double slots = 768.0, overhead_steps = 6.0;
+    const double overhead_steps = 6.0;
     int best = 1; double best_score = 0.0;
     for (int S = 1; S <= 16; ++S) {
         const double k = (double)k_steps / S;
@@ -868,18 +873,30 @@ static int pick_bm(int64_t B, int P, int Cout) {
     return n_tiles >= thr ? 256 : 128;
 }
 
+// Tile width of a launch that runs 128-row tiles: 64 columns (4 workgroups per CU, each half the work) where the
+// 128 x 128 tiling gives few, coarse workgroups.  NAFP_BN64: 0 never, 2 whenever Cout allows, 1 (default) by tile count.
+static int pick_bn(int64_t n_tiles128, int Cout) {
+    static const int mode = []() { const char* e = getenv("NAFP_BN64"); return e ? atoi(e) : 1; }();
+    static const int64_t thr = []() { const char* e = getenv("NAFP_BN64_TILES"); return e ? atoll(e) : (int64_t)1000; }();
+    if (mode == 0 || Cout % 64 != 0) return 128;
+    if (mode == 2) return 64;
+    return n_tiles128 < thr ? 64 : 128;
+}
+
 int64_t conv_gemm_slab_floats(int64_t B, const ConvGeom& g, bool with_dgrad) {
     const int P = g.Fout * g.Tout;
     const int BM = pick_bm(B, P, g.Cout);
     const int pt = tile_pt(P), ST = BM / pt;
     const int64_t n_tiles = ((B + ST - 1) / ST) * ((P + pt - 1) / pt) * (g.Cout / BN);
-    const int S = BM == 256 ? 1 : choose_split(n_tiles, live_k_steps(g), B * P * g.Cout);
+    const int bn = BM == 256 ? 128 : pick_bn(n_tiles, g.Cout);
+    const int S = BM == 256 ? 1 : choose_split(n_tiles * (BN / bn), live_k_steps(g), B * P * g.Cout, bn == 64 ? 1024.0 : 768.0);
     int64_t need = S > 1 ? (int64_t)S * B * P * g.Cout : 0;
     if (with_dgrad && g.Cin % BN == 0 && pick_bm(B, g.Fin * g.Tin, g.Cin) == 128) {
         const int Pd = g.Fin * g.Tin;
         const int ptd = tile_pt(Pd), STd = 128 / ptd;
         const int64_t tiles_d = ((B + STd - 1) / STd) * ((Pd + ptd - 1) / ptd) * (g.Cin / BN);
-        const int Sd = choose_split(tiles_d, dgrad_k_steps(g), B * Pd * g.Cin);
+        const int bnd = pick_bn(tiles_d, g.Cin);
+        const int Sd = choose_split(tiles_d * (BN / bnd), dgrad_k_steps(g), B * Pd * g.Cin, bnd == 64 ? 1024.0 : 768.0);
         if (Sd > 1) need = std::max(need, (int64_t)Sd * B * Pd * g.Cin);
     }
     return need;
@@ -937,15 +954,17 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     static const int abl = []() { const char* e = getenv("NAFP_ABL"); return e ? atoi(e) : 0; }();
     p.abl = a.plain ? 0 : abl;
     const int n_pb = (p.P + p.PT - 1) / p.PT;
-    const int64_t n_tiles = (int64_t)p.n_sg * n_pb * (p.Cout / BN);
+    const int64_t n_tiles128 = (int64_t)p.n_sg * n_pb * (p.Cout / BN);
+    const int bn = (BM == 256 || a.f0_feat) ? 128 : pick_bn(n_tiles128, p.Cout);
+    const int64_t n_tiles = n_tiles128 * (BN / bn);
     int S = 1;
     const int64_t out_floats = B * p.P * p.Cout;
     if (a.slab && !a.f0_feat && BM == 128) {
-        S = choose_split(n_tiles, k_steps, out_floats);
+        S = choose_split(n_tiles, k_steps, out_floats, bn == 64 ? 1024.0 : 768.0);
         if ((int64_t)S * out_floats > a.slab_floats) S = 1;
     }
     if (S > 1) { p.mode = a.plain ? 1 : 2; p.n_split = S; p.y = a.slab; p.bias = nullptr; }
-    const dim3 grid((unsigned)((int64_t)p.n_sg * n_pb), (unsigned)(p.Cout / BN), (unsigned)S);
+    const dim3 grid((unsigned)((int64_t)p.n_sg * n_pb), (unsigned)(p.Cout / bn), (unsigned)S);
     int rc;
     p.f0_feat = nullptr; p.f0_w = nullptr; p.f0_bias = nullptr; p.f0_gamma = nullptr;
     p.f0_T = 0; p.f0_stride = 1; p.f0_pad = 0;
@@ -956,10 +975,11 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
             return NAFP_ERR_UNSUPPORTED;
         p.f0_feat = a.f0_feat; p.f0_w = a.f0_w; p.f0_bias = a.f0_bias; p.f0_gamma = a.f0_gamma;
         p.f0_T = a.f0_geom->Tin; p.f0_stride = a.f0_geom->stride; p.f0_pad = a.f0_geom->pad;
-        return launch_variant(conv_gemm_k16s3_fuse0, 128, 16, 3, p, grid, st);
+        return launch_variant(conv_gemm_k16s3_fuse0, 128, 128, 16, 3, p, grid, st);
     }
-    rc = BM == 256 ? launch_variant(conv_gemm_m256k16s3, 256, 16, 3, p, grid, st)
-                   : launch_variant(conv_gemm_k16s3, 128, 16, 3, p, grid, st);
+    rc = BM == 256 ? launch_variant(conv_gemm_m256k16s3, 256, 128, 16, 3, p, grid, st)
+         : bn == 64 ? launch_variant(conv_gemm_n64k16s3, 128, 64, 16, 3, p, grid, st)
+                    : launch_variant(conv_gemm_k16s3, 128, 128, 16, 3, p, grid, st);
     if (rc != NAFP_OK || S == 1) return rc;
     if (a.plain) {
         const int64_t n4 = out_floats / 4;

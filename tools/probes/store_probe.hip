@@ -40,8 +40,8 @@ void run(const char* name, float4* out, float4* gamma, float* x, size_t n4) {
 int main() {
     const size_t n4 = (size_t)640 * 524288 / 4;            // conv0's output at B = 640
     float4 *out, *gamma; float* x;
-    hipMalloc(&out, n4 * 16); hipMalloc(&gamma, 2 << 20); hipMalloc(&x, 4096);
-    hipMemset(gamma, 0, 2 << 20); hipMemset(x, 0, 4096);
+    hipMalloc(&out, n4 * 16); hipMalloc(&gamma, 8 << 20); hipMalloc(&x, 4096);
+    hipMemset(gamma, 0, 8 << 20); hipMemset(x, 0, 4096);
     run<0, 8>("store only, 32 KB / WG", out, gamma, x, n4);
     run<0, 16>("store only, 64 KB / WG", out, gamma, x, n4);
     run<0, 2>("store only, 8 KB / WG", out, gamma, x, n4);
