@@ -37,7 +37,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // the Cout = 128 channels of one (f, t_out) position, a wave stores 1 KiB
 // contiguous.  Stores z = gamma0 . v; statistics are those of v.
 // ============================================================================
-constexpr int ROWS0 = 4;
+
 
 // STORE = false: statistics only (the activation is re-generated inside conv1, see FUSE0).
 //
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(
         const float* __restrict__ gamma, float* __restrict__ y, float* __restrict__ v_out,
         double* __restrict__ stats, int F, int Tin, int Tout, int Cout, int stride, int pad,
         const float* __restrict__ gstat, int group_size, int segment_norm) {
-    constexpr int NP = 8;                           // positions per thread and batch
+    constexpr int NP = 4;                           // positions per thread and batch
     __shared__ float s_x[ROWS0 * 64 + 8];           // rows of the input, Tin <= 64, with one zero in front (index -1)
     __shared__ double red[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -95,13 +95,20 @@ __global__ __launch_bounds__(256) void conv0_kernel(
     const float* gin = STORE ? gamma + ((int64_t)f0 * Tout) * Cout : nullptr;
     __syncthreads();
     float s = 0.f, q = 0.f;
+    // software pipeline over batches of NP positions: the gamma loads of batch i+1 are in flight while batch i computes
+    float4 g[NP], gn[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int p = pslot + i * pos_per_iter;
+        g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (STORE && p < npos) g[i] = *(const float4*)(gin + (int64_t)p * Cout + 4 * cg);
+    }
     for (int p0 = pslot; p0 < npos; p0 += NP * pos_per_iter) {
-        float4 g[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            const int p = p0 + i * pos_per_iter;
-            g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (STORE && p < npos) g[i] = *(const float4*)(gin + (int64_t)p * Cout + 4 * cg);
+            const int p = p0 + (NP + i) * pos_per_iter;
+            gn[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (STORE && p < npos) gn[i] = *(const float4*)(gin + (int64_t)p * Cout + 4 * cg);
         }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -126,6 +133,8 @@ __global__ __launch_bounds__(256) void conv0_kernel(
                 if (v_out) *(float4*)(v_out + (yout - y) + (int64_t)p * Cout + 4 * cg) = tq;   // training keeps the pre-activation
             }
         }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) g[i] = gn[i];
     }
     double ds = wave_sum((double)s), dq = wave_sum((double)q);
     if (lane == 0) { red[wave] = ds; red[4 + wave] = dq; }
@@ -140,10 +149,20 @@ int launch_conv0(const float* feat, const float* w3, const float* bias, const fl
                  float* v_out, double* stats, int64_t B, const ConvGeom& g, hipStream_t st, const float* gstat,
                  int group_size, int segment_norm) {
     if (g.Cin != 1 || g.axis != 0 || (g.Cout % 4) != 0 || 256 % (g.Cout / 4) != 0 || g.Tin > 64) return NAFP_ERR_UNSUPPORTED;
-    const int64_t blocks = B * ((g.Fin + ROWS0 - 1) / ROWS0);
-    conv0_kernel<true, ROWS0><<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, gamma, y, v_out, stats, g.Fin,
-                                                                      g.Tin, g.Tout, g.Cout, g.stride, g.pad, gstat,
-                                                                      group_size, segment_norm);
+    static const int rows = []() { const char* e = getenv("NAFP_CONV0_ROWS"); return e ? atoi(e) : 8; }();
+    if (rows == 4) {
+        const int64_t blocks = B * ((g.Fin + 3) / 4);
+        conv0_kernel<true, 4><<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, gamma, y, v_out, stats, g.Fin, g.Tin, g.Tout,
+                                                                    g.Cout, g.stride, g.pad, gstat, group_size, segment_norm);
+    } else if (rows == 16) {
+        const int64_t blocks = B * ((g.Fin + 15) / 16);
+        conv0_kernel<true, 16><<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, gamma, y, v_out, stats, g.Fin, g.Tin, g.Tout,
+                                                                     g.Cout, g.stride, g.pad, gstat, group_size, segment_norm);
+    } else {
+        const int64_t blocks = B * ((g.Fin + 7) / 8);
+        conv0_kernel<true, 8><<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, gamma, y, v_out, stats, g.Fin, g.Tin, g.Tout,
+                                                                    g.Cout, g.stride, g.pad, gstat, group_size, segment_norm);
+    }
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }
