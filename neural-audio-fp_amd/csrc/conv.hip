@@ -149,7 +149,9 @@ int launch_conv0(const float* feat, const float* w3, const float* bias, const fl
                  float* v_out, double* stats, int64_t B, const ConvGeom& g, hipStream_t st, const float* gstat,
                  int group_size, int segment_norm) {
     if (g.Cin != 1 || g.axis != 0 || (g.Cout % 4) != 0 || 256 % (g.Cout / 4) != 0 || g.Tin > 64) return NAFP_ERR_UNSUPPORTED;
-    static const int rows = []() { const char* e = getenv("NAFP_CONV0_ROWS"); return e ? atoi(e) : 8; }();
+    // rows per workgroup, measured at B = 640 on one box (ms): 4 -> 0.339, 8 -> 0.291, 16 -> 0.272 (the plain per-position
+    // loop of round 1 ran 0.344; a store-only kernel of this shape 0.230: tools/probes/store_probe.hip)
+    static const int rows = []() { const char* e = getenv("NAFP_CONV0_ROWS"); return e ? atoi(e) : 16; }();
     if (rows == 4) {
         const int64_t blocks = B * ((g.Fin + 3) / 4);
         conv0_kernel<true, 4><<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, gamma, y, v_out, stats, g.Fin, g.Tin, g.Tout,
@@ -157,6 +159,10 @@ int launch_conv0(const float* feat, const float* w3, const float* bias, const fl
     } else if (rows == 16) {
         const int64_t blocks = B * ((g.Fin + 15) / 16);
         conv0_kernel<true, 16><<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, gamma, y, v_out, stats, g.Fin, g.Tin, g.Tout,
+                                                                     g.Cout, g.stride, g.pad, gstat, group_size, segment_norm);
+    } else if (rows == 32) {
+        const int64_t blocks = B * ((g.Fin + 31) / 32);
+        conv0_kernel<true, 32><<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, gamma, y, v_out, stats, g.Fin, g.Tin, g.Tout,
                                                                      g.Cout, g.stride, g.pad, gstat, group_size, segment_norm);
     } else {
         const int64_t blocks = B * ((g.Fin + 7) / 8);
