@@ -775,50 +775,78 @@ static int launch_variant(KernelT kernel, int BM, int BNt, int BK, int NSTAGE, c
 
 // Split-K finish: sums the S partial slabs in a fixed order (deterministic), then the same
 // epilogue as the fused path: v = ELU(r_b*A + c_b*G + Hb), statistics of v, z = gamma_out . v.
-// One workgroup per output row (sample, position).
+// A workgroup owns 4096 consecutive output floats (4 ... 16 rows of Cout = 1024 ... 256): the per-sample scalars of the
+// few samples it touches are formed once in LDS, a thread finishes 4 float4 with the S slab loads of each in flight
+// together, and the statistics meet per sample in LDS before one pair of double atomics per (workgroup, sample).
+// (Round 1 ran one workgroup per output row: 640 ... 5120 workgroups of a few hundred bytes each, latency-bound.)
+constexpr int FIN_F4 = 1024;            // float4 per workgroup
+constexpr int FIN_MAXS = 64;            // samples a workgroup may touch (4096 / Cout rows, Cout >= 64)
 __global__ __launch_bounds__(256) void splitk_finish_kernel(
         const float* __restrict__ slab, int S, const float* __restrict__ G, const float* __restrict__ Hb,
         const float* __restrict__ gamma_out, const double* __restrict__ stats_in,
         double* __restrict__ stats_out, float* __restrict__ y, float* __restrict__ v_out, int B, int P, int Cout,
         double inv_n_in) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t row = blockIdx.x;
-    const int b = (int)(row / P), pos = (int)(row - (int64_t)b * P);
-    const double mean = stats_in[2 * (int64_t)b] * inv_n_in;
-    double var = stats_in[2 * (int64_t)b + 1] * inv_n_in - mean * mean;
-    var = var > 0.0 ? var : 0.0;
-    const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
-    const float rb = (float)rstd, cb = (float)(-mean * rstd);
-    const int64_t slab_stride = (int64_t)B * P * Cout;
-    float s = 0.f, q = 0.f;
-    for (int n = tid * 4; n < Cout; n += 1024) {
-        const float* src = slab + row * Cout + n;
-        float4 acc = *(const float4*)src;
+    __shared__ float sR[FIN_MAXS], sC[FIN_MAXS], sS[FIN_MAXS], sQ[FIN_MAXS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int c4 = Cout / 4;
+    const int64_t total = (int64_t)B * P * c4;
+    const int64_t i0 = (int64_t)blockIdx.x * FIN_F4;
+    const int64_t i_last = std::min<int64_t>(total, i0 + FIN_F4) - 1;
+    const int b_first = (int)((i0 / c4) / P), b_last = (int)((i_last / c4) / P);
+    if (tid <= b_last - b_first) {
+        const int b = b_first + tid;
+        const double mean = stats_in[2 * (int64_t)b] * inv_n_in;
+        double var = stats_in[2 * (int64_t)b + 1] * inv_n_in - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
+        sR[tid] = (float)rstd; sC[tid] = (float)(-mean * rstd);
+        sS[tid] = 0.f; sQ[tid] = 0.f;
+    }
+    __syncthreads();
+    const int64_t slab_stride4 = total;                 // float4 per slab
+#pragma unroll 1
+    for (int e = 0; e < FIN_F4 / 256; ++e) {
+        const int64_t idx = i0 + e * 256 + tid;
+        const bool live = idx < total;
+        const int64_t ii = live ? idx : i0;
+        const int64_t row = ii / c4;
+        const int n = (int)(ii - row * c4) * 4;
+        const int b = (int)(row / P), pos = (int)(row - (int64_t)b * P);
+        const float4* src = (const float4*)slab + ii;
+        float4 acc = src[0];
         for (int sp = 1; sp < S; ++sp) {
-            const float4 t = *(const float4*)(src + sp * slab_stride);
+            const float4 t = src[sp * slab_stride4];
             acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
         }
         const float4 g4 = *(const float4*)(G + (int64_t)pos * Cout + n);
         const float4 h4 = *(const float4*)(Hb + (int64_t)pos * Cout + n);
         const float4 go = *(const float4*)(gamma_out + (int64_t)pos * Cout + n);
+        const float rb = sR[b - b_first], cb = sC[b - b_first];
         float4 tq, v;
         tq.x = fmaf(rb, acc.x, fmaf(cb, g4.x, h4.x));
         tq.y = fmaf(rb, acc.y, fmaf(cb, g4.y, h4.y));
         tq.z = fmaf(rb, acc.z, fmaf(cb, g4.z, h4.z));
         tq.w = fmaf(rb, acc.w, fmaf(cb, g4.w, h4.w));
         v.x = elu1(tq.x); v.y = elu1(tq.y); v.z = elu1(tq.z); v.w = elu1(tq.w);
-        s += (v.x + v.y) + (v.z + v.w);
-        q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-        *(float4*)(y + row * Cout + n) = make_float4(v.x * go.x, v.y * go.y, v.z * go.z, v.w * go.w);
-        if (v_out) *(float4*)(v_out + row * Cout + n) = tq;
+        float s = live ? (v.x + v.y) + (v.z + v.w) : 0.f;
+        float q = live ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f;
+        if (live) {
+            ((float4*)y)[idx] = make_float4(v.x * go.x, v.y * go.y, v.z * go.z, v.w * go.w);
+            if (v_out) ((float4*)v_out)[idx] = tq;
+        }
+        // statistics: a wave usually sits inside one sample
+        const int b0w = __builtin_amdgcn_readfirstlane(b);
+        if (__all(b == b0w)) {
+            s = wave_sum(s); q = wave_sum(q);
+            if (lane == 0) { atomicAdd(sS + (b0w - b_first), s); atomicAdd(sQ + (b0w - b_first), q); }
+        } else {
+            atomicAdd(sS + (b - b_first), s); atomicAdd(sQ + (b - b_first), q);
+        }
     }
-    const double ds = wave_sum((double)s), dq = wave_sum((double)q);
-    __shared__ double red[8];
-    if (lane == 0) { red[wave] = ds; red[4 + wave] = dq; }
     __syncthreads();
-    if (tid == 0) {
-        atomicAdd(stats_out + 2 * (int64_t)b, red[0] + red[1] + red[2] + red[3]);
-        atomicAdd(stats_out + 2 * (int64_t)b + 1, red[4] + red[5] + red[6] + red[7]);
+    if (tid <= b_last - b_first) {
+        atomicAdd(stats_out + 2 * (int64_t)(b_first + tid), (double)sS[tid]);
+        atomicAdd(stats_out + 2 * (int64_t)(b_first + tid) + 1, (double)sQ[tid]);
     }
 }
 
@@ -1013,8 +1041,9 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
         NAFP_LAUNCH_CHECK();
         return NAFP_OK;
     }
-    splitk_finish_kernel<<<dim3((unsigned)(B * p.P)), 256, 0, st>>>(a.slab, S, a.G, a.Hb, a.gamma_out, a.stats_in,
-                                                                   a.stats_out, a.y, a.v_out, p.B, p.P, g.Cout, p.inv_n_in);
+    if (FIN_F4 * 4 / g.Cout + 1 > FIN_MAXS) return NAFP_ERR_UNSUPPORTED;
+    splitk_finish_kernel<<<dim3((unsigned)((out_floats / 4 + FIN_F4 - 1) / FIN_F4)), 256, 0, st>>>(
+        a.slab, S, a.G, a.Hb, a.gamma_out, a.stats_in, a.stats_out, a.y, a.v_out, p.B, p.P, g.Cout, p.inv_n_in);
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }
