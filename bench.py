@@ -65,29 +65,15 @@ def make_audio(n, seed, torch):
     return x.float()
 
 
-def cpu_baseline(target_s=12.0, max_batches=40):
-    import numpy as np
+def _cpu_worker(args):
+    """One process of the CPU baseline: `threads` intra-op threads, batches of 125 for ~target_s seconds."""
+    threads, target_s, max_batches, seed = args
     import torch
     from oracle import nnfp as o_nnfp, torch_ref
-    cores = os.cpu_count() or 1
-    w = o_nnfp.init_weights(seed=0)
-    tf = torch_ref.TorchFingerprinter(w)
-    x = make_audio(125, 7, torch)                       # TS_BATCH_SZ of config/default.yaml
+    torch.set_num_threads(threads)
+    tf = torch_ref.TorchFingerprinter(o_nnfp.init_weights(seed=0))
+    x = make_audio(125, seed, torch)
     with torch.no_grad():
-        # pick the fastest intra-op thread count on this host (all cores is NOT the fastest on a
-        # many-core box at batch 125); each trial is one warm-up + one timed batch
-        best_t, best_n = None, 1
-        for nt in sorted({min(cores, c) for c in (8, 16, 32, 64, 128, cores)}):
-            torch.set_num_threads(nt)
-            tf(torch_ref.melspec_layer(x))
-            t0 = time.perf_counter()
-            tf(torch_ref.melspec_layer(x))
-            dt = time.perf_counter() - t0
-            if best_t is None or dt < best_t:
-                best_t, best_n = dt, nt
-            if dt > 8.0:
-                break
-        torch.set_num_threads(best_n)
         tf(torch_ref.melspec_layer(x))                  # warm-up (oneDNN primitive caches)
         n, t0 = 0, time.perf_counter()
         while True:
@@ -96,10 +82,43 @@ def cpu_baseline(target_s=12.0, max_batches=40):
             el = time.perf_counter() - t0
             if el >= target_s or n >= 125 * max_batches:
                 break
-    return {'value': round(n / el, 2), 'unit': 'segments/s', 'cores': torch.get_num_threads(),
-            'kind': 'port', 'host_cores': cores,
-            'sample': f'{n} segments in batches of 125 (TS_BATCH_SZ), torch-CPU fp32 restatement '
-                      f'of melspec+encoder (oracle/torch_ref.py), {el:.1f} s, best of the thread counts tried'}
+    return n, el
+
+
+def cpu_baseline(target_s=12.0, max_batches=40):
+    """The oracle's torch-CPU restatement of melspec + encoder on the HOST CORES OF THIS BOX (kind "port"): first the
+    fastest intra-op thread count of one process is found (all cores is not the fastest at batch 125), then as many
+    such processes as fit the box run side by side, each on its own batches; the value is their summed throughput."""
+    import multiprocessing as mp
+    import torch
+    from oracle import nnfp as o_nnfp, torch_ref
+    cores = os.cpu_count() or 1
+    w = o_nnfp.init_weights(seed=0)
+    tf = torch_ref.TorchFingerprinter(w)
+    x = make_audio(125, 7, torch)                       # TS_BATCH_SZ of config/default.yaml
+    with torch.no_grad():
+        best_t, best_n = None, 1
+        for nt in sorted({min(cores, c) for c in (8, 16, 32, 64)}):
+            torch.set_num_threads(nt)
+            tf(torch_ref.melspec_layer(x))
+            t0 = time.perf_counter()
+            tf(torch_ref.melspec_layer(x))
+            dt = time.perf_counter() - t0
+            # efficiency per core decides: the processes below fill the box
+            if best_t is None or dt * nt < best_t * best_n:
+                best_t, best_n = dt, nt
+            if dt > 8.0:
+                break
+    procs = max(1, min(cores // best_n, 16))
+    ctx = mp.get_context('spawn')
+    with ctx.Pool(procs) as pool:
+        res = pool.map(_cpu_worker, [(best_n, target_s, max_batches, 7 + k) for k in range(procs)])
+    n = sum(r[0] for r in res)
+    el = max(r[1] for r in res)
+    return {'value': round(sum(r[0] / r[1] for r in res), 2), 'unit': 'segments/s', 'cores': procs * best_n,
+            'kind': 'port', 'host_cores': cores, 'processes': procs, 'threads_per_process': best_n,
+            'sample': f'{n} segments in batches of 125 (TS_BATCH_SZ), torch-CPU fp32 restatement of melspec+encoder '
+                      f'(oracle/torch_ref.py), {procs} processes x {best_n} threads side by side for {el:.1f} s'}
 
 
 def train_region(cfg, world, rank, dist, global_bsz, steps, torch, warmup=2):

@@ -786,7 +786,9 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(
         const float* __restrict__ gamma_out, const double* __restrict__ stats_in,
         double* __restrict__ stats_out, float* __restrict__ y, float* __restrict__ v_out, int B, int P, int Cout,
         double inv_n_in) {
-    __shared__ float sR[FIN_MAXS], sC[FIN_MAXS], sS[FIN_MAXS], sQ[FIN_MAXS];
+    __shared__ float sR[FIN_MAXS], sC[FIN_MAXS];
+    __shared__ float sPart[4][FIN_F4 / 256][2][2];     // [wave][pass][first / last sample of the wave][sum, sumsq]
+    __shared__ int sPartB[4][FIN_F4 / 256][2];
     const int tid = threadIdx.x, lane = tid & 63;
     const int c4 = Cout / 4;
     const int64_t total = (int64_t)B * P * c4;
@@ -800,7 +802,6 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(
         var = var > 0.0 ? var : 0.0;
         const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
         sR[tid] = (float)rstd; sC[tid] = (float)(-mean * rstd);
-        sS[tid] = 0.f; sQ[tid] = 0.f;
     }
     __syncthreads();
     const int64_t slab_stride4 = total;                 // float4 per slab
@@ -834,19 +835,27 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(
             ((float4*)y)[idx] = make_float4(v.x * go.x, v.y * go.y, v.z * go.z, v.w * go.w);
             if (v_out) ((float4*)v_out)[idx] = tq;
         }
-        // statistics: a wave usually sits inside one sample
-        const int b0w = __builtin_amdgcn_readfirstlane(b);
-        if (__all(b == b0w)) {
-            s = wave_sum(s); q = wave_sum(q);
-            if (lane == 0) { atomicAdd(sS + (b0w - b_first), s); atomicAdd(sQ + (b0w - b_first), q); }
-        } else {
-            atomicAdd(sS + (b - b_first), s); atomicAdd(sQ + (b - b_first), q);
+        // statistics, in a fixed order: a wave covers 256 consecutive floats (Cout >= 128: a wave spans at most two rows, so
+        // at most two samples): one partial sum for the sample of its first lane, one for that of its last lane
+        const int b_lo = __shfl(b, 0, 64), b_hi = __shfl(b, 63, 64);
+        const float s_lo = wave_sum(b == b_lo ? s : 0.f), q_lo = wave_sum(b == b_lo ? q : 0.f);
+        const float s_hi = wave_sum(b != b_lo ? s : 0.f), q_hi = wave_sum(b != b_lo ? q : 0.f);
+        if (lane == 0) {
+            const int w = tid >> 6;
+            sPart[w][e][0][0] = s_lo; sPart[w][e][0][1] = q_lo; sPartB[w][e][0] = b_lo;
+            sPart[w][e][1][0] = s_hi; sPart[w][e][1][1] = q_hi; sPartB[w][e][1] = b_hi != b_lo ? b_hi : -1;
         }
     }
     __syncthreads();
     if (tid <= b_last - b_first) {
-        atomicAdd(stats_out + 2 * (int64_t)(b_first + tid), (double)sS[tid]);
-        atomicAdd(stats_out + 2 * (int64_t)(b_first + tid) + 1, (double)sQ[tid]);
+        const int b = b_first + tid;
+        double ds = 0.0, dq = 0.0;
+        for (int w = 0; w < 4; ++w)
+            for (int e = 0; e < FIN_F4 / 256; ++e)
+                for (int h = 0; h < 2; ++h)
+                    if (sPartB[w][e][h] == b) { ds += (double)sPart[w][e][h][0]; dq += (double)sPart[w][e][h][1]; }
+        atomicAdd(stats_out + 2 * (int64_t)b, ds);
+        atomicAdd(stats_out + 2 * (int64_t)b + 1, dq);
     }
 }
 
@@ -1041,7 +1050,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
         NAFP_LAUNCH_CHECK();
         return NAFP_OK;
     }
-    if (FIN_F4 * 4 / g.Cout + 1 > FIN_MAXS) return NAFP_ERR_UNSUPPORTED;
+    if (FIN_F4 * 4 / g.Cout + 1 > FIN_MAXS || g.Cout < 128) return NAFP_ERR_UNSUPPORTED;      // a wave (256 floats) spans <= 2 rows
     splitk_finish_kernel<<<dim3((unsigned)((out_floats / 4 + FIN_F4 - 1) / FIN_F4)), 256, 0, st>>>(
         a.slab, S, a.G, a.Hb, a.gamma_out, a.stats_in, a.stats_out, a.y, a.v_out, p.B, p.P, g.Cout, p.inv_n_in);
     NAFP_LAUNCH_CHECK();

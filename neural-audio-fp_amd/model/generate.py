@@ -110,7 +110,7 @@ def overwrite_refused(key, target_path):
     prompt cannot be answered; the file is then overwritten, with a notice."""
     if (key == 'dummy_db') & os.path.exists(target_path):
         if not sys.stdin or not sys.stdin.isatty():
-            print(f'{target_path} exists; stdin is not a terminal: overwriting.')
+            print(f'{target_path} exists; stdin is not a terminal, nobody to ask: the file will be overwritten (overwrite prompt skipped).')
             return False
         answer = input(f'{target_path} exists. Will you overwrite (y/N)?')
         return answer.lower() not in ['y', 'yes']

@@ -116,7 +116,7 @@ def test_fused_conv0_option_is_bit_identical(nafp):
         got_flat, got = m_fp.front_conv(feat), m_fp(feat)
         m_fp.set_option(1, 0)
         # statistics are accumulated with double atomics in a different order: allow 1 ulp-level noise
-        assert float((got_flat - ref_flat).abs().max()) < 1e-5
+        assert float((got_flat - ref_flat).abs().max()) < 3e-5          # values of magnitude ~3; the oracle bound is 2e-4
         assert float((got - ref).abs().max()) < 1e-6
 
 
@@ -164,8 +164,9 @@ def test_run_py_generate_default_sources(nafp, cfg, tmp_path):
 
 def test_window_ingest_is_bit_identical_to_row_ingest(nafp, cfg, tmp_path):
     """nafp_melspec_forward_windows_i16 (whole files uploaded once, windows indexed on the device) vs the
-    materialised int16 rows: same arithmetic, so the fingerprints are equal bit for bit, across file
-    boundaries, short files, zero-padded tails and ragged launches."""
+    materialised int16 rows: same arithmetic, so the log-mel features are equal bit for bit across file boundaries,
+    short files, zero-padded tails and ragged launches; the fingerprints agree to the run-to-run noise of the encoder
+    (its per-sample LayerNorm statistics meet through atomics whose order is not fixed: DESIGN.md)."""
     from neural_audio_fp_amd.model import generate as g
     from neural_audio_fp_amd.model.utils.audio_utils import SegmentSource
     rng = np.random.default_rng(11)
@@ -182,7 +183,14 @@ def test_window_ingest_is_bit_identical_to_row_ingest(nafp, cfg, tmp_path):
         g.write_fingerprints(src, g.StreamedEmbedder(m_pre, m_fp, windows=windows), arr, group=7, launch_rows=21)
         outs.append(arr)
     assert np.abs(outs[0]).sum() > 0
-    assert np.array_equal(outs[0], outs[1])
+    assert np.abs(outs[0] - outs[1]).max() < 1e-6
+    # the front end itself, bit for bit: rows [0, 21) as materialised int16 rows and as windows of the uploaded files
+    rows = torch.from_numpy(src.read_rows(0, 21)).cuda()
+    _, n, arena, used, off, valid = next(src.iter_windows(0, 21, 21))
+    pcm = torch.from_numpy(np.asarray(arena[:max(used, 1)])).cuda()
+    f_rows = m_pre(rows, group_size=7)
+    f_win = m_pre.forward_windows(pcm, torch.from_numpy(off).cuda(), torch.from_numpy(valid).cuda(), group_size=7)
+    assert n == 21 and torch.equal(f_rows, f_win)
 
 
 def test_generate_with_synthesised_queries(nafp, cfg, tmp_path):
