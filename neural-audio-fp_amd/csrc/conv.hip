@@ -663,6 +663,15 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         }                                                                                      \
     }
     if (MIL == 2) { NAFP_EPI_LOAD(0, 0) NAFP_EPI_LOAD(1, MIL - 1) }
+    // Output stores through buffer descriptors re-based on the tile's first sample: the lane part of an address is one
+    // 32-bit register per 4-row group, the sample step a scalar, rows beyond the batch are out of range (dropped by the
+    // hardware) -- no 64-bit address arithmetic and no predication around the stores.
+    const int ystep_b = p.P * p.Cout * 4;                                  // bytes to the same position of the next sample
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
+        p.y + (int64_t)b0 * p.P * p.Cout, 0, (int)((unsigned)nb * (unsigned)ystep_b), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
+        (p.v_out ? p.v_out : p.y) + (int64_t)b0 * p.P * p.Cout, 0, (int)((unsigned)nb * (unsigned)ystep_b), 0x00020000);
+    const bool buf_st = !(p.abl & 256);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         const int ms = MIL == 2 ? mi : 0;
@@ -687,9 +696,15 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
                     const float tpre = fmaf(rb, acc[mi][ni][r], fmaf(cb, Gv[ms][rg][ni], Hv[ms][rg][ni]));
                     float v = (p.abl & 128) ? tpre : elu1(tpre);          // ablation 128: no exp
                     v = valid ? v : 0.f;
-                    if (valid && !((p.abl & 64) && v != 12345.678f)) {   // ablation 64: no stores
+                    if (buf_st) {
+                        const int voff = pvalid ? ((sl0 * p.P + pos) * p.Cout + n_base) * 4 : (int)0x80000000;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v * gv[ms][rg][ni]), rsY, voff,
+                                                              q * ystep_b + ni * 128, 0);
+                        if (p.v_out)                                         // training keeps the pre-activation
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, tpre), rsV, voff, q * ystep_b + ni * 128, 0);
+                    } else if (valid && !((p.abl & 64) && v != 12345.678f)) {   // ablation 64: no stores
                         yrow[q * ystep + ni * 32] = v * gv[ms][rg][ni];
-                        if (p.v_out) p.v_out[(yrow - p.y) + q * ystep + ni * 32] = tpre;    // training keeps the pre-activation
+                        if (p.v_out) p.v_out[(yrow - p.y) + q * ystep + ni * 32] = tpre;
                     }
                     rs += v; rq += v * v;
                 }
