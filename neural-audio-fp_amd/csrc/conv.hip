@@ -794,8 +794,8 @@ static int launch_variant(KernelT kernel, int BM, int BNt, int BK, int NSTAGE, c
 // few samples it touches are formed once in LDS, a thread finishes 4 float4 with the S slab loads of each in flight
 // together, and the statistics meet per sample in LDS before one pair of double atomics per (workgroup, sample).
 // (Round 1 ran one workgroup per output row: 640 ... 5120 workgroups of a few hundred bytes each, latency-bound.)
-constexpr int FIN_F4 = 1024;            // float4 per workgroup
 constexpr int FIN_MAXS = 64;            // samples a workgroup may touch (4096 / Cout rows, Cout >= 64)
+template <int FIN_F4>                   // float4 per workgroup: 1024, 512 or 256 (the launch wants >= 1024 workgroups)
 __global__ __launch_bounds__(256) void splitk_finish_kernel(
         const float* __restrict__ slab, int S, const float* __restrict__ G, const float* __restrict__ Hb,
         const float* __restrict__ gamma_out, const double* __restrict__ stats_in,
@@ -1065,9 +1065,14 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
         NAFP_LAUNCH_CHECK();
         return NAFP_OK;
     }
-    if (FIN_F4 * 4 / g.Cout + 1 > FIN_MAXS || g.Cout < 128) return NAFP_ERR_UNSUPPORTED;      // a wave (256 floats) spans <= 2 rows
-    splitk_finish_kernel<<<dim3((unsigned)((out_floats / 4 + FIN_F4 - 1) / FIN_F4)), 256, 0, st>>>(
-        a.slab, S, a.G, a.Hb, a.gamma_out, a.stats_in, a.stats_out, a.y, a.v_out, p.B, p.P, g.Cout, p.inv_n_in);
+    if (4096 / g.Cout + 1 > FIN_MAXS || g.Cout < 128) return NAFP_ERR_UNSUPPORTED;      // a wave (256 floats) spans <= 2 rows
+    const int64_t f4 = out_floats / 4;
+#define NAFP_FIN(E_) splitk_finish_kernel<E_><<<dim3((unsigned)((f4 + (E_) - 1) / (E_))), 256, 0, st>>>( \
+        a.slab, S, a.G, a.Hb, a.gamma_out, a.stats_in, a.stats_out, a.y, a.v_out, p.B, p.P, g.Cout, p.inv_n_in)
+    if (f4 >= 1024 * 1024) NAFP_FIN(1024);
+    else if (f4 >= 1024 * 512) NAFP_FIN(512);
+    else NAFP_FIN(256);
+#undef NAFP_FIN
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }
