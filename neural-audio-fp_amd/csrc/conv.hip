@@ -239,11 +239,6 @@ struct ConvKernelParams {
     unsigned wp_bytes;
     int n_split;              // split-K factor (blockIdx.z); > 1 writes raw partial sums to `y` = slab
     int abl;                  // ablation flags for kernel-time breakdown (NAFP_ABL env; 0 in production)
-    // Start stagger (experiment, NAFP_STAGGER): the first workgroups to arrive on a CU draw a ticket from a per-CU
-    // counter and sleep ticket * stagger_cycles, so that the co-resident workgroups of a CU run their prologue / epilogue
-    // phases at different times instead of in lockstep (all workgroups of a launch start together and take equally long).
-    int* stagger_ctr;         // (2048) zeroed per launch, or null
-    int stagger_cycles, stagger_slots;
     // FUSE0 (conv1 only): the A operand z0 = gamma0 . ELU(conv0(feat)) is generated in-kernel
     // from the log-mel features instead of being read from memory (`x` unused).
     const float* f0_feat;     // (B, F0, T0)
@@ -358,20 +353,6 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;       // wm < BM / 64
-    if (p.stagger_ctr) {
-        // HW_REG_HW_ID (id 4): cu_id [11:8], sh_id [12], se_id [15:13]; HW_REG_XCC_ID (id 20): xcc_id [3:0]
-        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
-        const int cu = (int)(((xcc & 7u) << 8) | ((hw >> 8) & 0xffu));
-        int* sTicket = (int*)(smem + NSTAGE * STAGE + 2 * BM + 31);
-        if (tid == 0) *sTicket = atomicAdd(p.stagger_ctr + cu, 1);
-        __syncthreads();
-        const int ticket = *sTicket;
-        if (ticket > 0 && ticket < p.stagger_slots) {
-            const long long t_end = (long long)__builtin_readcyclecounter() + (long long)ticket * p.stagger_cycles;
-            while ((long long)__builtin_readcyclecounter() < t_end) __builtin_amdgcn_s_sleep(64);
-        }
-        __syncthreads();
-    }
     const int sg = blockIdx.x % p.n_sg, pb = blockIdx.x / p.n_sg;
     const int tile_n0 = blockIdx.y * BNT;
     const int K = 3 * p.Cin;
@@ -1049,7 +1030,6 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     p.wp_bytes = (unsigned)wbytes;
     static const int abl = []() { const char* e = getenv("NAFP_ABL"); return e ? atoi(e) : 0; }();
     p.abl = a.plain ? 0 : abl;
-    p.stagger_ctr = nullptr; p.stagger_cycles = 0; p.stagger_slots = 0;
     const int n_pb = (p.P + p.PT - 1) / p.PT;
     const int64_t n_tiles128 = (int64_t)p.n_sg * n_pb * (p.Cout / BN);
     const int bn = (BM == 256 || a.f0_feat) ? 128 : pick_bn(n_tiles128, p.Cout);
@@ -1073,19 +1053,6 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
         p.f0_feat = a.f0_feat; p.f0_w = a.f0_w; p.f0_bias = a.f0_bias; p.f0_gamma = a.f0_gamma;
         p.f0_T = a.f0_geom->Tin; p.f0_stride = a.f0_geom->stride; p.f0_pad = a.f0_geom->pad;
         return launch_variant(conv_gemm_k16s3_fuse0, 128, 128, 16, 3, p, grid, st);
-    }
-    {
-        // NAFP_STAGGER = percent of a tile's MFMA time between the starts of co-resident workgroups (0 = off)
-        static const int stag = []() { const char* e = getenv("NAFP_STAGGER"); return e ? atoi(e) : 0; }();
-        static int* d_ctr = nullptr;
-        if (stag > 0 && S == 1 && !a.plain && n_tiles >= 1500) {
-            if (!d_ctr) NAFP_HIP_CHECK(hipMalloc(&d_ctr, 2048 * sizeof(int)));
-            NAFP_HIP_CHECK(hipMemsetAsync(d_ctr, 0, 2048 * sizeof(int), st));
-            const int slots = BM == 256 ? 2 : (bn == 64 ? 4 : 3);
-            p.stagger_ctr = d_ctr; p.stagger_slots = slots;
-            // a tile's wall time with `slots` workgroups sharing the SIMDs: k_steps * 32 MFMA * 64 cycles * slots * (tile / 128x128 per wave = 1)
-            p.stagger_cycles = (int)((int64_t)k_steps * 2048 * slots / slots * stag / 100);
-        }
     }
     rc = BM == 256 ? launch_variant(conv_gemm_m256k16s3, 256, 128, 16, 3, p, grid, st)
          : bn == 64 ? launch_variant(conv_gemm_n64k16s3, 128, 64, 16, 3, p, grid, st)
