@@ -159,3 +159,26 @@ def test_trainer_on_a_dataset_directory(nafp, cfg, tmp_path):
     ck = torch.load(tmp_path / 'logs' / 'checkpoint' / 'dirs' / 'ckpt-2.pt', weights_only=True)
     assert ck['optimizer']['iterations'] == 2 * (n_seg // 16)
     assert hist[1] < hist[0]
+
+
+@pytest.mark.parametrize('emb_sz', [64, 256])
+def test_train_step_with_other_embedding_widths(nafp, cfg, emb_sz):
+    """MODEL.EMB_SZ 64 / 256 (nnfp.py:250) through setup() / train_step(): encoder tail, NT-Xent and both backward
+    passes at that width; the loss of the first step equals the oracle's NT-Xent on the step's embeddings and a few
+    steps on a fixed batch descend."""
+    from neural_audio_fp_amd.model import trainer as T
+    from oracle import ntxent as o_nt
+    c = copy.deepcopy(cfg)
+    c['MODEL']['EMB_SZ'] = emb_sz
+    c['BSZ']['TR_BATCH_SZ'], c['BSZ']['TR_N_ANCHOR'] = 32, 16
+    c['TRAIN']['OPTIMIZER'], c['TRAIN']['LR'] = 'Adam', 1e-4
+    m_pre, m_specaug, m_fp, opt, loss_obj, bucket = T.setup(c, 100)
+    assert m_fp.emb_sz == emb_sz
+    xa, xp = _pairs(16, 31)
+    X = (torch.from_numpy(xa).cuda(), torch.from_numpy(xp).cuda())
+    emb0 = m_fp(m_pre(torch.cat(X, 0))).cpu().numpy()
+    assert emb0.shape == (32, emb_sz)
+    losses = [float(T.train_step(X, m_pre, _NoAug(), m_fp, loss_obj, opt, bucket)[0]) for _ in range(8)]
+    want = o_nt.compute_loss(emb0[:16], emb0[16:], c['LOSS']['TAU'])[0]
+    assert abs(losses[0] - want) < 1e-4 * max(1.0, abs(want))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
