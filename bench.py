@@ -346,7 +346,8 @@ def main():
                                    '(BASELINE.json configs[1]); seeded glorot weights',
                        'segments_per_step_per_gpu': BSZ, 'parallelism': f'segment-sharded x{world}, no collective'},
             'roofline': {
-                'bound': 'mfma', 'kernel': 'conv_gemm_k16s3 (15 launches/step, fp32 v_mfma_f32_32x32x2_f32)',
+                'bound': 'mfma', 'kernel': 'conv_gemm_* (15 launches/step: tile variants m256k16s3 / k16s3 / k16s3_fuse0 / n64k16s3 '
+                                                   'of one template, fp32 v_mfma_f32_32x32x2_f32)',
                 'achieved': round(ach, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_unit': 'bytes/launch',
                 'traffic_source': traffic_src,
