@@ -163,6 +163,14 @@ int nafp_encoder_forward_raw(nafp_encoder* enc, const float* raw_feat, const flo
 int nafp_encoder_profile_enable(nafp_encoder* enc, int max_forwards);
 int nafp_encoder_profile_count(const nafp_encoder* enc);   /* forwards recorded so far */
 int nafp_encoder_profile_read(nafp_encoder* enc, int slot, float* ms_out_host);
+/* Diagnostic, process-wide: while `dev_buf` is non-null every forward GEMM-conv launch (full mode) whose conv has
+ * (cin, cout, output positions per segment) as given stamps the shader clock at the phase boundaries of each tile:
+ * 8 u64 per wave, 8 wave slots per workgroup, workgroups in launch order -- [hw_id | xcc_id << 32, entry, geometry done,
+ * first operands landed, K-loop done, after the barrier behind it, epilogue stores issued, end].  `capacity_u64` bounds
+ * the buffer (launches needing more are not recorded).  nafp_conv_timeline_grid returns {grid x, y, z, tile rows, tile
+ * columns} of the last recorded launch.  tools/conv_timeline.py turns the stamps into per-phase times and per-CU overlap. */
+int nafp_conv_timeline(void* dev_buf, int64_t capacity_u64, int cin, int cout, int positions);
+int nafp_conv_timeline_grid(int* out5_host);
 
 /* Training (model/trainer.py:41-47: emb = m_fp(feat) under tf.GradientTape, then
  * tape.gradient(loss, m_fp.trainable_variables)).  forward_train is nafp_encoder_forward that

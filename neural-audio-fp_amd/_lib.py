@@ -49,6 +49,8 @@ PROTOTYPES = {
     'nafp_encoder_profile_enable': (c_int, [c_void_p, c_int]),
     'nafp_encoder_profile_count': (c_int, [c_void_p]),
     'nafp_encoder_profile_read': (c_int, [c_void_p, c_int, c_void_p]),
+    'nafp_conv_timeline': (c_int, [c_void_p, c_i64, c_int, c_int, c_int]),
+    'nafp_conv_timeline_grid': (c_int, [c_void_p]),
     'nafp_encoder_set_option': (c_int, [c_void_p, c_int, c_int]),
     'nafp_encoder_train_workspace_bytes': (c_i64, [c_void_p, c_i64]),
     'nafp_encoder_forward_train': (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p]),

@@ -430,6 +430,15 @@ extern "C" int nafp_encoder_profile_read(nafp_encoder* e, int slot, float* ms_ou
     return NAFP_OK;
 }
 
+extern "C" int nafp_conv_timeline(void* dev_buf, int64_t capacity_u64, int cin, int cout, int positions) {
+    if (dev_buf && capacity_u64 <= 0) return NAFP_ERR_INVALID_ARG;
+    return conv_timeline_set((unsigned long long*)dev_buf, capacity_u64, cin, cout, positions);
+}
+extern "C" int nafp_conv_timeline_grid(int* out5_host) {
+    if (!out5_host) return NAFP_ERR_INVALID_ARG;
+    return conv_timeline_grid(out5_host);
+}
+
 extern "C" int nafp_encoder_div_enc(nafp_encoder* e, const float* flat, int64_t n_seg,
                                     float* out_emb, int l2norm, void* stream) {
     if (!e || !flat || !out_emb || n_seg < 0) return NAFP_ERR_INVALID_ARG;

@@ -214,6 +214,16 @@ int launch_conv0_stats(const float* feat, const float* w3, const float* bias, do
 // ============================================================================
 constexpr int BN = 128;          // BM (tile rows) is a template parameter: 128 (4 waves) or 256 (8 waves)
 
+// Ablation switches for the kernel-time breakdowns of DESIGN.md (NAFP_ABL env -> ConvKernelParams::abl) exist only in a
+// library built with -DNAFP_ABLATION (NAFP_ABLATION=1 python build.py): in the production build every test below is a
+// compile-time 0 -- the runtime branches they put into the epilogue made hipcc serialise its loads and stores
+// (an s_waitcnt vmcnt(0) per group), which cost far more than the branches themselves.
+#ifdef NAFP_ABLATION
+#define NAFP_ABL(p_, bits_) ((p_).abl & (bits_))
+#else
+#define NAFP_ABL(p_, bits_) (0)
+#endif
+
 struct ConvKernelParams {
     const float* x;           // (B, Fin, Tin, Cin)
     const float* wp;          // (Cout, 3*Cin)
@@ -239,6 +249,8 @@ struct ConvKernelParams {
     unsigned wp_bytes;
     int n_split;              // split-K factor (blockIdx.z); > 1 writes raw partial sums to `y` = slab
     int abl;                  // ablation flags for kernel-time breakdown (NAFP_ABL env; 0 in production)
+    unsigned long long* tl;   // diagnostic phase timeline (nafp_conv_timeline), null in production: 8 u64 per wave
+    int opt;                  // bit 0: the geometry prologue runs at raised wave priority, bit 1: the epilogue does (NAFP_GEMM_PRIO)
     // FUSE0 (conv1 only): the A operand z0 = gamma0 . ELU(conv0(feat)) is generated in-kernel
     // from the log-mel features instead of being read from memory (`x` unused).
     const float* f0_feat;     // (B, F0, T0)
@@ -327,7 +339,11 @@ __device__ __forceinline__ int tile_pos(const ConvKernelParams& p, int idx) {
     return (2 * e + 1 - p.perm_c0) * p.Tout + (j - e * p.Tout);
 }
 
-template <int BM, int BNT, int BK, int NSTAGE, bool FUSE0>
+// EPI selects the epilogue the instantiation carries (one per kernel: the others' code and registers are not in it):
+//   0 FULL for inference (tile = 4 or 8 samples per position: statistics in registers), 1 the same + the pre-activation
+//   kept for the backward pass, 2 FULL for any tile shape (statistics through LDS; v_out by a runtime test),
+//   3 PLAIN (raw sums + bias: DGRAD, weight-derived tensors, split-K partial slabs).
+template <int BM, int BNT, int BK, int NSTAGE, bool FUSE0, int EPI>
 __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     static_assert(!FUSE0 || (BK == 16 && BM == 128), "the in-kernel conv0 generator is written for BK = 16, BM = 128");
     static_assert(BM == 128 || BM == 256, "tile rows");
@@ -356,6 +372,20 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     const int sg = blockIdx.x % p.n_sg, pb = blockIdx.x / p.n_sg;
     const int tile_n0 = blockIdx.y * BNT;
     const int K = 3 * p.Cin;
+    // diagnostic timeline: lane 0 of every wave stamps the shader clock at the phase boundaries of its tile
+#define NAFP_TL(k_)                                                                            \
+    if (p.tl && lane == 0)                                                                     \
+        p.tl[(((size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z)) * 8 + wave) * 8 + (k_)] = \
+            __builtin_readcyclecounter();
+    if (p.tl && lane == 0)
+        p.tl[(((size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z)) * 8 + wave) * 8] =
+            (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) |                    // HW_REG_HW_ID: wave/simd/cu/sh/se
+            ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32);             // HW_REG_XCC_ID
+    NAFP_TL(1)
+    // A workgroup's prologue and epilogue are short VALU / memory-issue sections; next to the older waves' MFMA streams on
+    // the same SIMDs they only get the issue slots those leave over, which stretches them several-fold and keeps the
+    // workgroup's LDS and registers parked.  Raised priority lets them through (the MFMA streams lose a few slots).
+    if (p.opt & 1) __builtin_amdgcn_s_setprio(3);
     const int ST1 = p.ST - 1;
     const int b0 = sg * p.ST;                       // first sample of this tile
     const int nb = min(p.ST, p.B - b0);             // valid samples in this tile
@@ -395,7 +425,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         const int pc = lane % CH;
         const int swz = BK == 32 ? ((lr >> 1) & 7) : ((lr >> 2) & 3);
         const int lc = pc ^ swz;
-        const int pos = tile_pos(p, pb * p.PT + (lr >> p.log2ST));
+        const int pos = tile_pos(p, (NAFP_ABL(p, 1024) ? 0 : pb) * p.PT + (lr >> p.log2ST));   // ablation 1024: every tile stages the rows of tile 0..7 (L2 hits)
         const int sl = lr & ST1;
         voffA[q] = 0; vmaskA[q] = 0;
         if (pos < p.P && sl < nb) {
@@ -465,7 +495,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     const int s_begin = (int)(((int64_t)n_steps_all * blockIdx.z) / p.n_split);
     const int n_steps = (int)(((int64_t)n_steps_all * (blockIdx.z + 1)) / p.n_split);
 
-    const u32x4 rsA = make_rsrc(p.x + (int64_t)b0 * p.sample_in, (unsigned)nb * (unsigned)p.sample_in * 4u);
+    const u32x4 rsA = make_rsrc(p.x + (int64_t)(NAFP_ABL(p, 1024) ? (sg & 7) * p.ST : b0) * p.sample_in,
+                                NAFP_ABL(p, 512) ? 0u : (unsigned)nb * (unsigned)p.sample_in * 4u);   // ablation 512: every A lane out of range (zero fill, no memory traffic)
     const u32x4 rsB = make_rsrc(p.wp, p.wp_bytes);
     const unsigned lds0 = (unsigned)(unsigned long long)(lds_ptr_t)smem + (unsigned)(wave * 32 * BK * 4);
     const unsigned ldsB0 = (unsigned)(unsigned long long)(lds_ptr_t)smem + (unsigned)((TILE + wave * BROWS * BK) * 4);
@@ -524,6 +555,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
+    NAFP_TL(2)
+    if (p.opt & 1) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
         if (s_begin + s < n_steps) {
@@ -539,11 +572,72 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     const int rswz = BK == 32 ? ((rl >> 1) & 7) : ((rl >> 2) & 3);     // wm*64, 32*mi do not change swz
     const int aoff = (wm * 64 + rl) * BK, boff = TILE + (wn * (BNT / 2) + rl) * BK;     // (NIB <= NI: the B pieces ride in the A loop)
     int slot = 0;
-    if (p.abl & 8) {          // ablation: prologue + pipeline fill only (wait for the prefilled stages, then leave)
+    if NAFP_ABL(p, 8) {          // ablation: prologue + pipeline fill only (wait for the prefilled stages, then leave)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (acc[0][0][0] == 12345.678f) p.y[tid] = smem[tid];
         return;
     }
+    // Operand fragments of half a K-step (8 k-values): lane (row rl, half hh) reads logical chunk 2*kk + hh of its
+    // A rows (2 x 32-row blocks) and B rows (NIW x 32-column blocks); one fragment set feeds 4 * 2 * NIW MFMAs.
+#define NAFP_LD_FRAG(St_, kk_, a_, b_)                                                         \
+    {                                                                                          \
+        const int pc4_l = ((2 * (kk_) + hh) ^ rswz) * 4;                                       \
+        _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) a_[mi] = *(const float4*)((St_) + aoff + mi * 32 * BK + pc4_l);   \
+        _Pragma("unroll") for (int ni = 0; ni < NIW; ++ni) b_[ni] = *(const float4*)((St_) + boff + ni * 32 * BK + pc4_l); \
+    }
+#define NAFP_MM_FRAG(a_, b_)                                                                   \
+    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                           \
+        _Pragma("unroll") for (int ni = 0; ni < NIW; ++ni) {                                   \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[mi].x, b_[ni].x, acc[mi][ni], 0, 0, 0); \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[mi].y, b_[ni].y, acc[mi][ni], 0, 0, 0); \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[mi].z, b_[ni].z, acc[mi][ni], 0, 0, 0); \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[mi].w, b_[ni].w, acc[mi][ni], 0, 0, 0); \
+        }
+#define NAFP_WAIT_STEP(s_)                                                                     \
+    if (NSTAGE == 2 || (s_) + NSTAGE - 2 >= n_steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "i"((NSTAGE - 2) * (NI + NIB)) : "memory");
+    // Skewed K-loop (BK = 16 = two fragment sets per step): the second half of step s is multiplied AFTER the barrier of
+    // step s + 1, so that every LDS read has a block of MFMAs whose operands are already in registers in front of it --
+    //   wait, barrier | read R0 = first half of s | DMA of s + 2 | MFMA R1 (second half of s - 1) | read R1 = second
+    //   half of s | MFMA R0 -- and a wave issues MFMAs back to back from one barrier to the next.
+    if (!FUSE0 && BK == 16 && !NAFP_ABL(p, 4 | 2048) && s_begin < n_steps) {
+        float4 a0[2], b0[NIW], a1[2], b1[NIW];
+        {
+            NAFP_WAIT_STEP(s_begin)
+            __builtin_amdgcn_s_barrier();
+            NAFP_TL(3)
+            const float* St = smem + slot * STAGE;
+            NAFP_LD_FRAG(St, 0, a0, b0)
+            NAFP_LD_FRAG(St, 1, a1, b1)
+            __builtin_amdgcn_sched_barrier(0);
+            if (s_begin + NSTAGE - 1 < n_steps && !NAFP_ABL(p, 1)) { NAFP_DMA_STEP(s_begin + NSTAGE - 1, NSTAGE - 1) }
+            __builtin_amdgcn_sched_barrier(0);
+            NAFP_MM_FRAG(a0, b0)
+            __builtin_amdgcn_sched_barrier(0);
+            slot = 1;
+        }
+        for (int s = s_begin + 1; s < n_steps; ++s) {
+            // R1 (the last reads of slot s - 1) has landed: after the barrier that slot may be overwritten
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            NAFP_WAIT_STEP(s)
+            __builtin_amdgcn_s_barrier();
+            const bool has_next = s + NSTAGE - 1 < n_steps && !NAFP_ABL(p, 1);
+            int nslot = slot + NSTAGE - 1; if (nslot >= NSTAGE) nslot -= NSTAGE;
+            const float* St = smem + slot * STAGE;
+            NAFP_LD_FRAG(St, 0, a0, b0)
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) { NAFP_DMA_STEP(s + NSTAGE - 1, nslot) }
+            __builtin_amdgcn_sched_barrier(0);
+            NAFP_MM_FRAG(a1, b1)
+            __builtin_amdgcn_sched_barrier(0);
+            NAFP_LD_FRAG(St, 1, a1, b1)
+            __builtin_amdgcn_sched_barrier(0);
+            NAFP_MM_FRAG(a0, b0)
+            __builtin_amdgcn_sched_barrier(0);
+            if (++slot == NSTAGE) slot = 0;
+        }
+        NAFP_MM_FRAG(a1, b1)
+    } else
     for (int s = s_begin; s < n_steps; ++s) {
         // my DMA of step s has landed; after the barrier everybody's has, and everybody has
         // finished reading slot (s-1) % NSTAGE, which the next DMA overwrites.
@@ -553,10 +647,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         else if (NSTAGE == 2 || s + NSTAGE - 2 >= n_steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" :: "i"((NSTAGE - 2) * (NI + NIB)) : "memory");
         __builtin_amdgcn_s_barrier();
-        const bool has_next = s + NSTAGE - 1 < n_steps && !(p.abl & 1);
+        const bool has_next = s + NSTAGE - 1 < n_steps && !NAFP_ABL(p, 1);
         int nslot = slot + NSTAGE - 1; if (nslot >= NSTAGE) nslot -= NSTAGE;
         const float* St = smem + slot * STAGE;
-        if (p.abl & 4) {
+        if NAFP_ABL(p, 4) {
             if (has_next) { NAFP_DMA_STEP(s + NSTAGE - 1, nslot) }
             if (++slot == NSTAGE) slot = 0;
             continue;
@@ -596,9 +690,12 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         if (FUSE0 && has_next) NAFP_GEN_STORE(s + NSTAGE - 1, nslot)
         if (++slot == NSTAGE) slot = 0;
     }
+    NAFP_TL(4)
+    if (p.opt & 2) __builtin_amdgcn_s_setprio(3);
     __syncthreads();          // all waves are done with the operand tiles: LDS is reused below
+    NAFP_TL(5)
 
-    if (p.abl & 2) {          // ablation: no epilogue (keep the accumulators alive)
+    if NAFP_ABL(p, 2) {          // ablation: no epilogue (keep the accumulators alive)
         float t = 0.f;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -615,24 +712,35 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     const int ncol = lane & 31;
     const int n_base = tile_n0 + wn * (BNT / 2) + ncol;
     const int g4 = p.ST >> 2;                         // sample quads per position
-    if (p.mode != 0) {
-        // PLAIN: y = acc (+ bias)
+    const int ystep_b = p.P * p.Cout * 4;                                  // bytes to the same position of the next sample
+    if (EPI == 3) {
+        // PLAIN: y = acc (+ bias).  Stores go through a buffer descriptor re-based on the tile's first sample (of this
+        // split-K slab): rows beyond the batch and position slots beyond P are out of range and dropped by the hardware,
+        // so the 64 stores of a lane are straight-line code with nothing to wait for in between.
         float bv[NIW];
 #pragma unroll
         for (int ni = 0; ni < NIW; ++ni) bv[ni] = p.bias ? p.bias[n_base + ni * 32] : 0.f;
 #pragma unroll
+        for (int ni = 0; ni < NIW; ++ni) asm volatile("" : "+v"(bv[ni]));   // the bias has landed HERE (else hipcc waits -- vmcnt(0), stores included -- in front of every use)
+        const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(
+            p.y + ((int64_t)blockIdx.z * p.B + b0) * p.P * p.Cout, 0, (int)((unsigned)nb * (unsigned)ystep_b), 0x00020000);
+#pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int lr = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int pos = sPos[lr >> p.log2ST];
-                const int b = sg * p.ST + (lr & ST1);
-                if (pos < p.P && b < p.B) {
+            for (int rg = 0; rg < 4; ++rg) {
+                const int grp = wm * 16 + mi * 8 + 2 * rg + (lane >> 5);      // = tile row >> 2: 4 samples of one position
+                const int pos = sPos[grp >> (p.log2ST - 2)];
+                const int sl0 = (grp & (g4 - 1)) << 2;
+                const int voff = pos < p.P ? ((sl0 * p.P + pos) * p.Cout + n_base) * 4 : (int)0x80000000;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int ni = 0; ni < NIW; ++ni)
-                        p.y[(((int64_t)blockIdx.z * p.B + b) * p.P + pos) * p.Cout + n_base + ni * 32] = acc[mi][ni][r] + bv[ni];
-                }
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc[mi][ni][rg * 4 + q] + bv[ni]), rsP, voff,
+                                                              q * ystep_b + ni * 128, 0);
             }
+        NAFP_TL(6)
+        NAFP_TL(7)
         return;
     }
 
@@ -640,84 +748,86 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
     float* rowS = smem;                 // [BM] (LDS tiles are free again: last loop barrier passed)
     float* rowQ = smem + BM;
-    const bool fast_stats = p.ST == 4 || p.ST == 8;
+    const bool fast_stats = EPI != 2 || p.ST == 4 || p.ST == 8;
     if (!fast_stats) {
         if (tid < BM) { rowS[tid] = 0.f; rowQ[tid] = 0.f; }           // NT >= BM
         __syncthreads();
     }
-    // All position-indexed operands first (48 independent loads in flight together),
-    // then the arithmetic: issuing them group by group exposed one L2 round trip per group.
-    // (BM = 256 runs at 128 VGPRs: there the operands are fetched per 32-row block, 24 at a time.)
-    constexpr int MIL = BM == 256 ? 1 : 2;            // 32-row blocks whose operands are resident at once
+    // All position-indexed operands first (48 independent loads in flight together), then the arithmetic: issuing them
+    // group by group exposed one L2 round trip per group.  (BM = 256 runs at 128 VGPRs: there the operands are fetched
+    // per 32-row block, 24 at a time.)  Loads and stores go through buffer descriptors -- position slots beyond P and
+    // rows beyond the batch are out of range (loads return 0, stores are dropped by the hardware), the lane part of an
+    // address is one 32-bit register per 4-row group, the sample step a scalar -- and the loop body is instantiated per
+    // (keep the pre-activation, statistics path) so that it is straight-line code: any runtime branch in it makes hipcc
+    // put an s_waitcnt vmcnt(0) -- outstanding stores included -- in front of every block.
+    constexpr int MIL = (BM == 256 || EPI == 2) ? 1 : 2;   // 32-row blocks whose operands are resident at once
     float Gv[MIL][4][NIW], Hv[MIL][4][NIW], gv[MIL][4][NIW];
+    const int pc_bytes = p.P * p.Cout * 4;
+    const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0, pc_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Hb), 0, pc_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gamma_out), 0, pc_bytes, 0x00020000);
 #define NAFP_EPI_LOAD(mi_, slot_)                                                              \
     _Pragma("unroll") for (int rg = 0; rg < 4; ++rg) {                                         \
         const int grp_l = wm * 16 + (mi_) * 8 + 2 * rg + (lane >> 5);                          \
         const int pos_l = pb * p.PT + (grp_l >> (p.log2ST - 2));                               \
-        const int pofs_l = (pos_l < p.P ? pos_l : 0) * p.Cout + n_base;                        \
+        const int pofs_l = pos_l < p.P ? (pos_l * p.Cout + n_base) * 4 : (int)0x80000000;      \
         _Pragma("unroll") for (int ni = 0; ni < NIW; ++ni) {                                   \
-            if (p.abl & 32) { Gv[slot_][rg][ni] = 0.5f; Hv[slot_][rg][ni] = 0.25f; gv[slot_][rg][ni] = 1.5f; continue; } \
-            Gv[slot_][rg][ni] = p.G[pofs_l + ni * 32];                                         \
-            Hv[slot_][rg][ni] = p.Hb[pofs_l + ni * 32];                                        \
-            gv[slot_][rg][ni] = p.gamma_out[pofs_l + ni * 32];                                 \
+            if NAFP_ABL(p, 32) { Gv[slot_][rg][ni] = 0.5f; Hv[slot_][rg][ni] = 0.25f; gv[slot_][rg][ni] = 1.5f; continue; } \
+            Gv[slot_][rg][ni] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsG, pofs_l, ni * 128, 0)); \
+            Hv[slot_][rg][ni] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsH, pofs_l, ni * 128, 0)); \
+            gv[slot_][rg][ni] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsg, pofs_l, ni * 128, 0)); \
         }                                                                                      \
     }
     if (MIL == 2) { NAFP_EPI_LOAD(0, 0) NAFP_EPI_LOAD(1, MIL - 1) }
-    // Output stores through buffer descriptors re-based on the tile's first sample: the lane part of an address is one
-    // 32-bit register per 4-row group, the sample step a scalar, rows beyond the batch are out of range (dropped by the
-    // hardware) -- no 64-bit address arithmetic and no predication around the stores.
-    const int ystep_b = p.P * p.Cout * 4;                                  // bytes to the same position of the next sample
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
         p.y + (int64_t)b0 * p.P * p.Cout, 0, (int)((unsigned)nb * (unsigned)ystep_b), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
         (p.v_out ? p.v_out : p.y) + (int64_t)b0 * p.P * p.Cout, 0, (int)((unsigned)nb * (unsigned)ystep_b), 0x00020000);
-    const bool buf_st = !(p.abl & 256);
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int ms = MIL == 2 ? mi : 0;
-        if (MIL == 1) { NAFP_EPI_LOAD(mi, 0) }
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const int grp = wm * 16 + mi * 8 + 2 * rg + (lane >> 5);      // = lr >> 2
-            const int pos = pb * p.PT + (grp >> (p.log2ST - 2));
-            const int sl0 = (grp & (g4 - 1)) << 2;                         // first of the 4 samples
-            const bool pvalid = pos < p.P;
-            float* yrow = p.y + ((int64_t)(sg * p.ST + sl0) * p.P + pos) * p.Cout + n_base;
-            const int64_t ystep = (int64_t)p.P * p.Cout;                   // next sample, same position
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = rg * 4 + q;
-                const int sl = sl0 + q;
-                const bool valid = pvalid && (sg * p.ST + sl) < p.B;
-                const float rb = sRB[sl], cb = sCB[sl];
-                float rs = 0.f, rq = 0.f;
-#pragma unroll
-                for (int ni = 0; ni < NIW; ++ni) {
-                    const float tpre = fmaf(rb, acc[mi][ni][r], fmaf(cb, Gv[ms][rg][ni], Hv[ms][rg][ni]));
-                    float v = (p.abl & 128) ? tpre : elu1(tpre);          // ablation 128: no exp
-                    v = valid ? v : 0.f;
-                    if (buf_st) {
-                        const int voff = pvalid ? ((sl0 * p.P + pos) * p.Cout + n_base) * 4 : (int)0x80000000;
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v * gv[ms][rg][ni]), rsY, voff,
-                                                              q * ystep_b + ni * 128, 0);
-                        if (p.v_out)                                         // training keeps the pre-activation
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, tpre), rsV, voff, q * ystep_b + ni * 128, 0);
-                    } else if (valid && !((p.abl & 64) && v != 12345.678f)) {   // ablation 64: no stores
-                        yrow[q * ystep + ni * 32] = v * gv[ms][rg][ni];
-                        if (p.v_out) p.v_out[(yrow - p.y) + q * ystep + ni * 32] = tpre;
-                    }
-                    rs += v; rq += v * v;
-                }
-                if (fast_stats) { s4[q] += rs; q4[q] += rq; }
-                else {
-#pragma unroll
-                    for (int o = 16; o > 0; o >>= 1) { rs += __shfl_xor(rs, o, 64); rq += __shfl_xor(rq, o, 64); }
-                    if (ncol == 0) { atomicAdd(rowS + (grp << 2) + q, rs); atomicAdd(rowQ + (grp << 2) + q, rq); }
-                }
-            }
-        }
+#define NAFP_EPI_MAIN(KEEP_, FAST_)                                                            \
+    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) {                                         \
+        const int ms = MIL == 2 ? mi : 0;                                                      \
+        if (MIL == 1) { NAFP_EPI_LOAD(mi, 0) }                                                 \
+        _Pragma("unroll") for (int rg = 0; rg < 4; ++rg) {                                     \
+            const int grp = wm * 16 + mi * 8 + 2 * rg + (lane >> 5);      /* = tile row >> 2 */ \
+            const int pos = pb * p.PT + (grp >> (p.log2ST - 2));                               \
+            const int sl0 = (grp & (g4 - 1)) << 2;                         /* first of the 4 samples */ \
+            const bool pvalid = pos < p.P;                                                     \
+            const int voff = pvalid ? ((sl0 * p.P + pos) * p.Cout + n_base) * 4 : (int)0x80000000; \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                    \
+                const int r = rg * 4 + q;                                                      \
+                const int sl = sl0 + q;                                                        \
+                const bool valid = pvalid && (sg * p.ST + sl) < p.B;                           \
+                const float rb = sRB[sl], cb = sCB[sl];                                        \
+                float rs = 0.f, rq = 0.f;                                                      \
+                _Pragma("unroll") for (int ni = 0; ni < NIW; ++ni) {                           \
+                    const float tpre = fmaf(rb, acc[mi][ni][r], fmaf(cb, Gv[ms][rg][ni], Hv[ms][rg][ni])); \
+                    float v = NAFP_ABL(p, 128) ? tpre : elu1(tpre);       /* ablation 128: no exp */ \
+                    v = valid ? v : 0.f;                                                       \
+                    if (!NAFP_ABL(p, 64))                                  /* ablation 64: no stores */ \
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v * gv[ms][rg][ni]), rsY, voff, \
+                                                              q * ystep_b + ni * 128, 0);      \
+                    if (KEEP_)                                             /* training keeps the pre-activation */ \
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, tpre), rsV, voff, q * ystep_b + ni * 128, 0); \
+                    rs += v; rq += v * v;                                                      \
+                }                                                                              \
+                if (FAST_) { s4[q] += rs; q4[q] += rq; }                                       \
+                else {                                                                         \
+                    _Pragma("unroll") for (int o = 16; o > 0; o >>= 1) { rs += __shfl_xor(rs, o, 64); rq += __shfl_xor(rq, o, 64); } \
+                    if (ncol == 0) { atomicAdd(rowS + (grp << 2) + q, rs); atomicAdd(rowQ + (grp << 2) + q, rq); } \
+                }                                                                              \
+            }                                                                                  \
+        }                                                                                      \
     }
-    if (p.abl & 16) {         // ablation: no statistics reduction (keep the sums alive)
+    if (EPI == 0) { NAFP_EPI_MAIN(false, true) }
+    else if (EPI == 1) { NAFP_EPI_MAIN(true, true) }
+    else if (fast_stats) {
+        if (p.v_out) { NAFP_EPI_MAIN(true, true) } else { NAFP_EPI_MAIN(false, true) }
+    } else {
+        if (p.v_out) { NAFP_EPI_MAIN(true, false) } else { NAFP_EPI_MAIN(false, false) }
+    }
+#undef NAFP_EPI_MAIN
+    NAFP_TL(6)
+    if NAFP_ABL(p, 16) {         // ablation: no statistics reduction (keep the sums alive)
         if (s4[0] + s4[1] + s4[2] + s4[3] + q4[0] + q4[1] + q4[2] + q4[3] == 12345.678f) p.y[tid] = 1.f;
         return;
     }
@@ -760,24 +870,37 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
             }
         }
     }
+    NAFP_TL(7)
+#undef NAFP_TL
 }
 
-// One __global__ per staging variant (launch bounds are not template-dependent).
-#define NAFP_GEMM_KERNEL(name_, BM_, BN_, BK_, NSTAGE_, MINW_, FUSE0_)                       \
+// One __global__ per tile shape and epilogue (launch bounds are not template-dependent).
+#define NAFP_GEMM_KERNEL(name_, BM_, BN_, BK_, NSTAGE_, MINW_, FUSE0_, EPI_)                 \
     __global__ __launch_bounds__(2 * BM_, MINW_) void name_(const ConvKernelParams p) {       \
-        conv_gemm_body<BM_, BN_, BK_, NSTAGE_, FUSE0_>(p);                                    \
+        conv_gemm_body<BM_, BN_, BK_, NSTAGE_, FUSE0_, EPI_>(p);                              \
     }
+#define NAFP_GEMM_KERNELS(name_, BM_, BN_, MINW_)                                             \
+    NAFP_GEMM_KERNEL(name_##_infer, BM_, BN_, 16, 3, MINW_, false, 0)                         \
+    NAFP_GEMM_KERNEL(name_##_train, BM_, BN_, 16, 3, MINW_, false, 1)                         \
+    NAFP_GEMM_KERNEL(name_##_any, BM_, BN_, 16, 3, MINW_, false, 2)                           \
+    NAFP_GEMM_KERNEL(name_##_plain, BM_, BN_, 16, 3, MINW_, false, 3)                         \
+    static void (*const name_##_tab[4])(const ConvKernelParams) = {name_##_infer, name_##_train, name_##_any, name_##_plain};
 // BK = 16, 3 stages, 3 workgroups/CU.  The other staging points were built and measured on the MI355X
 // (segments/s at BSZ 640, same run): k16s3 148.2 k | k32s2 (2 WG/CU) 143.6 k | k16s2 (4 WG/CU) 142.7 k |
 // k16s4 (2 WG/CU) 140.9 k | k32s3 (1 WG/CU) 116.4 k; they are not compiled any more.
-NAFP_GEMM_KERNEL(conv_gemm_k16s3, 128, 128, 16, 3, 3, false)
-NAFP_GEMM_KERNEL(conv_gemm_k16s3_fuse0, 128, 128, 16, 3, 3, true)    // conv1 with conv0 generated in-kernel
+NAFP_GEMM_KERNELS(conv_gemm_k16s3, 128, 128, 3)
+NAFP_GEMM_KERNEL(conv_gemm_k16s3_fuse0, 128, 128, 16, 3, 3, true, 0)   // conv1 with conv0 generated in-kernel (inference)
 // 128 x 64 tile (each wave 64 x 32), 36 KB ring -> 4 workgroups per CU: twice the workgroups of half the size for the
 // launches whose 128 x 128 tiling leaves the CUs unevenly loaded or forces a split along K (the mid and late convs)
-NAFP_GEMM_KERNEL(conv_gemm_n64k16s3, 128, 64, 16, 3, 4, false)
+NAFP_GEMM_KERNELS(conv_gemm_n64k16s3, 128, 64, 4)
 // 256 x 128 tile, 8 waves (4 x 2), 72 KB ring -> 2 workgroups = 16 waves per CU (4 per SIMD): the weight tile is staged
 // once per 256 rows instead of once per 128, and a workgroup's fixed costs (geometry, pipeline fill) cover twice the output
-NAFP_GEMM_KERNEL(conv_gemm_m256k16s3, 256, 128, 16, 3, 4, false)
+NAFP_GEMM_KERNEL(conv_gemm_m256k16s3_infer, 256, 128, 16, 3, 4, false, 0)
+NAFP_GEMM_KERNEL(conv_gemm_m256k16s3_train, 256, 128, 16, 3, 4, false, 1)
+NAFP_GEMM_KERNEL(conv_gemm_m256k16s3_plain, 256, 128, 16, 3, 4, false, 3)
+// (no generic-statistics instantiation: the launcher takes the 128-row tile when 256 rows are not 4 or 8 samples per position)
+static void (*const conv_gemm_m256k16s3_tab[4])(const ConvKernelParams) = {conv_gemm_m256k16s3_infer, conv_gemm_m256k16s3_train, nullptr,
+                                                                            conv_gemm_m256k16s3_plain};
 
 template <typename KernelT>
 static int launch_variant(KernelT kernel, int BM, int BNt, int BK, int NSTAGE, const ConvKernelParams& p, dim3 grid, hipStream_t st) {
@@ -979,6 +1102,14 @@ int64_t conv_gemm_slab_floats(int64_t B, const ConvGeom& g, bool with_dgrad) {
     return need;
 }
 
+// Diagnostic (nafp_conv_timeline): the forward GEMM conv of the given shape stamps its phase boundaries into `buf`.
+static struct { unsigned long long* buf; int64_t capacity; int cin, cout, positions; int last_grid[5]; } g_timeline = {};
+int conv_timeline_set(unsigned long long* buf, int64_t capacity_u64, int cin, int cout, int positions) {
+    g_timeline.buf = buf; g_timeline.capacity = capacity_u64; g_timeline.cin = cin; g_timeline.cout = cout; g_timeline.positions = positions;
+    return NAFP_OK;
+}
+int conv_timeline_grid(int* out5) { for (int i = 0; i < 5; ++i) out5[i] = g_timeline.last_grid[i]; return NAFP_OK; }
+
 int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStream_t st) {
     if (g.Cin % 32 != 0 || g.Cout % BN != 0 || B > (1 << 24)) return NAFP_ERR_UNSUPPORTED;
     ConvKernelParams p;
@@ -989,6 +1120,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     p.B = (int)B; p.P = g.Fout * g.Tout;
     int BM = a.f0_feat ? 128 : pick_bm(B, a.dgrad ? g.Fin * g.Tin : p.P, a.dgrad ? g.Cin : g.Cout);
     int pt = tile_pt(p.P);
+    if (BM == 256 && !a.plain && !a.dgrad && 256 / pt != 8) BM = 128;      // FULL mode on 256 rows keeps its statistics in registers: 8 samples per position
     p.PT = pt; p.ST = BM / pt;
     p.log2ST = 0;
     while ((1 << p.log2ST) < p.ST) ++p.log2ST;
@@ -1030,6 +1162,9 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     p.wp_bytes = (unsigned)wbytes;
     static const int abl = []() { const char* e = getenv("NAFP_ABL"); return e ? atoi(e) : 0; }();
     p.abl = a.plain ? 0 : abl;
+    p.tl = nullptr;
+    static const int gemm_prio = []() { const char* e = getenv("NAFP_GEMM_PRIO"); return e ? atoi(e) : 0; }();
+    p.opt = gemm_prio;
     const int n_pb = (p.P + p.PT - 1) / p.PT;
     const int64_t n_tiles128 = (int64_t)p.n_sg * n_pb * (p.Cout / BN);
     const int bn = (BM == 256 || a.f0_feat) ? 128 : pick_bn(n_tiles128, p.Cout);
@@ -1042,6 +1177,12 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     }
     if (S > 1) { p.mode = a.plain ? 1 : 2; p.n_split = S; p.y = a.slab; p.bias = nullptr; }
     const dim3 grid((unsigned)((int64_t)p.n_sg * n_pb), (unsigned)(p.Cout / bn), (unsigned)S);
+    if (g_timeline.buf && !a.plain && !a.dgrad && g.Cin == g_timeline.cin && g.Cout == g_timeline.cout && p.P == g_timeline.positions &&
+        (int64_t)grid.x * grid.y * grid.z * 64 <= g_timeline.capacity) {
+        p.tl = g_timeline.buf;
+        g_timeline.last_grid[0] = (int)grid.x; g_timeline.last_grid[1] = (int)grid.y; g_timeline.last_grid[2] = (int)grid.z;
+        g_timeline.last_grid[3] = BM; g_timeline.last_grid[4] = bn;
+    }
     int rc;
     p.f0_feat = nullptr; p.f0_w = nullptr; p.f0_bias = nullptr; p.f0_gamma = nullptr;
     p.f0_T = 0; p.f0_stride = 1; p.f0_pad = 0;
@@ -1052,11 +1193,14 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
             return NAFP_ERR_UNSUPPORTED;
         p.f0_feat = a.f0_feat; p.f0_w = a.f0_w; p.f0_bias = a.f0_bias; p.f0_gamma = a.f0_gamma;
         p.f0_T = a.f0_geom->Tin; p.f0_stride = a.f0_geom->stride; p.f0_pad = a.f0_geom->pad;
+        if (a.v_out || (p.ST != 4 && p.ST != 8)) return NAFP_ERR_UNSUPPORTED;          // the fused kernel carries the inference epilogue only
         return launch_variant(conv_gemm_k16s3_fuse0, 128, 128, 16, 3, p, grid, st);
     }
-    rc = BM == 256 ? launch_variant(conv_gemm_m256k16s3, 256, 128, 16, 3, p, grid, st)
-         : bn == 64 ? launch_variant(conv_gemm_n64k16s3, 128, 64, 16, 3, p, grid, st)
-                    : launch_variant(conv_gemm_k16s3, 128, 128, 16, 3, p, grid, st);
+    const bool fast_st = p.ST == 4 || p.ST == 8;
+    const int epi = p.mode != 0 ? 3 : (!fast_st ? 2 : (p.v_out ? 1 : 0));
+    rc = BM == 256 ? launch_variant(conv_gemm_m256k16s3_tab[epi], 256, 128, 16, 3, p, grid, st)
+         : bn == 64 ? launch_variant(conv_gemm_n64k16s3_tab[epi], 128, 64, 16, 3, p, grid, st)
+                    : launch_variant(conv_gemm_k16s3_tab[epi], 128, 128, 16, 3, p, grid, st);
     if (rc != NAFP_OK || S == 1) return rc;
     if (a.plain) {
         const int64_t n4 = out_floats / 4;
@@ -1368,7 +1512,7 @@ int launch_dgrad_ln(const DgradLnArgs& a, int64_t B, const ConvGeom& g, hipStrea
     p.sample_in = (int64_t)g.Fout * g.Tout * g.Cout;
     const int S = g.axis == 0 ? g.Cout : g.Tout * g.Cout;
     p.tap_stride = -(S / g.stride);
-    p.inv_n_in = 1.0; p.mode = 1; p.n_split = 1; p.abl = 0;
+    p.inv_n_in = 1.0; p.mode = 1; p.n_split = 1; p.abl = 0; p.tl = nullptr; p.opt = 0;
     p.perm_on = 0; p.perm_n0 = 0; p.perm_c0 = 0;        // one position per workgroup: no class ordering needed
     p.wp_bytes = (unsigned)((int64_t)g.Cout * 3 * g.Cin * 4);
     p.f0_feat = nullptr; p.f0_w = nullptr; p.f0_bias = nullptr; p.f0_gamma = nullptr; p.f0_T = 0; p.f0_stride = 1; p.f0_pad = 0;

@@ -118,6 +118,8 @@ int launch_conv0_stats(const float* feat, const float* w3, const float* bias, do
                        const ConvGeom& g, hipStream_t st);
 int64_t conv_gemm_slab_floats(int64_t B, const ConvGeom& g, bool with_dgrad = false);   // workspace the split-K policy wants
 int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStream_t st);
+int conv_timeline_set(unsigned long long* buf, int64_t capacity_u64, int cin, int cout, int positions);
+int conv_timeline_grid(int* out5);
 
 // Transposed conv of layer j fused with the LayerNorm + ELU backward of layer j-1 (conv.hip, dgrad_ln_kernel): reads
 // dts_j, t_{j-1} and the per-sample scalars of layer j-1, writes dts_{j-1} and accumulates dgamma / dbeta / dbias / S1 /
