@@ -29,6 +29,23 @@
 namespace nafp {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+// bits of a float as the int the buffer-store builtins take.  By value on purpose: hipcc (ROCm 7.2) miscompiles
+// __builtin_bit_cast(int, v.y) on a vector ELEMENT expression -- it reads element 0.
+__device__ __forceinline__ int f2i(float x) { return __builtin_bit_cast(int, x); }
+
+// keras ELU(alpha = 1) on a pair: max(t, exp(min(t, 0)) - 1) -- equal to elu1() (nafp_common.h) except where exp(t) - 1
+// rounds below t (|t| < 1e-7: a difference of < 6e-8).  min(exp2(m), 1) with exp2 >= 0 is v_exp_f32's clamp modifier.
+__device__ __forceinline__ f32x2 elu2(f32x2 t) {
+    const f32x2 m = t * 1.44269504088896341f;
+    f32x2 e;
+    e.x = fminf(fmaxf(__builtin_amdgcn_exp2f(m.x), 0.f), 1.f);
+    e.y = fminf(fmaxf(__builtin_amdgcn_exp2f(m.y), 0.f), 1.f);
+    e = e - 1.0f;
+    f32x2 r;
+    r.x = fmaxf(t.x, e.x); r.y = fmaxf(t.y, e.y);
+    return r;
+}
 
 // ============================================================================
 // conv0: b0.conv1x3, Cin = 1 (nnfp.py:48-53 on the (F,T,1) log-mel input).
@@ -220,6 +237,8 @@ constexpr int BN = 128;          // BM (tile rows) is a template parameter: 128 
 // (an s_waitcnt vmcnt(0) per group), which cost far more than the branches themselves.
 #ifdef NAFP_ABLATION
 #define NAFP_ABL(p_, bits_) ((p_).abl & (bits_))
+#elif defined(NAFP_ABL_CONST)      // compile-time ablation (-DNAFP_ABL_CONST=<bits>): no runtime branches, clean code
+#define NAFP_ABL(p_, bits_) ((NAFP_ABL_CONST) & (bits_))
 #else
 #define NAFP_ABL(p_, bits_) (0)
 #endif
@@ -309,11 +328,12 @@ __device__ __forceinline__ RowGeom row_geom(const ConvKernelParams& p, int pos) 
         const int n_out = p.axis == 0 ? p.Tin : p.Fin;
         const int S = p.axis == 0 ? p.Cin : p.Tin * p.Cin;
         const int A0 = p.axis == 0 ? (fo * p.Tin) * p.Cin : to * p.Cin;
-        g.inner = A0 + (u * S) / p.stride;
+        const int sh = p.stride == 2 ? 1 : 0;                     // the encoder's strides are 1 and 2 (checked by the launcher)
+        g.inner = A0 + ((u * S) >> sh);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int d = u - k;
-            if (d >= 0 && d % p.stride == 0 && d / p.stride < n_out) g.mask |= 1u << k;
+            if (d >= 0 && (d & sh) == 0 && (d >> sh) < n_out) g.mask |= 1u << k;
         }
     }
     return g;
@@ -339,6 +359,22 @@ __device__ __forceinline__ int tile_pos(const ConvKernelParams& p, int idx) {
     return (2 * e + 1 - p.perm_c0) * p.Tout + (j - e * p.Tout);
 }
 
+// Sum over each 32-lane half of a wave with DPP row shifts (VALU only, no LDS crossbar): afterwards lane 31 holds the sum
+// of lanes 0..31 and lane 63 the sum of lanes 32..63.
+__device__ __forceinline__ float half_wave_sum_dpp(float x) {
+    int v = __builtin_bit_cast(int, x);
+#define NAFP_DPP_ADD(ctrl_, rmask_)                                                                       \
+    v = __builtin_bit_cast(int, __builtin_bit_cast(float, v) +                                            \
+                                    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, v, ctrl_, rmask_, 0xf, true)));
+    NAFP_DPP_ADD(0x111, 0xf)      // row_shr:1
+    NAFP_DPP_ADD(0x112, 0xf)      // row_shr:2
+    NAFP_DPP_ADD(0x114, 0xf)      // row_shr:4
+    NAFP_DPP_ADD(0x118, 0xf)      // row_shr:8   -> lane 15 of every 16-lane row holds the row's sum
+    NAFP_DPP_ADD(0x142, 0xa)      // row_bcast:15 into rows 1 and 3: lanes 31 and 63 hold the half sums
+#undef NAFP_DPP_ADD
+    return __builtin_bit_cast(float, v);
+}
+
 // EPI selects the epilogue the instantiation carries (one per kernel: the others' code and registers are not in it):
 //   0 FULL for inference (tile = 4 or 8 samples per position: statistics in registers), 1 the same + the pre-activation
 //   kept for the backward pass, 2 FULL for any tile shape (statistics through LDS; v_out by a runtime test),
@@ -361,11 +397,13 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     constexpr int TILEB = BNT * BK;                 // floats of the B tile
     constexpr int STAGE = TILE + TILEB;            // A | B
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // [stage 0: A | B] ... [stage NSTAGE-1] [sRB[128]] [sCB[128]] [sPos[32]] [FUSE0: conv0 w (3,Cin) | bias (Cin)]
+    // [stage 0: A | B] ... [stage NSTAGE-1] [sRB[BM]] [sCB[BM]] [sPos[32]] [sInner[32]] [sMask[32]] [FUSE0: conv0 w (3,Cin) | bias (Cin)]
     float* sRB = smem + NSTAGE * STAGE;
     float* sCB = sRB + BM;
-    int* sPos = (int*)(sCB + BM);                  // position of each of the tile's PT position slots (epilogue)
-    float* sW0 = sCB + BM + 32;
+    int* sPos = (int*)(sCB + BM);                  // per position slot of the tile (PT <= 32): the position it serves,
+    int* sInner = sPos + 32;                       //   the source offset of its tap 0 inside a sample,
+    unsigned* sMask = (unsigned*)(sPos + 64);      //   and which taps read real data (row_geom())
+    float* sW0 = sCB + BM + 96;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;       // wm < BM / 64
@@ -390,20 +428,24 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     const int b0 = sg * p.ST;                       // first sample of this tile
     const int nb = min(p.ST, p.B - b0);             // valid samples in this tile
 
-    // ---- per-sample LayerNorm scalars of the INPUT (FULL): r_b and -mu_b r_b ----
-    if (tid < p.ST) {
-        const int b = b0 + tid;
-        float r = 0.f, c = 0.f;
-        if (p.mode == 0 && b < p.B) {
-            const double mean = p.stats_in[2 * (int64_t)b] * p.inv_n_in;
-            double var = p.stats_in[2 * (int64_t)b + 1] * p.inv_n_in - mean * mean;
-            var = var > 0.0 ? var : 0.0;
-            const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
-            r = (float)rstd; c = (float)(-mean * rstd);
-        }
-        sRB[tid] = r; sCB[tid] = c;
+    // ---- source geometry of the tile's position slots (threads 0 .. PT-1): all rows of a slot differ only by the sample,
+    // so the divisions of tile_pos() / row_geom() are done once per slot, not once per row and user.  The per-sample
+    // LayerNorm statistics of the INPUT (FULL mode; threads 64 ..) are requested here and used further down ----
+    const bool stat_thread = tid >= 64 && tid < 64 + p.ST;
+    double st_sum = 0.0, st_sq = 0.0;             // loaded here, turned into (r, c) after the first DMAs are on their way
+    if (stat_thread && p.mode == 0 && b0 + tid - 64 < p.B) {
+        st_sum = p.stats_in[2 * (int64_t)(b0 + tid - 64)];
+        st_sq = p.stats_in[2 * (int64_t)(b0 + tid - 64) + 1];
     }
-    if (tid >= NT - 32 && tid < NT - 32 + p.PT) sPos[tid - (NT - 32)] = tile_pos(p, pb * p.PT + tid - (NT - 32));
+    if (tid < 32) {
+        int pos = p.P, inner = 0; unsigned mask = 0;
+        if (tid < p.PT) {
+            pos = tile_pos(p, pb * p.PT + tid);
+            if (pos < p.P) { const RowGeom rg = row_geom(p, pos); inner = rg.inner; mask = rg.mask; }
+        }
+        sPos[tid] = pos; sInner[tid] = inner; sMask[tid] = mask;
+    }
+    __syncthreads();
 
     // ---- DMA geometry.  Wave w stages rows [32w, 32w+32) of A and of B; instruction q
     // covers rows 32w + q*RPI + lane/CH, physical chunk pc = lane % CH, which must hold
@@ -425,13 +467,12 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         const int pc = lane % CH;
         const int swz = BK == 32 ? ((lr >> 1) & 7) : ((lr >> 2) & 3);
         const int lc = pc ^ swz;
-        const int pos = tile_pos(p, (NAFP_ABL(p, 1024) ? 0 : pb) * p.PT + (lr >> p.log2ST));   // ablation 1024: every tile stages the rows of tile 0..7 (L2 hits)
+        const int slot_q = lr >> p.log2ST;
         const int sl = lr & ST1;
         voffA[q] = 0; vmaskA[q] = 0;
-        if (pos < p.P && sl < nb) {
-            const RowGeom rg = row_geom(p, pos);
-            voffA[q] = (unsigned)(sl * (int)p.sample_in + rg.inner + lc * 4) * 4u;   // may wrap for an invalid tap: masked
-            vmaskA[q] = rg.mask;
+        if (sPos[slot_q] < p.P && sl < nb) {
+            voffA[q] = (unsigned)(sl * (int)p.sample_in + sInner[slot_q] + lc * 4) * 4u;   // may wrap for an invalid tap: masked
+            vmaskA[q] = sMask[slot_q];
         }
     }
     // ---- FUSE0 generator geometry: thread t builds row t>>1, channels 8*(t&1)..+8 of every
@@ -468,18 +509,11 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         }
         __syncthreads();       // sW0 is read by the generator below
     }
-    // Taps that read only zero padding for EVERY row of this tile are skipped.  Each wave
-    // derives the tile-wide mask on its own (lane l inspects rows l and l+64, then a
-    // wave-wide OR), so no LDS traffic and no barrier is needed in the prologue.
+    // Taps that read only zero padding for EVERY row of this tile are skipped (wave-wide OR over the slots' masks;
+    // slots beyond P hold 0).
     unsigned live = 0;
     {
-        unsigned m = 0;
-#pragma unroll
-        for (int hrow = 0; hrow < BM / 64; ++hrow) {
-            const int lr = lane + 64 * hrow;
-            const int pos = tile_pos(p, pb * p.PT + (lr >> p.log2ST));
-            if (pos < p.P && (lr & ST1) < nb) m |= row_geom(p, pos).mask;
-        }
+        const unsigned m = sMask[lane & 31];
 #pragma unroll
         for (int t = 0; t < 3; ++t)
             if (__ballot((m >> t) & 1u) != 0ull) live |= 1u << t;
@@ -495,7 +529,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     const int s_begin = (int)(((int64_t)n_steps_all * blockIdx.z) / p.n_split);
     const int n_steps = (int)(((int64_t)n_steps_all * (blockIdx.z + 1)) / p.n_split);
 
-    const u32x4 rsA = make_rsrc(p.x + (int64_t)(NAFP_ABL(p, 1024) ? (sg & 7) * p.ST : b0) * p.sample_in,
+    const u32x4 rsA = make_rsrc(p.x + (int64_t)b0 * p.sample_in,
                                 NAFP_ABL(p, 512) ? 0u : (unsigned)nb * (unsigned)p.sample_in * 4u);   // ablation 512: every A lane out of range (zero fill, no memory traffic)
     const u32x4 rsB = make_rsrc(p.wp, p.wp_bytes);
     const unsigned lds0 = (unsigned)(unsigned long long)(lds_ptr_t)smem + (unsigned)(wave * 32 * BK * 4);
@@ -567,10 +601,46 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
             }
         }
 
+    // per-sample LayerNorm scalars of the input: r_b and -mu_b r_b (first needed by the epilogue, many barriers away)
+    if (stat_thread) {
+        float r = 0.f, c = 0.f;
+        if (p.mode == 0 && b0 + tid - 64 < p.B) {
+            const double mean = st_sum * p.inv_n_in;
+            double var = st_sq * p.inv_n_in - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
+            r = (float)rstd; c = (float)(-mean * rstd);
+        }
+        sRB[tid - 64] = r; sCB[tid - 64] = c;
+    }
+
     // operand read addresses (floats): row*BK + ((lc ^ swz(row)) * 4), lc = 2*kk + (lane>>5)
     const int rl = lane & 31, hh = lane >> 5;
     const int rswz = BK == 32 ? ((rl >> 1) & 7) : ((rl >> 2) & 3);     // wm*64, 32*mi do not change swz
     const int aoff = (wm * 64 + rl) * BK, boff = TILE + (wn * (BNT / 2) + rl) * BK;     // (NIB <= NI: the B pieces ride in the A loop)
+    // epilogue operands (declared here: the first 32-row block's are requested under the last MFMAs of the K-loop)
+    // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).
+    const int ncol = lane & 31;
+    const int n_base = tile_n0 + wn * (BNT / 2) + ncol;
+    const int g4 = p.ST >> 2;                         // sample quads per position
+    constexpr int MIL = 1;            // 32-row blocks whose operands are resident at once (2 = all 48 values: spills at 168 VGPRs)
+    float Gv[MIL][4][NIW], Hv[MIL][4][NIW], gv[MIL][4][NIW];
+    const int pc_bytes = p.P * p.Cout * 4;
+    const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0, pc_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Hb), 0, pc_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gamma_out), 0, pc_bytes, 0x00020000);
+#define NAFP_EPI_LOAD(mi_, slot_)                                                              \
+    _Pragma("unroll") for (int rg = 0; rg < 4; ++rg) {                                         \
+        const int grp_l = wm * 16 + (mi_) * 8 + 2 * rg + (lane >> 5);                          \
+        const int pos_l = pb * p.PT + (grp_l >> (p.log2ST - 2));                               \
+        const int pofs_l = pos_l < p.P ? (pos_l * p.Cout + n_base) * 4 : (int)0x80000000;      \
+        _Pragma("unroll") for (int ni = 0; ni < NIW; ++ni) {                                   \
+            if NAFP_ABL(p, 32) { Gv[slot_][rg][ni] = 0.5f; Hv[slot_][rg][ni] = 0.25f; gv[slot_][rg][ni] = 1.5f; continue; } \
+            Gv[slot_][rg][ni] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsG, pofs_l, ni * 128, 0)); \
+            Hv[slot_][rg][ni] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsH, pofs_l, ni * 128, 0)); \
+            gv[slot_][rg][ni] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsg, pofs_l, ni * 128, 0)); \
+        }                                                                                      \
+    }
     int slot = 0;
     if NAFP_ABL(p, 8) {          // ablation: prologue + pipeline fill only (wait for the prefilled stages, then leave)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -602,6 +672,37 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     //   half of s | MFMA R0 -- and a wave issues MFMAs back to back from one barrier to the next.
     if (!FUSE0 && BK == 16 && !NAFP_ABL(p, 4 | 2048) && s_begin < n_steps) {
         float4 a0[2], b0[NIW], a1[2], b1[NIW];
+        // The DMA of step s + 2 is issued in two pieces BETWEEN the MFMA groups of the step (an in-order wave issues the
+        // piece's scalar address arithmetic, m0 moves and buffer_loads in the gaps while the matrix pipe works through the
+        // MFMAs in front of them; ahead of the first MFMA they were ~300 idle pipe cycles per step for a wave that is alone
+        // on its SIMD).  The step to stage next is tracked by running (tap slot, channel) counters -- no division per step.
+        // The lane part of the A addresses is kept per CURRENT tap (recomputed when the tap changes, once per Cin / 16 steps),
+        // and the loop body exists once per ring slot (3 copies), so that every LDS address is a base register plus an
+        // immediate: a K-step issues no VALU instruction besides its MFMAs.
+        int d_tsel = (s_begin + NSTAGE - 1) / cpt, d_c0 = ((s_begin + NSTAGE - 1) - d_tsel * cpt) * BK;
+        int d_tap = 0; unsigned d_tapb = 0;
+        unsigned cur_va[NI];
+#define NAFP_DMA_TAP()                                                                         \
+        {                                                                                      \
+            d_tap = (int)((tap_pack >> (2 * d_tsel)) & 3u); d_tapb = (unsigned)(d_tap * p.tap_stride) * 4u; \
+            _Pragma("unroll") for (int q = 0; q < NI; ++q) cur_va[q] = ((vmaskA[q] >> d_tap) & 1u) ? voffA[q] + d_tapb : OOB; \
+        }
+        NAFP_DMA_TAP()
+#define NAFP_DMA_PIECE(q_, slot_)                                                              \
+        {                                                                                      \
+            lds_dma16(lds0 + (unsigned)((slot_) * STAGE * 4) + (q_) * RPI * BK * 4, cur_va[q_], rsA, (unsigned)(d_c0 * 4)); \
+            if ((q_) < NIB) lds_dma16(ldsB0 + (unsigned)((slot_) * STAGE * 4) + (q_) * RPI * BK * 4, voffB[(q_) < NIB ? (q_) : 0], rsB, \
+                                      (unsigned)((d_tap * p.Cin + d_c0) * 4));                 \
+            if ((q_) == NI - 1) { d_c0 += BK; if (d_c0 == p.Cin) { d_c0 = 0; ++d_tsel; NAFP_DMA_TAP() } } \
+        }
+#define NAFP_MM_HALF(a_, b_, mi_)                                                              \
+        _Pragma("unroll") for (int ni = 0; ni < NIW; ++ni) {                                   \
+            acc[mi_][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[mi_].x, b_[ni].x, acc[mi_][ni], 0, 0, 0); \
+            acc[mi_][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[mi_].y, b_[ni].y, acc[mi_][ni], 0, 0, 0); \
+            acc[mi_][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[mi_].z, b_[ni].z, acc[mi_][ni], 0, 0, 0); \
+            acc[mi_][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[mi_].w, b_[ni].w, acc[mi_][ni], 0, 0, 0); \
+        }
+        static_assert(NI == 2, "the DMA of a step is issued as two pieces");
         {
             NAFP_WAIT_STEP(s_begin)
             __builtin_amdgcn_s_barrier();
@@ -610,33 +711,64 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
             NAFP_LD_FRAG(St, 0, a0, b0)
             NAFP_LD_FRAG(St, 1, a1, b1)
             __builtin_amdgcn_sched_barrier(0);
-            if (s_begin + NSTAGE - 1 < n_steps && !NAFP_ABL(p, 1)) { NAFP_DMA_STEP(s_begin + NSTAGE - 1, NSTAGE - 1) }
+            if (s_begin + NSTAGE - 1 < n_steps && !NAFP_ABL(p, 1)) { NAFP_DMA_PIECE(0, NSTAGE - 1) NAFP_DMA_PIECE(1, NSTAGE - 1) }
             __builtin_amdgcn_sched_barrier(0);
             NAFP_MM_FRAG(a0, b0)
             __builtin_amdgcn_sched_barrier(0);
             slot = 1;
         }
-        for (int s = s_begin + 1; s < n_steps; ++s) {
-            // R1 (the last reads of slot s - 1) has landed: after the barrier that slot may be overwritten
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            NAFP_WAIT_STEP(s)
-            __builtin_amdgcn_s_barrier();
-            const bool has_next = s + NSTAGE - 1 < n_steps && !NAFP_ABL(p, 1);
-            int nslot = slot + NSTAGE - 1; if (nslot >= NSTAGE) nslot -= NSTAGE;
-            const float* St = smem + slot * STAGE;
-            NAFP_LD_FRAG(St, 0, a0, b0)
-            __builtin_amdgcn_sched_barrier(0);
-            if (has_next) { NAFP_DMA_STEP(s + NSTAGE - 1, nslot) }
-            __builtin_amdgcn_sched_barrier(0);
-            NAFP_MM_FRAG(a1, b1)
-            __builtin_amdgcn_sched_barrier(0);
-            NAFP_LD_FRAG(St, 1, a1, b1)
-            __builtin_amdgcn_sched_barrier(0);
-            NAFP_MM_FRAG(a0, b0)
-            __builtin_amdgcn_sched_barrier(0);
-            if (++slot == NSTAGE) slot = 0;
+        // one K-step on ring slot SLOT_ (compile-time); leaves the loop before the last step's second MFMA group
+#define NAFP_K_STEP(SLOT_, NSLOT_)                                                             \
+        {                                                                                      \
+            /* R1 (the last reads of the previous slot) has landed: after the barrier that slot may be overwritten */ \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                 \
+            NAFP_WAIT_STEP(s)                                                                  \
+            __builtin_amdgcn_s_barrier();                                                      \
+            const bool has_next = s + NSTAGE - 1 < n_steps && !NAFP_ABL(p, 1);                 \
+            const int nslot = (NSLOT_);                                                        \
+            const float* St = smem + (SLOT_) * STAGE;                                          \
+            NAFP_LD_FRAG(St, 0, a0, b0)                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+            NAFP_MM_HALF(a1, b1, 0)                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+            if (has_next) { NAFP_DMA_PIECE(0, nslot) }                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+            NAFP_MM_HALF(a1, b1, 1)                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+            if (has_next) { NAFP_DMA_PIECE(1, nslot) }                                         \
+            NAFP_LD_FRAG(St, 1, a1, b1)                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+            if (s == n_steps - 1) break;          /* the last step's second MFMA group runs below, behind the operand requests */ \
+            NAFP_MM_FRAG(a0, b0)                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+            ++s;                                                                               \
         }
+        static_assert(NSTAGE == 3, "the K-loop body is written out once per ring slot");
+        if (s_begin + 1 < n_steps) {
+            if (BNT == 128) {
+                for (int s = s_begin + 1;;) {
+                    NAFP_K_STEP(1, 0)
+                    NAFP_K_STEP(2, 1)
+                    NAFP_K_STEP(0, 2)
+                }
+            } else {            // 64-column tiles: one rolled copy (the three-copy form makes hipcc spill at their 128-VGPR budget)
+                int rs = 1;
+                for (int s = s_begin + 1;;) {
+                    NAFP_K_STEP(rs, (rs == 0 ? 2 : rs - 1))
+                    if (++rs == NSTAGE) rs = 0;
+                }
+            }
+        }
+#undef NAFP_K_STEP
+        // the epilogue's positional operands of the first 32-row block are requested HERE: their round trip (several
+        // thousand cycles next to the other workgroups' operand and store traffic) runs under the last 16 or 32 MFMAs
+        if ((EPI == 0 || EPI == 1) && BM == 128) { NAFP_EPI_LOAD(0, 0) }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s_begin + 1 < n_steps) { NAFP_MM_FRAG(a0, b0) }
         NAFP_MM_FRAG(a1, b1)
+#undef NAFP_DMA_PIECE
+#undef NAFP_DMA_TAP
+#undef NAFP_MM_HALF
     } else
     for (int s = s_begin; s < n_steps; ++s) {
         // my DMA of step s has landed; after the barrier everybody's has, and everybody has
@@ -692,7 +824,9 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     }
     NAFP_TL(4)
     if (p.opt & 2) __builtin_amdgcn_s_setprio(3);
-    __syncthreads();          // all waves are done with the operand tiles: LDS is reused below
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // all waves are done with the operand tiles: LDS is reused below (a bare barrier: the
+                                    // fence of __syncthreads() would wait for the operand loads that are in flight)
     NAFP_TL(5)
 
     if NAFP_ABL(p, 2) {          // ablation: no epilogue (keep the accumulators alive)
@@ -709,9 +843,6 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     // ---- epilogue ----
     // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).
     // Row groups of 4 (r & 3) = 4 consecutive samples at one position.
-    const int ncol = lane & 31;
-    const int n_base = tile_n0 + wn * (BNT / 2) + ncol;
-    const int g4 = p.ST >> 2;                         // sample quads per position
     const int ystep_b = p.P * p.Cout * 4;                                  // bytes to the same position of the next sample
     if (EPI == 3) {
         // PLAIN: y = acc (+ bias).  Stores go through a buffer descriptor re-based on the tile's first sample (of this
@@ -745,7 +876,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     }
 
     // FULL: v = ELU(r_b*acc + c_b*G + Hb); stats of v; store z = gamma_out * v
-    float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x2 s2[2] = {{0.f, 0.f}, {0.f, 0.f}}, q2[2] = {{0.f, 0.f}, {0.f, 0.f}};   // per-lane sums of v and v^2 of sample slots (0, 1) and (2, 3)
     float* rowS = smem;                 // [BM] (LDS tiles are free again: last loop barrier passed)
     float* rowQ = smem + BM;
     const bool fast_stats = EPI != 2 || p.ST == 4 || p.ST == 8;
@@ -760,60 +891,54 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     // address is one 32-bit register per 4-row group, the sample step a scalar -- and the loop body is instantiated per
     // (keep the pre-activation, statistics path) so that it is straight-line code: any runtime branch in it makes hipcc
     // put an s_waitcnt vmcnt(0) -- outstanding stores included -- in front of every block.
-    constexpr int MIL = (BM == 256 || EPI == 2) ? 1 : 2;   // 32-row blocks whose operands are resident at once
-    float Gv[MIL][4][NIW], Hv[MIL][4][NIW], gv[MIL][4][NIW];
-    const int pc_bytes = p.P * p.Cout * 4;
-    const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0, pc_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Hb), 0, pc_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gamma_out), 0, pc_bytes, 0x00020000);
-#define NAFP_EPI_LOAD(mi_, slot_)                                                              \
-    _Pragma("unroll") for (int rg = 0; rg < 4; ++rg) {                                         \
-        const int grp_l = wm * 16 + (mi_) * 8 + 2 * rg + (lane >> 5);                          \
-        const int pos_l = pb * p.PT + (grp_l >> (p.log2ST - 2));                               \
-        const int pofs_l = pos_l < p.P ? (pos_l * p.Cout + n_base) * 4 : (int)0x80000000;      \
-        _Pragma("unroll") for (int ni = 0; ni < NIW; ++ni) {                                   \
-            if NAFP_ABL(p, 32) { Gv[slot_][rg][ni] = 0.5f; Hv[slot_][rg][ni] = 0.25f; gv[slot_][rg][ni] = 1.5f; continue; } \
-            Gv[slot_][rg][ni] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsG, pofs_l, ni * 128, 0)); \
-            Hv[slot_][rg][ni] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsH, pofs_l, ni * 128, 0)); \
-            gv[slot_][rg][ni] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsg, pofs_l, ni * 128, 0)); \
-        }                                                                                      \
-    }
-    if (MIL == 2) { NAFP_EPI_LOAD(0, 0) NAFP_EPI_LOAD(1, MIL - 1) }
+    constexpr bool PREF = (EPI == 0 || EPI == 1) && !FUSE0 && BK == 16 && BM == 128;   // block 0 was requested inside the K-loop (8-wave tiles run at 128 VGPRs: no room)
+    if (MIL == 2) { if (!PREF) { NAFP_EPI_LOAD(0, 0) } NAFP_EPI_LOAD(1, MIL - 1) }
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
         p.y + (int64_t)b0 * p.P * p.Cout, 0, (int)((unsigned)nb * (unsigned)ystep_b), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
         (p.v_out ? p.v_out : p.y) + (int64_t)b0 * p.P * p.Cout, 0, (int)((unsigned)nb * (unsigned)ystep_b), 0x00020000);
+    // The arithmetic runs on PAIRS of samples with the packed f32 instructions (v_pk_fma / v_pk_mul / v_pk_add: two
+    // elements per issue slot): the f32 MFMAs execute at the f32 vector rate, and the timeline of this kernel shows the
+    // SIMDs' issue time split between MFMAs and everything else -- every VALU instruction of the epilogue is paid for in
+    // MFMA time, so the epilogue is written for instruction count.  ELU(t) = max(t, exp(min(t, 0)) - 1), the min folded
+    // into v_exp's clamp modifier (exp > 1 -> 1).  No select on row validity: rows beyond the batch or beyond P have
+    // zero accumulators; a slot beyond P also reads G = Hb = 0 (buffer range) and contributes ELU(0) = 0 to the sums, a
+    // sample beyond the batch only touches its own sums, which are dropped; their stores are out of range.
 #define NAFP_EPI_MAIN(KEEP_, FAST_)                                                            \
     _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) {                                         \
         const int ms = MIL == 2 ? mi : 0;                                                      \
-        if (MIL == 1) { NAFP_EPI_LOAD(mi, 0) }                                                 \
+        if (MIL == 1 && !(PREF && mi == 0)) { NAFP_EPI_LOAD(mi, 0) }                           \
         _Pragma("unroll") for (int rg = 0; rg < 4; ++rg) {                                     \
             const int grp = wm * 16 + mi * 8 + 2 * rg + (lane >> 5);      /* = tile row >> 2 */ \
             const int pos = pb * p.PT + (grp >> (p.log2ST - 2));                               \
             const int sl0 = (grp & (g4 - 1)) << 2;                         /* first of the 4 samples */ \
-            const bool pvalid = pos < p.P;                                                     \
-            const int voff = pvalid ? ((sl0 * p.P + pos) * p.Cout + n_base) * 4 : (int)0x80000000; \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                    \
-                const int r = rg * 4 + q;                                                      \
-                const int sl = sl0 + q;                                                        \
-                const bool valid = pvalid && (sg * p.ST + sl) < p.B;                           \
-                const float rb = sRB[sl], cb = sCB[sl];                                        \
-                float rs = 0.f, rq = 0.f;                                                      \
+            const int voff = pos < p.P ? ((sl0 * p.P + pos) * p.Cout + n_base) * 4 : (int)0x80000000; \
+            _Pragma("unroll") for (int qp = 0; qp < 2; ++qp) {             /* samples sl0 + 2 qp, + 1 */ \
+                const int r0 = rg * 4 + 2 * qp;                                                \
+                const f32x2 rb2 = *(const f32x2*)(sRB + sl0 + 2 * qp), cb2 = *(const f32x2*)(sCB + sl0 + 2 * qp); \
+                f32x2 rs2 = {0.f, 0.f}, rq2 = {0.f, 0.f};                                      \
                 _Pragma("unroll") for (int ni = 0; ni < NIW; ++ni) {                           \
-                    const float tpre = fmaf(rb, acc[mi][ni][r], fmaf(cb, Gv[ms][rg][ni], Hv[ms][rg][ni])); \
-                    float v = NAFP_ABL(p, 128) ? tpre : elu1(tpre);       /* ablation 128: no exp */ \
-                    v = valid ? v : 0.f;                                                       \
-                    if (!NAFP_ABL(p, 64))                                  /* ablation 64: no stores */ \
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v * gv[ms][rg][ni]), rsY, voff, \
-                                                              q * ystep_b + ni * 128, 0);      \
-                    if (KEEP_)                                             /* training keeps the pre-activation */ \
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, tpre), rsV, voff, q * ystep_b + ni * 128, 0); \
-                    rs += v; rq += v * v;                                                      \
+                    const f32x2 a2 = {acc[mi][ni][r0], acc[mi][ni][r0 + 1]};                   \
+                    const f32x2 t2 = __builtin_elementwise_fma(rb2, a2, __builtin_elementwise_fma(cb2, (f32x2)(Gv[ms][rg][ni]), (f32x2)(Hv[ms][rg][ni]))); \
+                    const f32x2 v2 = NAFP_ABL(p, 128) ? t2 : elu2(t2);    /* ablation 128: no exp */ \
+                    const f32x2 z2 = v2 * gv[ms][rg][ni];                                      \
+                    if (!NAFP_ABL(p, 64)) {                                /* ablation 64: no stores */ \
+                        __builtin_amdgcn_raw_buffer_store_b32(f2i(z2.x), rsY, voff, (2 * qp) * ystep_b + ni * 128, 0); \
+                        __builtin_amdgcn_raw_buffer_store_b32(f2i(z2.y), rsY, voff, (2 * qp + 1) * ystep_b + ni * 128, 0); \
+                    }                                                                          \
+                    if (KEEP_) {                                           /* training keeps the pre-activation */ \
+                        __builtin_amdgcn_raw_buffer_store_b32(f2i(t2.x), rsV, voff, (2 * qp) * ystep_b + ni * 128, 0); \
+                        __builtin_amdgcn_raw_buffer_store_b32(f2i(t2.y), rsV, voff, (2 * qp + 1) * ystep_b + ni * 128, 0); \
+                    }                                                                          \
+                    rs2 += v2; rq2 = __builtin_elementwise_fma(v2, v2, rq2);                   \
                 }                                                                              \
-                if (FAST_) { s4[q] += rs; q4[q] += rq; }                                       \
+                if (FAST_) { s2[qp] += rs2; q2[qp] += rq2; }                                   \
                 else {                                                                         \
-                    _Pragma("unroll") for (int o = 16; o > 0; o >>= 1) { rs += __shfl_xor(rs, o, 64); rq += __shfl_xor(rq, o, 64); } \
-                    if (ncol == 0) { atomicAdd(rowS + (grp << 2) + q, rs); atomicAdd(rowQ + (grp << 2) + q, rq); } \
+                    _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2) {                         \
+                        float rs = rs2[h2], rq = rq2[h2];                                      \
+                        _Pragma("unroll") for (int o = 16; o > 0; o >>= 1) { rs += __shfl_xor(rs, o, 64); rq += __shfl_xor(rq, o, 64); } \
+                        if (ncol == 0) { atomicAdd(rowS + (grp << 2) + 2 * qp + h2, rs); atomicAdd(rowQ + (grp << 2) + 2 * qp + h2, rq); } \
+                    }                                                                          \
                 }                                                                              \
             }                                                                                  \
         }                                                                                      \
@@ -828,23 +953,24 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
 #undef NAFP_EPI_MAIN
     NAFP_TL(6)
     if NAFP_ABL(p, 16) {         // ablation: no statistics reduction (keep the sums alive)
-        if (s4[0] + s4[1] + s4[2] + s4[3] + q4[0] + q4[1] + q4[2] + q4[3] == 12345.678f) p.y[tid] = 1.f;
+        if (s2[0].x + s2[0].y + s2[1].x + s2[1].y + q2[0].x + q2[0].y + q2[1].x + q2[1].y == 12345.678f) p.y[tid] = 1.f;
         return;
     }
     if (fast_stats) {
         // ST == 4: the tile's 4 samples are the 4 register slots (r & 3) of every lane.
         // ST == 8: lanes 0..31 hold samples 0..3, lanes 32..63 samples 4..7 (grp & 1 == lane >> 5 for every block).
+        // Each 32-lane half is summed with DPP row operations (VALU only); lanes 31 and 63 hand the half sums to LDS
+        // (no barrier in front: nothing else lives in the first bytes of the operand ring any more), one thread per
+        // (statistic, sample) adds the waves' parts in a fixed order and issues the global atomic.
         double* red = (double*)smem;        // [NW waves][half][sum | sumsq][4]
-        const bool two = p.ST == 8;
-        __syncthreads();
+        float hs[4], hq[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            double ds = (double)s4[q], dq = (double)q4[q];
+        for (int q = 0; q < 4; ++q) { hs[q] = half_wave_sum_dpp(s2[q >> 1][q & 1]); hq[q] = half_wave_sum_dpp(q2[q >> 1][q & 1]); }
+        if ((lane & 31) == 31) {
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) { ds += __shfl_xor(ds, o, 64); dq += __shfl_xor(dq, o, 64); }
-            if (!two) { ds += __shfl_xor(ds, 32, 64); dq += __shfl_xor(dq, 32, 64); }
-            if ((lane & 31) == 0 && (two || lane == 0)) {
-                red[wave * 16 + (lane >> 5) * 8 + q] = ds; red[wave * 16 + (lane >> 5) * 8 + 4 + q] = dq;
+            for (int q = 0; q < 4; ++q) {
+                red[wave * 16 + (lane >> 5) * 8 + q] = (double)hs[q];
+                red[wave * 16 + (lane >> 5) * 8 + 4 + q] = (double)hq[q];
             }
         }
         __syncthreads();
@@ -853,8 +979,13 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
             const int b = sg * p.ST + sl;
             if (b < p.B) {
                 double t = 0.0;
+                if (p.ST == 8) {
 #pragma unroll
-                for (int w = 0; w < NW; ++w) t += red[w * 16 + (sl >> 2) * 8 + which * 4 + (sl & 3)];
+                    for (int w = 0; w < NW; ++w) t += red[w * 16 + (sl >> 2) * 8 + which * 4 + (sl & 3)];
+                } else {
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) t += red[w * 16 + which * 4 + sl] + red[w * 16 + 8 + which * 4 + sl];
+                }
                 atomicAdd(p.stats_out + 2 * (int64_t)b + which, t);
             }
         }
@@ -904,7 +1035,7 @@ static void (*const conv_gemm_m256k16s3_tab[4])(const ConvKernelParams) = {conv_
 
 template <typename KernelT>
 static int launch_variant(KernelT kernel, int BM, int BNt, int BK, int NSTAGE, const ConvKernelParams& p, dim3 grid, hipStream_t st) {
-    const int lds = (NSTAGE * (BM + BNt) * BK + 2 * BM + 32 + (p.f0_feat ? 4 * p.Cin : 0)) * (int)sizeof(float);
+    const int lds = (NSTAGE * (BM + BNt) * BK + 2 * BM + 96 + (p.f0_feat ? 4 * p.Cin : 0)) * (int)sizeof(float);
     NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     kernel<<<grid, 2 * BM, lds, st>>>(p);
     NAFP_LAUNCH_CHECK();
@@ -1135,7 +1266,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     if (a.dgrad) {
         // backward w.r.t. the conv input: rows = input positions, source = dT (B,Fout,Tout,Cout),
         // weights = wp flipped to (Cin, 3*Cout); see row_geom()
-        if (!a.plain || g.Cout % 32 != 0 || g.Cin % BN != 0) return NAFP_ERR_UNSUPPORTED;
+        if (!a.plain || g.Cout % 32 != 0 || g.Cin % BN != 0 || (g.stride != 1 && g.stride != 2)) return NAFP_ERR_UNSUPPORTED;
         p.dgrad = 1;
         p.Fin = g.Fout; p.Tin = g.Tout; p.Cin = g.Cout; p.Cout = g.Cin; p.Tout = g.Tin;
         p.P = g.Fin * g.Tin;
@@ -1236,22 +1367,6 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
 // a row meet through 5 shuffles and one LDS atomic.
 //   grid = (positions x chunks of sample groups, C / 128); 256 threads = 2 x 2 waves of 64 x 64, BK = 16, 3-stage ring.
 // ============================================================================
-// Sum over each 32-lane half of a wave with DPP row shifts (VALU only, no LDS crossbar): afterwards lane 31 holds the sum
-// of lanes 0..31 and lane 63 the sum of lanes 32..63.
-__device__ __forceinline__ float half_wave_sum_dpp(float x) {
-    int v = __builtin_bit_cast(int, x);
-#define NAFP_DPP_ADD(ctrl_, rmask_)                                                                       \
-    v = __builtin_bit_cast(int, __builtin_bit_cast(float, v) +                                            \
-                                    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, v, ctrl_, rmask_, 0xf, true)));
-    NAFP_DPP_ADD(0x111, 0xf)      // row_shr:1
-    NAFP_DPP_ADD(0x112, 0xf)      // row_shr:2
-    NAFP_DPP_ADD(0x114, 0xf)      // row_shr:4
-    NAFP_DPP_ADD(0x118, 0xf)      // row_shr:8   -> lane 15 of every 16-lane row holds the row's sum
-    NAFP_DPP_ADD(0x142, 0xa)      // row_bcast:15 into rows 1 and 3: lanes 31 and 63 hold the half sums
-#undef NAFP_DPP_ADD
-    return __builtin_bit_cast(float, v);
-}
-
 struct DgradLnParams {
     ConvKernelParams c;            // the transposed conv (dgrad = 1): x = dts_j, wp = Wd_j, P / Tout / ... of its OUTPUT rows
     const float* t;                // (B, P, C)  pre-activation of layer j-1

@@ -110,6 +110,26 @@ def main():
     print(f'workgroup end -> next workgroup entry on the same CU: median {np.median(gaps):.0f} cycles, p90 {np.percentile(gaps, 90):.0f}')
     print(f'entry -> first K-step (geometry + fill): mean {(k0 - s0).mean():.0f}; K-loop end -> workgroup end: mean {(e1 - k1).mean():.0f}')
     print(f'workgroups per CU: min {min(res_all)} max {max(res_all)}')
+    # per SIMD: share of the SIMD's busy span with n waves inside their K-loop, and the MFMA work per covered cycle
+    sk = (cu_key * 4 + simd).ravel()
+    w0, w1 = t[..., 3].ravel(), t[..., 4].ravel()
+    ws, we = t[..., 1].ravel(), t[..., 7].ravel()
+    order = np.argsort(sk, kind='stable')
+    sk, w0, w1, ws, we = sk[order], w0[order], w1[order], ws[order], we[order]
+    bounds = np.flatnonzero(np.diff(sk)) + 1
+    occ = np.zeros(16); span_tot = 0.0; n_wt = 0
+    for a, b in zip(np.r_[0, bounds], np.r_[bounds, len(sk)]):
+        ev = np.concatenate([np.stack([w0[a:b], np.ones(b - a)], 1), np.stack([w1[a:b], -np.ones(b - a)], 1)])
+        ev = ev[np.argsort(ev[:, 0], kind='stable')]
+        lvl = 0
+        for i in range(len(ev) - 1):
+            lvl += int(ev[i, 1])
+            occ[min(lvl, 15)] += ev[i + 1, 0] - ev[i, 0]
+        lo, hi = ws[a:b].min(), we[a:b].max()
+        occ[0] += (ev[0, 0] - lo) + (hi - ev[-1, 0])
+        span_tot += hi - lo; n_wt += b - a
+    print('per SIMD, share of its span with n waves inside the K-loop: ' + '  '.join(f'{n}: {100 * v / occ.sum():.1f} %' for n, v in enumerate(occ) if v / occ.sum() > 0.0005))
+    print(f'MFMA cycles needed / SIMD span: {100 * n_wt * mfma_per_wave * 64 / span_tot:.1f} %;  / span with >= 1 wave in the K-loop: {100 * n_wt * mfma_per_wave * 64 / (occ.sum() - occ[0]):.1f} %')
 
 
 if __name__ == '__main__':
