@@ -269,7 +269,7 @@ struct ConvKernelParams {
     int n_split;              // split-K factor (blockIdx.z); > 1 writes raw partial sums to `y` = slab
     int abl;                  // ablation flags for kernel-time breakdown (NAFP_ABL env; 0 in production)
     unsigned long long* tl;   // diagnostic phase timeline (nafp_conv_timeline), null in production: 8 u64 per wave
-    int opt;                  // bit 0: the geometry prologue runs at raised wave priority, bit 1: the epilogue does (NAFP_GEMM_PRIO)
+    int opt;                  // bit 0: the geometry prologue runs at raised wave priority, bit 1: the epilogue does (NAFP_GEMM_PRIO); bit 2: 3-D grid
     // FUSE0 (conv1 only): the A operand z0 = gamma0 . ELU(conv0(feat)) is generated in-kernel
     // from the log-mel features instead of being read from memory (`x` unused).
     const float* f0_feat;     // (B, F0, T0)
@@ -300,6 +300,8 @@ __device__ __forceinline__ u32x4 make_rsrc(const void* base, unsigned bytes) {
 // The kernel counts these itself with s_waitcnt vmcnt(N).
 __device__ __forceinline__ void lds_dma16(unsigned lds_addr, unsigned voff, u32x4 rsrc, unsigned soff) {
     unsigned keep;
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);      // wave-uniform by construction; say so to the compiler
+    soff = __builtin_amdgcn_readfirstlane(soff);              // (a uniform value it keeps in a VGPR is not a legal "s" operand)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 4\n\t"
                  "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
@@ -407,8 +409,11 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;       // wm < BM / 64
-    const int sg = blockIdx.x % p.n_sg, pb = blockIdx.x / p.n_sg;
-    const int tile_n0 = blockIdx.y * BNT;
+    // grid = (sample groups, position blocks, column tiles): no division to take a block id apart
+    // (split-K launches keep (sample groups x position blocks, column tiles, parts): their dispatch order matters more)
+    int sg = blockIdx.x, pb = blockIdx.y, colz = blockIdx.z, zsp = 0;      // ..., column tile, split-K part
+    if (!(p.opt & 4)) { pb = blockIdx.x / p.n_sg; sg = blockIdx.x - pb * p.n_sg; colz = blockIdx.y; zsp = blockIdx.z; }
+    const int tile_n0 = colz * BNT;
     const int K = 3 * p.Cin;
     // diagnostic timeline: lane 0 of every wave stamps the shader clock at the phase boundaries of its tile
 #define NAFP_TL(k_)                                                                            \
@@ -526,8 +531,15 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     const int cpt = p.Cin / BK;                 // K-steps per tap
     const int n_steps_all = n_live * cpt;
     // split-K: this workgroup owns K-steps [s_begin, n_steps) of the tile's live steps
-    const int s_begin = (int)(((int64_t)n_steps_all * blockIdx.z) / p.n_split);
-    const int n_steps = (int)(((int64_t)n_steps_all * (blockIdx.z + 1)) / p.n_split);
+    int s_begin = 0, n_steps = n_steps_all;
+    if (p.n_split > 1) {
+        s_begin = (int)((unsigned)(n_steps_all * zsp) / (unsigned)p.n_split);
+        n_steps = (int)((unsigned)(n_steps_all * (zsp + 1)) / (unsigned)p.n_split);
+    }
+    // (tap slot, channel) of a K-step; without split-K the steps asked for are 0, 1, 2 and a tap has >= 2 steps: no division
+#define NAFP_STEP_AT(step_, tsel_, c0_)                                                        \
+    const int tsel_ = s_begin == 0 ? ((step_) >= cpt ? 1 : 0) : (step_) / cpt;                 \
+    const int c0_ = ((step_) - tsel_ * cpt) * BK;
 
     const u32x4 rsA = make_rsrc(p.x + (int64_t)b0 * p.sample_in,
                                 NAFP_ABL(p, 512) ? 0u : (unsigned)nb * (unsigned)p.sample_in * 4u);   // ablation 512: every A lane out of range (zero fill, no memory traffic)
@@ -538,9 +550,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     // Issue the DMA of K-step s_ into ring slot slot_ (wave-uniform LDS bases).
 #define NAFP_DMA_STEP(s_, slot_)                                                              \
     {                                                                                          \
-        const int tsel_l = (s_) / cpt;                                                         \
+        NAFP_STEP_AT(s_, tsel_l, c0_l)                                                         \
         const int tap_l = (int)((tap_pack >> (2 * tsel_l)) & 3u);                              \
-        const int c0_l = ((s_) - tsel_l * cpt) * BK;                                           \
         const unsigned la_l = lds0 + (unsigned)((slot_) * STAGE * 4);                          \
         const unsigned lb_l = ldsB0 + (unsigned)((slot_) * STAGE * 4);                         \
         const unsigned tapb_l = (unsigned)(tap_l * p.tap_stride) * 4u;                         \
@@ -679,7 +690,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         // The lane part of the A addresses is kept per CURRENT tap (recomputed when the tap changes, once per Cin / 16 steps),
         // and the loop body exists once per ring slot (3 copies), so that every LDS address is a base register plus an
         // immediate: a K-step issues no VALU instruction besides its MFMAs.
-        int d_tsel = (s_begin + NSTAGE - 1) / cpt, d_c0 = ((s_begin + NSTAGE - 1) - d_tsel * cpt) * BK;
+        NAFP_STEP_AT(s_begin + NSTAGE - 1, d_tsel0, d_c00)
+        int d_tsel = d_tsel0, d_c0 = d_c00;
         int d_tap = 0; unsigned d_tapb = 0;
         unsigned cur_va[NI];
 #define NAFP_DMA_TAP()                                                                         \
@@ -854,7 +866,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
 #pragma unroll
         for (int ni = 0; ni < NIW; ++ni) asm volatile("" : "+v"(bv[ni]));   // the bias has landed HERE (else hipcc waits -- vmcnt(0), stores included -- in front of every use)
         const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(
-            p.y + ((int64_t)blockIdx.z * p.B + b0) * p.P * p.Cout, 0, (int)((unsigned)nb * (unsigned)ystep_b), 0x00020000);
+            p.y + ((int64_t)zsp * p.B + b0) * p.P * p.Cout, 0, (int)((unsigned)nb * (unsigned)ystep_b), 0x00020000);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -1307,7 +1319,12 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
         if ((int64_t)S * out_floats > a.slab_floats) S = 1;
     }
     if (S > 1) { p.mode = a.plain ? 1 : 2; p.n_split = S; p.y = a.slab; p.bias = nullptr; }
-    const dim3 grid((unsigned)((int64_t)p.n_sg * n_pb), (unsigned)(p.Cout / bn), (unsigned)S);
+    static const int grid3d = []() { const char* e = getenv("NAFP_GRID3D"); return e ? atoi(e) : 1; }();
+    const bool g3 = S == 1 && grid3d != 0 && (grid3d == 1 || BM == 256 || bn == 128);
+    if (g3) p.opt |= 4;
+    const dim3 grid = g3 ? dim3((unsigned)p.n_sg, (unsigned)n_pb, (unsigned)(p.Cout / bn))
+                         : dim3((unsigned)((int64_t)p.n_sg * n_pb), (unsigned)(p.Cout / bn), (unsigned)S);
+    if (n_pb > 65535 || p.Cout / bn > 65535) return NAFP_ERR_UNSUPPORTED;
     if (g_timeline.buf && !a.plain && !a.dgrad && g.Cin == g_timeline.cin && g.Cout == g_timeline.cout && p.P == g_timeline.positions &&
         (int64_t)grid.x * grid.y * grid.z * 64 <= g_timeline.capacity) {
         p.tl = g_timeline.buf;
