@@ -257,7 +257,11 @@ def main():
     for i in range(max(args.warmup, n_str)):
         step_on(i)
     torch.cuda.synchronize()
-    m_fp.profile_enable(args.steps)
+    # HIP events of the timed region: 4 per forward on the launch stream (before conv0, before conv1, after conv15, after
+    # the tail) -- the 15 GEMM-conv launches are timed as ONE span per step, average launch = span / 15.  Stamping every
+    # launch (18 events) idles the GPU ~5 us per stamp = 0.1 ms per step; the per-conv split is taken from a second,
+    # untimed pass below.
+    m_fp.profile_enable(args.steps, coarse=True)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * args.steps)]
     if dist:
         dist.barrier()
@@ -277,6 +281,14 @@ def main():
 
     prof = m_fp.profile_read()
     mel_ms = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(args.steps)) / args.steps
+    # per-conv split: the same steps once more on one stream with a stamp after every launch (outside the timed region)
+    n_fine = min(args.steps, 8)
+    m_fp.profile_enable(n_fine)
+    for i in range(n_fine):
+        with torch.cuda.stream(streams[0]):
+            m_fp(m_pre(pool[i % n_pool], group_size=BSZ, defer=True))
+    torch.cuda.synchronize()
+    prof_fine = m_fp.profile_read()
     # Outside the timed region: the same steps on ONE stream, so that each kernel's duration is
     # its own (in the pipelined region kernels of different batches share the chip and the
     # per-launch durations include that sharing).
@@ -352,13 +364,17 @@ def main():
                 'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_unit': 'bytes/launch',
                 'traffic_source': traffic_src,
                 'flops_per_launch_avg': gemm_flops_per_step / 15, 'ms_per_launch_avg': round(gemm_ms / 15, 5),
-                'note': 'durations from HIP events recorded by the library on the launch stream inside the '
-                        'timed region' + ('' if n_str == 1 else f'; {n_str} batches are in flight on separate '
+                'note': 'HIP events recorded by the library on the launch stream inside the timed region: one span per step '
+                        'from the first GEMM-conv launch to the end of the last (split-K finish kernels and inter-launch gaps '
+                        'included), average launch = span / 15' + ('' if n_str == 1 else f'; {n_str} batches are in flight on separate '
                         'streams there, so launches of different batches share the chip; "isolated" = the same '
                         'launches alone on one stream (un-timed pass after the region)')},
             'stage_ms_per_step': {'melspec(2 kernels)': round(mel_ms, 4), 'conv0': round(conv0_ms, 4),
                                   'conv_gemm x15': round(gemm_ms, 4), 'tail': round(tail_ms, 4),
-                                  'per_conv': [round(sum(p[k] for p in prof) / len(prof), 4) for k in range(17)]},
+                                  'per_conv': [round(sum(p[k] for p in prof_fine) / len(prof_fine), 4) for k in range(17)],
+                                  'per_conv_note': 'conv0, the 15 GEMM convs, tail: from a second, untimed pass with a HIP event '
+                                                   'after every launch (each such stamp idles the GPU ~5 us, so their sum exceeds '
+                                                   'the timed "conv_gemm x15" span)'},
             'frontend_hbm': {'bound': 'hbm', 'kernel': 'melspec_kernel (STFT + mel + log; the max subtraction is applied by conv0 on load)',
                              'algorithmic_bytes_per_segment': 32000 + 32768,
                              'achieved': round(BSZ * (32000 + 32768) / (mel_ms * 1e-3) / 1e9, 2), 'peak': 8000.0, 'unit': 'GB/s',

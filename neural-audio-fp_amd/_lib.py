@@ -48,6 +48,7 @@ PROTOTYPES = {
                                          c_int, c_void_p]),
     'nafp_encoder_profile_enable': (c_int, [c_void_p, c_int]),
     'nafp_encoder_profile_count': (c_int, [c_void_p]),
+    'nafp_encoder_profile_coarse': (c_int, [c_void_p, c_int]),
     'nafp_encoder_profile_read': (c_int, [c_void_p, c_int, c_void_p]),
     'nafp_conv_timeline': (c_int, [c_void_p, c_i64, c_int, c_int, c_int]),
     'nafp_conv_timeline_grid': (c_int, [c_void_p]),

@@ -90,6 +90,7 @@ struct nafp_encoder {
     // optional per-kernel event timing (nafp_encoder_profile_*)
     std::vector<hipEvent_t> prof_events;  // (max_forwards, 18)
     int prof_max = 0, prof_count = 0;
+    int prof_coarse = 0;                  // 1: stamp only around conv0, the 15 GEMM convs as a group, and the tail
     // nafp_encoder_backward records one event per gradient group (layers complete last to first), so that a
     // communication stream can start reducing a group while the rest of the backward pass still runs
     hipEvent_t grad_events[NAFP_GRAD_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
@@ -393,7 +394,7 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
         }
         rc = launch_conv_gemm(a, n_seg, e->geom[j], st);
         if (rc != NAFP_OK) return rc;
-        if (ev) NAFP_HIP_CHECK(hipEventRecord(ev[j + 1], st));
+        if (ev && (!e->prof_coarse || j == 15)) NAFP_HIP_CHECK(hipEventRecord(ev[j + 1], st));
         cur = nxt;
     }
     TailArgs t;
@@ -420,12 +421,25 @@ extern "C" int nafp_encoder_profile_enable(nafp_encoder* e, int max_forwards) {
     return NAFP_OK;
 }
 
+extern "C" int nafp_encoder_profile_coarse(nafp_encoder* e, int coarse) {
+    if (!e) return NAFP_ERR_INVALID_ARG;
+    e->prof_coarse = coarse != 0;
+    return NAFP_OK;
+}
+
 extern "C" int nafp_encoder_profile_count(const nafp_encoder* e) { return e ? e->prof_count : -1; }
 
 extern "C" int nafp_encoder_profile_read(nafp_encoder* e, int slot, float* ms_out_host) {
     if (!e || !ms_out_host || slot < 0 || slot >= e->prof_count) return NAFP_ERR_INVALID_ARG;
     hipEvent_t* ev = e->prof_events.data() + (size_t)18 * slot;
     NAFP_HIP_CHECK(hipEventSynchronize(ev[17]));
+    if (e->prof_coarse) {       // conv0 | the 15 GEMM convs (incl. split-K finishes) as ONE span in slot 1 | zeros | tail
+        for (int k = 0; k < 17; ++k) ms_out_host[k] = 0.f;
+        NAFP_HIP_CHECK(hipEventElapsedTime(ms_out_host + 0, ev[0], ev[1]));
+        NAFP_HIP_CHECK(hipEventElapsedTime(ms_out_host + 1, ev[1], ev[16]));
+        NAFP_HIP_CHECK(hipEventElapsedTime(ms_out_host + 16, ev[16], ev[17]));
+        return NAFP_OK;
+    }
     for (int k = 0; k < 17; ++k) NAFP_HIP_CHECK(hipEventElapsedTime(ms_out_host + k, ev[k], ev[k + 1]));
     return NAFP_OK;
 }

@@ -278,12 +278,16 @@ class FingerPrinter:
         _lib.check(self._lib.nafp_encoder_set_option(self._h, int(option), int(value)), 'encoder_set_option')
 
     # ---- per-kernel HIP-event timing (bench.py roofline leg) ----------------
-    def profile_enable(self, max_forwards):
+    def profile_enable(self, max_forwards, coarse=False):
+        """HIP-event stamps for the next `max_forwards` forwards.  coarse: 4 stamps per forward (conv0 | the 15 GEMM
+        convs as ONE span | tail) instead of 18 -- every stamp between two kernels idles the GPU for ~5 us."""
         with torch.cuda.device(self.device):
+            _lib.check(self._lib.nafp_encoder_profile_coarse(self._h, 1 if coarse else 0), 'profile_coarse')
             _lib.check(self._lib.nafp_encoder_profile_enable(self._h, int(max_forwards)), 'profile_enable')
 
     def profile_read(self):
-        """-> list of 17-float lists (ms): conv0, 15 implicit-GEMM convs, tail; one per forward."""
+        """-> list of 17-float lists (ms): conv0, 15 implicit-GEMM convs, tail; one per forward
+        (coarse stamps: conv0, the span of all 15 GEMM convs, zeros, tail)."""
         out = []
         buf = (ctypes.c_float * 17)()
         for s in range(self._lib.nafp_encoder_profile_count(self._h)):
