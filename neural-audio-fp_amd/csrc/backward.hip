@@ -382,6 +382,137 @@ __global__ __launch_bounds__(256, 3) void wgrad_kernel(const WgradParams p) {
             }
 }
 
+// wgrad, regular shapes (every layer of the 1-s encoder down to P = 16): Tout | 16, 16 | P, Fout a power of two and the
+// source extent along the tap axis = stride x the output extent.  Then a lane's DMA rows move through X in a straight
+// line -- row m = m0 + 16 s + r sits at (line = m >> log2 Tout, to = r mod Tout) and the source line index is linear
+// in `line` ACROSS sample boundaries -- so a K-step's addresses are a per-lane base (computed once) plus a scalar
+// offset, rows beyond the chunk are cut by the D descriptor's range (X may read on: it multiplies zeros), and the only
+// per-step vector work is the padding test of the rows at a sample's edge when the taps run along F.
+// The f32 MFMAs share the SIMD's issue time with every VALU instruction (see conv.hip): the generic kernel above spends
+// ~160 VALU instructions per 32 MFMAs on row bookkeeping, this one at most 12.  The loop body exists once per ring slot
+// so that LDS addresses are immediates.
+__global__ __launch_bounds__(256, 3) void wgrad_fast_kernel(const WgradParams p, const int lt, const int lfo) {
+    constexpr int NST = 3, KR = 16;
+    constexpr int TILE = KR * 128, STAGE = 2 * TILE;           // X rows | D rows
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave >> 1, wn = wave & 1;
+    const int ctiles = p.Cin / 128;
+    const int tap = (p.tap_pack >> (2 * (blockIdx.z / ctiles))) & 3, c0 = (blockIdx.z % ctiles) * 128, n0 = blockIdx.y * 128;
+    const long long M = (long long)p.B * p.P;
+    const long long m0 = (long long)blockIdx.x * p.rows_per_wg;               // multiple of 16
+    const long long m_end = std::min<long long>(M, m0 + p.rows_per_wg);
+    const int n_steps = (int)((m_end - m0 + KR - 1) / KR);
+    const int b_first = (int)(m0 / p.P);
+    const int chunk = lane & 31, hh = lane >> 5;
+    const long long x_bytes = ((long long)(m_end - 1) / p.P - b_first + 1) * p.sample_in * 4;
+    const u32x4b rsX = make_rsrc_b(p.X + (long long)b_first * p.sample_in, (unsigned)std::min<long long>(x_bytes, 0x7fffffffll));
+    const u32x4b rsD = make_rsrc_b(p.D + m0 * p.Cout, (unsigned)((m_end - m0) * p.Cout * 4));
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
+
+    // per-lane bases of the two DMA instructions of this wave (rows r = 4 wave + 2 i + hh of every step)
+    const int dl = KR >> lt;                                   // source/output lines per step
+    const int fmask = (1 << lfo) - 1;
+    unsigned vxb[2], vdb[2]; int fo0[2];
+    bool okc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 4 * wave + 2 * i + hh;
+        const long long line = ((m0 + r) >> lt);               // = b * Fout + fo of step 0
+        const int to = r & ((1 << lt) - 1);
+        long long src;                                         // floats from the start of X
+        if (p.axis == 0) {
+            const int t = to * p.stride - p.pad + tap;
+            okc[i] = t >= 0 && t < p.Tin;
+            src = (line * p.Tin + t) * p.Cin;
+        } else {
+            okc[i] = true;
+            src = (((long long)p.stride * line - p.pad + tap) * p.Tin + to) * p.Cin;
+        }
+        fo0[i] = (int)(line & fmask);
+        vxb[i] = (unsigned)((src - (long long)b_first * p.sample_in + c0 + 4 * chunk) * 4);
+        vdb[i] = (unsigned)(((long long)r * p.Cout + n0 + 4 * chunk) * 4);
+    }
+    const unsigned dX = (unsigned)((p.axis == 0 ? dl : dl * p.stride) * p.Tin * p.Cin * 4);   // bytes per step
+    const unsigned dD = (unsigned)(KR * p.Cout * 4);
+    const int Fout = 1 << lfo;
+
+#define NAFP_WGF_DMA(s_, slot_)                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                    \
+        bool ok_l = okc[i];                                                                            \
+        if (p.axis == 1) {                                     /* padding rows at the edge of a sample */ \
+            const int f_l = ((fo0[i] + (s_) * dl) & fmask) * p.stride - p.pad + tap;                   \
+            ok_l = f_l >= 0 && f_l < p.stride * Fout;                                                  \
+        }                                                                                              \
+        const unsigned la_l = lds0 + (unsigned)(((slot_) * STAGE + (4 * wave + 2 * i) * 128) * 4);     \
+        lds_dma16_b(la_l, ok_l ? vxb[i] : OOB, rsX, (unsigned)(s_) * dX);                              \
+        lds_dma16_b(la_l + TILE * 4, vdb[i], rsD, (unsigned)(s_) * dD);                                \
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ci][ni][r] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < n_steps) NAFP_WGF_DMA(s, s)
+
+    // MFMA operands: lane (rl, hh) owns the column PAIR 2 rl, 2 rl + 1 of its wave's 64 columns (tiles ci / ni = 0, 1 are
+    // the even / odd columns), so that the two values of a k-row are one 8-byte LDS read at base + immediate.
+    const int rl = lane & 31;
+    typedef float f32x2w __attribute__((ext_vector_type(2)));
+    const float* Xl = smem + hh * 128 + wc * 64 + 2 * rl;
+    const float* Dl = smem + TILE + hh * 128 + wn * 64 + 2 * rl;
+    int slot = 0;
+    for (int s = 0; s < n_steps; ++s) {
+        if (s + NST - 2 >= n_steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // one younger step (4 DMA) may stay in flight
+        __builtin_amdgcn_s_barrier();
+        const float* Xs = Xl + slot * STAGE;
+        const float* Ds = Dl + slot * STAGE;
+        f32x2w a[KR / 2], bq[KR / 2];
+#pragma unroll
+        for (int kp = 0; kp < KR / 2; ++kp) {
+            a[kp] = *(const f32x2w*)(Xs + 2 * kp * 128);
+            bq[kp] = *(const f32x2w*)(Ds + 2 * kp * 128);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        int nslot = slot + NST - 1; if (nslot >= NST) nslot -= NST;
+#pragma unroll
+        for (int kp = 0; kp < KR / 2; ++kp) {
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[ci][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp][ci], bq[kp][ni], acc[ci][ni], 0, 0, 0);
+            if (kp == 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + NST - 1 < n_steps) { NAFP_WGF_DMA(s + NST - 1, nslot) }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (++slot == NST) slot = 0;
+    }
+#undef NAFP_WGF_DMA
+    // D[i = c][j = n]: lane holds n = 2 (lane & 31) + ni, rows c = 2 ((r&3) + 8(r>>2) + 4*hh) + ci
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = c0 + wc * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * hh) + ci;
+                const int n = n0 + wn * 64 + 2 * rl + ni;
+                atomicAdd(p.dW + ((long long)tap * p.Cin + c) * p.Cout + n, acc[ci][ni][r]);
+            }
+}
+
 int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const ConvGeom& g, hipStream_t st) {
     if (g.Cin % 128 != 0 || g.Cout % 128 != 0) return NAFP_ERR_UNSUPPORTED;
     WgradParams p;
@@ -412,9 +543,17 @@ int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const Con
     const int lds = 3 * 2 * 16 * 128 * (int)sizeof(float);
     if (!attr) {
         NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr = true;
     }
-    wgrad_kernel<<<dim3(gx, g.Cout / 128, p.n_live * g.Cin / 128), 256, lds, st>>>(p);
+    // regular shapes take the kernel whose K-steps are (nearly) free of vector instructions
+    auto log2_exact = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+    const int lt = log2_exact(g.Tout), lfo = log2_exact(g.Fout);
+    static const bool fast_on = []() { const char* e = getenv("NAFP_WGRAD_FAST"); return !e || e[0] != '0'; }();
+    const bool fast = fast_on && lt >= 0 && lt <= 4 && lfo >= 0 && p.P % 16 == 0 && (g.stride == 1 || g.stride == 2) &&
+                      (g.axis == 0 ? (g.Fin == g.Fout) : (g.Fin == g.stride * g.Fout && g.Tin == g.Tout));
+    if (fast) wgrad_fast_kernel<<<dim3(gx, g.Cout / 128, p.n_live * g.Cin / 128), 256, lds, st>>>(p, lt, lfo);
+    else wgrad_kernel<<<dim3(gx, g.Cout / 128, p.n_live * g.Cin / 128), 256, lds, st>>>(p);
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }
