@@ -321,7 +321,7 @@ static int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 extern "C" int64_t nafp_encoder_workspace_bytes(const nafp_encoder* e, int64_t n_seg) {
     if (!e || n_seg < 0) return -1;
-    const int64_t stats = align_up((int64_t)sizeof(double) * 2 * 16 * n_seg, 256);
+    const int64_t stats = align_up((int64_t)sizeof(double) * 2 * 16 * n_seg, 256) + NAFP_TICKET_SLOTS * (int64_t)sizeof(unsigned);
     const int64_t a = align_up((int64_t)sizeof(float) * e->bufA_per_seg * n_seg, 256);
     const int64_t b = align_up((int64_t)sizeof(float) * e->bufB_per_seg * n_seg, 256);
     int64_t slab = 0;
@@ -358,14 +358,16 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
     if (n_seg * e->bufA_per_seg >= ((int64_t)1 << 40)) return NAFP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)align_up((int64_t)(uintptr_t)workspace, 256);
-    const int64_t stats_bytes = align_up((int64_t)sizeof(double) * 2 * 16 * n_seg, 256);
+    const int64_t stats_only = align_up((int64_t)sizeof(double) * 2 * 16 * n_seg, 256);
+    const int64_t stats_bytes = stats_only + NAFP_TICKET_SLOTS * (int64_t)sizeof(unsigned);
     double* stats = (double*)ws;
+    unsigned* tickets = (unsigned*)(ws + stats_only);       // arrival counters of the split-K launches (zero between launches)
     float* bufA = (float*)(ws + stats_bytes);
     float* bufB = (float*)(ws + stats_bytes + align_up((int64_t)sizeof(float) * e->bufA_per_seg * n_seg, 256));
     float* slab = (float*)((char*)bufB + align_up((int64_t)sizeof(float) * e->bufB_per_seg * n_seg, 256));
     int64_t slab_floats = 0;
     for (int j = 1; j < 16; ++j) slab_floats = std::max(slab_floats, conv_gemm_slab_floats(n_seg, e->geom[j]));
-    NAFP_HIP_CHECK(hipMemsetAsync(stats, 0, sizeof(double) * 2 * 16 * n_seg, st));
+    NAFP_HIP_CHECK(hipMemsetAsync(stats, 0, stats_bytes, st));        // statistics + counters, one fill
     hipEvent_t* ev = nullptr;
     if (e->prof_max > 0 && e->prof_count < e->prof_max) ev = e->prof_events.data() + (size_t)18 * e->prof_count++;
     if (ev) NAFP_HIP_CHECK(hipEventRecord(ev[0], st));
@@ -387,7 +389,7 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
         a.x = cur; a.stats_in = stats + 2 * n_seg * (j - 1);
         a.wp = e->d_w[j]; a.G = e->d_G[j]; a.Hb = e->d_Hb[j]; a.gamma_out = e->d_gamma[j];
         a.y = nxt; a.stats_out = stats + 2 * n_seg * j; a.plain = false;
-        a.slab = slab_floats ? slab : nullptr; a.slab_floats = slab_floats;
+        a.slab = slab_floats ? slab : nullptr; a.slab_floats = slab_floats; a.tickets = tickets;
         if (j == 1 && fuse0) {
             a.x = nullptr; a.f0_feat = feat; a.f0_w = e->d_w[0]; a.f0_bias = e->d_bias[0];
             a.f0_gamma = e->d_gamma[0]; a.f0_geom = &e->geom[0];
@@ -472,7 +474,7 @@ extern "C" int nafp_encoder_div_enc(nafp_encoder* e, const float* flat, int64_t 
 namespace {
 struct TrainLayout {
     int64_t B;
-    double* stats; float* mr; float* sc;
+    double* stats; unsigned* tickets; float* mr; float* sc;
     // zeroed together at the start of the backward pass: per-layer LN sums, S1/S2 of every layer
     char* zero_begin; int64_t zero_bytes;
     double* lnsum[16]; float* S1[16]; float* S2[16];
@@ -488,6 +490,7 @@ TrainLayout train_layout(const nafp_encoder* e, int64_t B, void* ws) {
     char* p0 = p;
     auto take = [&](int64_t bytes) { char* r = p; p += (bytes + 255) / 256 * 256; return r; };
     L.stats = (double*)take((int64_t)sizeof(double) * 2 * 16 * B);
+    L.tickets = (unsigned*)take(NAFP_TICKET_SLOTS * (int64_t)sizeof(unsigned));      // directly behind the statistics: one fill covers both
     L.mr = (float*)take((int64_t)sizeof(float) * 2 * 16 * B);
     L.sc = (float*)take((int64_t)sizeof(float) * 8 * B);
     L.zero_begin = p;
@@ -528,7 +531,7 @@ extern "C" int nafp_encoder_forward_train(nafp_encoder* e, const float* feat, in
     if (workspace_bytes < nafp_encoder_train_workspace_bytes(e, n_seg)) return NAFP_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     TrainLayout L = train_layout(e, n_seg, workspace);
-    NAFP_HIP_CHECK(hipMemsetAsync(L.stats, 0, sizeof(double) * 2 * 16 * n_seg, st));
+    NAFP_HIP_CHECK(hipMemsetAsync(L.stats, 0, (char*)(L.tickets + NAFP_TICKET_SLOTS) - (char*)L.stats, st));
     // (layer 0 keeps no pre-activation: the backward pass regenerates it from `feat`, 3 FMAs per element)
     int rc = launch_conv0(feat, e->d_w[0], e->d_bias[0], e->d_gamma[0], L.z[0], nullptr, L.stats, n_seg, e->geom[0], st);
     if (rc != NAFP_OK) return rc;
@@ -537,7 +540,7 @@ extern "C" int nafp_encoder_forward_train(nafp_encoder* e, const float* feat, in
         a.x = L.z[j - 1]; a.stats_in = L.stats + 2 * n_seg * (j - 1);
         a.wp = e->d_w[j]; a.G = e->d_G[j]; a.Hb = e->d_Hb[j]; a.gamma_out = e->d_gamma[j];
         a.y = L.z[j]; a.v_out = L.v[j]; a.stats_out = L.stats + 2 * n_seg * j; a.plain = false;
-        a.slab = L.slab_floats ? L.slab : nullptr; a.slab_floats = L.slab_floats;
+        a.slab = L.slab_floats ? L.slab : nullptr; a.slab_floats = L.slab_floats; a.tickets = L.tickets;
         rc = launch_conv_gemm(a, n_seg, e->geom[j], st);
         if (rc != NAFP_OK) return rc;
     }

@@ -268,6 +268,8 @@ struct ConvKernelParams {
     unsigned wp_bytes;
     int n_split;              // split-K factor (blockIdx.z); > 1 writes raw partial sums to `y` = slab
     int abl;                  // ablation flags for kernel-time breakdown (NAFP_ABL env; 0 in production)
+    unsigned* tickets;        // split-K with the finish in-kernel (EPI 4): one arrival counter per output tile, zero between launches
+    float* y_final;           //   ... and the output tensor (`y` is the slab of partial sums there)
     unsigned long long* tl;   // diagnostic phase timeline (nafp_conv_timeline), null in production: 8 u64 per wave
     int opt;                  // bit 0: the geometry prologue runs at raised wave priority, bit 1: the epilogue does (NAFP_GEMM_PRIO); bit 2: 3-D grid
     // FUSE0 (conv1 only): the A operand z0 = gamma0 . ELU(conv0(feat)) is generated in-kernel
@@ -438,7 +440,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     // LayerNorm statistics of the INPUT (FULL mode; threads 64 ..) are requested here and used further down ----
     const bool stat_thread = tid >= 64 && tid < 64 + p.ST;
     double st_sum = 0.0, st_sq = 0.0;             // loaded here, turned into (r, c) after the first DMAs are on their way
-    if (stat_thread && p.mode == 0 && b0 + tid - 64 < p.B) {
+    if (stat_thread && p.mode != 1 && b0 + tid - 64 < p.B) {
         st_sum = p.stats_in[2 * (int64_t)(b0 + tid - 64)];
         st_sq = p.stats_in[2 * (int64_t)(b0 + tid - 64) + 1];
     }
@@ -615,7 +617,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     // per-sample LayerNorm scalars of the input: r_b and -mu_b r_b (first needed by the epilogue, many barriers away)
     if (stat_thread) {
         float r = 0.f, c = 0.f;
-        if (p.mode == 0 && b0 + tid - 64 < p.B) {
+        if (p.mode != 1 && b0 + tid - 64 < p.B) {
             const double mean = st_sum * p.inv_n_in;
             double var = st_sq * p.inv_n_in - mean * mean;
             var = var > 0.0 ? var : 0.0;
@@ -887,11 +889,67 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         return;
     }
 
+    if (EPI == 4) {
+        // Split-K finished in-kernel.  Every part writes its partial sums to its slab THROUGH the caches (sc0 sc1: the
+        // XCDs' L2s are not coherent with each other), waits for the write acknowledgements, and draws an arrival ticket
+        // for its output tile (device-scope atomic).  The workgroup that draws the last ticket re-reads all parts --
+        // its own included, from memory, in part order: the sum does not depend on who arrives last -- and runs the FULL
+        // epilogue below on the total; the others leave.  One launch and one round trip of the output less per conv than
+        // slab + finish kernel.
+        const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(
+            p.y + ((int64_t)zsp * p.B + b0) * p.P * p.Cout, 0, (int)((unsigned)nb * (unsigned)ystep_b), 0x00020000);
+        int voffs[2][4];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int grp = wm * 16 + mi * 8 + 2 * rg + (lane >> 5);
+                const int pos = pb * p.PT + (grp >> (p.log2ST - 2));
+                const int sl0 = (grp & (g4 - 1)) << 2;
+                voffs[mi][rg] = pos < p.P ? ((sl0 * p.P + pos) * p.Cout + n_base) * 4 : (int)0x80000000;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int ni = 0; ni < NIW; ++ni)
+                        __builtin_amdgcn_raw_buffer_store_b32(f2i(acc[mi][ni][rg * 4 + q]), rsP, voffs[mi][rg], q * ystep_b + ni * 128, 17);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // my part is in memory
+        __builtin_amdgcn_s_barrier();                                 // ... and so is every wave's of this workgroup
+        unsigned* sTicket = (unsigned*)smem;
+        const unsigned tile_id = (unsigned)((pb * p.n_sg + sg) * (p.Cout / BNT) + colz);
+        if (tid == 0) sTicket[0] = __hip_atomic_fetch_add(p.tickets + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned ticket = sTicket[0];
+        if (ticket != (unsigned)(p.n_split - 1)) return;
+        __syncthreads();                                              // sTicket is read: LDS is reused by the statistics below
+        if (tid == 0) p.tickets[tile_id] = 0u;                        // ready for the next launch
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NIW; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        for (int z = 0; z < p.n_split; ++z) {
+            const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(
+                p.y + ((int64_t)z * p.B + b0) * p.P * p.Cout, 0, (int)((unsigned)nb * (unsigned)ystep_b), 0x00020000);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int ni = 0; ni < NIW; ++ni)
+                            acc[mi][ni][rg * 4 + q] += __builtin_bit_cast(
+                                float, __builtin_amdgcn_raw_buffer_load_b32(rsZ, voffs[mi][rg], q * ystep_b + ni * 128, 17));
+        }
+    }
+
     // FULL: v = ELU(r_b*acc + c_b*G + Hb); stats of v; store z = gamma_out * v
     f32x2 s2[2] = {{0.f, 0.f}, {0.f, 0.f}}, q2[2] = {{0.f, 0.f}, {0.f, 0.f}};   // per-lane sums of v and v^2 of sample slots (0, 1) and (2, 3)
     float* rowS = smem;                 // [BM] (LDS tiles are free again: last loop barrier passed)
     float* rowQ = smem + BM;
-    const bool fast_stats = EPI != 2 || p.ST == 4 || p.ST == 8;
+    const bool fast_stats = (EPI != 2 && EPI != 4) || p.ST == 4 || p.ST == 8;
     if (!fast_stats) {
         if (tid < BM) { rowS[tid] = 0.f; rowQ[tid] = 0.f; }           // NT >= BM
         __syncthreads();
@@ -906,9 +964,9 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     constexpr bool PREF = (EPI == 0 || EPI == 1) && !FUSE0 && BK == 16 && BM == 128;   // block 0 was requested inside the K-loop (8-wave tiles run at 128 VGPRs: no room)
     if (MIL == 2) { if (!PREF) { NAFP_EPI_LOAD(0, 0) } NAFP_EPI_LOAD(1, MIL - 1) }
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
-        p.y + (int64_t)b0 * p.P * p.Cout, 0, (int)((unsigned)nb * (unsigned)ystep_b), 0x00020000);
+        (EPI == 4 ? p.y_final : p.y) + (int64_t)b0 * p.P * p.Cout, 0, (int)((unsigned)nb * (unsigned)ystep_b), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
-        (p.v_out ? p.v_out : p.y) + (int64_t)b0 * p.P * p.Cout, 0, (int)((unsigned)nb * (unsigned)ystep_b), 0x00020000);
+        (p.v_out ? p.v_out : (EPI == 4 ? p.y_final : p.y)) + (int64_t)b0 * p.P * p.Cout, 0, (int)((unsigned)nb * (unsigned)ystep_b), 0x00020000);
     // The arithmetic runs on PAIRS of samples with the packed f32 instructions (v_pk_fma / v_pk_mul / v_pk_add: two
     // elements per issue slot): the f32 MFMAs execute at the f32 vector rate, and the timeline of this kernel shows the
     // SIMDs' issue time split between MFMAs and everything else -- every VALU instruction of the epilogue is paid for in
@@ -1035,7 +1093,13 @@ NAFP_GEMM_KERNELS(conv_gemm_k16s3, 128, 128, 3)
 NAFP_GEMM_KERNEL(conv_gemm_k16s3_fuse0, 128, 128, 16, 3, 3, true, 0)   // conv1 with conv0 generated in-kernel (inference)
 // 128 x 64 tile (each wave 64 x 32), 36 KB ring -> 4 workgroups per CU: twice the workgroups of half the size for the
 // launches whose 128 x 128 tiling leaves the CUs unevenly loaded or forces a split along K (the mid and late convs)
-NAFP_GEMM_KERNELS(conv_gemm_n64k16s3, 128, 64, 4)
+NAFP_GEMM_KERNEL(conv_gemm_n64k16s3_infer, 128, 64, 16, 3, 4, false, 0)
+NAFP_GEMM_KERNEL(conv_gemm_n64k16s3_train, 128, 64, 16, 3, 4, false, 1)
+NAFP_GEMM_KERNEL(conv_gemm_n64k16s3_any, 128, 64, 16, 3, 4, false, 2)
+NAFP_GEMM_KERNEL(conv_gemm_n64k16s3_plain, 128, 64, 16, 3, 4, false, 3)
+NAFP_GEMM_KERNEL(conv_gemm_n64k16s3_splitfin, 128, 64, 16, 3, 4, false, 4)      // split-K part + in-kernel finish by the last arriver
+static void (*const conv_gemm_n64k16s3_tab[5])(const ConvKernelParams) = {conv_gemm_n64k16s3_infer, conv_gemm_n64k16s3_train, conv_gemm_n64k16s3_any,
+                                                                           conv_gemm_n64k16s3_plain, conv_gemm_n64k16s3_splitfin};
 // 256 x 128 tile, 8 waves (4 x 2), 72 KB ring -> 2 workgroups = 16 waves per CU (4 per SIMD): the weight tile is staged
 // once per 256 rows instead of once per 128, and a workgroup's fixed costs (geometry, pipeline fill) cover twice the output
 NAFP_GEMM_KERNEL(conv_gemm_m256k16s3_infer, 256, 128, 16, 3, 4, false, 0)
@@ -1319,6 +1383,12 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
         if ((int64_t)S * out_floats > a.slab_floats) S = 1;
     }
     if (S > 1) { p.mode = a.plain ? 1 : 2; p.n_split = S; p.y = a.slab; p.bias = nullptr; }
+    // FULL split launches on 64-column tiles finish in-kernel (last-arriver) when the caller provides arrival counters
+    // (measured per conv at B = 640: with >= 320 output tiles the last arrivers finish faster than a second launch --
+    // conv7 0.119 -> 0.104 ms, conv9 0.193 -> 0.178 --, with 160 or fewer the finish kernel's finer split wins by 2-8 %)
+    static const int fin_min = []() { const char* e = getenv("NAFP_SPLIT_INKERNEL"); return e ? atoi(e) : 320; }();
+    const bool in_kernel_finish = fin_min > 0 && S > 1 && !a.plain && bn == 64 && a.tickets && n_tiles >= fin_min && n_tiles <= NAFP_TICKET_SLOTS;
+    p.tickets = in_kernel_finish ? a.tickets : nullptr; p.y_final = a.y;
     static const int grid3d = []() { const char* e = getenv("NAFP_GRID3D"); return e ? atoi(e) : 1; }();
     const bool g3 = S == 1 && grid3d != 0 && (grid3d == 1 || BM == 256 || bn == 128);
     if (g3) p.opt |= 4;
@@ -1345,11 +1415,11 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
         return launch_variant(conv_gemm_k16s3_fuse0, 128, 128, 16, 3, p, grid, st);
     }
     const bool fast_st = p.ST == 4 || p.ST == 8;
-    const int epi = p.mode != 0 ? 3 : (!fast_st ? 2 : (p.v_out ? 1 : 0));
+    const int epi = in_kernel_finish ? 4 : p.mode != 0 ? 3 : (!fast_st ? 2 : (p.v_out ? 1 : 0));
     rc = BM == 256 ? launch_variant(conv_gemm_m256k16s3_tab[epi], 256, 128, 16, 3, p, grid, st)
          : bn == 64 ? launch_variant(conv_gemm_n64k16s3_tab[epi], 128, 64, 16, 3, p, grid, st)
                     : launch_variant(conv_gemm_k16s3_tab[epi], 128, 128, 16, 3, p, grid, st);
-    if (rc != NAFP_OK || S == 1) return rc;
+    if (rc != NAFP_OK || S == 1 || in_kernel_finish) return rc;
     if (a.plain) {
         const int64_t n4 = out_floats / 4;
         plain_finish_kernel<<<dim3((unsigned)std::min<int64_t>((n4 + 255) / 256, 8192)), 256, 0, st>>>(a.slab, S, a.bias, a.y, n4,
@@ -1644,7 +1714,7 @@ int launch_dgrad_ln(const DgradLnArgs& a, int64_t B, const ConvGeom& g, hipStrea
     p.sample_in = (int64_t)g.Fout * g.Tout * g.Cout;
     const int S = g.axis == 0 ? g.Cout : g.Tout * g.Cout;
     p.tap_stride = -(S / g.stride);
-    p.inv_n_in = 1.0; p.mode = 1; p.n_split = 1; p.abl = 0; p.tl = nullptr; p.opt = 0;
+    p.inv_n_in = 1.0; p.mode = 1; p.n_split = 1; p.abl = 0; p.tl = nullptr; p.opt = 0; p.tickets = nullptr; p.y_final = nullptr;
     p.perm_on = 0; p.perm_n0 = 0; p.perm_c0 = 0;        // one position per workgroup: no class ordering needed
     p.wp_bytes = (unsigned)((int64_t)g.Cout * 3 * g.Cin * 4);
     p.f0_feat = nullptr; p.f0_w = nullptr; p.f0_bias = nullptr; p.f0_gamma = nullptr; p.f0_T = 0; p.f0_stride = 1; p.f0_pad = 0;

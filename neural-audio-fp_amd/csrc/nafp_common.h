@@ -93,6 +93,7 @@ int launch_conv0(const float* feat, const float* w3, const float* bias, const fl
                  const float* gstat = nullptr, int group_size = 0, int segment_norm = 0);
 
 // implicit-GEMM conv (see conv.hip for the LayerNorm folding).
+constexpr int NAFP_TICKET_SLOTS = 4096;      // output tiles of a split-K launch that finishes in-kernel
 struct ConvGemmArgs {
     const float* x;          // (B,Fin,Tin,Cin): z of the previous conv (FULL) or a raw image (PLAIN)
     const float* wp;         // packed (Cout, 3*Cin), k = tap*Cin + cin
@@ -108,6 +109,7 @@ struct ConvGemmArgs {
     bool dgrad;              // PLAIN only: y (B,Fin,Tin,Cin) = transposed conv of x = dT (B,Fout,Tout,Cout) with wp = (Cin, 3*Cout)
     float* slab;             // split-K partial sums workspace (or nullptr: never split)
     int64_t slab_floats;
+    unsigned* tickets;       // NAFP_TICKET_SLOTS arrival counters, zero on entry and on exit (or nullptr: split launches use slab + finish kernel)
     // optional: generate the A operand from the log-mel features (conv0 fused into conv1);
     // `x` is then unused.  f0_geom = geometry of conv0.
     const float* f0_feat; const float* f0_w; const float* f0_bias; const float* f0_gamma;
