@@ -1226,6 +1226,13 @@ static int choose_split(int64_t n_tiles, int k_steps, int64_t out_floats, double
     if (force == 0) return 1;
     if (force > 0) return force;
     if (n_tiles >= 3072) return 1;
+    if (slots == 768.0 && n_tiles <= 200) {
+        // few 128 x 128 tiles (the late convs): measured at B = 640 (tools/plan_sweep.sh) a 3-way split is the best or within
+        // 2 % of it for 80 and 160 tiles, 6-way for 40; keep at least 8 K-steps per part
+        int S = n_tiles <= 40 ? 6 : 3;
+        while (S > 1 && (k_steps / S < 8 || (int64_t)S * out_floats * 4 > ((int64_t)64 << 20))) --S;
+        return S;
+    }
     const double overhead_steps = 6.0;
     int best = 1; double best_score = 0.0;
     for (int S = 1; S <= 16; ++S) {
@@ -1282,12 +1289,28 @@ static int pick_bm(int64_t B, int P, int Cout) {
 
 // Tile width of a launch that runs 128-row tiles: 64 columns (4 workgroups per CU, each half the work) where the
 // 128 x 128 tiling gives few, coarse workgroups.  NAFP_BN64: 0 never, 2 whenever Cout allows, 1 (default) by tile count.
+// Diagnostic override for tile-plan sweeps: NAFP_FWD_PLAN="bn:S" forces the column width and split factor of every forward
+// FULL launch on 128-row tiles (where legal); tools/plan_sweep.sh runs the combinations and prints per-conv times.
+struct PlanOverride { int bn, S; };
+static const PlanOverride& plan_override() {
+    static const PlanOverride po = []() {
+        PlanOverride r{0, 0};
+        const char* e = getenv("NAFP_FWD_PLAN");
+        if (e) sscanf(e, "%d:%d", &r.bn, &r.S);
+        return r;
+    }();
+    return po;
+}
+
 static int pick_bn(int64_t n_tiles128, int Cout) {
     static const int mode = []() { const char* e = getenv("NAFP_BN64"); return e ? atoi(e) : 1; }();
     static const int64_t thr = []() { const char* e = getenv("NAFP_BN64_TILES"); return e ? atoll(e) : (int64_t)1000; }();
     if (mode == 0 || Cout % 64 != 0) return 128;
     if (mode == 2) return 64;
-    return n_tiles128 < thr ? 64 : 128;
+    // plan sweep at B = 640 (tools/plan_sweep.sh): with <= 160 tiles of 128 x 128 (convs 9-15) the 128-column tile with a
+    // split-K of 3-6 beats the 64-column tile by 8-10 %; with 320-640 tiles (convs 6-8) the 64-column tile wins or ties
+    static const int64_t lo = []() { const char* e = getenv("NAFP_BN64_MIN"); return e ? atoll(e) : (int64_t)200; }();
+    return (n_tiles128 < thr && n_tiles128 >= lo) ? 64 : 128;
 }
 
 int64_t conv_gemm_slab_floats(int64_t B, const ConvGeom& g, bool with_dgrad) {
@@ -1296,7 +1319,8 @@ int64_t conv_gemm_slab_floats(int64_t B, const ConvGeom& g, bool with_dgrad) {
     const int pt = tile_pt(P), ST = BM / pt;
     const int64_t n_tiles = ((B + ST - 1) / ST) * ((P + pt - 1) / pt) * (g.Cout / BN);
     const int bn = BM == 256 ? 128 : pick_bn(n_tiles, g.Cout);
-    const int S = BM == 256 ? 1 : choose_split(n_tiles * (BN / bn), live_k_steps(g), B * P * g.Cout, bn == 64 ? 1024.0 : 768.0);
+    int S = BM == 256 ? 1 : choose_split(n_tiles * (BN / bn), live_k_steps(g), B * P * g.Cout, bn == 64 ? 1024.0 : 768.0);
+    if (BM == 128 && plan_override().S > 0) S = std::max(S, plan_override().S);
     int64_t need = S > 1 ? (int64_t)S * B * P * g.Cout : 0;
     if (with_dgrad && g.Cin % BN == 0 && pick_bm(B, g.Fin * g.Tin, g.Cin) == 128) {
         const int Pd = g.Fin * g.Tin;
@@ -1374,12 +1398,15 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     p.opt = gemm_prio;
     const int n_pb = (p.P + p.PT - 1) / p.PT;
     const int64_t n_tiles128 = (int64_t)p.n_sg * n_pb * (p.Cout / BN);
-    const int bn = (BM == 256 || a.f0_feat) ? 128 : pick_bn(n_tiles128, p.Cout);
+    int bn = (BM == 256 || a.f0_feat) ? 128 : pick_bn(n_tiles128, p.Cout);
+    const bool plan_forced = BM == 128 && !a.plain && !a.dgrad && !a.f0_feat && plan_override().bn > 0;
+    if (plan_forced && (plan_override().bn == 128 || p.Cout % 64 == 0)) bn = plan_override().bn;
     const int64_t n_tiles = n_tiles128 * (BN / bn);
     int S = 1;
     const int64_t out_floats = B * p.P * p.Cout;
     if (a.slab && !a.f0_feat && BM == 128) {
         S = choose_split(n_tiles, k_steps, out_floats, bn == 64 ? 1024.0 : 768.0);
+        if (plan_forced && plan_override().S > 0) { S = plan_override().S; while (S > 1 && k_steps / S < 4) --S; }
         if ((int64_t)S * out_floats > a.slab_floats) S = 1;
     }
     if (S > 1) { p.mode = a.plain ? 1 : 2; p.n_split = S; p.y = a.slab; p.bias = nullptr; }
