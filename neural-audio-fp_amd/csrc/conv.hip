@@ -1422,7 +1422,9 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     const dim3 grid = g3 ? dim3((unsigned)p.n_sg, (unsigned)n_pb, (unsigned)(p.Cout / bn))
                          : dim3((unsigned)((int64_t)p.n_sg * n_pb), (unsigned)(p.Cout / bn), (unsigned)S);
     if (n_pb > 65535 || p.Cout / bn > 65535) return NAFP_ERR_UNSUPPORTED;
-    if (g_timeline.buf && !a.plain && !a.dgrad && g.Cin == g_timeline.cin && g.Cout == g_timeline.cout && p.P == g_timeline.positions &&
+    // (cin < 0 in nafp_conv_timeline selects the transposed conv -- DGRAD -- of the layer with that |cin|)
+    if (g_timeline.buf && ((!a.plain && !a.dgrad && g.Cin == g_timeline.cin) || (a.dgrad && g.Cin == -g_timeline.cin)) &&
+        g.Cout == g_timeline.cout && g.Fout * g.Tout == g_timeline.positions &&
         (int64_t)grid.x * grid.y * grid.z * 64 <= g_timeline.capacity) {
         p.tl = g_timeline.buf;
         g_timeline.last_grid[0] = (int)grid.x; g_timeline.last_grid[1] = (int)grid.y; g_timeline.last_grid[2] = (int)grid.z;

@@ -39,6 +39,7 @@ def geometry(j, F=256, T=32):
 def main():
     j = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 640
+    dgrad = len(sys.argv) > 3 and sys.argv[3] == 'dgrad'          # the transposed conv of layer j in a train step
     cfg = yaml.safe_load(open(os.path.join(ROOT, 'config', 'default.yaml')))
     lib = _lib.load()
     pre = nafp.get_melspec_layer(cfg)
@@ -50,9 +51,14 @@ def main():
     cin, cout, pos = geometry(j)
     cap = 1 << 24
     buf = torch.zeros(cap, dtype=torch.int64, device='cuda')
-    rc = lib.nafp_conv_timeline(ctypes.c_void_p(buf.data_ptr()), cap, cin, cout, pos)
+    rc = lib.nafp_conv_timeline(ctypes.c_void_p(buf.data_ptr()), cap, -cin if dgrad else cin, cout, pos)
     assert rc == 0
-    emb = fp(pre(x, group_size=B))
+    if dgrad:
+        feat = pre(x, group_size=B)
+        emb = fp.forward_train(feat)
+        fp.backward(torch.randn_like(emb))
+    else:
+        emb = fp(pre(x, group_size=B))
     torch.cuda.synchronize()
     lib.nafp_conv_timeline(None, 0, 0, 0, 0)
     g = (ctypes.c_int * 5)()
