@@ -113,7 +113,7 @@ for key, part in (('melspec_kernel', 'melspec_kernel'), ('melspec_finalize_kerne
         kt['bytes_per_segment'] = (kt['fetch_bytes_x2_corrected'] + kt['write_bytes']) / BSZ
         front[key] = kt
 fe_total = sum(front[k]['fetch_bytes_x2_corrected'] + front[k]['write_bytes'] for k in front if k.startswith('melspec'))
-json.dump({'tag': tag, 'kernel': 'conv_gemm_k16s3', 'per_launch_bytes': traffic,
+json.dump({'tag': tag, 'kernel': 'conv_gemm_* (the 15 GEMM-conv launches of a step)', 'per_launch_bytes': traffic,
            'frontend': {'kernels': front, 'bytes_per_launch': fe_total, 'bytes_per_segment': fe_total / BSZ,
                         'algorithmic_bytes_per_segment': 32000 + 32768,
                         'ratio_to_algorithmic': fe_total / BSZ / (32000 + 32768) if fe_total else None,
@@ -144,17 +144,27 @@ with open(os.path.join(dst, f'{tag}_summary.md'), 'w') as f:
             f'roofline {bj["roofline"]["achieved"]} / {bj["roofline"]["peak"]} TFLOP/s '
             f'= {bj["roofline"]["frac"]} (HIP-event mean launch {bj["roofline"]["ms_per_launch_avg"]} ms).\n\n')
     f.write('## Kernel stats (rocprofv3 --stats)\n\n| kernel | calls | avg us | total ms | % |\n|---|---|---|---|---|\n')
-    for r in stats[:8]:
+    for r in stats[:12]:
         f.write(f'| `{r["Name"][:70]}` | {r["Calls"]} | {float(r["AverageNs"]) / 1e3:.1f} | '
                 f'{float(r["TotalDurationNs"]) / 1e6:.2f} | {r["Percentage"]} |\n')
-    full = [(g, v) for g, v in gemm_all if len(v) >= 30]
-    tot = sum(sum(v) for g, v in full); cnt = sum(len(v) for g, v in full)
-    f.write(f'\nGEMM-conv launches of the bench steps only (the 30 one-off PLAIN launches of set_weights '
-            f'excluded): {cnt} launches, mean {tot / cnt / 1e3:.1f} us under the profiler vs '
-            f'{bj["roofline"]["ms_per_launch_avg"] * 1e3:.1f} us from HIP events un-profiled.  The HIP events '
-            f'bracket each conv launch INCLUDING its split-K finish kernel where one exists '
-            f'(`splitk_finish_kernel`: 8 per step, ~16 us each = +8.5 us per conv launch on average), '
-            f'which is the difference.\n\n')
+    # per bench step (from one melspec_kernel to the next): the durations of the GEMM-conv kernels and their split-K
+    # finish kernels, summed; the timed region's HIP events give the SPAN from the first to the last of them
+    tr = sorted(trace, key=lambda r: int(r['Start_Timestamp']))
+    marks = [i for i, r in enumerate(tr) if 'melspec_kernel' in r['Kernel_Name']]
+    per_step = []
+    for a_, b_ in zip(marks[:-1], marks[1:]):
+        ks = [r for r in tr[a_:b_] if GEMM in r['Kernel_Name'] or 'splitk_finish' in r['Kernel_Name']]
+        if ks:
+            per_step.append((sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in ks),
+                             int(ks[-1]['End_Timestamp']) - int(ks[0]['Start_Timestamp']), len(ks)))
+    per_step = per_step[5:35]                      # the 30 timed steps (after 5 warm-up steps; the per-conv pass follows)
+    busy = sum(p[0] for p in per_step) / len(per_step) / 1e3
+    span = sum(p[1] for p in per_step) / len(per_step) / 1e3
+    f.write(f'\nGEMM convs of one timed bench step under the profiler ({per_step[0][2]} kernels: 15 `conv_gemm_*` launches + the '
+            f'split-K finish kernels of the launches that still use one): kernel durations sum to {busy:.0f} us '
+            f'= {busy / 15:.1f} us per conv launch; first start to last end {span:.0f} us = {span / 15:.1f} us per launch.  '
+            f'The un-profiled HIP events of the timed region measure that span: {bj["roofline"]["ms_per_launch_avg"] * 1e3:.1f} us '
+            f'per launch (`roofline.ms_per_launch_avg`).\n\n')
     f.write('## HBM traffic of the dominant kernel (separate PMC passes)\n\n')
     if traffic:
         f.write(f'* FETCH_SIZE (x2 gfx950 correction): {fetch_bytes_per_launch / 1e6:.1f} MB per launch (mean of {f_n})\n')
