@@ -165,6 +165,26 @@ with open(os.path.join(dst, f'{tag}_summary.md'), 'w') as f:
             f'= {busy / 15:.1f} us per conv launch; first start to last end {span:.0f} us = {span / 15:.1f} us per launch.  '
             f'The un-profiled HIP events of the timed region measure that span: {bj["roofline"]["ms_per_launch_avg"] * 1e3:.1f} us '
             f'per launch (`roofline.ms_per_launch_avg`).\n\n')
+    # per-conv kernel durations of the timed steps (4 stamps per forward, none between the convs): mean over the steps
+    seqs = []
+    for a_, b_ in list(zip(marks[:-1], marks[1:]))[5:35]:
+        ks = [r for r in tr[a_:b_] if GEMM in r['Kernel_Name'] or 'splitk_finish' in r['Kernel_Name']]
+        seqs.append([(r['Kernel_Name'].split('(')[0].replace('nafp::', '').replace('void ', ''),
+                      (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3) for r in ks])
+    if seqs and all(len(q) == len(seqs[0]) for q in seqs):
+        macs_l = bench.conv_effective_macs()
+        f.write('Per launch, in launch order (mean over the 30 timed steps, kernel durations from the trace; a split-K finish '
+                'kernel is added to its conv):\n\n| conv | kernel | us | TFLOP/s |\n|---|---|---|---|\n')
+        j = 0; rows_out = []
+        for k in range(len(seqs[0])):
+            name = seqs[0][k][0]; us = sum(q[k][1] for q in seqs) / len(seqs)
+            if 'splitk_finish' in name:
+                rows_out[-1][2] += us; rows_out[-1][1] += ' + finish'
+            else:
+                j += 1; rows_out.append([j, name, us])
+        for j, name, us in rows_out:
+            f.write(f'| {j} | `{name}` | {us:.1f} | {2 * macs_l[j] * BSZ / (us * 1e-6) / 1e12:.0f} |\n')
+        f.write('\n')
     f.write('## HBM traffic of the dominant kernel (separate PMC passes)\n\n')
     if traffic:
         f.write(f'* FETCH_SIZE (x2 gfx950 correction): {fetch_bytes_per_launch / 1e6:.1f} MB per launch (mean of {f_n})\n')
