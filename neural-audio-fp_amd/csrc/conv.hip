@@ -757,7 +757,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
             __builtin_amdgcn_sched_barrier(0);                                                 \
             ++s;                                                                               \
         }
-        static_assert(NSTAGE == 3, "the K-loop body is written out once per ring slot");
+        static_assert(NSTAGE == 3 || BNT == 64, "the K-loop body is written out once per ring slot (128-column tiles)");
         if (s_begin + 1 < n_steps) {
             if (BNT == 128) {
                 for (int s = s_begin + 1;;) {
@@ -768,7 +768,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
             } else {            // 64-column tiles: one rolled copy (the three-copy form makes hipcc spill at their 128-VGPR budget)
                 int rs = 1;
                 for (int s = s_begin + 1;;) {
-                    NAFP_K_STEP(rs, (rs == 0 ? 2 : rs - 1))
+                    NAFP_K_STEP(rs, (rs == 0 ? NSTAGE - 1 : rs - 1))
                     if (++rs == NSTAGE) rs = 0;
                 }
             }
@@ -1098,6 +1098,13 @@ NAFP_GEMM_KERNEL(conv_gemm_n64k16s3_train, 128, 64, 16, 3, 4, false, 1)
 NAFP_GEMM_KERNEL(conv_gemm_n64k16s3_any, 128, 64, 16, 3, 4, false, 2)
 NAFP_GEMM_KERNEL(conv_gemm_n64k16s3_plain, 128, 64, 16, 3, 4, false, 3)
 NAFP_GEMM_KERNEL(conv_gemm_n64k16s3_splitfin, 128, 64, 16, 3, 4, false, 4)      // split-K part + in-kernel finish by the last arriver
+// 128 x 64 tile on a 2-stage ring (24 KB): 5 workgroups per CU = 1280 slots -- the mid convs' 640 / 1280 tiles (x split-K) then
+// fill exactly one round instead of leaving a last round with one workgroup per CU (which runs at half the pipe rate)
+NAFP_GEMM_KERNEL(conv_gemm_n64k16s2_infer, 128, 64, 16, 2, 5, false, 0)
+NAFP_GEMM_KERNEL(conv_gemm_n64k16s2_train, 128, 64, 16, 2, 5, false, 1)
+NAFP_GEMM_KERNEL(conv_gemm_n64k16s2_splitfin, 128, 64, 16, 2, 5, false, 4)
+static void (*const conv_gemm_n64k16s2_tab[5])(const ConvKernelParams) = {conv_gemm_n64k16s2_infer, conv_gemm_n64k16s2_train, nullptr, nullptr,
+                                                                           conv_gemm_n64k16s2_splitfin};
 static void (*const conv_gemm_n64k16s3_tab[5])(const ConvKernelParams) = {conv_gemm_n64k16s3_infer, conv_gemm_n64k16s3_train, conv_gemm_n64k16s3_any,
                                                                            conv_gemm_n64k16s3_plain, conv_gemm_n64k16s3_splitfin};
 // 256 x 128 tile, 8 waves (4 x 2), 72 KB ring -> 2 workgroups = 16 waves per CU (4 per SIMD): the weight tile is staged
@@ -1218,6 +1225,12 @@ static int live_k_steps(const ConvGeom& g) {
     return n_live * g.Cin / 16;
 }
 
+// 64-column tiles of the FORWARD pass run on the 2-stage ring, 5 workgroups per CU (NAFP_N64S2=0: the 3-stage, 4-per-CU kernel)
+static bool n64_two_stage() {
+    static const bool on = []() { const char* e = getenv("NAFP_N64S2"); return !e || e[0] != '0'; }();
+    return on;
+}
+
 static int choose_split(int64_t n_tiles, int k_steps, int64_t out_floats, double slots = 768.0) {
     // Score each split factor S by (how full the last round of workgroups is) x (share of a
     // workgroup's time spent in its K-loop rather than prologue/epilogue); 768 = 256 CUs x 3
@@ -1226,6 +1239,9 @@ static int choose_split(int64_t n_tiles, int k_steps, int64_t out_floats, double
     if (force == 0) return 1;
     if (force > 0) return force;
     if (n_tiles >= 3072) return 1;
+    if (slots == 1280.0)       // forward, 64-column tiles, 5 per CU.  Measured at B = 640: 1280 tiles (convs 6, 8) fill the slots and are
+        // best unsplit; 640 tiles in two parts: conv9 (96 K-steps) 0.187 -> 0.167 ms, conv7 (48 K-steps) 0.098 -> 0.096
+        return (n_tiles >= 1000 || k_steps / 2 < 24 || 2 * out_floats * 4 > ((int64_t)64 << 20)) ? 1 : 2;
     if (slots == 768.0 && n_tiles <= 200) {
         // few 128 x 128 tiles (the late convs): measured at B = 640 (tools/plan_sweep.sh) a 3-way split is the best or within
         // 2 % of it for 80 and 160 tiles, 6-way for 40; keep at least 8 K-steps per part
@@ -1302,7 +1318,7 @@ static const PlanOverride& plan_override() {
     return po;
 }
 
-static int pick_bn(int64_t n_tiles128, int Cout) {
+static int pick_bn(int64_t n_tiles128, int Cout, int k_steps = 0) {
     static const int mode = []() { const char* e = getenv("NAFP_BN64"); return e ? atoi(e) : 1; }();
     static const int64_t thr = []() { const char* e = getenv("NAFP_BN64_TILES"); return e ? atoll(e) : (int64_t)1000; }();
     if (mode == 0 || Cout % 64 != 0) return 128;
@@ -1318,8 +1334,8 @@ int64_t conv_gemm_slab_floats(int64_t B, const ConvGeom& g, bool with_dgrad) {
     const int BM = pick_bm(B, P, g.Cout);
     const int pt = tile_pt(P), ST = BM / pt;
     const int64_t n_tiles = ((B + ST - 1) / ST) * ((P + pt - 1) / pt) * (g.Cout / BN);
-    const int bn = BM == 256 ? 128 : pick_bn(n_tiles, g.Cout);
-    int S = BM == 256 ? 1 : choose_split(n_tiles * (BN / bn), live_k_steps(g), B * P * g.Cout, bn == 64 ? 1024.0 : 768.0);
+    const int bn = BM == 256 ? 128 : pick_bn(n_tiles, g.Cout, live_k_steps(g));
+    int S = BM == 256 ? 1 : choose_split(n_tiles * (BN / bn), live_k_steps(g), B * P * g.Cout, bn == 64 ? (n64_two_stage() ? 1280.0 : 1024.0) : 768.0);
     if (BM == 128 && plan_override().S > 0) S = std::max(S, plan_override().S);
     int64_t need = S > 1 ? (int64_t)S * B * P * g.Cout : 0;
     if (with_dgrad && g.Cin % BN == 0 && pick_bm(B, g.Fin * g.Tin, g.Cin) == 128) {
@@ -1398,14 +1414,14 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     p.opt = gemm_prio;
     const int n_pb = (p.P + p.PT - 1) / p.PT;
     const int64_t n_tiles128 = (int64_t)p.n_sg * n_pb * (p.Cout / BN);
-    int bn = (BM == 256 || a.f0_feat) ? 128 : pick_bn(n_tiles128, p.Cout);
+    int bn = (BM == 256 || a.f0_feat) ? 128 : pick_bn(n_tiles128, p.Cout, (a.plain || a.dgrad) ? 0 : k_steps);
     const bool plan_forced = BM == 128 && !a.plain && !a.dgrad && !a.f0_feat && plan_override().bn > 0;
     if (plan_forced && (plan_override().bn == 128 || p.Cout % 64 == 0)) bn = plan_override().bn;
     const int64_t n_tiles = n_tiles128 * (BN / bn);
     int S = 1;
     const int64_t out_floats = B * p.P * p.Cout;
     if (a.slab && !a.f0_feat && BM == 128) {
-        S = choose_split(n_tiles, k_steps, out_floats, bn == 64 ? 1024.0 : 768.0);
+        S = choose_split(n_tiles, k_steps, out_floats, bn == 64 ? ((n64_two_stage() && !a.plain) ? 1280.0 : 1024.0) : 768.0);
         if (plan_forced && plan_override().S > 0) { S = plan_override().S; while (S > 1 && k_steps / S < 4) --S; }
         if ((int64_t)S * out_floats > a.slab_floats) S = 1;
     }
@@ -1445,7 +1461,9 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     }
     const bool fast_st = p.ST == 4 || p.ST == 8;
     const int epi = in_kernel_finish ? 4 : p.mode != 0 ? 3 : (!fast_st ? 2 : (p.v_out ? 1 : 0));
+    const bool two_stage = n64_two_stage() && bn == 64 && (epi == 0 || epi == 1 || epi == 4);
     rc = BM == 256 ? launch_variant(conv_gemm_m256k16s3_tab[epi], 256, 128, 16, 3, p, grid, st)
+         : (bn == 64 && two_stage) ? launch_variant(conv_gemm_n64k16s2_tab[epi], 128, 64, 16, 2, p, grid, st)
          : bn == 64 ? launch_variant(conv_gemm_n64k16s3_tab[epi], 128, 64, 16, 3, p, grid, st)
                     : launch_variant(conv_gemm_k16s3_tab[epi], 128, 128, 16, 3, p, grid, st);
     if (rc != NAFP_OK || S == 1 || in_kernel_finish) return rc;

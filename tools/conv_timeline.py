@@ -26,9 +26,10 @@ CH = [128, 128, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512, 1024, 1024, 10
 def geometry(j, F=256, T=32):
     """(cin, cout, positions) of conv j of the encoder (nnfp.py:193-197: 1x3 stride (1,2) then 3x1 stride (2,1))."""
     cin = 1
+    st_t = [2, 2, 2, 2, 1, 2, 1, 2]          # stride of block i's 1x3 conv along T (model/fp/nnfp.py: strides table)
     for k in range(j + 1):
         if k % 2 == 0:
-            T = (T + 1) // 2
+            T = -(-T // st_t[k // 2])
         else:
             F = (F + 1) // 2
         if k == j:
