@@ -156,7 +156,11 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
             tt.z = fmaf(x2, k2.z, fmaf(x1, k1.z, fmaf(x0, k0.z, kb.z)));
             tt.w = fmaf(x2, k2.w, fmaf(x1, k1.w, fmaf(x0, k0.w, kb.w)));
         } else {
+#ifdef NAFP_LNB_NT_LOAD
+            { typedef float f4nt __attribute__((ext_vector_type(4))); const f4nt q = __builtin_nontemporal_load((const f4nt*)(tpre + b * n) + ii); tt = make_float4(q.x, q.y, q.z, q.w); }
+#else
             tt = ((const float4*)(tpre + b * n))[ii];
+#endif
         }
         float4 o;
         float q1 = 0.f, q2 = 0.f;
@@ -178,7 +182,11 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
             gw1.x = fmaf(x1, o.x, gw1.x); gw1.y = fmaf(x1, o.y, gw1.y); gw1.z = fmaf(x1, o.z, gw1.z); gw1.w = fmaf(x1, o.w, gw1.w);
             gw2.x = fmaf(x2, o.x, gw2.x); gw2.y = fmaf(x2, o.y, gw2.y); gw2.z = fmaf(x2, o.z, gw2.z); gw2.w = fmaf(x2, o.w, gw2.w);
         }
+#ifdef NAFP_LNB_NT_STORE
+        if (live && !(CONV0 && c0.dW0)) { typedef float f4nt __attribute__((ext_vector_type(4))); const f4nt q = {o.x, o.y, o.z, o.w}; __builtin_nontemporal_store(q, (f4nt*)dp); }
+#else
         if (live && !(CONV0 && c0.dW0)) *dp = o;               // (nothing reads dts_0 once dW0 is formed here)
+#endif
         if (lnsum_below) {
             // wave sums of (q1, q2) in 7 shuffles: fold the halves, then q1 lives in lanes 0..31 and q2 in 32..63
             if (!live) { q1 = 0.f; q2 = 0.f; }
