@@ -892,8 +892,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int ni = 0; ni < NIW; ++ni)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc[mi][ni][rg * 4 + q] + bv[ni]), rsP, voff,
-                                                              q * ystep_b + ni * 128, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(f2i(acc[mi][ni][rg * 4 + q] + bv[ni]), rsP, voff, q * ystep_b + ni * 128, 0);
             }
         NAFP_TL(6)
         NAFP_TL(7)
