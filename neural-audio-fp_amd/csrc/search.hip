@@ -103,57 +103,66 @@ __global__ __launch_bounds__(256, 2) void search_topk_kernel(
     }
     (void)OOB;
     if (t0 < t1) NAFP_S_DMA(t0, 0)
-    int slot = 0;
-    for (int64_t t = t0; t < t1; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (t + 1 < t1) NAFP_S_DMA(t + 1, slot ^ 1)
-        const float* St = smem + slot * TILE;
-        f32x16 acc[2];
+    // The f32 MFMAs share the SIMD's issue time with every vector instruction (conv.hip), so the scan loop is written for
+    // instruction count: operand addresses are per-lane constants (the swizzled chunk of every kk, computed once) plus
+    // immediates, the accumulators start at -|x|^2/2 (the key needs no subtraction), and a block of 16 scores is tested
+    // against the K-th best with one max tree before any per-score work.
+    unsigned aoff[D / 8];                          // byte offset of (row rl, logical chunk 2kk + hh) inside a tile
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < D / 8; ++kk) {
-            float4 a[2];
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const int row = mi * 32 + rl;
-                a[mi] = *(const float4*)(St + row * D + (((2 * kk + hh) ^ (row & (CH - 1))) * 4));
-            }
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].x, qr[kk].x, acc[mi], 0, 0, 0);
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].y, qr[kk].y, acc[mi], 0, 0, 0);
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].z, qr[kk].z, acc[mi], 0, 0, 0);
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, qr[kk].w, acc[mi], 0, 0, 0);
-            }
-        }
-        // selection: D[i = index row][j = query]: this lane holds rows (r&3) + 8(r>>2) + 4hh of block mi
-        const float* hp = hn + t * TILE_ROWS;                  // wave-uniform -> scalar loads
-        const int base_id = (int)(t * TILE_ROWS);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = mi * 32 + 8 * (r >> 2) + (r & 3);
-                const float h = hh ? hp[o + 4] : hp[o];
-                const float key = acc[mi][r] - h;
-                if (key > sc[K - 1]) {
-                    const int nid = base_id + o + 4 * hh;
-#pragma unroll
-                    for (int j = K - 1; j >= 1; --j) {
-                        const bool cj = key > sc[j], cp = key > sc[j - 1];
-                        id[j] = cj ? (cp ? id[j - 1] : nid) : id[j];
-                        sc[j] = cj ? (cp ? sc[j - 1] : key) : sc[j];
-                    }
-                    if (key > sc[0]) { sc[0] = key; id[0] = nid; }
-                }
-            }
-        slot ^= 1;
+    for (int kk = 0; kk < D / 8; ++kk) aoff[kk] = (unsigned)((rl * D + (((2 * kk + hh) ^ (rl & (CH - 1))) * 4)) * 4);
+    const char* sbase = (const char*)smem;
+#define NAFP_S_TILE(SLOT_)                                                                          \
+    {                                                                                               \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
+        __builtin_amdgcn_s_barrier();                                                               \
+        asm volatile("" ::: "memory");                                                              \
+        if (t + 1 < t1) NAFP_S_DMA(t + 1, (SLOT_) ^ 1)                                              \
+        const float* hp = hn + t * TILE_ROWS;                  /* wave-uniform -> scalar loads */   \
+        f32x16 acc[2];                                                                              \
+        _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                            \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                        \
+                const int o = mi * 32 + 8 * (r >> 2) + (r & 3);                                     \
+                acc[mi][r] = -(hh ? hp[o + 4] : hp[o]);                                             \
+            }                                                                                       \
+        _Pragma("unroll") for (int kk = 0; kk < D / 8; ++kk) {                                      \
+            float4 a[2];                                                                            \
+            _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                        \
+                a[mi] = *(const float4*)(sbase + aoff[kk] + ((SLOT_) * TILE + mi * 32 * D) * 4);    \
+            _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) {                                      \
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].x, qr[kk].x, acc[mi], 0, 0, 0); \
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].y, qr[kk].y, acc[mi], 0, 0, 0); \
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].z, qr[kk].z, acc[mi], 0, 0, 0); \
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, qr[kk].w, acc[mi], 0, 0, 0); \
+            }                                                                                       \
+        }                                                                                           \
+        /* selection: D[i = index row][j = query]: this lane holds rows (r&3) + 8(r>>2) + 4hh of block mi */ \
+        const int base_id = (int)(t * TILE_ROWS);                                                   \
+        _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) {                                          \
+            float m = fmaxf(acc[mi][0], acc[mi][1]);                                                \
+            _Pragma("unroll") for (int r = 2; r < 16; r += 2) m = fmaxf(m, fmaxf(acc[mi][r], acc[mi][r + 1])); \
+            if (m > sc[K - 1]) {                                                                    \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                    \
+                    const float key = acc[mi][r];                                                   \
+                    if (key > sc[K - 1]) {                                                          \
+                        const int nid = base_id + mi * 32 + 8 * (r >> 2) + (r & 3) + 4 * hh;        \
+                        _Pragma("unroll") for (int j = K - 1; j >= 1; --j) {                        \
+                            const bool cj = key > sc[j], cp = key > sc[j - 1];                      \
+                            id[j] = cj ? (cp ? id[j - 1] : nid) : id[j];                            \
+                            sc[j] = cj ? (cp ? sc[j - 1] : key) : sc[j];                            \
+                        }                                                                           \
+                        if (key > sc[0]) { sc[0] = key; id[0] = nid; }                              \
+                    }                                                                               \
+                }                                                                                   \
+            }                                                                                       \
+        }                                                                                           \
+        if (++t >= t1) break;                                                                       \
     }
+    if (t0 < t1)
+        for (int64_t t = t0;;) {
+            NAFP_S_TILE(0)
+            NAFP_S_TILE(1)
+        }
+#undef NAFP_S_TILE
 #undef NAFP_S_DMA
     if (qn < nq) {
         const int64_t o = ((int64_t)qn * n_lists + blockIdx.y * 2 + hh) * K;
