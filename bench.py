@@ -257,12 +257,12 @@ def main():
     for i in range(max(args.warmup, n_str)):
         step_on(i)
     torch.cuda.synchronize()
-    # HIP events of the timed region: 4 per forward on the launch stream (before conv0, before conv1, after conv15, after
-    # the tail) -- the 15 GEMM-conv launches are timed as ONE span per step, average launch = span / 15.  Stamping every
-    # launch (18 events) idles the GPU ~5 us per stamp = 0.1 ms per step; the per-conv split is taken from a second,
-    # untimed pass below.
-    m_fp.profile_enable(args.steps, coarse=True)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * args.steps)]
+    # HIP events of the timed region: 2 per forward on the launch stream (before conv1, after conv15) -- the 15 GEMM-conv
+    # launches are timed as ONE span per step, average launch = span / 15.  Every stamp between two kernels idles the GPU
+    # (~6 us each with 4 stamps, ~23 us each with one after every launch), so everything else -- the per-conv split, conv0,
+    # the front end, the tail -- is taken from a second, untimed pass below.
+    m_fp.profile_enable(args.steps, coarse=2)
+    ev = None
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -280,15 +280,19 @@ def main():
     assert emb.shape == (BSZ, 128) and bool(torch.isfinite(emb).all())
 
     prof = m_fp.profile_read()
-    mel_ms = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(args.steps)) / args.steps
-    # per-conv split: the same steps once more on one stream with a stamp after every launch (outside the timed region)
+    # per-stage split: the same steps once more on one stream with a stamp after every launch (outside the timed region)
     n_fine = min(args.steps, 8)
     m_fp.profile_enable(n_fine)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * n_fine)]
     for i in range(n_fine):
         with torch.cuda.stream(streams[0]):
-            m_fp(m_pre(pool[i % n_pool], group_size=BSZ, defer=True))
+            ev[2 * i].record()
+            feat = m_pre(pool[i % n_pool], group_size=BSZ, defer=True)
+            ev[2 * i + 1].record()
+            m_fp(feat)
     torch.cuda.synchronize()
     prof_fine = m_fp.profile_read()
+    mel_ms = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(n_fine)) / n_fine
     # Outside the timed region: the same steps on ONE stream, so that each kernel's duration is
     # its own (in the pipelined region kernels of different batches share the chip and the
     # per-launch durations include that sharing).
@@ -337,8 +341,8 @@ def main():
         gemm_flops_per_step = 2.0 * sum(macs[1:]) * BSZ            # the 15 implicit-GEMM launches
         gemm_ms = sum(sum(p[1:16]) for p in prof) / len(prof)      # per step, all 15 launches
         ach = gemm_flops_per_step / (gemm_ms * 1e-3) / 1e12
-        conv0_ms = sum(p[0] for p in prof) / len(prof)
-        tail_ms = sum(p[16] for p in prof) / len(prof)
+        conv0_ms = sum(p[0] for p in prof_fine) / len(prof_fine)
+        tail_ms = sum(p[16] for p in prof_fine) / len(prof_fine)
         value = world * BSZ * args.steps / el
         traffic, traffic_src, fe_traffic = None, None, None
         tp = os.path.join(ROOT, 'profiles', 'traffic.json')
@@ -372,9 +376,10 @@ def main():
             'stage_ms_per_step': {'melspec(2 kernels)': round(mel_ms, 4), 'conv0': round(conv0_ms, 4),
                                   'conv_gemm x15': round(gemm_ms, 4), 'tail': round(tail_ms, 4),
                                   'per_conv': [round(sum(p[k] for p in prof_fine) / len(prof_fine), 4) for k in range(17)],
-                                  'per_conv_note': 'conv0, the 15 GEMM convs, tail: from a second, untimed pass with a HIP event '
-                                                   'after every launch (each such stamp idles the GPU ~5 us, so their sum exceeds '
-                                                   'the timed "conv_gemm x15" span)'},
+                                  'per_conv_note': '"conv_gemm x15" is the span timed inside the timed region; melspec, conv0, tail and '
+                                                   'per_conv (conv0, the 15 GEMM convs, tail) come from a second, untimed pass with a HIP '
+                                                   'event after every launch -- each such stamp idles the GPU, so the per-conv values sum '
+                                                   'to more than the timed span (un-stamped kernel durations: profiles/*_summary.md)'},
             'frontend_hbm': {'bound': 'hbm', 'kernel': 'melspec_kernel (STFT + mel + log; the max subtraction is applied by conv0 on load)',
                              'algorithmic_bytes_per_segment': 32000 + 32768,
                              'achieved': round(BSZ * (32000 + 32768) / (mel_ms * 1e-3) / 1e9, 2), 'peak': 8000.0, 'unit': 'GB/s',

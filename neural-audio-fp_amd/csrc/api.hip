@@ -90,7 +90,7 @@ struct nafp_encoder {
     // optional per-kernel event timing (nafp_encoder_profile_*)
     std::vector<hipEvent_t> prof_events;  // (max_forwards, 18)
     int prof_max = 0, prof_count = 0;
-    int prof_coarse = 0;                  // 1: stamp only around conv0, the 15 GEMM convs as a group, and the tail
+    int prof_coarse = 0;                  // 1: stamp only around conv0, the 15 GEMM convs as a group, and the tail; 2: only around the GEMM convs
     // nafp_encoder_backward records one event per gradient group (layers complete last to first), so that a
     // communication stream can start reducing a group while the rest of the backward pass still runs
     hipEvent_t grad_events[NAFP_GRAD_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
@@ -370,7 +370,7 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
     NAFP_HIP_CHECK(hipMemsetAsync(stats, 0, stats_bytes, st));        // statistics + counters, one fill
     hipEvent_t* ev = nullptr;
     if (e->prof_max > 0 && e->prof_count < e->prof_max) ev = e->prof_events.data() + (size_t)18 * e->prof_count++;
-    if (ev) NAFP_HIP_CHECK(hipEventRecord(ev[0], st));
+    if (ev && e->prof_coarse < 2) NAFP_HIP_CHECK(hipEventRecord(ev[0], st));
 
     // conv0 is either materialised (z0 written to bufA) or -- default -- only its statistics are
     // computed here and conv1 re-generates z0 tiles in-kernel from the log-mel features
@@ -406,7 +406,7 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
     t.D = (int)e->flat_dim; t.Q = e->emb_sz; t.S = e->S; t.l2norm = l2norm;
     rc = launch_tail(t, n_seg, st);
     if (rc != NAFP_OK) return rc;
-    if (ev) NAFP_HIP_CHECK(hipEventRecord(ev[17], st));
+    if (ev && e->prof_coarse < 2) NAFP_HIP_CHECK(hipEventRecord(ev[17], st));
     return NAFP_OK;
 }
 
@@ -425,7 +425,7 @@ extern "C" int nafp_encoder_profile_enable(nafp_encoder* e, int max_forwards) {
 
 extern "C" int nafp_encoder_profile_coarse(nafp_encoder* e, int coarse) {
     if (!e) return NAFP_ERR_INVALID_ARG;
-    e->prof_coarse = coarse != 0;
+    e->prof_coarse = coarse < 0 ? 0 : (coarse > 2 ? 2 : coarse);
     return NAFP_OK;
 }
 
@@ -434,7 +434,12 @@ extern "C" int nafp_encoder_profile_count(const nafp_encoder* e) { return e ? e-
 extern "C" int nafp_encoder_profile_read(nafp_encoder* e, int slot, float* ms_out_host) {
     if (!e || !ms_out_host || slot < 0 || slot >= e->prof_count) return NAFP_ERR_INVALID_ARG;
     hipEvent_t* ev = e->prof_events.data() + (size_t)18 * slot;
-    NAFP_HIP_CHECK(hipEventSynchronize(ev[17]));
+    NAFP_HIP_CHECK(hipEventSynchronize(e->prof_coarse == 2 ? ev[16] : ev[17]));
+    if (e->prof_coarse == 2) {  // only the span of the 15 GEMM convs
+        for (int k = 0; k < 17; ++k) ms_out_host[k] = 0.f;
+        NAFP_HIP_CHECK(hipEventElapsedTime(ms_out_host + 1, ev[1], ev[16]));
+        return NAFP_OK;
+    }
     if (e->prof_coarse) {       // conv0 | the 15 GEMM convs (incl. split-K finishes) as ONE span in slot 1 | zeros | tail
         for (int k = 0; k < 17; ++k) ms_out_host[k] = 0.f;
         NAFP_HIP_CHECK(hipEventElapsedTime(ms_out_host + 0, ev[0], ev[1]));

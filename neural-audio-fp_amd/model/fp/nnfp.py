@@ -282,7 +282,7 @@ class FingerPrinter:
         """HIP-event stamps for the next `max_forwards` forwards.  coarse: 4 stamps per forward (conv0 | the 15 GEMM
         convs as ONE span | tail) instead of 18 -- every stamp between two kernels idles the GPU for ~5 us."""
         with torch.cuda.device(self.device):
-            _lib.check(self._lib.nafp_encoder_profile_coarse(self._h, 1 if coarse else 0), 'profile_coarse')
+            _lib.check(self._lib.nafp_encoder_profile_coarse(self._h, int(coarse)), 'profile_coarse')     # 0 / 1 (True) / 2: only the GEMM span
             _lib.check(self._lib.nafp_encoder_profile_enable(self._h, int(max_forwards)), 'profile_enable')
 
     def profile_read(self):
