@@ -325,6 +325,31 @@ def main():
             pel = float(t[0])
         pipelined = {'streams': 4, 'value': round(world * BSZ * args.steps / pel, 1), 'unit': 'segments/s',
                      'ms_per_step': round(pel / args.steps * 1e3, 4)}
+    # EXPERIMENTAL, reported separately and never as `value`: the unsplit GEMM convs with split-bf16 products (f32 operands
+    # split into hi + lo bf16 in registers, hi*hi + hi*lo + lo*hi on the bf16 matrix pipe, f32 accumulation:
+    # NAFP_OPT_BF16X3).  Narrower arithmetic than the reference's f32, so its error against the f32 path is measured here.
+    bf16x3 = None
+    if n_str == 1 and not args.no_pipelined:
+        with torch.cuda.stream(streams[0]):
+            ref_emb = m_fp(m_pre(pool[0], group_size=BSZ, defer=True)).clone()
+            m_fp.set_option(3, 1)
+            got_emb = m_fp(m_pre(pool[0], group_size=BSZ, defer=True)).clone()
+            for i in range(3):
+                m_fp(m_pre(pool[i % n_pool], group_size=BSZ, defer=True))
+        torch.cuda.synchronize()
+        tb0 = time.perf_counter()
+        with torch.cuda.stream(streams[0]):
+            for i in range(args.steps):
+                m_fp(m_pre(pool[i % n_pool], group_size=BSZ, defer=True))
+        torch.cuda.synchronize()
+        bel = time.perf_counter() - tb0
+        m_fp.set_option(3, 0)
+        bf16x3 = {'value': round(world * BSZ * args.steps / bel, 1), 'unit': 'segments/s', 'ms_per_step': round(bel / args.steps * 1e3, 4),
+                  'dtype': 'bf16 x 3 products (hi*hi + hi*lo + lo*hi), f32 accumulation, f32 storage',
+                  'max_abs_diff_vs_f32_path': float((got_emb - ref_emb).abs().max()),
+                  'min_cosine_vs_f32_path': float((got_emb * ref_emb).sum(1).min()),
+                  'note': 'experimental option NAFP_OPT_BF16X3 on the unsplit GEMM convs (convs 1-6, 8 at BSZ 640); NOT the '
+                          "reference's arithmetic, not part of `value`"}
     train = None
     if not args.no_train:
         train = train_region(cfg, world, rank, dist, args.train_bsz, args.train_steps, torch)
@@ -390,6 +415,8 @@ def main():
         out['config']['streams'] = n_str
         if pipelined:
             out['pipelined'] = pipelined
+        if bf16x3:
+            out['bf16x3_experimental'] = bf16x3
         if train:
             out['train'] = train
         if iso:

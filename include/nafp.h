@@ -200,7 +200,7 @@ int nafp_encoder_backward(nafp_encoder* enc, const float* feat, const float* d_e
 int nafp_encoder_grad_group_range(const nafp_encoder* enc, int group, int* first_tensor, int* last_tensor);
 int nafp_encoder_grad_group_wait(nafp_encoder* enc, int group, void* stream);
 
-/* Execution options of an encoder handle (results are identical either way).
+/* Execution options of an encoder handle (results are identical either way, except NAFP_OPT_BF16X3).
  *   NAFP_OPT_FUSE_CONV0  0 (default): b0.conv1x3 writes its activation, b0.conv3x1 reads it back.
  *                        1: only conv0's LayerNorm statistics are computed up front and conv1
  *                           re-generates its input tiles in-kernel from the log-mel features.
@@ -211,6 +211,11 @@ int nafp_encoder_grad_group_wait(nafp_encoder* enc, int group, void* stream);
  *                        batches >= 64; 2: wherever the geometry permits. */
 #define NAFP_OPT_FUSE_CONV0 1
 #define NAFP_OPT_FUSED_LN_BWD 2
+/* EXPERIMENTAL, changes the arithmetic (the only option that does): the unsplit GEMM convs of nafp_encoder_forward form their
+ * products on the bf16 matrix pipe from f32 operands split into hi + lo bf16 halves (hi*hi + hi*lo + lo*hi, f32
+ * accumulation).  Fingerprints move at the 1e-6 level against the f32 path.  Off by default; bench.py reports it as a
+ * separate object with its measured error, never as the headline value. */
+#define NAFP_OPT_BF16X3 3
 int nafp_encoder_set_option(nafp_encoder* enc, int option, int value);
 
 /* m_fp.div_enc(x) alone (nnfp.py:141-156; called separately at trainer.py:73-76). */

@@ -90,6 +90,7 @@ struct nafp_encoder {
     // optional per-kernel event timing (nafp_encoder_profile_*)
     std::vector<hipEvent_t> prof_events;  // (max_forwards, 18)
     int prof_max = 0, prof_count = 0;
+    bool opt_bf16x3 = false;              // NAFP_OPT_BF16X3 (experimental)
     int prof_coarse = 0;                  // 1: stamp only around conv0, the 15 GEMM convs as a group, and the tail; 2: only around the GEMM convs
     // nafp_encoder_backward records one event per gradient group (layers complete last to first), so that a
     // communication stream can start reducing a group while the rest of the backward pass still runs
@@ -243,6 +244,7 @@ extern "C" int nafp_encoder_set_option(nafp_encoder* e, int option, int value) {
     if (!e) return NAFP_ERR_INVALID_ARG;
     switch (option) {
         case NAFP_OPT_FUSE_CONV0: e->opt_fuse_conv0 = value != 0; return NAFP_OK;
+        case NAFP_OPT_BF16X3: e->opt_bf16x3 = value != 0; return NAFP_OK;
         case NAFP_OPT_FUSED_LN_BWD:
             if (value < 0 || value > 2) return NAFP_ERR_INVALID_ARG;
             e->opt_fused_ln_bwd = value; return NAFP_OK;
@@ -389,7 +391,7 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
         a.x = cur; a.stats_in = stats + 2 * n_seg * (j - 1);
         a.wp = e->d_w[j]; a.G = e->d_G[j]; a.Hb = e->d_Hb[j]; a.gamma_out = e->d_gamma[j];
         a.y = nxt; a.stats_out = stats + 2 * n_seg * j; a.plain = false;
-        a.slab = slab_floats ? slab : nullptr; a.slab_floats = slab_floats; a.tickets = tickets;
+        a.slab = slab_floats ? slab : nullptr; a.slab_floats = slab_floats; a.tickets = tickets; a.bf16x3 = e->opt_bf16x3;
         if (j == 1 && fuse0) {
             a.x = nullptr; a.f0_feat = feat; a.f0_w = e->d_w[0]; a.f0_bias = e->d_bias[0];
             a.f0_gamma = e->d_gamma[0]; a.f0_geom = &e->geom[0];

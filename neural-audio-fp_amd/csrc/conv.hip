@@ -394,7 +394,11 @@ __device__ __forceinline__ float half_wave_sum_dpp(float x) {
 //   0 FULL for inference (tile = 4 or 8 samples per position: statistics in registers), 1 the same + the pre-activation
 //   kept for the backward pass, 2 FULL for any tile shape (statistics through LDS; v_out by a runtime test),
 //   3 PLAIN (raw sums + bias: DGRAD, weight-derived tensors, split-K partial slabs).
-template <int BM, int BNT, int BK, int NSTAGE, bool FUSE0, int EPI>
+// PREC = 1 (experimental, inference only, NAFP_OPT_BF16X3): the products are formed on the bf16 matrix pipe from f32 operands
+// split in registers into hi + lo bf16 halves, hi*hi + hi*lo + lo*hi with f32 accumulation (lo*lo, ~2^-16 of a product,
+// is dropped).  Not the arithmetic of the reference: results differ from the f32 path at the 1e-6 level of a fingerprint
+// component; bench.py reports it as a separate object with its measured error and never as `value`.
+template <int BM, int BNT, int BK, int NSTAGE, bool FUSE0, int EPI, int PREC = 0>
 __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     static_assert(!FUSE0 || (BK == 16 && BM == 128), "the in-kernel conv0 generator is written for BK = 16, BM = 128");
     static_assert(BM == 128 || BM == 256, "tile rows");
@@ -728,6 +732,52 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
             acc[mi_][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[mi_].w, b_[ni].w, acc[mi_][ni], 0, 0, 0); \
         }
         static_assert(NI == 2, "the DMA of a step is issued as two pieces");
+        if (PREC == 1) {
+            // one K-step = 16 k = one v_mfma_f32_32x32x16_bf16 per product term: lane (row rl, half hh) holds k = 8 hh .. 8 hh + 7
+            // of its A rows and B rows (logical chunks 2 hh and 2 hh + 1 of the stage)
+            typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+            for (int s = s_begin; s < n_steps; ++s) {
+                NAFP_WAIT_STEP(s)
+                __builtin_amdgcn_s_barrier();
+                if (s == s_begin) { NAFP_TL(3) }
+                const bool has_next = s + NSTAGE - 1 < n_steps;
+                int nslot = slot + NSTAGE - 1; if (nslot >= NSTAGE) nslot -= NSTAGE;
+                const float* St = smem + slot * STAGE;
+                float4 af[2][2], bf[NIW][2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int pc4 = ((2 * hh + c) ^ rswz) * 4;
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) af[mi][c] = *(const float4*)(St + aoff + mi * 32 * BK + pc4);
+#pragma unroll
+                    for (int ni = 0; ni < NIW; ++ni) bf[ni][c] = *(const float4*)(St + boff + ni * 32 * BK + pc4);
+                }
+                if (has_next) { NAFP_DMA_PIECE(0, nslot) NAFP_DMA_PIECE(1, nslot) }
+                bf16x8 ah[2], al[2], bh[NIW], bl[NIW];
+#define NAFP_SPLIT8(f_, hi_, lo_)                                                              \
+                {                                                                                  \
+                    const float x_l[8] = {f_[0].x, f_[0].y, f_[0].z, f_[0].w, f_[1].x, f_[1].y, f_[1].z, f_[1].w}; \
+                    _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                \
+                        const __bf16 h_l = (__bf16)x_l[e];                                         \
+                        hi_[e] = h_l; lo_[e] = (__bf16)(x_l[e] - (float)h_l);                      \
+                    }                                                                              \
+                }
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) NAFP_SPLIT8(af[mi], ah[mi], al[mi])
+#pragma unroll
+                for (int ni = 0; ni < NIW; ++ni) NAFP_SPLIT8(bf[ni], bh[ni], bl[ni])
+#undef NAFP_SPLIT8
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NIW; ++ni) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                    }
+                if (++slot == NSTAGE) slot = 0;
+            }
+        } else {
         {
             NAFP_WAIT_STEP(s_begin)
             __builtin_amdgcn_s_barrier();
@@ -791,6 +841,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         __builtin_amdgcn_sched_barrier(0);
         if (s_begin + 1 < n_steps) { NAFP_MM_FRAG(a0, b0) }
         NAFP_MM_FRAG(a1, b1)
+        }
 #undef NAFP_DMA_PIECE
 #undef NAFP_DMA_TAP
 #undef NAFP_MM_HALF
@@ -971,7 +1022,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     // address is one 32-bit register per 4-row group, the sample step a scalar -- and the loop body is instantiated per
     // (keep the pre-activation, statistics path) so that it is straight-line code: any runtime branch in it makes hipcc
     // put an s_waitcnt vmcnt(0) -- outstanding stores included -- in front of every block.
-    constexpr bool PREF = (EPI == 0 || EPI == 1) && !FUSE0 && BK == 16 && BM == 128;   // block 0 was requested inside the K-loop (8-wave tiles run at 128 VGPRs: no room)
+    constexpr bool PREF = (EPI == 0 || EPI == 1) && !FUSE0 && BK == 16 && BM == 128 && PREC == 0;   // block 0 was requested inside the K-loop (8-wave tiles run at 128 VGPRs: no room)
     if (MIL == 2) { if (!PREF) { NAFP_EPI_LOAD(0, 0) } NAFP_EPI_LOAD(1, MIL - 1) }
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
         (EPI == 4 ? p.y_final : p.y) + (int64_t)b0 * p.P * p.Cout, 0, (int)((unsigned)nb * (unsigned)ystep_b), 0x00020000);
@@ -1090,6 +1141,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     __global__ __launch_bounds__(2 * BM_, MINW_) void name_(const ConvKernelParams p) {       \
         conv_gemm_body<BM_, BN_, BK_, NSTAGE_, FUSE0_, EPI_>(p);                              \
     }
+#define NAFP_GEMM_KERNEL_BF16X3(name_, BM_, BN_, NSTAGE_, MINW_)                                \
+    __global__ __launch_bounds__(2 * BM_, MINW_) void name_(const ConvKernelParams p) {       \
+        conv_gemm_body<BM_, BN_, 16, NSTAGE_, false, 0, 1>(p);                                \
+    }
 #define NAFP_GEMM_KERNELS(name_, BM_, BN_, MINW_)                                             \
     NAFP_GEMM_KERNEL(name_##_infer, BM_, BN_, 16, 3, MINW_, false, 0)                         \
     NAFP_GEMM_KERNEL(name_##_train, BM_, BN_, 16, 3, MINW_, false, 1)                         \
@@ -1125,6 +1180,11 @@ NAFP_GEMM_KERNEL(conv_gemm_m256k16s3_plain, 256, 128, 16, 3, 4, false, 3)
 // (no generic-statistics instantiation: the launcher takes the 128-row tile when 256 rows are not 4 or 8 samples per position)
 static void (*const conv_gemm_m256k16s3_tab[4])(const ConvKernelParams) = {conv_gemm_m256k16s3_infer, conv_gemm_m256k16s3_train, nullptr,
                                                                             conv_gemm_m256k16s3_plain};
+
+// experimental split-bf16 products (inference epilogue only), one per tile shape
+NAFP_GEMM_KERNEL_BF16X3(conv_gemm_k16s3_infer_bf16x3, 128, 128, 3, 3)
+NAFP_GEMM_KERNEL_BF16X3(conv_gemm_m256k16s3_infer_bf16x3, 256, 128, 3, 4)
+NAFP_GEMM_KERNEL_BF16X3(conv_gemm_n64k16s2_infer_bf16x3, 128, 64, 2, 5)
 
 template <typename KernelT>
 static int launch_variant(KernelT kernel, int BM, int BNt, int BK, int NSTAGE, const ConvKernelParams& p, dim3 grid, hipStream_t st) {
@@ -1472,6 +1532,10 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     const bool fast_st = p.ST == 4 || p.ST == 8;
     const int epi = in_kernel_finish ? 4 : p.mode != 0 ? 3 : (!fast_st ? 2 : (p.v_out ? 1 : 0));
     const bool two_stage = n64_two_stage() && bn == 64 && (epi == 0 || epi == 1 || epi == 4);
+    if (a.bf16x3 && epi == 0 && (bn == 128 || two_stage))
+        return BM == 256 ? launch_variant(conv_gemm_m256k16s3_infer_bf16x3, 256, 128, 16, 3, p, grid, st)
+             : bn == 64 ? launch_variant(conv_gemm_n64k16s2_infer_bf16x3, 128, 64, 16, 2, p, grid, st)
+                        : launch_variant(conv_gemm_k16s3_infer_bf16x3, 128, 128, 16, 3, p, grid, st);
     rc = BM == 256 ? launch_variant(conv_gemm_m256k16s3_tab[epi], 256, 128, 16, 3, p, grid, st)
          : (bn == 64 && two_stage) ? launch_variant(conv_gemm_n64k16s2_tab[epi], 128, 64, 16, 2, p, grid, st)
          : bn == 64 ? launch_variant(conv_gemm_n64k16s3_tab[epi], 128, 64, 16, 3, p, grid, st)

@@ -272,7 +272,8 @@ class FingerPrinter:
                        'encoder_grad_group_wait')
 
     def set_option(self, option, value):
-        """Execution options of the library handle (include/nafp.h NAFP_OPT_*); results do not change."""
+        """Execution options of the library handle (include/nafp.h NAFP_OPT_*); results do not change, except for the
+        experimental option 3 (NAFP_OPT_BF16X3: split-bf16 products, off by default)."""
         if int(option) == 1:
             self._fuse0 = bool(value)
         _lib.check(self._lib.nafp_encoder_set_option(self._h, int(option), int(value)), 'encoder_set_option')

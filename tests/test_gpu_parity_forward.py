@@ -147,3 +147,21 @@ def test_deferred_log_mel_tail_is_bit_identical(nafp, cfg, feat_kind):
             assert float((got - ref).abs().max()) < 1e-6
             flat_ref, flat = m_fp.front_conv(ref_feat), m_fp.front_conv(d)
             assert float((flat - flat_ref).abs().max()) < 1e-5
+
+
+def test_experimental_bf16x3_option_stays_within_the_contract(nafp):
+    """NAFP_OPT_BF16X3 (experimental, off by default): split-bf16 products on the unsplit GEMM convs.  Not the reference's
+    arithmetic -- the fingerprints move, but by far less than the 1e-3 cosine contract; switching it off restores the f32
+    path exactly."""
+    rng = np.random.default_rng(12)
+    feat = torch.from_numpy((-rng.uniform(0, 1.2, size=(640, 256, 32, 1))).astype(np.float32)).cuda()
+    m_fp = nafp.FingerPrinter(seed=3)
+    ref = m_fp(feat).clone()
+    m_fp.set_option(3, 1)
+    got = m_fp(feat).clone()
+    m_fp.set_option(3, 0)
+    back = m_fp(feat).clone()
+    assert float((got - ref).abs().max()) > 0.0                      # it does change the arithmetic
+    assert float((got - ref).abs().max()) < 1e-4
+    assert float((1 - (got * ref).sum(1)).max()) < 1e-6
+    assert float((back - ref).abs().max()) < 1e-6
