@@ -257,10 +257,11 @@ def main():
     for i in range(max(args.warmup, n_str)):
         step_on(i)
     torch.cuda.synchronize()
-    # HIP events of the timed region: 2 per forward on the launch stream (before conv1, after conv15) -- the 15 GEMM-conv
-    # launches are timed as ONE span per step, average launch = span / 15.  Every stamp between two kernels idles the GPU
-    # (~6 us each with 4 stamps, ~23 us each with one after every launch), so everything else -- the per-conv split, conv0,
-    # the front end, the tail -- is taken from a second, untimed pass below.
+    # HIP events of the timed region: 2 per forward, attached by the library to the dispatch packets of conv1 (start) and
+    # of the last GEMM-conv kernel (stop) on the launch stream -- the 15 GEMM-conv launches are timed as ONE span per step,
+    # average launch = span / 15.  An event RECORDED between two kernels idles the GPU (~20 us of un-overlapped dispatch
+    # set-up each), so everything else -- the per-conv split, conv0, the front end, the tail -- is taken from a second,
+    # untimed pass below.
     m_fp.profile_enable(args.steps, coarse=2)
     ev = None
     if dist:

@@ -165,7 +165,8 @@ int nafp_encoder_profile_count(const nafp_encoder* enc);   /* forwards recorded 
 /* coarse != 0: a forward records 4 stamps instead of 18 -- before conv0, before conv1, after conv15, after the tail --
  * and profile_read returns [conv0, the 15 GEMM convs as one span, 0 ..., tail].  Every stamp between two kernels costs
  * about 5 us of idle GPU (measured: 18 stamps = 0.1 ms of a 3.7 ms forward), so a timed region uses the coarse form.
- * coarse == 2: only the two stamps around the 15 GEMM convs (profile_read returns just that span in slot 1). */
+ * coarse == 2: only the span of the 15 GEMM convs (profile_read returns it in slot 1), taken from the dispatch packets of
+ * the first and the last of their kernels (hipExtLaunchKernel): no queue entry, no idle time. */
 int nafp_encoder_profile_coarse(nafp_encoder* enc, int coarse);
 int nafp_encoder_profile_read(nafp_encoder* enc, int slot, float* ms_out_host);
 /* Diagnostic, process-wide: while `dev_buf` is non-null every forward GEMM-conv launch (full mode) whose conv has

@@ -383,7 +383,8 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
                    : launch_conv0(feat, e->d_w[0], e->d_bias[0], e->d_gamma[0], bufA, nullptr, stats, n_seg, e->geom[0], st,
                                   gstat, group_size, segment_norm);
     if (rc != NAFP_OK) return rc;
-    if (ev) NAFP_HIP_CHECK(hipEventRecord(ev[1], st));
+    static const bool prof_ext = []() { const char* v = getenv("NAFP_PROF_EXT"); return !v || v[0] != '0'; }();
+    if (ev && (e->prof_coarse < 2 || !prof_ext)) NAFP_HIP_CHECK(hipEventRecord(ev[1], st));      // (coarse 2: the stamp rides on conv1's dispatch)
     float* cur = bufA;
     for (int j = 1; j < 16; ++j) {
         float* nxt = (j % 2 == 0) ? bufA : bufB;
@@ -396,9 +397,13 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
             a.x = nullptr; a.f0_feat = feat; a.f0_w = e->d_w[0]; a.f0_bias = e->d_bias[0];
             a.f0_gamma = e->d_gamma[0]; a.f0_geom = &e->geom[0];
         }
+        if (ev && e->prof_coarse == 2 && prof_ext) {          // the GEMM span without a queue entry: start on conv1's dispatch, stop on conv15's last
+            if (j == 1) a.ev_start = ev[1];
+            if (j == 15) a.ev_stop = ev[16];
+        }
         rc = launch_conv_gemm(a, n_seg, e->geom[j], st);
         if (rc != NAFP_OK) return rc;
-        if (ev && (!e->prof_coarse || j == 15)) NAFP_HIP_CHECK(hipEventRecord(ev[j + 1], st));
+        if (ev && (!e->prof_coarse || (j == 15 && (e->prof_coarse == 1 || !prof_ext)))) NAFP_HIP_CHECK(hipEventRecord(ev[j + 1], st));
         cur = nxt;
     }
     TailArgs t;

@@ -23,6 +23,7 @@
 // and the per-sample sum / sum-of-squares of v for the NEXT conv come out of the
 // epilogue as before.
 #include "nafp_common.h"
+#include <hip/hip_ext.h>
 
 #include <cstdlib>
 
@@ -1186,11 +1187,23 @@ NAFP_GEMM_KERNEL_BF16X3(conv_gemm_k16s3_infer_bf16x3, 128, 128, 3, 3)
 NAFP_GEMM_KERNEL_BF16X3(conv_gemm_m256k16s3_infer_bf16x3, 256, 128, 3, 4)
 NAFP_GEMM_KERNEL_BF16X3(conv_gemm_n64k16s2_infer_bf16x3, 128, 64, 2, 5)
 
+// Optional timing events of the launch in flight (ConvGemmArgs::ev_start / ev_stop): they ride on a kernel's own dispatch
+// packet (hipExtLaunchKernel: time stamps of its completion signal), so -- unlike hipEventRecord between two kernels -- they
+// put nothing into the queue and cost the GPU no idle time.
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+
 template <typename KernelT>
 static int launch_variant(KernelT kernel, int BM, int BNt, int BK, int NSTAGE, const ConvKernelParams& p, dim3 grid, hipStream_t st) {
     const int lds = (NSTAGE * (BM + BNt) * BK + 2 * BM + 96 + (p.f0_feat ? 4 * p.Cin : 0)) * (int)sizeof(float);
     NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    kernel<<<grid, 2 * BM, lds, st>>>(p);
+    if (g_ev_start || g_ev_stop) {
+        ConvKernelParams pc = p;
+        void* args[] = {(void*)&pc};
+        NAFP_HIP_CHECK(hipExtLaunchKernel((const void*)kernel, grid, dim3(2 * BM), args, (size_t)lds, st, g_ev_start, g_ev_stop, 0));
+        g_ev_start = nullptr; g_ev_stop = nullptr;
+    } else {
+        kernel<<<grid, 2 * BM, lds, st>>>(p);
+    }
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }
@@ -1517,6 +1530,8 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
         g_timeline.last_grid[3] = BM; g_timeline.last_grid[4] = bn;
     }
     int rc;
+    const bool finish_follows = S > 1 && !in_kernel_finish;
+    g_ev_start = a.ev_start; g_ev_stop = finish_follows ? nullptr : a.ev_stop;
     p.f0_feat = nullptr; p.f0_w = nullptr; p.f0_bias = nullptr; p.f0_gamma = nullptr;
     p.f0_T = 0; p.f0_stride = 1; p.f0_pad = 0;
     if (a.f0_feat) {
@@ -1550,11 +1565,15 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     }
     if (4096 / g.Cout + 1 > FIN_MAXS || g.Cout < 128) return NAFP_ERR_UNSUPPORTED;      // a wave (256 floats) spans <= 2 rows
     const int64_t f4 = out_floats / 4;
-#define NAFP_FIN(E_) splitk_finish_kernel<E_><<<dim3((unsigned)((f4 + (E_) - 1) / (E_))), 256, 0, st>>>( \
+#define NAFP_FIN(E_)                                                                                             \
+    if (a.ev_stop) hipExtLaunchKernelGGL(splitk_finish_kernel<E_>, dim3((unsigned)((f4 + (E_) - 1) / (E_))), dim3(256), 0, st, nullptr,   \
+                                         a.ev_stop, 0, (const float*)a.slab, S, a.G, a.Hb, a.gamma_out, a.stats_in, a.stats_out, a.y,   \
+                                         a.v_out, p.B, p.P, g.Cout, p.inv_n_in);                                   \
+    else splitk_finish_kernel<E_><<<dim3((unsigned)((f4 + (E_) - 1) / (E_))), 256, 0, st>>>(                       \
         a.slab, S, a.G, a.Hb, a.gamma_out, a.stats_in, a.stats_out, a.y, a.v_out, p.B, p.P, g.Cout, p.inv_n_in)
-    if (f4 >= 1024 * 1024) NAFP_FIN(1024);
-    else if (f4 >= 1024 * 512) NAFP_FIN(512);
-    else NAFP_FIN(256);
+    if (f4 >= 1024 * 1024) { NAFP_FIN(1024); }
+    else if (f4 >= 1024 * 512) { NAFP_FIN(512); }
+    else { NAFP_FIN(256); }
 #undef NAFP_FIN
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;

@@ -109,6 +109,7 @@ struct ConvGemmArgs {
     bool dgrad;              // PLAIN only: y (B,Fin,Tin,Cin) = transposed conv of x = dT (B,Fout,Tout,Cout) with wp = (Cin, 3*Cout)
     float* slab;             // split-K partial sums workspace (or nullptr: never split)
     int64_t slab_floats;
+    hipEvent_t ev_start, ev_stop;   // optional: time stamps attached to this conv's first / last kernel dispatch (no queue entry)
     bool bf16x3;             // experimental: split-bf16 products for the unsplit FULL launches (NAFP_OPT_BF16X3)
     unsigned* tickets;       // NAFP_TICKET_SLOTS arrival counters, zero on entry and on exit (or nullptr: split launches use slab + finish kernel)
     // optional: generate the A operand from the log-mel features (conv0 fused into conv1);
