@@ -403,9 +403,11 @@ def main():
                                   'conv_gemm x15': round(gemm_ms, 4), 'tail': round(tail_ms, 4),
                                   'per_conv': [round(sum(p[k] for p in prof_fine) / len(prof_fine), 4) for k in range(17)],
                                   'per_conv_note': '"conv_gemm x15" is the span timed inside the timed region; melspec, conv0, tail and '
-                                                   'per_conv (conv0, the 15 GEMM convs, tail) come from a second, untimed pass with a HIP '
-                                                   'event after every launch -- each such stamp idles the GPU, so the per-conv values sum '
-                                                   'to more than the timed span (un-stamped kernel durations: profiles/*_summary.md)'},
+                                                   'per_conv (conv0, the 15 GEMM convs, tail) come from a second, untimed pass: each GEMM '
+                                                   'conv from the start of its first kernel to the end of its last (dispatch-attached time '
+                                                   'stamps, split-K finish kernel included), conv0 / tail / melspec between recorded '
+                                                   'events.  Stamping every launch still costs: these figures sum to ~10 % more than the '
+                                                   'timed span; un-stamped kernel durations are in profiles/*_summary.md'},
             'frontend_hbm': {'bound': 'hbm', 'kernel': 'melspec_kernel (STFT + mel + log; the max subtraction is applied by conv0 on load)',
                              'algorithmic_bytes_per_segment': 32000 + 32768,
                              'achieved': round(BSZ * (32000 + 32768) / (mel_ms * 1e-3) / 1e9, 2), 'peak': 8000.0, 'unit': 'GB/s',

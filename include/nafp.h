@@ -162,11 +162,15 @@ int nafp_encoder_forward_raw(nafp_encoder* enc, const float* raw_feat, const flo
 #define NAFP_ENCODER_PROFILE_KERNELS 17
 int nafp_encoder_profile_enable(nafp_encoder* enc, int max_forwards);
 int nafp_encoder_profile_count(const nafp_encoder* enc);   /* forwards recorded so far */
-/* coarse != 0: a forward records 4 stamps instead of 18 -- before conv0, before conv1, after conv15, after the tail --
- * and profile_read returns [conv0, the 15 GEMM convs as one span, 0 ..., tail].  Every stamp between two kernels costs
- * about 5 us of idle GPU (measured: 18 stamps = 0.1 ms of a 3.7 ms forward), so a timed region uses the coarse form.
- * coarse == 2: only the span of the 15 GEMM convs (profile_read returns it in slot 1), taken from the dispatch packets of
- * the first and the last of their kernels (hipExtLaunchKernel): no queue entry, no idle time. */
+/* Stamp granularity of the forwards that follow.
+ *   0 (default): conv0, every GEMM conv, tail.  The GEMM convs are stamped on their own dispatch packets -- start of the
+ *      first kernel, end of the last (a split-K finish kernel included): hipExtLaunchKernel, nothing is put into the queue --,
+ *      conv0 and the tail between recorded events.  (Stamping every launch is still not free: the per-conv figures sum to
+ *      about 10 % more than the span mode 2 measures for the same launches.)
+ *   1: conv0 | the 15 GEMM convs as one span | tail, between recorded events (an event recorded between two kernels costs
+ *      the GPU about 20 us of un-overlapped dispatch set-up).
+ *   2: only the span of the 15 GEMM convs, from the dispatch packets of conv1 and of the last GEMM-conv kernel: no queue
+ *      entry at all -- what a timed region uses.  profile_read returns the span in slot 1, zeros elsewhere. */
 int nafp_encoder_profile_coarse(nafp_encoder* enc, int coarse);
 int nafp_encoder_profile_read(nafp_encoder* enc, int slot, float* ms_out_host);
 /* Diagnostic, process-wide: while `dev_buf` is non-null every forward GEMM-conv launch (full mode) whose conv has

@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256) void add_bias_kernel(const BiasTable t) {
 
 using namespace nafp;
 
+constexpr int NAFP_PROF_EV = 34;
 struct nafp_encoder {
     int in_f, in_t, emb_sz;
     std::vector<ConvGeom> geom;           // 16
@@ -88,7 +89,7 @@ struct nafp_encoder {
     // per-segment workspace layout (floats)
     int64_t bufA_per_seg = 0, bufB_per_seg = 0;
     // optional per-kernel event timing (nafp_encoder_profile_*)
-    std::vector<hipEvent_t> prof_events;  // (max_forwards, 18)
+    std::vector<hipEvent_t> prof_events;  // (max_forwards, NAFP_PROF_EV): [conv0 a, b | conv j start, stop (j = 1..15) | tail a, b]
     int prof_max = 0, prof_count = 0;
     bool opt_bf16x3 = false;              // NAFP_OPT_BF16X3 (experimental)
     int prof_coarse = 0;                  // 1: stamp only around conv0, the 15 GEMM convs as a group, and the tail; 2: only around the GEMM convs
@@ -371,7 +372,7 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
     for (int j = 1; j < 16; ++j) slab_floats = std::max(slab_floats, conv_gemm_slab_floats(n_seg, e->geom[j]));
     NAFP_HIP_CHECK(hipMemsetAsync(stats, 0, stats_bytes, st));        // statistics + counters, one fill
     hipEvent_t* ev = nullptr;
-    if (e->prof_max > 0 && e->prof_count < e->prof_max) ev = e->prof_events.data() + (size_t)18 * e->prof_count++;
+    if (e->prof_max > 0 && e->prof_count < e->prof_max) ev = e->prof_events.data() + (size_t)NAFP_PROF_EV * e->prof_count++;
     if (ev && e->prof_coarse < 2) NAFP_HIP_CHECK(hipEventRecord(ev[0], st));
 
     // conv0 is either materialised (z0 written to bufA) or -- default -- only its statistics are
@@ -383,8 +384,7 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
                    : launch_conv0(feat, e->d_w[0], e->d_bias[0], e->d_gamma[0], bufA, nullptr, stats, n_seg, e->geom[0], st,
                                   gstat, group_size, segment_norm);
     if (rc != NAFP_OK) return rc;
-    static const bool prof_ext = []() { const char* v = getenv("NAFP_PROF_EXT"); return !v || v[0] != '0'; }();
-    if (ev && (e->prof_coarse < 2 || !prof_ext)) NAFP_HIP_CHECK(hipEventRecord(ev[1], st));      // (coarse 2: the stamp rides on conv1's dispatch)
+    if (ev && e->prof_coarse < 2) NAFP_HIP_CHECK(hipEventRecord(ev[1], st));
     float* cur = bufA;
     for (int j = 1; j < 16; ++j) {
         float* nxt = (j % 2 == 0) ? bufA : bufB;
@@ -397,13 +397,15 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
             a.x = nullptr; a.f0_feat = feat; a.f0_w = e->d_w[0]; a.f0_bias = e->d_bias[0];
             a.f0_gamma = e->d_gamma[0]; a.f0_geom = &e->geom[0];
         }
-        if (ev && e->prof_coarse == 2 && prof_ext) {          // the GEMM span without a queue entry: start on conv1's dispatch, stop on conv15's last
-            if (j == 1) a.ev_start = ev[1];
-            if (j == 15) a.ev_stop = ev[16];
+        // time stamps that ride on the kernels' own dispatch packets (no queue entry, no idle time): every conv's first and
+        // last kernel (all stamps), or only conv1's start and conv15's stop (the GEMM span of a timed region)
+        if (ev && e->prof_coarse == 0) { a.ev_start = ev[2 * j]; a.ev_stop = ev[2 * j + 1]; }
+        if (ev && e->prof_coarse == 2) {
+            if (j == 1) a.ev_start = ev[2];
+            if (j == 15) a.ev_stop = ev[31];
         }
         rc = launch_conv_gemm(a, n_seg, e->geom[j], st);
         if (rc != NAFP_OK) return rc;
-        if (ev && (!e->prof_coarse || (j == 15 && (e->prof_coarse == 1 || !prof_ext)))) NAFP_HIP_CHECK(hipEventRecord(ev[j + 1], st));
         cur = nxt;
     }
     TailArgs t;
@@ -411,16 +413,17 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
     t.w1p = e->d_w1p; t.b1p = e->d_b1p; t.w2p = e->d_w2p; t.b2 = e->d_b2;
     t.out_flat = out_flat; t.out_emb = out_emb;
     t.D = (int)e->flat_dim; t.Q = e->emb_sz; t.S = e->S; t.l2norm = l2norm;
+    if (ev && e->prof_coarse < 2) NAFP_HIP_CHECK(hipEventRecord(ev[32], st));
     rc = launch_tail(t, n_seg, st);
     if (rc != NAFP_OK) return rc;
-    if (ev && e->prof_coarse < 2) NAFP_HIP_CHECK(hipEventRecord(ev[17], st));
+    if (ev && e->prof_coarse < 2) NAFP_HIP_CHECK(hipEventRecord(ev[33], st));
     return NAFP_OK;
 }
 
 extern "C" int nafp_encoder_profile_enable(nafp_encoder* e, int max_forwards) {
     if (!e || max_forwards < 0 || max_forwards > 4096) return NAFP_ERR_INVALID_ARG;
     profile_free(e);
-    for (int i = 0; i < max_forwards * 18; ++i) {
+    for (int i = 0; i < max_forwards * NAFP_PROF_EV; ++i) {
         hipEvent_t ev;
         // no system-scope fence at the stamp: with the default flags every record made the GPU write its caches back
         // (measured: 15 stamps between the GEMM convs cost 0.35 ms of a 3.6 ms forward)
@@ -444,21 +447,21 @@ extern "C" int nafp_encoder_profile_count(const nafp_encoder* e) { return e ? e-
 
 extern "C" int nafp_encoder_profile_read(nafp_encoder* e, int slot, float* ms_out_host) {
     if (!e || !ms_out_host || slot < 0 || slot >= e->prof_count) return NAFP_ERR_INVALID_ARG;
-    hipEvent_t* ev = e->prof_events.data() + (size_t)18 * slot;
-    NAFP_HIP_CHECK(hipEventSynchronize(e->prof_coarse == 2 ? ev[16] : ev[17]));
-    if (e->prof_coarse == 2) {  // only the span of the 15 GEMM convs
-        for (int k = 0; k < 17; ++k) ms_out_host[k] = 0.f;
-        NAFP_HIP_CHECK(hipEventElapsedTime(ms_out_host + 1, ev[1], ev[16]));
+    hipEvent_t* ev = e->prof_events.data() + (size_t)NAFP_PROF_EV * slot;
+    NAFP_HIP_CHECK(hipEventSynchronize(e->prof_coarse == 2 ? ev[31] : ev[33]));
+    for (int k = 0; k < 17; ++k) ms_out_host[k] = 0.f;
+    if (e->prof_coarse == 2) {  // only the span of the 15 GEMM convs (first dispatch start -> last dispatch end)
+        NAFP_HIP_CHECK(hipEventElapsedTime(ms_out_host + 1, ev[2], ev[31]));
         return NAFP_OK;
     }
+    NAFP_HIP_CHECK(hipEventElapsedTime(ms_out_host + 0, ev[0], ev[1]));
+    NAFP_HIP_CHECK(hipEventElapsedTime(ms_out_host + 16, ev[32], ev[33]));
     if (e->prof_coarse) {       // conv0 | the 15 GEMM convs (incl. split-K finishes) as ONE span in slot 1 | zeros | tail
-        for (int k = 0; k < 17; ++k) ms_out_host[k] = 0.f;
-        NAFP_HIP_CHECK(hipEventElapsedTime(ms_out_host + 0, ev[0], ev[1]));
-        NAFP_HIP_CHECK(hipEventElapsedTime(ms_out_host + 1, ev[1], ev[16]));
-        NAFP_HIP_CHECK(hipEventElapsedTime(ms_out_host + 16, ev[16], ev[17]));
+        NAFP_HIP_CHECK(hipEventElapsedTime(ms_out_host + 1, ev[1], ev[32]));
         return NAFP_OK;
     }
-    for (int k = 0; k < 17; ++k) NAFP_HIP_CHECK(hipEventElapsedTime(ms_out_host + k, ev[k], ev[k + 1]));
+    // every conv: start of its first kernel -> end of its last (a split-K finish kernel included)
+    for (int j = 1; j < 16; ++j) NAFP_HIP_CHECK(hipEventElapsedTime(ms_out_host + j, ev[2 * j], ev[2 * j + 1]));
     return NAFP_OK;
 }
 
