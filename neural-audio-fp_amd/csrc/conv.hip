@@ -240,11 +240,21 @@ int launch_conv0_stats(const float* feat, const float* w3, const float* bias, do
 //   barrier -> issue DMA of step s+NSTAGE-1 into the buffer everybody just left ->
 //   MFMAs of step s.  Taps that hit only zero padding for every row of the tile
 //   are skipped.
+//
+//   What bounds the kernel (measured with nafp_conv_timeline): the f32 MFMA runs at the packed-f32
+//   vector rate and shares the SIMD's issue time with every VALU instruction, so the kernel is written for
+//   instruction count -- K-steps that issue nothing but MFMAs, LDS reads and DMA (skewed across the barrier, body
+//   once per ring slot), an epilogue on sample pairs with v_pk_* arithmetic and straight-line buffer loads/stores
+//   (one instantiation per epilogue kind), geometry once per position slot through LDS.
+//   Env knobs for A/B runs (all read once): NAFP_BM256 (min 128-row tiles for the 256-row tile), NAFP_BN64 /
+//   NAFP_BN64_TILES / NAFP_BN64_MIN (64-column tiles), NAFP_N64S2 (their 2-stage, 5-per-CU kernel), NAFP_SPLITK,
+//   NAFP_SPLIT_INKERNEL (min tiles for the in-kernel split-K finish), NAFP_FWD_PLAN (force tile:split), NAFP_GRID3D,
+//   NAFP_GEMM_PRIO, NAFP_CONV0_ROWS.
 // ============================================================================
 constexpr int BN = 128;          // BM (tile rows) is a template parameter: 128 (4 waves) or 256 (8 waves)
 
 // Ablation switches for the kernel-time breakdowns of DESIGN.md (NAFP_ABL env -> ConvKernelParams::abl) exist only in a
-// library built with -DNAFP_ABLATION (NAFP_ABLATION=1 python build.py): in the production build every test below is a
+// library built with -DNAFP_ABLATION (tools/build_variant.sh abl neural-audio-fp_amd/csrc/conv.hip -DNAFP_ABLATION): in the production build every test below is a
 // compile-time 0 -- the runtime branches they put into the epilogue made hipcc serialise its loads and stores
 // (an s_waitcnt vmcnt(0) per group), which cost far more than the branches themselves.
 #ifdef NAFP_ABLATION
