@@ -837,12 +837,16 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
                     NAFP_K_STEP(2, 1)
                     NAFP_K_STEP(0, 2)
                 }
-            } else {            // 64-column tiles: one rolled copy (the three-copy form makes hipcc spill at their 128-VGPR budget)
+            } else {            // 64-column tiles: one rolled copy (the three-copy form makes hipcc spill at their register budget).
+                // The last step is written out behind the loop instead of leaving it through a mid-body break: with the break
+                // hipcc copies the 12 fragment registers of R1 at the end of every iteration.
                 int rs = 1;
-                for (int s = s_begin + 1;;) {
+                int s = s_begin + 1;
+                for (; s < n_steps - 1;) {
                     NAFP_K_STEP(rs, (rs == 0 ? NSTAGE - 1 : rs - 1))
                     if (++rs == NSTAGE) rs = 0;
                 }
+                do { NAFP_K_STEP(rs, (rs == 0 ? NSTAGE - 1 : rs - 1)) } while (false);     // s == n_steps - 1: leaves at its break
             }
         }
 #undef NAFP_K_STEP
