@@ -227,3 +227,20 @@ def test_generate_with_synthesised_queries(nafp, cfg, tmp_path):
     hit = idx.search(q, 3)[1]
     # random-weight network, augmented + shifted queries of stationary tones: the right CLIP is found (its segments look alike)
     assert (hit[:, 0] // 24 == np.arange(n) // 24).mean() > 0.8
+
+
+def test_split_k_arrival_counters_are_left_clean(nafp):
+    """The split-K launches that finish in-kernel (conv.hip, EPI 4) count arrivals per output tile in the workspace and the
+    last arriver resets its counter.  Alternating batch sizes -- different tile counts, with and without such launches, on
+    the SAME workspace -- must therefore reproduce the first result, and two identical launches must agree to the ulp level
+    (the parts are summed in part order; only the double atomics of the statistics have no fixed order)."""
+    rng = np.random.default_rng(21)
+    feat = torch.from_numpy((-rng.uniform(0, 1.2, size=(640, 256, 32, 1))).astype(np.float32)).cuda()
+    m_fp = nafp.FingerPrinter(seed=2)
+    first = m_fp(feat).clone()
+    for n in (129, 640, 37, 320, 640):
+        out = m_fp(feat[:n]).clone()
+        assert bool(torch.isfinite(out).all())
+        assert float((out - first[:n]).abs().max()) < 3e-6
+    again = m_fp(feat).clone()
+    assert float((again - first).abs().max()) < 1e-6
