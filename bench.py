@@ -6,16 +6,27 @@
 One "step" = one pass of  audio -> log-mel -> encoder -> L2-normalised fingerprint
 over one batch of 640 synthetic 1-s segments that are already resident in HBM
 (BASELINE.json configs[1]: "Fingerprint generate, d=128 encoder, BSZ=640, 1xMI355X").
-With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank owns its
-own batches: generation shards by segment with no data-path collective, so scaling
-is weak and `value` is the whole-job segments/s.
+With N > 1 every rank (one per GPU, torch.distributed over RCCL) owns its own batches:
+generation shards by segment with no data-path collective, so scaling is weak and `value`
+is the whole-job segments/s.  `python bench.py --gpus N` with no WORLD_SIZE in the
+environment starts the N ranks ITSELF (`python -m torch.distributed.run --nproc-per-node N
+bench.py ...` as a child process, before anything in this process touches the GPU), relays
+rank 0's JSON line and exits with the child's return code; under torch.distributed.run
+(WORLD_SIZE set) it is one of the ranks.
+
+The timed region (EXACTLY --steps steps between barrier + synchronize) is repeated
+--repeats times; `ms_per_step` / `value` are the MEDIAN region, `spread` holds all of them.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     the dominant kernel (the fp32-MFMA implicit-GEMM convs): algorithmic
                FLOPs per launch / mean launch duration from HIP events recorded on the
                launch stream inside the timed region, vs the 157.3 TFLOP/s fp32 matrix peak
-  cpu_baseline the oracle's torch-CPU restatement of the same graph timed on the host
+  cpu_baseline the oracle's torch-CPU restatement of the same graph timed on ALL host
                cores of this box on a bounded sample (kind "port": TensorFlow is absent)
+  e2e_generate disk -> .mm through `write_fingerprints` on the 100-clip config-1 set and a
+               600-clip set (second figure), with the ingest / launch split
+  train, train_1280   contrastive train steps/s at global BSZ 5120 / LAMB (configs[3]) and
+               BSZ 1280 / Adam (configs[2])
 """
 import argparse
 import json
@@ -97,19 +108,21 @@ def cpu_baseline(target_s=12.0, max_batches=40):
     tf = torch_ref.TorchFingerprinter(w)
     x = make_audio(125, 7, torch)                       # TS_BATCH_SZ of config/default.yaml
     with torch.no_grad():
-        best_t, best_n = None, 1
+        best_t, best_n, sweep = None, 1, {}
         for nt in sorted({min(cores, c) for c in (8, 16, 32, 64)}):
             torch.set_num_threads(nt)
             tf(torch_ref.melspec_layer(x))
             t0 = time.perf_counter()
             tf(torch_ref.melspec_layer(x))
             dt = time.perf_counter() - t0
+            sweep[str(nt)] = round(dt, 3)
             # efficiency per core decides: the processes below fill the box
             if best_t is None or dt * nt < best_t * best_n:
                 best_t, best_n = dt, nt
             if dt > 8.0:
                 break
-    procs = max(1, min(cores // best_n, 16))
+    procs = max(1, cores // best_n)                     # fill the host: every logical core gets a thread
+    best_n = cores // procs
     ctx = mp.get_context('spawn')
     with ctx.Pool(procs) as pool:
         res = pool.map(_cpu_worker, [(best_n, target_s, max_batches, 7 + k) for k in range(procs)])
@@ -117,20 +130,22 @@ def cpu_baseline(target_s=12.0, max_batches=40):
     el = max(r[1] for r in res)
     return {'value': round(sum(r[0] / r[1] for r in res), 2), 'unit': 'segments/s', 'cores': procs * best_n,
             'kind': 'port', 'host_cores': cores, 'processes': procs, 'threads_per_process': best_n,
+            'thread_sweep_s_per_batch': sweep,
             'sample': f'{n} segments in batches of 125 (TS_BATCH_SZ), torch-CPU fp32 restatement of melspec+encoder '
                       f'(oracle/torch_ref.py), {procs} processes x {best_n} threads side by side for {el:.1f} s'}
 
 
-def train_region(cfg, world, rank, dist, global_bsz, steps, torch, warmup=2):
+def train_region(cfg, world, rank, dist, global_bsz, steps, torch, warmup=2, optimizer='LAMB'):
     """Second half of BASELINE.json's metric: contrastive-train steps/s at a GLOBAL batch of 5120
     (configs[3]: config/640_lamb.yaml scaled, LAMB, tau 0.05), strong scaling: every rank takes
     5120/N segments (anchors + replicas), all-gathers the embeddings, all-reduces the gradients.
-    A step = melspec + spec-augment + forward + NT-Xent + backward + (collectives) + LAMB."""
+    A step = melspec + spec-augment + forward + NT-Xent + backward + (collectives) + optimizer.
+    Also used for configs[2] (BSZ 1280, Adam: `train_1280`)."""
     import copy
     from neural_audio_fp_amd.model import trainer as T
     c = copy.deepcopy(cfg)
     c['BSZ']['TR_BATCH_SZ'], c['BSZ']['TR_N_ANCHOR'] = global_bsz, global_bsz // 2
-    c['TRAIN']['OPTIMIZER'], c['TRAIN']['LR'] = 'LAMB', 1e-4
+    c['TRAIN']['OPTIMIZER'], c['TRAIN']['LR'] = optimizer, 1e-4
     if (global_bsz // 2) % world:
         return {'skipped': f'global batch {global_bsz} does not split over {world} ranks'}
     m_pre, m_specaug, m_fp, opt, loss_obj, bucket = T.setup(c, 1000)
@@ -161,7 +176,8 @@ def train_region(cfg, world, rank, dist, global_bsz, steps, torch, warmup=2):
         torch.cuda.synchronize()
         bucket.timed = False
         pieces = bucket.read_timings() or []
-        coll = {'all_gather(emb)_ms': None, 'reduce_scatter(d emb)_ms': None,
+        coll = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
+                'all_gather(emb)_ms': None, 'reduce_scatter(d emb)_ms': None,
                 'all_reduce(grad pieces)_ms': [round(x, 4) for x in pieces],
                 'grad_piece_MB': [round(p.numel() * 4 / 1e6, 2) for p in bucket.pieces],
                 'overlap': 'gradient pieces run on a communication stream behind per-group events of the backward pass; '
@@ -175,12 +191,97 @@ def train_region(cfg, world, rank, dist, global_bsz, steps, torch, warmup=2):
     tf = flops / (el / steps) / 1e12
     return {'metric': 'contrastive train steps/s', 'value': round(steps / el, 4), 'unit': 'steps/s',
             'global_batch': global_bsz, 'per_gpu_batch': global_bsz // world, 'n_gpus': world, 'steps': steps,
-            'warmup': warmup, 'ms_per_step': round(el / steps * 1e3, 3), 'scaling': 'strong', 'optimizer': 'LAMB',
+            'warmup': warmup, 'ms_per_step': round(el / steps * 1e3, 3), 'scaling': 'strong', 'optimizer': optimizer,
             'segments_per_s': round(global_bsz * steps / el, 1), 'loss': round(float(loss), 4),
             'algorithmic_TFLOP_per_step': round(flops / 1e12, 3), 'achieved_TFLOP/s': round(tf, 2),
             'mfma_frac_of_peak': round(tf / (FP32_MFMA_PEAK_TFLOPS * world), 4),
             'collectives': coll,
             'data': 'synthetic (seeded noise anchors, replicas = anchors + noise at 5 dB SNR), resident in HBM'}
+
+
+def e2e_generate(cfg, torch, n_small=100, n_large=600):
+    """SURVEY.md 8d config 2, second figure: DISK -> .mm through the product's own `write_fingerprints` (whole-file
+    upload into pinned arenas, device-side windows, 4 HIP streams, pinned download, memmap store), on the config-1 set
+    (100 clips x 30 s, 16-bit 8 kHz mono WAV: `default_rng(1000+k)` noise + 3 tones, TS_BATCH_SZ 125 -> 5,900 segments)
+    and on a 600-clip set (35,400 segments).  The files were written a moment ago, so "disk" is the page cache of this
+    box.  Split: `ingest_only` = the host side alone (header scan excluded; file reads into the pinned arenas + window
+    plan, no GPU work), `device_only` = the headline single-stream figure of this run."""
+    import shutil
+    import tempfile
+    import wave
+    import numpy as np
+    from neural_audio_fp_amd.model import generate as g
+    from neural_audio_fp_amd.model.utils.audio_utils import SegmentSource
+    d = tempfile.mkdtemp(prefix='nafp_e2e_')
+    try:
+        t = np.arange(240000) / 8000.0
+        for k in range(n_large):
+            rng = np.random.default_rng(1000 + k)
+            x = rng.integers(-8192, 8192, size=240000).astype(np.float64)
+            for f in rng.uniform(300, 3900, size=3):
+                x += 4000 * np.sin(2 * np.pi * f * t)
+            with wave.open(os.path.join(d, f'{k:05d}.wav'), 'w') as w:
+                w.setnchannels(1); w.setsampwidth(2); w.setframerate(8000)
+                w.writeframes(np.clip(x, -32768, 32767).astype('<i2').tobytes())
+        paths = sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith('.wav'))
+        m_pre, m_fp = g.build_fp(cfg)
+        group = int(cfg['BSZ']['TS_BATCH_SZ'])
+        out = {'unit': 'segments/s', 'group_size': group, 'launch_segments': g.LAUNCH_SEGMENTS, 'streams': g.N_STREAMS,
+               'source': '16-bit 8 kHz mono WAV, 30 s each, written by this run (page cache), read by riff_scan + whole-file '
+                         'upload; output = np.memmap float32 (n,128) + flush'}
+        for name, n in (('clips_100', n_small), ('clips_600', n_large)):
+            t0 = time.perf_counter()
+            src = SegmentSource(paths[:n], bsz=group)
+            scan_s = time.perf_counter() - t0
+            arr = np.memmap(os.path.join(d, f'{name}.mm'), dtype='float32', mode='w+', shape=(src.n_samples, 128))
+            emb = g.StreamedEmbedder(m_pre, m_fp)
+            runs = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                g.write_fingerprints(src, emb, arr, group)
+                arr.flush()
+                runs.append(time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            for _ in src.iter_windows(0, src.n_samples, -(-g.LAUNCH_SEGMENTS // group) * group, alloc=emb.alloc):
+                pass
+            ingest_s = time.perf_counter() - t0
+            best = min(runs)
+            assert bool(np.isfinite(arr[-1]).all()) and abs(float(np.linalg.norm(arr[src.n_samples // 2])) - 1.0) < 1e-4
+            out[name] = {'segments': int(src.n_samples), 'value': round(src.n_samples / best, 1),
+                         'seconds_runs': [round(r, 4) for r in runs], 'header_scan_s': round(scan_s, 4),
+                         'ingest_only_s': round(ingest_s, 4), 'ingest_only_segments_per_s': round(src.n_samples / ingest_s, 1)}
+            del arr
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as ONE child process tree
+    (`python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>`), relay rank 0's JSON line, return
+    the child's exit code.  This parent never initialises the GPU (no HIP call, no torch.cuda.is_available()), so
+    nothing that touched the GPU is replaced or forked."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = []
+    for line in child.stdout:
+        if line.startswith('{'):
+            lines.append(line)
+        else:
+            sys.stderr.write(line)
+    rc = child.wait()
+    for line in lines:
+        sys.stdout.write(line)
+    sys.stdout.flush()
+    return rc
 
 
 def main():
@@ -192,7 +293,9 @@ def main():
                     help='streams of the timed region (1: every kernel runs alone, so HIP-event launch '
                          'durations are the kernels own).  With 1, a second region with 4 streams is '
                          'timed afterwards and reported as "pipelined".')
+    ap.add_argument('--repeats', type=int, default=5, help='timed regions of --steps steps each; the median is reported')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-e2e', action='store_true', help='skip the disk -> .mm figures (reported as "e2e_generate")')
     ap.add_argument('--no-train', action='store_true', help='skip the contrastive-train region (reported as "train")')
     ap.add_argument('--train-steps', type=int, default=6)
     ap.add_argument('--train-bsz', type=int, default=5120, help='GLOBAL train batch (BASELINE.json configs[3])')
@@ -201,10 +304,15 @@ def main():
                          'averages cover the single-stream launches only)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))                # nothing above has touched the GPU
+
     import torch
     import yaml
     import __graft_entry__
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != max(args.gpus, 1):
+        sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}')
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if rank == 0:
@@ -262,22 +370,27 @@ def main():
     # average launch = span / 15.  An event RECORDED between two kernels idles the GPU (~20 us of un-overlapped dispatch
     # set-up each), so everything else -- the per-conv split, conv0, the front end, the tail -- is taken from a second,
     # untimed pass below.
-    m_fp.profile_enable(args.steps, coarse=2)
+    reps = max(1, args.repeats)
+    m_fp.profile_enable(args.steps * reps, coarse=2)
     ev = None
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        emb = step_on(i, ev)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([el], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t[0])
+    regions = []
+    for _ in range(reps):
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            emb = step_on(i, ev)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([el], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t[0])
+        regions.append(el)
+    el = sorted(regions)[len(regions) // 2]             # the median region is the one reported
     assert emb.shape == (BSZ, 128) and bool(torch.isfinite(emb).all())
 
     prof = m_fp.profile_read()
@@ -351,9 +464,15 @@ def main():
                   'min_cosine_vs_f32_path': float((got_emb * ref_emb).sum(1).min()),
                   'note': 'experimental option NAFP_OPT_BF16X3 on the unsplit GEMM convs (convs 1-6, 8 at BSZ 640); NOT the '
                           "reference's arithmetic, not part of `value`"}
-    train = None
+    train, train_1280 = None, None
     if not args.no_train:
         train = train_region(cfg, world, rank, dist, args.train_bsz, args.train_steps, torch)
+        if world == 1:                                  # BSZ 1280, Adam, one GPU
+            train_1280 = train_region(cfg, world, rank, dist, min(1280, args.train_bsz), max(args.train_steps, 12), torch,
+                                      warmup=3, optimizer='Adam')
+    e2e = None
+    if world == 1 and not args.no_e2e:
+        e2e = e2e_generate(cfg, torch)
     iso = None
     if n_str > 1:
         m_fp.profile_enable(6)
@@ -381,6 +500,10 @@ def main():
             'metric': 'fingerprint generation throughput (1-s segments/s)',
             'value': round(value, 1), 'unit': 'segments/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(el / args.steps * 1e3, 4),
+            'repeats': reps,
+            'spread': {'ms_per_step_all': [round(r / args.steps * 1e3, 4) for r in regions],
+                       'min': round(min(regions) / args.steps * 1e3, 4), 'max': round(max(regions) / args.steps * 1e3, 4),
+                       'note': f'{reps} timed regions of {args.steps} steps each; ms_per_step / value = the median region'},
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
             'config': {'workload': 'generate: f32 audio (640,1,8000) resident in HBM -> log-mel -> '
@@ -422,6 +545,10 @@ def main():
             out['bf16x3_experimental'] = bf16x3
         if train:
             out['train'] = train
+        if train_1280:
+            out['train_1280'] = train_1280
+        if e2e:
+            out['e2e_generate'] = e2e
         if iso:
             iso_ms = sum(sum(p[1:16]) for p in iso) / len(iso)
             iso_ach = gemm_flops_per_step / (iso_ms * 1e-3) / 1e12

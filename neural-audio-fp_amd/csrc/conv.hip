@@ -998,7 +998,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         const unsigned ticket = sTicket[0];
         if (ticket != (unsigned)(p.n_split - 1)) return;
         __syncthreads();                                              // sTicket is read: LDS is reused by the statistics below
-        if (tid == 0) p.tickets[tile_id] = 0u;                        // ready for the next launch
+        if (tid == 0)                                                 // ready for the next launch; agent scope like every other access
+            __hip_atomic_store(p.tickets + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll

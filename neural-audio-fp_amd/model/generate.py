@@ -106,21 +106,34 @@ def prune_checkpoints(checkpoint_root_dir, checkpoint_name, max_to_keep=3, keep_
 
 
 def overwrite_refused(key, target_path):
-    """The question of generate.py:55-58, answered without exiting.  No terminal on stdin (batch job, torchrun): the
-    prompt cannot be answered; the file is then overwritten, with a notice."""
+    """The question of generate.py:55-58, answered without exiting: 0 = go ahead, 1 = the user declined, 2 = nobody
+    could be asked.  The reference calls `input()`: a terminal or a piped answer is read the same way, and an exhausted
+    stdin (batch job, nohup, torchrun) raises EOFError there.  Here that case refuses -- the expensive dummy_db.mm is
+    never overwritten silently -- unless NAFP_OVERWRITE=1 says so explicitly."""
     if (key == 'dummy_db') & os.path.exists(target_path):
-        if not sys.stdin or not sys.stdin.isatty():
-            print(f'{target_path} exists; stdin is not a terminal, nobody to ask: the file will be overwritten (overwrite prompt skipped).')
-            return False
-        answer = input(f'{target_path} exists. Will you overwrite (y/N)?')
-        return answer.lower() not in ['y', 'yes']
-    return False
+        if os.environ.get('NAFP_OVERWRITE', '').lower() in ('1', 'y', 'yes', 'true'):
+            print(f'{target_path} exists; NAFP_OVERWRITE is set: the file will be overwritten.')
+            return 0
+        try:
+            answer = input(f'{target_path} exists. Will you overwrite (y/N)?')
+        except (EOFError, OSError):
+            print(f'\n{target_path} exists and there is nobody to ask (stdin is closed): NOT overwriting.  Set '
+                  'NAFP_OVERWRITE=1 to overwrite without the prompt, or pass --skip_dummy.', file=sys.stderr)
+            return 2
+        return 0 if answer.lower() in ['y', 'yes'] else 1
+    return 0
+
+
+def _leave(refused):
+    """generate.py:58 exits quietly when the user says no; an unanswerable prompt is an error exit."""
+    sys.exit(None if refused == 1 else f'generate: refused to overwrite (code {refused})')
 
 
 def prevent_overwrite(key, target_path):
     """generate.py:55-58."""
-    if overwrite_refused(key, target_path):
-        sys.exit()
+    refused = overwrite_refused(key, target_path)
+    if refused:
+        _leave(refused)
 
 
 def get_data_source(cfg, source_root_dir, skip_dummy):
@@ -379,11 +392,11 @@ def generate_fingerprint(cfg, checkpoint_name, checkpoint_index, source_root_dir
     if not skip_dummy:
         # rank 0 asks; every rank learns the answer, so that all of them leave together (a lone sys.exit on
         # rank 0 would strand the others in the barrier below)
-        refused = [overwrite_refused('dummy_db', f'{output_root_dir}/dummy_db.mm') if rank == 0 else False]
+        refused = [overwrite_refused('dummy_db', f'{output_root_dir}/dummy_db.mm') if rank == 0 else 0]
         if dist:
             dist.broadcast_object_list(refused, src=0)
         if refused[0]:
-            sys.exit()
+            _leave(refused[0])
 
     embed = StreamedEmbedder(m_pre, m_fp)
 

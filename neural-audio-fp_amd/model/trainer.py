@@ -45,8 +45,10 @@ def build_fp(cfg):
 
 
 def _dist():
+    """torch.distributed when a process group exists -- also a group of ONE rank (legal for RCCL): the step then runs
+    the same collectives as on a node (tests/test_gpu_train_dp.py drives that on the 1-GPU box)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         return dist
     return None
 
@@ -171,14 +173,16 @@ def scatter_embedding_gradients(dist, loss_local, d_a_all, d_b_all, n_anchors):
 
 
 def _reduce_scatter(dist, recv, send):
-    """recv = sum over ranks of send[rank] (reduce_scatter_tensor over RCCL; a backend without it -- some gloo
-    builds, CPU tests only -- falls back to an all-reduce and a slice)."""
-    try:
+    """recv = sum over ranks of send[rank].  The path is chosen ONCE from the backend, never from an exception:
+    RCCL ('nccl') runs `reduce_scatter_tensor` and every error it raises propagates (a rank that swallowed one would
+    issue a different collective than its peers); gloo -- the CPU-side test harness, which has no tensor
+    reduce-scatter -- sums the whole send buffer and keeps this rank's chunk."""
+    if dist.get_backend() == 'nccl':
         dist.reduce_scatter_tensor(recv, send.view(-1))
-    except (RuntimeError, NotImplementedError):
-        full = send.clone()
-        dist.all_reduce(full)
-        recv.copy_(full[dist.get_rank()])
+        return
+    full = send.clone()
+    dist.all_reduce(full)
+    recv.copy_(full[dist.get_rank()])
 
 
 def val_step(X, m_pre, m_fp, loss_obj):

@@ -1,6 +1,7 @@
 """Worker of tests/test_gpu_train_dp.py: one rank of a 2- or 4-process data-parallel train step.
 Both ranks share cuda:0 and talk over gloo (the GPU box has one GPU; on a node the same code
-runs one rank per GPU over RCCL).  Usage: python -m torch.distributed.run ... _dp_train_worker.py OUT_DIR"""
+runs one rank per GPU over RCCL).  With BACKEND = nccl and one process the same step runs its collectives on RCCL
+itself (a group of one rank).  Usage: python -m torch.distributed.run ... _dp_train_worker.py OUT_DIR [N] [BACKEND]"""
 import os
 import sys
 
@@ -26,11 +27,14 @@ class Identity:
         return x
 
 
-def main(out_dir, n=4):
+def main(out_dir, n=4, backend='gloo'):
     n = int(n)
-    dist.init_process_group('gloo')
-    rank = dist.get_rank()
     torch.cuda.set_device(0)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+    else:
+        dist.init_process_group(backend)
+    rank = dist.get_rank()
     import neural_audio_fp_amd as nafp
     from neural_audio_fp_amd.model import trainer as T
     from neural_audio_fp_amd.model.fp.lamb_optimizer import LAMB
@@ -48,11 +52,12 @@ def main(out_dir, n=4):
         losses.append(float(loss))
         if step == 0:
             g0 = bucket.flat.detach().cpu().clone()
-    torch.save({'losses': losses, 'grad0': g0, 'params': [v.detach().cpu() for v in m_fp.trainable_variables]},
+    torch.save({'losses': losses, 'grad0': g0, 'params': [v.detach().cpu() for v in m_fp.trainable_variables],
+                'backend': dist.get_backend(), 'world': dist.get_world_size()},
                os.path.join(out_dir, f'rank{rank}.pt'))
     dist.barrier()
     dist.destroy_process_group()
 
 
 if __name__ == '__main__':
-    main(*sys.argv[1:3])
+    main(*sys.argv[1:4])

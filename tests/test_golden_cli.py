@@ -21,7 +21,7 @@ def _mine():
 def test_commands_arguments_and_options_match_the_reference():
     cli = _mine()
     assert sorted(cli.commands) == sorted(G['commands'])
-    declared_deviations = {('evaluate', 'index_type', 'default'): 'L2'}       # reference default 'ivfpq' (faiss) is not built
+    declared_deviations = {}
     extra_options = {'train': {'synthetic'}}
     for name, want in G['commands'].items():
         got = {p.name: p for p in cli.commands[name].params}

@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_line_contract():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '4', '--warmup', '2',
-                        '--train-steps', '2', '--train-bsz', '256'], cwd=ROOT, capture_output=True, text=True, timeout=900)
+                        '--repeats', '3', '--train-steps', '2', '--train-bsz', '256'], cwd=ROOT, capture_output=True, text=True,
+                       timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1
@@ -26,6 +27,9 @@ def test_bench_line_contract():
     assert d['unit'] == 'segments/s' and d['scaling'] == 'weak' and d['vs_baseline'] is None and d['dtype'] == 'f32'
     assert d['data'] == 'synthetic' and 'workload' in d['config'] and 'model' not in d['config']
     assert abs(d['value'] - 640 * 4 / (d['ms_per_step'] * 4 / 1e3)) < 1e-3 * d['value']              # value = units / time
+    sp = d['spread']
+    assert d['repeats'] == 3 and len(sp['ms_per_step_all']) == 3 and sp['min'] <= d['ms_per_step'] <= sp['max']
+    assert d['ms_per_step'] == sorted(sp['ms_per_step_all'])[1]                                       # the median region
     rf = d['roofline']
     for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
         assert k in rf, k
@@ -36,19 +40,31 @@ def test_bench_line_contract():
     for k in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert k in cb, k
     assert cb['kind'] == 'port' and cb['unit'] == 'segments/s' and cb['value'] > 0 and cb['cores'] >= 1
+    assert cb['cores'] > cb['host_cores'] - cb['processes'], cb                                       # the host is filled
     tr = d['train']
     assert tr['global_batch'] == 256 and tr['unit'] == 'steps/s' and tr['value'] > 0 and tr['scaling'] == 'strong'
+    t2 = d['train_1280']
+    assert t2['optimizer'] == 'Adam' and t2['global_batch'] == 256 and t2['value'] > 0
+    e = d['e2e_generate']
+    assert e['clips_100']['segments'] == 5900 and e['clips_600']['segments'] == 35400
+    assert e['clips_100']['value'] > 0 and e['clips_600']['value'] > 0 and e['clips_600']['ingest_only_segments_per_s'] > 0
 
 
-def test_bench_two_ranks_on_one_gpu_prints_train_with_collective_timings():
-    """The N > 1 path the driver launches (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`),
-    here with 2 ranks sharing cuda:0 over gloo (NAFP_BENCH_BACKEND / NAFP_BENCH_ONE_GPU: RCCL refuses two ranks per
-    GPU): ONE JSON line from rank 0, whole-job value, and the `train` object with per-collective timings."""
+@pytest.mark.parametrize('form', ['bare', 'torchrun'])
+def test_bench_two_ranks_on_one_gpu_prints_train_with_collective_timings(form):
+    """The two N > 1 forms: 'bare' = `python bench.py --gpus 2 ...` with no WORLD_SIZE (what the driver's BENCH/SCALE
+    command line looks like): bench.py starts the ranks itself as a child `torch.distributed.run` and relays rank 0's
+    line; 'torchrun' = already under `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...`.
+    Here 2 ranks share cuda:0 over gloo (NAFP_BENCH_BACKEND / NAFP_BENCH_ONE_GPU: RCCL refuses two ranks per GPU):
+    ONE JSON line from rank 0, whole-job value, and the `train` object with per-collective timings."""
     env = dict(os.environ, NAFP_BENCH_BACKEND='gloo', NAFP_BENCH_ONE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
     port = 29800 + (os.getpid() % 100)
-    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-                        '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
-                        '--gpus', '2', '--steps', '3', '--warmup', '1', '--train-steps', '2', '--train-bsz', '128'],
+    launcher = [] if form == 'bare' else ['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                                          '--master-addr', '127.0.0.1', '--master-port', str(port)]
+    r = subprocess.run([sys.executable] + launcher + [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                                                      '--repeats', '2', '--train-steps', '2', '--train-bsz', '128'],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -59,6 +75,7 @@ def test_bench_two_ranks_on_one_gpu_prints_train_with_collective_timings():
     tr = d['train']
     assert tr['n_gpus'] == 2 and tr['global_batch'] == 128 and tr['per_gpu_batch'] == 64 and tr['scaling'] == 'strong'
     c = tr['collectives']
+    assert c['backend'] == 'gloo' and c['world_size'] == 2
     assert c['all_gather(emb)_ms'] > 0 and c['reduce_scatter(d emb)_ms'] > 0
     assert len(c['all_reduce(grad pieces)_ms']) == 4 and all(x > 0 for x in c['all_reduce(grad pieces)_ms'])
     assert abs(sum(c['grad_piece_MB']) - 67.76) < 0.1

@@ -60,6 +60,43 @@ def test_multi_rank_step_equals_single_process_step(nafp, tmp_path, world, n):
     assert float(loss2) < float(loss)
 
 
+def test_one_rank_rccl_group_runs_every_collective_of_the_step(nafp, tmp_path):
+    """the distributed branch of `train_step` on the REAL backend.  A process group of one rank
+    is legal for RCCL, so `all_gather_into_tensor`, `reduce_scatter_tensor` (the nccl path of `_reduce_scatter`, no
+    fallback) and the 4 gradient-piece all-reduces on the communication stream all execute on RCCL; the step must equal
+    the non-distributed step on the same batch."""
+    from neural_audio_fp_amd.model import trainer as T
+    from neural_audio_fp_amd.model.fp.lamb_optimizer import LAMB
+    n = 6
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    port = 29400 + (os.getpid() % 150)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+                        '--master-addr', '127.0.0.1', '--master-port', str(port),
+                        os.path.join(ROOT, 'tests', '_dp_train_worker.py'), str(tmp_path), str(n), 'nccl'],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    got = torch.load(tmp_path / 'rank0.pt', weights_only=True)
+    assert got['backend'] == 'nccl' and got['world'] == 1
+    fa, fp = W.features(0, n)
+    X = (torch.from_numpy(fa).cuda(), torch.from_numpy(fp).cuda())
+    m_fp = nafp.FingerPrinter(seed=0)
+    m_fp.set_weights(_inputs.weight_list(_inputs.weights(seed=31)))
+    bucket = T.GradientBucket(m_fp)
+    opt = LAMB(learning_rate=1e-3)
+    loss_obj = nafp.NTxentLoss(n_org=n, n_rep=n, tau=0.05)
+    assert T._dist() is None                                        # this process: the plain single-device step
+    loss, _ = T.train_step(X, W.Identity(), W.Identity(), m_fp, loss_obj, opt, bucket)
+    assert abs(float(loss) - got['losses'][0]) < 1e-5 * max(1.0, abs(float(loss)))
+    g1 = bucket.flat.cpu()
+    o = 0
+    for v in m_fp.trainable_variables:
+        a, b = g1[o:o + v.numel()], got['grad0'][o:o + v.numel()]
+        o += v.numel()
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-9
+    loss2, _ = T.train_step(X, W.Identity(), W.Identity(), m_fp, loss_obj, opt, bucket)
+    assert abs(float(loss2) - got['losses'][1]) < 1e-3 * max(1.0, abs(float(loss2)))
+
+
 def test_weights_marked_dirty_then_four_streams(nafp):
     """the re-pack of the weights (nafp_encoder_set_weights: copies, packs, G/Hb launches into the handle's
     shared blob) is enqueued on ONE stream; forwards issued right afterwards on other streams must wait for it, and a
