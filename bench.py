@@ -96,7 +96,7 @@ def _cpu_worker(args):
     return n, el
 
 
-def cpu_baseline(target_s=12.0, max_batches=40):
+def cpu_baseline(target_s=10.0, max_batches=40):
     """The oracle's torch-CPU restatement of melspec + encoder on the HOST CORES OF THIS BOX (kind "port"): first the
     fastest intra-op thread count of one process is found (all cores is not the fastest at batch 125), then as many
     such processes as fit the box run side by side, each on its own batches; the value is their summed throughput."""
@@ -121,18 +121,26 @@ def cpu_baseline(target_s=12.0, max_batches=40):
                 best_t, best_n = dt, nt
             if dt > 8.0:
                 break
-    procs = max(1, cores // best_n)                     # fill the host: every logical core gets a thread
-    best_n = cores // procs
+    # Every logical core gets a thread (procs x threads == host cores), and -- because on an SMT / bandwidth-bound host the
+    # half-filled box can be the faster one -- the half-filled arrangement is timed as well: `value` is the better of the
+    # two, `process_sweep` shows both.
     ctx = mp.get_context('spawn')
-    with ctx.Pool(procs) as pool:
-        res = pool.map(_cpu_worker, [(best_n, target_s, max_batches, 7 + k) for k in range(procs)])
-    n = sum(r[0] for r in res)
-    el = max(r[1] for r in res)
-    return {'value': round(sum(r[0] / r[1] for r in res), 2), 'unit': 'segments/s', 'cores': procs * best_n,
-            'kind': 'port', 'host_cores': cores, 'processes': procs, 'threads_per_process': best_n,
-            'thread_sweep_s_per_batch': sweep,
-            'sample': f'{n} segments in batches of 125 (TS_BATCH_SZ), torch-CPU fp32 restatement of melspec+encoder '
-                      f'(oracle/torch_ref.py), {procs} processes x {best_n} threads side by side for {el:.1f} s'}
+    full = max(1, cores // best_n)
+    runs = {}
+    for procs in sorted({max(1, full // 2), full}):
+        threads = best_n if procs < full else max(best_n, cores // procs)
+        with ctx.Pool(procs) as pool:
+            res = pool.map(_cpu_worker, [(threads, target_s, max_batches, 7 + k) for k in range(procs)])
+        runs[procs] = {'processes': procs, 'threads_per_process': threads, 'cores': procs * threads,
+                       'value': round(sum(r[0] / r[1] for r in res), 2), 'segments': sum(r[0] for r in res),
+                       'seconds': round(max(r[1] for r in res), 1)}
+    best = max(runs.values(), key=lambda r: r['value'])
+    return {'value': best['value'], 'unit': 'segments/s', 'cores': best['cores'], 'kind': 'port', 'host_cores': cores,
+            'processes': best['processes'], 'threads_per_process': best['threads_per_process'],
+            'thread_sweep_s_per_batch': sweep, 'process_sweep': list(runs.values()),
+            'sample': f"{best['segments']} segments in batches of 125 (TS_BATCH_SZ), torch-CPU fp32 restatement of melspec+encoder "
+                      f"(oracle/torch_ref.py), {best['processes']} processes x {best['threads_per_process']} threads side by side "
+                      f"for {best['seconds']} s; the host was timed half-filled and filled ({cores} logical cores), the faster is reported"}
 
 
 def train_region(cfg, world, rank, dist, global_bsz, steps, torch, warmup=2, optimizer='LAMB'):

@@ -281,19 +281,22 @@ struct ConvKernelParams {
     int B, P;                 // samples; output positions per sample (Fout*Tout)
     int PT, ST, log2ST;       // tile = PT positions x ST samples
     int n_sg;                 // sample groups = ceil(B / ST)
+    int n_pb, log2_ncol;      // position blocks = ceil(P / PT); log2 of the column tiles (the XCD-aware 1-D grid, opt & 8)
     int64_t sample_in;        // Fin*Tin*Cin
     int tap_stride;           // elements between consecutive taps of one output row
     double inv_n_in;          // 1 / sample_in
     int mode;                 // 0 FULL, 1 PLAIN
     int dgrad;                // 1: transposed conv (backward w.r.t. the conv input), see row_geom()
-    int perm_on, perm_n0, perm_c0;   // DGRAD, stride 2: tile rows enumerate positions parity class by class (tile_pos())
+    int perm_on, perm_n0, perm_c0;   // 1 = DGRAD, stride 2: tile rows enumerate positions parity class by class; 2 = forward conv along T: the last
+                                     // output frame of every line goes last (tile_pos())
     unsigned wp_bytes;
     int n_split;              // split-K factor (blockIdx.z); > 1 writes raw partial sums to `y` = slab
     int abl;                  // ablation flags for kernel-time breakdown (NAFP_ABL env; 0 in production)
     unsigned* tickets;        // split-K with the finish in-kernel (EPI 4): one arrival counter per output tile, zero between launches
     float* y_final;           //   ... and the output tensor (`y` is the slab of partial sums there)
     unsigned long long* tl;   // diagnostic phase timeline (nafp_conv_timeline), null in production: 8 u64 per wave
-    int opt;                  // bit 0: the geometry prologue runs at raised wave priority, bit 1: the epilogue does (NAFP_GEMM_PRIO); bit 2: 3-D grid
+    int opt;                  // bit 0: the geometry prologue runs at raised wave priority, bit 1: the epilogue does (NAFP_GEMM_PRIO); bit 2: 3-D grid;
+                              // bit 3: 1-D grid in XCD-aware order, bit 4: ... row-fastest (see the block-id decode of conv_gemm_body)
     // FUSE0 (conv1 only): the A operand z0 = gamma0 . ELU(conv0(feat)) is generated in-kernel
     // from the log-mel features instead of being read from memory (`x` unused).
     const float* f0_feat;     // (B, F0, T0)
@@ -371,8 +374,20 @@ __device__ __forceinline__ RowGeom row_geom(const ConvKernelParams& p, int pos) 
 // coordinate is = perm_c0 mod 2, then the others).  A tile then holds rows of ONE class (up to the
 // single boundary tile) and the tile-wide dead-tap skip removes the structurally zero half of the
 // K-steps instead of multiplying zeros.
+//
+// perm_on == 2 (FORWARD conv along T, the minor coordinate): the LAST output coordinate of every line is the one whose
+// window hangs over the end of the input (TF SAME puts the odd padding element behind the data, nnfp.py:48-61), i.e. the
+// only positions whose tap 2 -- or, for the stride-1 two-frame layer, whose tap 0 resp. 2 -- reads zero padding.  They are
+// enumerated after all the others, so that a tile of PT positions (PT divides both class sizes, launch_conv_gemm) holds
+// one class and the tile-wide dead-tap skip drops that tap's K-steps: 1/3 of conv8's work, 1/6 of conv6's, 1/12 and 1/24
+// of conv4's and conv2's at the 1-s input.  (Along F the natural order already ends with that class: only PT matters.)
 __device__ __forceinline__ int tile_pos(const ConvKernelParams& p, int idx) {
     if (!p.perm_on || idx >= p.P) return idx;
+    if (p.perm_on == 2) {
+        const int L = p.Tout, lines = p.P / L, n0 = L - 1;
+        if (idx < lines * n0) { const int line = idx / n0; return line * L + (idx - line * n0); }
+        return (idx - lines * n0) * L + n0;
+    }
     const int n0 = p.perm_n0;
     if (p.axis == 0) {            // tap axis = minor coordinate, L = p.Tout per line
         const int L = p.Tout, lines = p.P / L, n1 = L - n0;
@@ -440,6 +455,30 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     // grid = (sample groups, position blocks, column tiles): no division to take a block id apart
     // (split-K launches keep (sample groups x position blocks, column tiles, parts): their dispatch order matters more)
     int sg = blockIdx.x, pb = blockIdx.y, colz = blockIdx.z, zsp = 0;      // ..., column tile, split-K part
+    if (p.opt & 8) {
+        // XCD-aware order on a 1-D grid: workgroup b runs on XCD b % 8 and every XCD has its own L2, so
+        // XCD x is handed the CONTIGUOUS chunk x of the work-item sequence v (a bijection for any total), and v is laid
+        // out so that the items which share an operand are neighbours inside a chunk:
+        //   column-fastest (opt & 16 clear; activations are the big operand): the column tiles -- and split-K parts -- of
+        //     one row tile run on one XCD at the same time and read its A rows from HBM once instead of once per column tile;
+        //   row-fastest (opt & 16; the late convs, weights >= activations): an XCD owns whole column tiles, their weight
+        //     slice is fetched by ONE L2 instead of by all eight.
+        const unsigned lin = blockIdx.x, total = gridDim.x;
+        const unsigned xcd = lin & 7u, base = total >> 3, rem = total & 7u;
+        unsigned v = xcd * base + (xcd < rem ? xcd : rem) + (lin >> 3);
+        unsigned rt;
+        if (p.opt & 16) {
+            const unsigned n_rt = (unsigned)(p.n_sg * p.n_pb);
+            unsigned t = v / n_rt; rt = v - t * n_rt;
+            if (p.n_split > 1) { const unsigned c = t / (unsigned)p.n_split; zsp = (int)(t - c * (unsigned)p.n_split); t = c; }
+            colz = (int)t;
+        } else {
+            colz = (int)(v & ((1u << p.log2_ncol) - 1u)); v >>= p.log2_ncol;
+            if (p.n_split > 1) { const unsigned r = v / (unsigned)p.n_split; zsp = (int)(v - r * (unsigned)p.n_split); v = r; }
+            rt = v;
+        }
+        pb = (int)(rt / (unsigned)p.n_sg); sg = (int)(rt - (unsigned)pb * (unsigned)p.n_sg);
+    } else
     if (!(p.opt & 4)) { pb = blockIdx.x / p.n_sg; sg = blockIdx.x - pb * p.n_sg; colz = blockIdx.y; zsp = blockIdx.z; }
     const int tile_n0 = colz * BNT;
     const int K = 3 * p.Cin;
@@ -671,7 +710,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
 #define NAFP_EPI_LOAD(mi_, slot_)                                                              \
     _Pragma("unroll") for (int rg = 0; rg < 4; ++rg) {                                         \
         const int grp_l = wm * 16 + (mi_) * 8 + 2 * rg + (lane >> 5);                          \
-        const int pos_l = pb * p.PT + (grp_l >> (p.log2ST - 2));                               \
+        const int pos_l = sPos[grp_l >> (p.log2ST - 2)];               /* = tile_pos(), P beyond the end */ \
         const int pofs_l = pos_l < p.P ? (pos_l * p.Cout + n_base) * 4 : (int)0x80000000;      \
         _Pragma("unroll") for (int ni = 0; ni < NIW; ++ni) {                                   \
             if NAFP_ABL(p, 32) { Gv[slot_][rg][ni] = 0.5f; Hv[slot_][rg][ni] = 0.25f; gv[slot_][rg][ni] = 1.5f; continue; } \
@@ -980,7 +1019,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int grp = wm * 16 + mi * 8 + 2 * rg + (lane >> 5);
-                const int pos = pb * p.PT + (grp >> (p.log2ST - 2));
+                const int pos = sPos[grp >> (p.log2ST - 2)];
                 const int sl0 = (grp & (g4 - 1)) << 2;
                 voffs[mi][rg] = pos < p.P ? ((sl0 * p.P + pos) * p.Cout + n_base) * 4 : (int)0x80000000;
 #pragma unroll
@@ -1057,7 +1096,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         if (MIL == 1 && !(PREF && mi == 0)) { NAFP_EPI_LOAD(mi, 0) }                           \
         _Pragma("unroll") for (int rg = 0; rg < 4; ++rg) {                                     \
             const int grp = wm * 16 + mi * 8 + 2 * rg + (lane >> 5);      /* = tile row >> 2 */ \
-            const int pos = pb * p.PT + (grp >> (p.log2ST - 2));                               \
+            const int pos = sPos[grp >> (p.log2ST - 2)];                                       \
             const int sl0 = (grp & (g4 - 1)) << 2;                         /* first of the 4 samples */ \
             const int voff = pos < p.P ? ((sl0 * p.P + pos) * p.Cout + n_base) * 4 : (int)0x80000000; \
             _Pragma("unroll") for (int qp = 0; qp < 2; ++qp) {             /* samples sl0 + 2 qp, + 1 */ \
@@ -1388,6 +1427,37 @@ static int tile_pt(int P) {
     return pt;
 }
 
+// Position slots of a FORWARD tile.  Default: the largest power of two <= min(P, 32).  Where a sizeable share of the output
+// positions has a tap that reads only zero padding -- TF SAME puts the odd padding element behind the data, so with stride 2
+// that is the LAST output coordinate along the conv axis (tap 2), and for the stride-1 layer on two frames each of the two
+// frames has its own dead tap -- the tile takes positions of ONE class (PT divides both class sizes; along T the classes
+// are made contiguous by tile_pos(), perm 2) and the kernel's tile-wide dead-tap skip drops that tap's K-steps.
+// Taken only when it saves >= 3 % of the launch's MACs and does not cost the launch its register-resident statistics
+// (4 or 8 samples per position).  At the 1-s input and B = 640: conv8 -1/3, conv6 -1/6, conv13 -1/6, convs 4 / 11 -1/12,
+// conv2 -1/24 of their K-steps.  NAFP_TAPCLASS=0 switches it off.
+struct FwdTile { int pt, perm; };
+static FwdTile fwd_tile(const ConvGeom& g, int BM) {
+    const int P = g.Fout * g.Tout;
+    FwdTile r{tile_pt(P), 0};
+    static const int mode = []() { const char* e = getenv("NAFP_TAPCLASS"); return e ? atoi(e) : 1; }();
+    const int L = g.axis == 0 ? g.Tout : g.Fout, n_in = g.axis == 0 ? g.Tin : g.Fin;
+    if (!mode || L < 2) return r;
+    auto mask = [&](int o) { unsigned m = 0; for (int t = 0; t < 3; ++t) { const int i = o * g.stride - g.pad + t; if (i >= 0 && i < n_in) m |= 1u << t; } return m; };
+    unsigned m0 = 0;
+    for (int o = 0; o + 1 < L; ++o) m0 |= mask(o);
+    const unsigned m1 = mask(L - 1);
+    const int n_all = __builtin_popcount(m0 | m1), n0 = __builtin_popcount(m0), n1 = __builtin_popcount(m1);
+    const int64_t c1 = P / L, c0 = (int64_t)c1 * (L - 1);                 // positions per class
+    if (n_all == 0 || (double)(c0 * (n_all - n0) + c1 * (n_all - n1)) < 0.03 * (double)P * n_all) return r;
+    int pt = 1;
+    while (pt * 2 <= 32 && c0 % (pt * 2) == 0 && c1 % (pt * 2) == 0) pt *= 2;
+    const int st = BM / pt, st_def = BM / r.pt;
+    const bool fast = st == 4 || st == 8, fast_def = st_def == 4 || st_def == 8;
+    if (st < 4 || (fast_def && !fast)) return r;
+    r.pt = pt; r.perm = g.axis == 0 ? 2 : 0;
+    return r;
+}
+
 // Tile height of a launch: 256 rows (8 waves, 2 workgroups per CU) when the launch has enough 128-row tiles to fill the
 // chip several times over with the larger tile as well -- those launches are never split along K; 128 rows otherwise.
 // NAFP_BM256 = minimum number of 128-row tiles (0 = never; default 2000).  Measured at B = 640, same box, ms per launch
@@ -1466,6 +1536,8 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     int BM = a.f0_feat ? 128 : pick_bm(B, a.dgrad ? g.Fin * g.Tin : p.P, a.dgrad ? g.Cin : g.Cout);
     int pt = tile_pt(p.P);
     if (BM == 256 && !a.plain && !a.dgrad && 256 / pt != 8) BM = 128;      // FULL mode on 256 rows keeps its statistics in registers: 8 samples per position
+    int fwd_perm = 0;
+    if (!a.plain && !a.dgrad && !a.f0_feat) { const FwdTile ft = fwd_tile(g, BM); pt = ft.pt; fwd_perm = ft.perm; }
     p.PT = pt; p.ST = BM / pt;
     p.log2ST = 0;
     while ((1 << p.log2ST) < p.ST) ++p.log2ST;
@@ -1475,7 +1547,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     p.inv_n_in = 1.0 / (double)p.sample_in;
     p.mode = a.plain ? 1 : 0;
     p.n_split = 1;
-    p.dgrad = 0; p.perm_on = 0; p.perm_n0 = 0; p.perm_c0 = 0;
+    p.dgrad = 0; p.perm_on = fwd_perm; p.perm_n0 = 0; p.perm_c0 = 0;
     int k_steps = live_k_steps(g);
     if (a.dgrad) {
         // backward w.r.t. the conv input: rows = input positions, source = dT (B,Fout,Tout,Cout),
@@ -1531,11 +1603,25 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     const bool in_kernel_finish = fin_min > 0 && S > 1 && !a.plain && bn == 64 && a.tickets && n_tiles >= fin_min && n_tiles <= NAFP_TICKET_SLOTS;
     p.tickets = in_kernel_finish ? a.tickets : nullptr; p.y_final = a.y;
     static const int grid3d = []() { const char* e = getenv("NAFP_GRID3D"); return e ? atoi(e) : 1; }();
-    const bool g3 = S == 1 && grid3d != 0 && (grid3d == 1 || BM == 256 || bn == 128);
+    // NAFP_XCDMAP: 0 = the plain 3-D grids, 1 (default) = 1-D grid in XCD-aware order, the operand to keep inside one L2 chosen
+    // by size (column-fastest unless the live weights outweigh the activations read), 2 / 3 = force column- / row-fastest
+    static const int xcdmap = []() { const char* e = getenv("NAFP_XCDMAP"); return e ? atoi(e) : 1; }();
+    const int n_col = p.Cout / bn;
+    p.n_pb = n_pb; p.log2_ncol = 0;
+    while ((1 << p.log2_ncol) < n_col) ++p.log2_ncol;
+    const int64_t total_wg = (int64_t)p.n_sg * n_pb * n_col * S;
+    const bool xm = xcdmap != 0 && !a.f0_feat && (1 << p.log2_ncol) == n_col && total_wg < ((int64_t)1 << 31);
+    const bool g3 = !xm && S == 1 && grid3d != 0 && (grid3d == 1 || BM == 256 || bn == 128);
     if (g3) p.opt |= 4;
-    const dim3 grid = g3 ? dim3((unsigned)p.n_sg, (unsigned)n_pb, (unsigned)(p.Cout / bn))
+    if (xm) {
+        p.opt |= 8;
+        const double a_bytes = (double)B * (double)p.sample_in * 4.0, w_bytes = (double)k_steps * 16.0 * p.Cout * 4.0;
+        if (xcdmap == 3 || (xcdmap == 1 && w_bytes > a_bytes)) p.opt |= 16;
+    }
+    const dim3 grid = xm ? dim3((unsigned)total_wg)
+                    : g3 ? dim3((unsigned)p.n_sg, (unsigned)n_pb, (unsigned)(p.Cout / bn))
                          : dim3((unsigned)((int64_t)p.n_sg * n_pb), (unsigned)(p.Cout / bn), (unsigned)S);
-    if (n_pb > 65535 || p.Cout / bn > 65535) return NAFP_ERR_UNSUPPORTED;
+    if (!xm && (n_pb > 65535 || p.Cout / bn > 65535)) return NAFP_ERR_UNSUPPORTED;
     // (cin < 0 in nafp_conv_timeline selects the transposed conv -- DGRAD -- of the layer with that |cin|)
     if (g_timeline.buf && ((!a.plain && !a.dgrad && g.Cin == g_timeline.cin) || (a.dgrad && g.Cin == -g_timeline.cin)) &&
         g.Cout == g_timeline.cout && g.Fout * g.Tout == g_timeline.positions &&

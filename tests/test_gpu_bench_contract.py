@@ -40,7 +40,8 @@ def test_bench_line_contract():
     for k in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert k in cb, k
     assert cb['kind'] == 'port' and cb['unit'] == 'segments/s' and cb['value'] > 0 and cb['cores'] >= 1
-    assert cb['cores'] > cb['host_cores'] - cb['processes'], cb                                       # the host is filled
+    assert max(r['cores'] for r in cb['process_sweep']) > cb['host_cores'] - cb['processes'], cb      # the filled host was timed
+    assert cb['value'] == max(r['value'] for r in cb['process_sweep'])
     tr = d['train']
     assert tr['global_batch'] == 256 and tr['unit'] == 'steps/s' and tr['value'] > 0 and tr['scaling'] == 'strong'
     t2 = d['train_1280']

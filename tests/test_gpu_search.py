@@ -70,9 +70,15 @@ def test_topk_l2_is_not_inner_product_and_handles_ties_and_short_index(nafp):
     assert (I3[:, 7:] == -1).all() and np.isinf(D3[:, 7:]).all() and (I3[:, :7] >= 0).all()
     with pytest.raises(NotImplementedError):
         idx3.search(q[:1], 33)
+    # the reference's default index type (run.py:118 'ivfpq') and the other approximate faiss types are served by the
+    # exact search, with a notice; only --nogpu has nothing behind it
+    from neural_audio_fp_amd.eval.eval_faiss import get_index
+    for name in ('ivfpq', 'IVF', 'ivfpq-rr', 'ivfpq-ondisk', 'hnsw'):
+        assert isinstance(get_index(name, x, x.shape), FlatL2Index)
     with pytest.raises(NotImplementedError):
-        from neural_audio_fp_amd.eval.eval_faiss import get_index
-        get_index('ivfpq', x, x.shape)
+        get_index('ivfpq', x, x.shape, use_gpu=False)
+    with pytest.raises(ValueError):
+        get_index('lsh', x, x.shape)
 
 
 def test_sequence_evaluation_matches_oracle_and_writes_reference_files(nafp, tmp_path):
