@@ -282,6 +282,7 @@ struct ConvKernelParams {
     int PT, ST, log2ST;       // tile = PT positions x ST samples
     int n_sg;                 // sample groups = ceil(B / ST)
     int n_pb, log2_ncol;      // position blocks = ceil(P / PT); log2 of the column tiles (the XCD-aware 1-D grid, opt & 8)
+    int xcd_group, xcd_full;  //   ... items per group, and the number of items in full blocks of 8 groups
     int64_t sample_in;        // Fin*Tin*Cin
     int tap_stride;           // elements between consecutive taps of one output row
     double inv_n_in;          // 1 / sample_in
@@ -456,16 +457,23 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     // (split-K launches keep (sample groups x position blocks, column tiles, parts): their dispatch order matters more)
     int sg = blockIdx.x, pb = blockIdx.y, colz = blockIdx.z, zsp = 0;      // ..., column tile, split-K part
     if (p.opt & 8) {
-        // XCD-aware order on a 1-D grid: workgroup b runs on XCD b % 8 and every XCD has its own L2, so
-        // XCD x is handed the CONTIGUOUS chunk x of the work-item sequence v (a bijection for any total), and v is laid
-        // out so that the items which share an operand are neighbours inside a chunk:
-        //   column-fastest (opt & 16 clear; activations are the big operand): the column tiles -- and split-K parts -- of
-        //     one row tile run on one XCD at the same time and read its A rows from HBM once instead of once per column tile;
-        //   row-fastest (opt & 16; the late convs, weights >= activations): an XCD owns whole column tiles, their weight
-        //     slice is fetched by ONE L2 instead of by all eight.
-        const unsigned lin = blockIdx.x, total = gridDim.x;
-        const unsigned xcd = lin & 7u, base = total >> 3, rem = total & 7u;
-        unsigned v = xcd * base + (xcd < rem ? xcd : rem) + (lin >> 3);
+        // XCD-aware order on a 1-D grid: workgroup b runs on XCD b % 8 and every XCD has its own L2.  The
+        // work items v are laid out so that the G items which share an operand are consecutive (G = p.xcd_group), and
+        // consecutive GROUPS go to the XCDs round-robin: group g = 8 * block + x is executed by the workgroups
+        // b = 8 * (block * G + i) + x, i < G -- all on XCD x, dispatched within 8 G ids of each other.  (A bijection on the
+        // full blocks of 8 G items; the tail keeps v = b.)  The dispatch order stays the tile order, so tiles of different
+        // cost -- the live-tap classes -- spread over the XCDs as on the plain grid.
+        //   column-fastest (opt & 16 clear; activations are the big operand): G = column tiles x split-K parts of one row
+        //     tile: they read its A rows from HBM once instead of once per column tile;
+        //   row-fastest (opt & 16; the late convs, live weights > activations): G = the row tiles of one (column tile, part):
+        //     that weight slice is fetched by ONE L2 instead of by all eight.
+        const unsigned lin = blockIdx.x, G = (unsigned)p.xcd_group;
+        unsigned v = lin;
+        if (lin < (unsigned)p.xcd_full) {
+            const unsigned xcd = lin & 7u, j = lin >> 3;
+            const unsigned blk = j / G, i = j - blk * G;
+            v = (blk * 8u + xcd) * G + i;
+        }
         unsigned rt;
         if (p.opt & 16) {
             const unsigned n_rt = (unsigned)(p.n_sg * p.n_pb);
@@ -1607,17 +1615,21 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     // by size (column-fastest unless the live weights outweigh the activations read), 2 / 3 = force column- / row-fastest
     static const int xcdmap = []() { const char* e = getenv("NAFP_XCDMAP"); return e ? atoi(e) : 1; }();
     const int n_col = p.Cout / bn;
-    p.n_pb = n_pb; p.log2_ncol = 0;
+    p.n_pb = n_pb; p.log2_ncol = 0; p.xcd_group = 1; p.xcd_full = 0;
     while ((1 << p.log2_ncol) < n_col) ++p.log2_ncol;
     const int64_t total_wg = (int64_t)p.n_sg * n_pb * n_col * S;
-    const bool xm = xcdmap != 0 && !a.f0_feat && (1 << p.log2_ncol) == n_col && total_wg < ((int64_t)1 << 31);
+    // (launches that finish their split-K in-kernel keep the plain grid: measured at B = 640 the map costs convs 7 and 9 5 us each)
+    bool xm = xcdmap != 0 && !a.f0_feat && !in_kernel_finish && (1 << p.log2_ncol) == n_col && total_wg < ((int64_t)1 << 31);
+    if (xm) {
+        const double a_bytes = (double)B * (double)p.sample_in * 4.0, w_bytes = (double)k_steps * 16.0 * p.Cout * 4.0;
+        const bool row_fast = xcdmap == 3 || (xcdmap == 1 && w_bytes > a_bytes);
+        p.xcd_group = row_fast ? p.n_sg * n_pb : n_col * S;
+        p.xcd_full = (int)(total_wg / (8 * (int64_t)p.xcd_group) * (8 * (int64_t)p.xcd_group));
+        if (p.xcd_group <= 1 || p.xcd_full == 0) xm = false;              // one item per group: the plain order already is this order
+        else p.opt |= row_fast ? (8 | 16) : 8;
+    }
     const bool g3 = !xm && S == 1 && grid3d != 0 && (grid3d == 1 || BM == 256 || bn == 128);
     if (g3) p.opt |= 4;
-    if (xm) {
-        p.opt |= 8;
-        const double a_bytes = (double)B * (double)p.sample_in * 4.0, w_bytes = (double)k_steps * 16.0 * p.Cout * 4.0;
-        if (xcdmap == 3 || (xcdmap == 1 && w_bytes > a_bytes)) p.opt |= 16;
-    }
     const dim3 grid = xm ? dim3((unsigned)total_wg)
                     : g3 ? dim3((unsigned)p.n_sg, (unsigned)n_pb, (unsigned)(p.Cout / bn))
                          : dim3((unsigned)((int64_t)p.n_sg * n_pb), (unsigned)(p.Cout / bn), (unsigned)S);

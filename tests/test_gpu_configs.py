@@ -208,7 +208,9 @@ def test_config4_two_ranks_write_one_million_row_memmap(nafp, cfg, tmp_path):
     for g0 in (0, meta['0'][1] - 125, meta['1'][0], n_rows - 125):             # first / last group of each rank
         x = FW.synth_rows(g0, 125, 'cuda')
         want = m_fp(m_pre(x, group_size=125)).cpu().numpy()
-        assert np.abs(np.asarray(db[g0:g0 + 125]) - want).max() < 1e-6, g0
+        # (the ranks ran launches of 625 rows, this is one of 125: tile shapes and split-K factors -- the fp32 summation
+        # order -- depend on the launch size, so the two agree to rounding, not bit for bit)
+        assert np.abs(np.asarray(db[g0:g0 + 125]) - want).max() < 3e-6, g0
     # search: every probed row comes back at its own id (eval_faiss.py:141-146, 209 with the exact index)
     from neural_audio_fp_amd.eval.eval_faiss import FlatL2Index
     index = FlatL2Index(128, capacity=n_rows)

@@ -7,10 +7,10 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
 python bench.py --steps 30 --warmup 5 > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-pipelined --no-train > $O/bench_trace.json 2> $O/trace.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipelined --no-train > /dev/null 2> $O/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipelined --no-train > /dev/null 2> $O/pmc_write.err
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq -o p -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipelined --no-train > /dev/null 2> $O/pmc_sq.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-pipelined --no-train --no-e2e > $O/bench_trace.json 2> $O/trace.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipelined --no-train --no-e2e > /dev/null 2> $O/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipelined --no-train --no-e2e > /dev/null 2> $O/pmc_write.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq -o p -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipelined --no-train --no-e2e > /dev/null 2> $O/pmc_sq.err
 find $O -name "*.csv" | head -20
 tail -c 600 $O/bench.json
 # train step (BSZ 1280, Adam: SURVEY 8d config 3) kernel trace
