@@ -213,9 +213,14 @@ int nafp_encoder_grad_group_wait(nafp_encoder* enc, int group, void* stream);
  *                        that produces its gradient (one read of the stored pre-activation, one write, instead of a
  *                        separate pass that re-reads and re-writes the gradient).  0 (default): never -- measured slower
  *                        than the separate pass; 1: for the layers of >= 32768 elements per sample at
- *                        batches >= 64; 2: wherever the geometry permits. */
+ *                        batches >= 64; 2: wherever the geometry permits.
+ *   NAFP_OPT_BWD_OVERLAP  training, 1: the weight gradients of nafp_encoder_backward run on a second, low-priority
+ *                        stream owned by the handle, next to the HBM-bound LayerNorm backward of the layer below;
+ *                        `stream` is made to wait for them before the last event of the call, so callers see the same
+ *                        ordering as with 0 (default: everything on `stream`; the overlap measured slower). */
 #define NAFP_OPT_FUSE_CONV0 1
 #define NAFP_OPT_FUSED_LN_BWD 2
+#define NAFP_OPT_BWD_OVERLAP 4
 /* EXPERIMENTAL, changes the arithmetic (the only option that does): the unsplit GEMM convs of nafp_encoder_forward form their
  * products on the bf16 matrix pipe from f32 operands split into hi + lo bf16 halves (hi*hi + hi*lo + lo*hi, f32
  * accumulation).  Fingerprints move at the 1e-6 level against the f32 path.  Off by default; bench.py reports it as a

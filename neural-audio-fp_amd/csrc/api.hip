@@ -97,6 +97,17 @@ struct nafp_encoder {
     // communication stream can start reducing a group while the rest of the backward pass still runs
     hipEvent_t grad_events[NAFP_GRAD_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
     bool grad_events_valid = false;
+    // NAFP_OPT_BWD_OVERLAP (default NAFP_BWD_OVERLAP env, else 0): the weight gradients of the backward pass run on a
+    // second, low-priority stream of the handle.  The chain  LayerNorm backward(j) -> transposed conv(j) -> LayerNorm
+    // backward(j-1) ...  is the critical path and alternates between an HBM-bound pass and an MFMA-bound one; wgrad(j) only
+    // needs dts_j and is needed at the very end, so it can fill the matrix pipes while the LayerNorm pass of the layer
+    // below streams (12 of 94 ms per step at BSZ 5120 are that pass running alone).  MEASURED SLOWER, hence off: side by
+    // side both kernels stretch to the sum of their solo times or beyond (BSZ 5120: wgrad_2 3.96 -> 6.67 ms next to
+    // ln_bwd_1 3.0 -> 6.6 ms; wgrad_1 8.85 -> 15.1 ms next to ln_bwd_0 2.45 -> 6.2 ms; step 93.3 -> 96.7 ms) -- the
+    // streaming pass starves wgrad's operand ring and its VALU work shares the SIMDs' issue slots with the f32 MFMAs.
+    int opt_bwd_overlap = []() { const char* v = getenv("NAFP_BWD_OVERLAP"); return v ? atoi(v) : 0; }();
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_main[16] = {}, ev_side[16] = {};
 };
 
 // gradient group k = parameter tensors [kGroupFirst[k], kGroupLast[k]] in COMPLETION order of the backward pass
@@ -237,6 +248,9 @@ extern "C" int nafp_encoder_destroy(nafp_encoder* e) {
     if (e->d_blob) (void)hipFree(e->d_blob);
     profile_free(e);
     for (auto& ev : e->grad_events) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : e->ev_main) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : e->ev_side) if (ev) (void)hipEventDestroy(ev);
+    if (e->side_stream) (void)hipStreamDestroy(e->side_stream);
     delete e;
     return NAFP_OK;
 }
@@ -249,6 +263,7 @@ extern "C" int nafp_encoder_set_option(nafp_encoder* e, int option, int value) {
         case NAFP_OPT_FUSED_LN_BWD:
             if (value < 0 || value > 2) return NAFP_ERR_INVALID_ARG;
             e->opt_fused_ln_bwd = value; return NAFP_OK;
+        case NAFP_OPT_BWD_OVERLAP: e->opt_bwd_overlap = value != 0; return NAFP_OK;
         default: return NAFP_ERR_INVALID_ARG;
     }
 }
@@ -594,6 +609,16 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
     for (auto& ev : e->grad_events)
         if (!ev) NAFP_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     e->grad_events_valid = false;
+    // the weight-gradient stream (see opt_bwd_overlap): lowest priority, so that the critical path keeps the right of way
+    const bool overlap = e->opt_bwd_overlap != 0;
+    if (overlap && !e->side_stream) {
+        int pr_least = 0, pr_greatest = 0;
+        NAFP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
+        NAFP_HIP_CHECK(hipStreamCreateWithPriority(&e->side_stream, hipStreamNonBlocking, pr_least));
+        for (auto& ev : e->ev_main) NAFP_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        for (auto& ev : e->ev_side) NAFP_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    hipStream_t sw = overlap ? e->side_stream : st;
     int rc = launch_stats_to_mr(L.stats, L.mr, e->d_inv_n, B, 16, st);
     if (rc != NAFP_OK) return rc;
     // tail: d_emb -> r * dxhat of the last conv + divide-and-encode gradients
@@ -617,13 +642,9 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
                                grads[4 * j + 1], L.S1[j], L.S2[j], B, P, g.Cout, st, j == 15, e->d_G[j], e->d_Hb[j], L.lnsum[j - 1]);
             if (rc != NAFP_OK) return rc;
         }
-        // dW_j = wgrad(z_{j-1}, r dt) + wgrad(gamma_{j-1}, sum_b c_b dt) + wgrad(beta_{j-1}, sum_b dt)
-        rc = launch_wgrad(L.z[j - 1], cur, grads[4 * j], B, g, st);
-        if (rc != NAFP_OK) return rc;
-        rc = launch_wgrad(e->d_gamma[j - 1], L.S1[j], grads[4 * j], 1, g, st);
-        if (rc != NAFP_OK) return rc;
-        rc = launch_wgrad(e->d_beta[j - 1], L.S2[j], grads[4 * j], 1, g, st);
-        if (rc != NAFP_OK) return rc;
+        // the transposed conv below writes `other`, which still holds dts_{j+1}: wgrad(j+1), on the weight-gradient stream,
+        // must be done with it
+        if (overlap && j < 15) NAFP_HIP_CHECK(hipStreamWaitEvent(st, e->ev_side[j + 1], 0));
         ln_done = j >= 2 && dgrad_ln_eligible(B, g, e->opt_fused_ln_bwd);   // (layer 0 keeps no pre-activation: see conv0 below)
         if (ln_done) {
             // transposed conv of dts_j with the LayerNorm + ELU backward of layer j-1 in its epilogue: `other` <- dts_{j-1}
@@ -645,11 +666,27 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
             rc = launch_conv_gemm(a, B, g, st);
             if (rc != NAFP_OK) return rc;
         }
+        // dW_j = wgrad(z_{j-1}, r dt) + wgrad(gamma_{j-1}, sum_b c_b dt) + wgrad(beta_{j-1}, sum_b dt).  On the weight-gradient
+        // stream it starts BEHIND the transposed conv of this layer (two MFMA-bound kernels side by side only share the
+        // pipes) and so runs next to the LayerNorm backward of layer j-1, which is HBM-bound and next on the main stream.
+        if (overlap) {
+            NAFP_HIP_CHECK(hipEventRecord(e->ev_main[j], st));
+            NAFP_HIP_CHECK(hipStreamWaitEvent(sw, e->ev_main[j], 0));
+        }
+        rc = launch_wgrad(L.z[j - 1], cur, grads[4 * j], B, g, sw);
+        if (rc != NAFP_OK) return rc;
+        rc = launch_wgrad(e->d_gamma[j - 1], L.S1[j], grads[4 * j], 1, g, sw);
+        if (rc != NAFP_OK) return rc;
+        rc = launch_wgrad(e->d_beta[j - 1], L.S2[j], grads[4 * j], 1, g, sw);
+        if (rc != NAFP_OK) return rc;
+        if (overlap) NAFP_HIP_CHECK(hipEventRecord(e->ev_side[j], sw));
         std::swap(cur, other);
         // layers j .. 15 (and the divide-and-encode tensors) are final from here on (when the LayerNorm backward of layer
         // j-1 ran fused, its dgamma / dbeta / dbias are final too: they belong to the next group or are simply early)
+        // (with the weight-gradient stream the event is recorded THERE: behind wgrad(j), and -- through ev_main[j] -- behind
+        // everything the main stream had enqueued up to the LayerNorm backward of layer j)
         for (int k = 0; k < NAFP_GRAD_GROUPS - 1; ++k)
-            if (4 * j == kGroupFirst[k]) NAFP_HIP_CHECK(hipEventRecord(e->grad_events[k], st));
+            if (4 * j == kGroupFirst[k]) NAFP_HIP_CHECK(hipEventRecord(e->grad_events[k], sw));
     }
     {
         const ConvGeom& g = e->geom[0];
@@ -663,6 +700,7 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
             if (rc != NAFP_OK) return rc;
         }
     }
+    if (overlap) NAFP_HIP_CHECK(hipStreamWaitEvent(st, e->ev_side[1], 0));      // every wgrad is done (the side stream runs them in order)
     NAFP_HIP_CHECK(hipEventRecord(e->grad_events[NAFP_GRAD_GROUPS - 1], st));
     e->grad_events_valid = true;
     return NAFP_OK;

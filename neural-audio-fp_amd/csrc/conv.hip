@@ -1443,10 +1443,10 @@ static int tile_pt(int P) {
 // Taken only when it saves >= 3 % of the launch's MACs and does not cost the launch its register-resident statistics
 // (4 or 8 samples per position).  At the 1-s input and B = 640: conv8 -1/3, conv6 -1/6, conv13 -1/6, convs 4 / 11 -1/12,
 // conv2 -1/24 of their K-steps.  NAFP_TAPCLASS=0 switches it off.
-struct FwdTile { int pt, perm; };
+struct FwdTile { int pt, perm; double saved; };
 static FwdTile fwd_tile(const ConvGeom& g, int BM) {
     const int P = g.Fout * g.Tout;
-    FwdTile r{tile_pt(P), 0};
+    FwdTile r{tile_pt(P), 0, 0.0};
     static const int mode = []() { const char* e = getenv("NAFP_TAPCLASS"); return e ? atoi(e) : 1; }();
     const int L = g.axis == 0 ? g.Tout : g.Fout, n_in = g.axis == 0 ? g.Tin : g.Fin;
     if (!mode || L < 2) return r;
@@ -1456,13 +1456,14 @@ static FwdTile fwd_tile(const ConvGeom& g, int BM) {
     const unsigned m1 = mask(L - 1);
     const int n_all = __builtin_popcount(m0 | m1), n0 = __builtin_popcount(m0), n1 = __builtin_popcount(m1);
     const int64_t c1 = P / L, c0 = (int64_t)c1 * (L - 1);                 // positions per class
-    if (n_all == 0 || (double)(c0 * (n_all - n0) + c1 * (n_all - n1)) < 0.03 * (double)P * n_all) return r;
+    const double saved = n_all == 0 ? 0.0 : (double)(c0 * (n_all - n0) + c1 * (n_all - n1)) / ((double)P * n_all);
+    if (saved < 0.03) return r;
     int pt = 1;
     while (pt * 2 <= 32 && c0 % (pt * 2) == 0 && c1 % (pt * 2) == 0) pt *= 2;
     const int st = BM / pt, st_def = BM / r.pt;
     const bool fast = st == 4 || st == 8, fast_def = st_def == 4 || st_def == 8;
     if (st < 4 || (fast_def && !fast)) return r;
-    r.pt = pt; r.perm = g.axis == 0 ? 2 : 0;
+    r.pt = pt; r.perm = g.axis == 0 ? 2 : 0; r.saved = saved;
     return r;
 }
 
@@ -1545,7 +1546,16 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     int pt = tile_pt(p.P);
     if (BM == 256 && !a.plain && !a.dgrad && 256 / pt != 8) BM = 128;      // FULL mode on 256 rows keeps its statistics in registers: 8 samples per position
     int fwd_perm = 0;
-    if (!a.plain && !a.dgrad && !a.f0_feat) { const FwdTile ft = fwd_tile(g, BM); pt = ft.pt; fwd_perm = ft.perm; }
+    if (!a.plain && !a.dgrad && !a.f0_feat) {
+        FwdTile ft = fwd_tile(g, BM);
+        if (BM == 256 && ft.saved == 0.0) {
+            // the 256-row tile cannot hold one class with 8 samples per position (conv8 at large batches: 16 positions
+            // per class), the 128-row tile can: a third of the K-steps outweighs the larger tile's few per cent
+            const FwdTile f2 = fwd_tile(g, 128);
+            if (f2.saved >= 0.10) { BM = 128; ft = f2; }
+        }
+        pt = ft.pt; fwd_perm = ft.perm;
+    }
     p.PT = pt; p.ST = BM / pt;
     p.log2ST = 0;
     while ((1 << p.log2ST) < p.ST) ++p.log2ST;
