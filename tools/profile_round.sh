@@ -3,18 +3,20 @@
 # PMC passes for HBM traffic (FETCH_SIZE / WRITE_SIZE cannot share a pass), and the plain bench.
 # Results land in gpurun_out/prof_<tag>/; tools/profile_summarize.py turns them into profiles/.
 TAG=${1:-r01}
-cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 O=gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
 python bench.py --steps 30 --warmup 5 > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-pipelined --no-train --no-e2e > $O/bench_trace.json 2> $O/trace.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipelined --no-train --no-e2e > /dev/null 2> $O/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipelined --no-train --no-e2e > /dev/null 2> $O/pmc_write.err
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq -o p -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipelined --no-train --no-e2e > /dev/null 2> $O/pmc_sq.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python bench.py --steps 30 --warmup 5 --repeats 1 --no-cpu-baseline --no-pipelined --no-train --no-e2e > $O/bench_trace.json 2> $O/trace.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- python bench.py --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-pipelined --no-train --no-e2e > /dev/null 2> $O/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- python bench.py --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-pipelined --no-train --no-e2e > /dev/null 2> $O/pmc_write.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq -o p -- python bench.py --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-pipelined --no-train --no-e2e > /dev/null 2> $O/pmc_sq.err
 find $O -name "*.csv" | head -20
 tail -c 600 $O/bench.json
 # train step (BSZ 1280, Adam: SURVEY 8d config 3) kernel trace
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_trace -o t -- python tools/train_probe.py 1280 adam 5 > $O/train_probe.txt 2> $O/train_trace.err
+# train step at the headline batch (BASELINE configs[3] on one GPU: BSZ 5120, LAMB)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/train5120_trace -o t -- python tools/train_probe.py 5120 lamb 3 > $O/train5120_probe.txt 2> $O/train5120_trace.err
 # eval side: exact search of 38,000 query segments over 10 M resident fingerprints; training loader
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/search_trace -o t -- python tools/search_bench.py 10000000 38000 2 > $O/search_bench.txt 2> $O/search_trace.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/loader_trace -o t -- python tools/loader_bench.py 300 > $O/loader_bench.txt 2> $O/loader_trace.err

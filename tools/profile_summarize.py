@@ -137,7 +137,7 @@ for r in sq:
 
 with open(os.path.join(dst, f'{tag}_summary.md'), 'w') as f:
     f.write(f'# Profile summary {tag}\n\n')
-    f.write('Command profiled: `python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-pipelined` '
+    f.write('Command profiled: `python bench.py --steps 30 --warmup 5 --repeats 1 --no-cpu-baseline --no-pipelined --no-train --no-e2e` '
             '(1x MI355X, BSZ 640 per step, single stream) under `rocprofv3 --kernel-trace --stats` '
             '(full CSV: `%s_kernel_stats.csv`).\n\n' % tag)
     f.write(f'Bench line of the same run (un-profiled): **{bj["value"]} {bj["unit"]}**, '
@@ -213,12 +213,13 @@ with open(os.path.join(dst, f'{tag}_summary.md'), 'w') as f:
         f.write(f'| {g} | {a["_dur"] / 1e3:.1f} | {clk:.2f} | {mf:.1f} | {occ:.1f} | '
                 f'{a["SQ_WAIT_ANY"] / a["SQ_WAVE_CYCLES"] * 100:.1f} | {a["SQ_WAIT_INST_ANY"] / a["SQ_WAVE_CYCLES"] * 100:.1f} | '
                 f'{a.get("SQ_LDS_BANK_CONFLICT", 0):.0f} |\n')
-# ---- train step (tools/train_probe.py 1280 adam 5 under --kernel-trace --stats) ----
-tt = os.path.join(src, 'train_trace', 't_kernel_stats.csv')
-if os.path.exists(tt):
-    shutil.copy(tt, os.path.join(dst, f'{tag}_train_kernel_stats.csv'))
-    tstats = read_csv(tt)
-    ttrace = read_csv(os.path.join(src, 'train_trace', 't_kernel_trace.csv'))
+# ---- train steps (tools/train_probe.py under --kernel-trace --stats) ----
+def train_section(dirname, probe_name, csv_name, title, cmd):
+    tt = os.path.join(src, dirname, 't_kernel_stats.csv')
+    if not os.path.exists(tt):
+        return
+    shutil.copy(tt, os.path.join(dst, csv_name))
+    ttrace = read_csv(os.path.join(src, dirname, 't_kernel_trace.csv'))
     ttrace.sort(key=lambda r: int(r['Start_Timestamp']))
     idx = [i for i, r in enumerate(ttrace) if 'melspec_kernel' in r['Kernel_Name']]
     a, b = idx[-2], idx[-1]
@@ -227,17 +228,26 @@ if os.path.exists(tt):
         n = r['Kernel_Name'].replace('nafp::', '').replace('void ', '').split('(')[0]
         agg2[n][0] += 1; agg2[n][1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
     span = (int(ttrace[b]['Start_Timestamp']) - int(ttrace[a]['Start_Timestamp'])) / 1e3
-    probe = open(os.path.join(src, 'train_probe.txt')).read() if os.path.exists(os.path.join(src, 'train_probe.txt')) else ''
+    pp = os.path.join(src, probe_name)
+    probe = open(pp).read() if os.path.exists(pp) else ''
     with open(os.path.join(dst, f'{tag}_summary.md'), 'a') as f:
-        f.write('\n## Train step (SURVEY 8d config 3: BSZ 1280 = 640 anchors + 640 replicas, Adam, 1 GPU)\n\n')
-        f.write('Command: `python tools/train_probe.py 1280 adam 5` under `rocprofv3 --kernel-trace --stats` '
-                f'(full CSV: `{tag}_train_kernel_stats.csv`).  One step (second to last of the run): '
+        f.write(f'\n## {title}\n\n')
+        f.write(f'Command: `{cmd}` under `rocprofv3 --kernel-trace --stats` '
+                f'(full CSV: `{csv_name}`).  One step (second to last of the run): '
                 f'{b - a} launches, {span / 1e3:.2f} ms from first to next-first kernel.\n\n')
         f.write('| kernel | launches/step | us/step |\n|---|---|---|\n')
         for n, (c, d) in sorted(agg2.items(), key=lambda kv: -kv[1][1])[:14]:
             f.write(f'| `{n[:60]}` | {c} | {d:.0f} |\n')
         if probe:
             f.write('\nUn-profiled stage timing of the same script (torch events):\n\n```\n' + probe.strip() + '\n```\n')
+
+
+train_section('train_trace', 'train_probe.txt', f'{tag}_train_kernel_stats.csv',
+              'Train step (SURVEY 8d config 3: BSZ 1280 = 640 anchors + 640 replicas, Adam, 1 GPU)',
+              'python tools/train_probe.py 1280 adam 5')
+train_section('train5120_trace', 'train5120_probe.txt', f'{tag}_train5120_kernel_stats.csv',
+              'Train step at the headline batch (BASELINE configs[3] on ONE GPU: global BSZ 5120, LAMB)',
+              'python tools/train_probe.py 5120 lamb 3')
 for name, title in (('search', 'Exact search (eval side): `python tools/search_bench.py 10000000 38000 2`'),
                     ('loader', 'Training loader + augmentation: `python tools/loader_bench.py 300`')):
     st = os.path.join(src, f'{name}_trace', 't_kernel_stats.csv')
