@@ -15,6 +15,7 @@
 #include "nafp_common.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace nafp {
@@ -356,6 +357,260 @@ __global__ __launch_bounds__(256, 2) void melspec_kernel(
     }
 }
 
+// ---- radix-16 front end -----------------------------------------------------------------------------------------------
+// The same workgroup layout as melspec_kernel, with the 1024-point FFT of a frame pair factored 16 x 16 x 4 and the two
+// radix-16 stages held in REGISTERS (16 points per lane): three LDS exchanges per FFT instead of five read-modify-write
+// passes, and every exchange conflict-free by construction.  With n = 64 n1 + l and k = k1 + 16 k2:
+//   A  lane l:            Y[k1, l] = W1024^(l k1) . DFT16_{n1}( w[n] z[n] )                 -> buf[68 k1 + l]
+//   B  lane (k1, r):      T[k1, r, q] = W64^(r q) . DFT16_{m}( Y[k1, 4 m + r] )             -> buf[68 k1 + 17 r + q]
+//   C  lane (k1, g):      X[k1 + 16 q + 256 p] = DFT4_{r}( T[k1, r, q] ),  q = 4 j + g      -> buf[nat(k)]
+// nat(k) = k with bit 3 flipped when bit 5 is set (keeps the C stores and the un-pack reads on 64 distinct banks).
+// The level-1 twiddles W1024^(l k1) depend on the lane only: 15 registers, loaded once per workgroup.
+constexpr int R16_BUF = 16 * 68;             // float2 per wave
+
+__device__ __forceinline__ void dft4(float2 u0, float2 u1, float2 u2, float2 u3, float2& o0, float2& o1, float2& o2, float2& o3) {
+    const float2 t0 = make_float2(u0.x + u2.x, u0.y + u2.y);
+    const float2 t1 = make_float2(u0.x - u2.x, u0.y - u2.y);
+    const float2 t2 = make_float2(u1.x + u3.x, u1.y + u3.y);
+    const float2 t3 = make_float2(u1.y - u3.y, -(u1.x - u3.x));   // (u1 - u3) * (-i)
+    o0 = make_float2(t0.x + t2.x, t0.y + t2.y);
+    o1 = make_float2(t1.x + t3.x, t1.y + t3.y);
+    o2 = make_float2(t0.x - t2.x, t0.y - t2.y);
+    o3 = make_float2(t1.x - t3.x, t1.y - t3.y);
+}
+
+// exp(-2 pi i m / 16) for the products b * c of the two radix-4 stages (b, c in 0..3)
+template <int M> __device__ __forceinline__ float2 w16() {
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508978f, H = 0.70710678118654752f;
+    return M == 0 ? make_float2(1.f, 0.f) : M == 1 ? make_float2(C1, -S1) : M == 2 ? make_float2(H, -H)
+         : M == 3 ? make_float2(S1, -C1) : M == 4 ? make_float2(0.f, -1.f) : M == 6 ? make_float2(-H, -H)
+         : make_float2(-C1, S1);            // M == 9
+}
+
+// x[k] <- sum_n x[n] exp(-2 pi i n k / 16), natural order in and out, all indices compile-time
+__device__ __forceinline__ void dft16(float2 (&x)[16]) {
+    float2 y[4][4];
+#define NAFP_S1(b_)                                                                            \
+    {                                                                                          \
+        float2 o0, o1, o2, o3;                                                                 \
+        dft4(x[b_], x[4 + b_], x[8 + b_], x[12 + b_], o0, o1, o2, o3);                         \
+        y[0][b_] = o0;                                                                         \
+        y[1][b_] = (b_) == 0 ? o1 : cmul(o1, w16<(b_) * 1>());                                 \
+        y[2][b_] = (b_) == 0 ? o2 : cmul(o2, w16<(b_) * 2>());                                 \
+        y[3][b_] = (b_) == 0 ? o3 : cmul(o3, w16<(b_) * 3>());                                 \
+    }
+    NAFP_S1(0) NAFP_S1(1) NAFP_S1(2) NAFP_S1(3)
+#undef NAFP_S1
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dft4(y[c][0], y[c][1], y[c][2], y[c][3], x[c], x[c + 4], x[c + 8], x[c + 12]);
+}
+
+__device__ __forceinline__ int nat_addr(int k) { return k ^ ((k >> 2) & 8); }
+
+// LDS carve (75,328 B: two workgroups per CU):
+//   sig  [SIG_CHUNK]            zero-padded samples of the 16-frame chunk (19 KB)
+//   buf  [4][R16_BUF] float2    one exchange buffer per wave (34 KB); re-used for the two magnitude spectra
+//   tile [n_mels][TILE_LD]      log-mel tile of the chunk (20 KB)
+//   tw64 [64] float2            exp(-2 pi i n / 64)
+template <typename TIn>
+__global__ __launch_bounds__(256, 2) void melspec_r16_kernel(
+        const TIn* __restrict__ audio, const int64_t* __restrict__ seg_offset, const int* __restrict__ seg_valid,
+        float* __restrict__ feat, float* __restrict__ group_stat,
+        const float2* __restrict__ tw, const float* __restrict__ window,
+        const int* __restrict__ mel_start, const float* __restrict__ mel_w,
+        int seg_len, int n_frames, int n_mels, int group_size) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t seg = blockIdx.x;
+    float* sig = smem;
+    float2* buf = (float2*)(smem + SIG_CHUNK) + wave * R16_BUF;
+    float* tile = smem + SIG_CHUNK + 4 * 2 * R16_BUF;
+    float2* tw64 = (float2*)(tile + n_mels * TILE_LD);
+    if (tid < 64) tw64[tid] = tw[16 * tid];
+
+    const TIn* a = audio + (seg_offset ? seg_offset[seg] : seg * seg_len);
+    const int n_valid = seg_valid ? min(seg_valid[seg], seg_len) : seg_len;
+    const bool has_mel = tid < n_mels;
+    int mstart = 0;
+    float mw[MAX_TAPS];
+#pragma unroll
+    for (int j = 0; j < MAX_TAPS; ++j) mw[j] = 0.f;
+    if (has_mel) {
+        mstart = mel_start[tid];
+#pragma unroll
+        for (int j = 0; j < MAX_TAPS; ++j) mw[j] = mel_w[tid * MAX_TAPS + j];
+    }
+    // per lane, once: the window of its 16 points n = 64 n1 + lane and the level-1 twiddles W1024^(lane k1)
+    float wreg[16];
+    float2 tw1[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { wreg[i] = window[64 * i + lane]; tw1[i] = tw[lane * i]; }
+    const int k1 = lane >> 2, r = lane & 3;
+
+    float lmax = -INFINITY, lmin = INFINITY;
+    const int n_pairs = (n_frames + 1) / 2;
+    float* out_seg = feat + seg * (int64_t)n_mels * n_frames;
+    const int chunk0 = blockIdx.y * CHUNK_FRAMES;
+    const int chunk_frames = min(CHUNK_FRAMES, n_frames - chunk0);
+    {
+        // zero-padded samples of this chunk into LDS (melspectrogram.py:59-65), all loads issued before the first LDS write
+        constexpr int STEPS = (SIG_CHUNK / 4 + 255) / 256;            // 5
+        const int s_base = chunk0 * HOP - NFFT / 2;                    // multiple of 4
+        const bool vec_ok = ((uintptr_t)a % (4 * sizeof(TIn))) == 0;
+        float4 v[STEPS];
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            const int i4 = st * 256 + tid;
+            const int s = s_base + 4 * i4;
+            v[st] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i4 < SIG_CHUNK / 4 && s + 3 >= 0 && s < n_valid) {
+                if (vec_ok && s >= 0 && s + 3 < n_valid) {
+                    if (sizeof(TIn) == 4) {
+                        v[st] = *(const float4*)((const float*)a + s);
+                    } else {
+                        const short4 q = *(const short4*)((const int16_t*)a + s);
+                        v[st] = make_float4(pcm_to_float<int16_t>(q.x), pcm_to_float<int16_t>(q.y),
+                                            pcm_to_float<int16_t>(q.z), pcm_to_float<int16_t>(q.w));
+                    }
+                } else {
+                    v[st].x = (s >= 0 && s < n_valid) ? pcm_to_float<TIn>(a[s]) : 0.f;
+                    v[st].y = (s + 1 >= 0 && s + 1 < n_valid) ? pcm_to_float<TIn>(a[s + 1]) : 0.f;
+                    v[st].z = (s + 2 >= 0 && s + 2 < n_valid) ? pcm_to_float<TIn>(a[s + 2]) : 0.f;
+                    v[st].w = (s + 3 >= 0 && s + 3 < n_valid) ? pcm_to_float<TIn>(a[s + 3]) : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            const int i4 = st * 256 + tid;
+            if (i4 < SIG_CHUNK / 4) *(float4*)(sig + 4 * i4) = v[st];
+        }
+    }
+    __syncthreads();
+    for (int round = 0; round < CHUNK_FRAMES / 8; ++round) {        // 4 waves x 2 frames per round
+        const int pair = chunk0 / 2 + round * 4 + wave;
+        const int f0 = 2 * pair, f1 = 2 * pair + 1;
+        const bool live = pair < n_pairs && f0 < chunk0 + chunk_frames;
+        float2 x[16];
+        if (live) {
+            // A: z = w (x_f0 + i x_f1) at n = 64 n1 + lane, DFT16 over n1, level-1 twiddle
+            const float* s0 = sig + (f0 - chunk0) * HOP + lane;
+            const bool has1 = f1 < n_frames;
+            const float* s1 = sig + ((has1 ? f1 : f0) - chunk0) * HOP + lane;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[i] = make_float2(wreg[i] * s0[64 * i], has1 ? wreg[i] * s1[64 * i] : 0.f);
+            dft16(x);
+            buf[lane] = x[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) buf[68 * i + lane] = cmul(x[i], tw1[i]);
+        }
+        NAFP_WAVE_SYNC();
+        if (live) {
+            // B: DFT16 over m of Y[k1, 4 m + r], level-2 twiddle W64^(r q)
+#pragma unroll
+            for (int m = 0; m < 16; ++m) x[m] = buf[68 * k1 + 4 * m + r];
+            dft16(x);
+#pragma unroll
+            for (int q = 1; q < 16; ++q) x[q] = cmul(x[q], tw64[r * q]);
+        }
+        NAFP_WAVE_SYNC();
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) buf[68 * k1 + 17 * r + q] = x[q];
+        }
+        NAFP_WAVE_SYNC();
+        if (live) {
+            // C: DFT4 over r of T[k1, r, q] for q = 4 j + g (g = this lane's r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float2* t = buf + 68 * k1 + 4 * j + r;
+                dft4(t[0], t[17], t[34], t[51], x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3]);
+            }
+        }
+        NAFP_WAVE_SYNC();
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) buf[nat_addr(k1 + 16 * (4 * j + r) + 256 * p)] = x[4 * j + p];
+        }
+        NAFP_WAVE_SYNC();
+        if (live) {
+            // un-pack: X0[k] = (Z[k]+conj Z[N-k])/2, X1[k] = (Z[k]-conj Z[N-k])/(2i); keep |.|
+            float m0[9], m1[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const int k = lane + 64 * j;
+                m0[j] = 0.f; m1[j] = 0.f;
+                if (k < NBIN) {
+                    const float2 z = buf[nat_addr(k)];
+                    const float2 zc = buf[nat_addr((NFFT - k) & (NFFT - 1))];
+                    const float ar = 0.5f * (z.x + zc.x), ai = 0.5f * (z.y - zc.y);
+                    const float br = 0.5f * (z.y + zc.y), bi = -0.5f * (z.x - zc.x);
+                    m0[j] = sqrtf(ar * ar + ai * ai);            // kapre Magnitude = tf.abs
+                    m1[j] = sqrtf(br * br + bi * bi);
+                }
+            }
+            NAFP_WAVE_SYNC();
+            float* mag0 = (float*)buf;             // [0..512]
+            float* mag1 = mag0 + 520;              // [0..512]
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const int k = lane + 64 * j;
+                if (k < NBIN) { mag0[k] = m0[j]; mag1[k] = m1[j]; }
+            }
+        }
+        __syncthreads();
+        if (has_mel) {
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) {
+                const int pp = chunk0 / 2 + round * 4 + wv;
+                const float* mg = (const float*)((float2*)(smem + SIG_CHUNK) + wv * R16_BUF);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int f = 2 * pp + h;
+                    if (f < chunk0 + chunk_frames && f < n_frames) {
+                        const float* mm = mg + h * 520 + mstart;
+                        float acc = 0.f;
+#pragma unroll
+                        for (int j = 0; j < MAX_TAPS; ++j) acc += mw[j] * mm[j];
+                        const float v = logf(fmaxf(acc + 0.06f, 1e-10f)) / 2.302585092994046f;     // melspectrogram.py:104,107
+                        tile[tid * TILE_LD + (f - chunk0)] = v;
+                        lmax = fmaxf(lmax, v);
+                        lmin = fminf(lmin, v);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (chunk_frames == CHUNK_FRAMES && (n_frames & 3) == 0) {
+        for (int idx = tid; idx < n_mels * (CHUNK_FRAMES / 4); idx += 256) {
+            const int m = idx / (CHUNK_FRAMES / 4), q = idx % (CHUNK_FRAMES / 4);
+            const float4 v = *(const float4*)(tile + m * TILE_LD + 4 * q);
+            *(float4*)(out_seg + (int64_t)m * n_frames + chunk0 + 4 * q) = v;
+        }
+    } else {
+        for (int idx = tid; idx < n_mels * chunk_frames; idx += 256) {
+            const int m = idx / chunk_frames, t = idx % chunk_frames;
+            out_seg[(int64_t)m * n_frames + chunk0 + t] = tile[m * TILE_LD + t];
+        }
+    }
+    __syncthreads();
+    lmax = wave_max(lmax);
+    lmin = wave_min(lmin);
+    float* red = tile;
+    if (lane == 0) { red[wave] = lmax; red[4 + wave] = lmin; }
+    __syncthreads();
+    if (tid == 0) {
+        const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const float mn = fminf(fminf(red[4], red[5]), fminf(red[6], red[7]));
+        const int64_t g = group_size > 0 ? seg / group_size : 0;
+        atomic_max_float(group_stat + 2 * g, mx);
+        atomic_min_float(group_stat + 2 * g + 1, mn);
+    }
+}
+
 // feat <- max(raw - group_max, -80) [; segment_norm]   (melspectrogram.py:108-111)
 __global__ __launch_bounds__(256) void melspec_finalize_kernel(
         float* __restrict__ feat, const float* __restrict__ group_stat, int64_t n_vec4,
@@ -390,10 +645,18 @@ static int melspec_forward(nafp_melspec* p, const TIn* audio, int64_t n_seg, int
     const int n_groups = (int)((n_seg + group_size - 1) / group_size);
     melspec_init_stats<<<(n_groups + 255) / 256, 256, 0, st>>>(group_stat, n_groups);
     NAFP_LAUNCH_CHECK();
-    const size_t lds = (size_t)(SIG_CHUNK + 4 * 2 * NFFT + p->n_mels * TILE_LD + 2 * N_TW) * sizeof(float);
-    melspec_kernel<TIn><<<dim3((unsigned)n_seg, (unsigned)((p->n_frames + CHUNK_FRAMES - 1) / CHUNK_FRAMES)), 256, lds, st>>>(
-        audio, seg_offset, seg_valid, feat, group_stat, p->d_twiddle, p->d_window, p->d_mel_start, p->d_mel_w,
-        p->seg_len, p->n_frames, p->n_mels, group_size);
+    // NAFP_MELSPEC_R4=1: the round-1/2 kernel (five in-place radix-4 passes through LDS) for A/B runs
+    static const bool r4 = []() { const char* e = getenv("NAFP_MELSPEC_R4"); return e && e[0] == '1'; }();
+    const dim3 grid((unsigned)n_seg, (unsigned)((p->n_frames + CHUNK_FRAMES - 1) / CHUNK_FRAMES));
+    if (r4) {
+        const size_t lds = (size_t)(SIG_CHUNK + 4 * 2 * NFFT + p->n_mels * TILE_LD + 2 * N_TW) * sizeof(float);
+        melspec_kernel<TIn><<<grid, 256, lds, st>>>(audio, seg_offset, seg_valid, feat, group_stat, p->d_twiddle, p->d_window,
+                                                    p->d_mel_start, p->d_mel_w, p->seg_len, p->n_frames, p->n_mels, group_size);
+    } else {
+        const size_t lds = (size_t)(SIG_CHUNK + 4 * 2 * R16_BUF + p->n_mels * TILE_LD + 2 * 64) * sizeof(float);
+        melspec_r16_kernel<TIn><<<grid, 256, lds, st>>>(audio, seg_offset, seg_valid, feat, group_stat, p->d_twiddle, p->d_window,
+                                                        p->d_mel_start, p->d_mel_w, p->seg_len, p->n_frames, p->n_mels, group_size);
+    }
     NAFP_LAUNCH_CHECK();
     if (segment_norm & NAFP_MELSPEC_DEFER) return NAFP_OK;   // raw log-mel + group_stat: the consumer finishes
     segment_norm &= 1;
@@ -465,6 +728,9 @@ extern "C" int nafp_melspec_create(nafp_melspec** plan, int fs, int seg_len, int
     const int lds = (SIG_CHUNK + 4 * 2 * NFFT + n_mels * TILE_LD + 2 * N_TW) * (int)sizeof(float);
     if ((e = hipFuncSetAttribute((const void*)melspec_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return fail(e);
     if ((e = hipFuncSetAttribute((const void*)melspec_kernel<int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return fail(e);
+    const int lds16 = (SIG_CHUNK + 4 * 2 * R16_BUF + n_mels * TILE_LD + 2 * 64) * (int)sizeof(float);
+    if ((e = hipFuncSetAttribute((const void*)melspec_r16_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16)) != hipSuccess) return fail(e);
+    if ((e = hipFuncSetAttribute((const void*)melspec_r16_kernel<int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16)) != hipSuccess) return fail(e);
     *plan = p;
     return NAFP_OK;
 }
