@@ -1470,6 +1470,24 @@ static FwdTile fwd_tile(const ConvGeom& g, int BM) {
     return r;
 }
 
+// Position slots of a DGRAD tile (rows = input positions of the conv).  With stride 2 the positions are enumerated parity
+// class by parity class (tile_pos(), perm 1: one class receives taps {0, 2}, the other only tap {1}) so that a tile of ONE
+// class skips the structurally zero taps; that needs PT to divide both class sizes.  The default (largest power of two
+// <= min(P, 32)) straddles the classes whenever a class has fewer than 32 positions -- the transposed convs of layers 9,
+// 10, 11, 13, 15 at the 1-s input then multiplied all three taps, twice the needed K-steps (BSZ 5120: dgrad_9 72
+// TFLOP/s of useful work, dgrad_13 59).  Any samples-per-position count works for the PLAIN epilogue.
+static int dgrad_tile_pt(const ConvGeom& g) {
+    const int P = g.Fin * g.Tin;
+    int pt = tile_pt(P);
+    const int L = g.axis == 0 ? g.Tin : g.Fin;
+    if (g.stride != 2 || L < 2) return pt;
+    const int c0 = g.pad & 1, n0 = (L - c0 + 1) / 2;
+    const int per = P / L;                                  // positions per coordinate value along the tap axis
+    const int s0 = per * n0, s1 = per * (L - n0);
+    while (pt > 1 && (s0 % pt != 0 || s1 % pt != 0)) pt >>= 1;
+    return pt;
+}
+
 // Tile height of a launch: 256 rows (8 waves, 2 workgroups per CU) when the launch has enough 128-row tiles to fill the
 // chip several times over with the larger tile as well -- those launches are never split along K; 128 rows otherwise.
 // NAFP_BM256 = minimum number of 128-row tiles (0 = never; default 2000).  Measured at B = 640, same box, ms per launch
@@ -1520,7 +1538,7 @@ int64_t conv_gemm_slab_floats(int64_t B, const ConvGeom& g, bool with_dgrad) {
     int64_t need = S > 1 ? (int64_t)S * B * P * g.Cout : 0;
     if (with_dgrad && g.Cin % BN == 0 && pick_bm(B, g.Fin * g.Tin, g.Cin) == 128) {
         const int Pd = g.Fin * g.Tin;
-        const int ptd = tile_pt(Pd), STd = 128 / ptd;
+        const int ptd = dgrad_tile_pt(g), STd = 128 / ptd;
         const int64_t tiles_d = ((B + STd - 1) / STd) * ((Pd + ptd - 1) / ptd) * (g.Cin / BN);
         const int bnd = pick_bn(tiles_d, g.Cin);
         const int Sd = choose_split(tiles_d * (BN / bnd), dgrad_k_steps(g), B * Pd * g.Cin, bnd == 64 ? 1024.0 : 768.0);
@@ -1577,7 +1595,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
         p.dgrad = 1;
         p.Fin = g.Fout; p.Tin = g.Tout; p.Cin = g.Cout; p.Cout = g.Cin; p.Tout = g.Tin;
         p.P = g.Fin * g.Tin;
-        pt = tile_pt(p.P);
+        pt = dgrad_tile_pt(g);
         p.PT = pt; p.ST = BM / pt;
         p.log2ST = 0;
         while ((1 << p.log2ST) < p.ST) ++p.log2ST;

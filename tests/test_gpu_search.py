@@ -138,3 +138,48 @@ def test_identical_top1_hits_for_gpu_and_oracle_fingerprints(nafp, cfg):
         hits[side] = idx.search(embs[side + '_q'], 1)[1][:, 0]
     assert np.array_equal(hits['gpu'], hits['cpu'])
     assert (hits['gpu'] == np.arange(60)).mean() > 0.9
+
+
+def test_identical_top1_hits_on_a_mini_set_of_overlapping_segments(nafp, cfg):
+    """The same gate on a stand-in for the reference's mini test set (no dataset exists in this image): 12 synthetic
+    30-s clips cut like `get_fns_seg_list` does (1-s segments, hop 0.5 s: 59 per clip, neighbours share half their
+    samples, so the nearest wrong answers are close) = 708 database segments in max-normalisation groups of 125; the
+    queries are the same segments with noise at 5 dB SNR and a random gain.  The fingerprints of the HIP path and of
+    the CPU restatement (oracle/torch_ref.py, held to oracle/nnfp.py by tests/test_oracle_nnfp.py) must give the SAME
+    top-1 segment for every query, and agree to 1 - cos < 1e-5."""
+    import _inputs
+    from oracle import torch_ref
+    from neural_audio_fp_amd.eval import eval_faiss as E
+    rng = np.random.default_rng(77)
+    t = np.arange(240000) / 8000.0
+    segs = []
+    for k in range(12):
+        clip = 0.05 * rng.normal(size=240000)
+        for f in rng.uniform(300, 3900, size=4):
+            clip += 0.1 * np.sin(2 * np.pi * f * t * (1.0 + 0.02 * np.sin(2 * np.pi * 0.3 * t)) + rng.uniform(0, 6.28))
+        clip *= np.interp(t, np.arange(31), rng.uniform(0.3, 1.0, size=31))          # slow level changes along the clip
+        segs += [clip[4000 * i:4000 * i + 8000] for i in range(59)]
+    x_db = np.stack(segs)[:, None, :].astype(np.float32)
+    noise = rng.normal(size=x_db.shape)
+    amp = np.sqrt((x_db ** 2).mean(-1, keepdims=True) / (noise ** 2).mean(-1, keepdims=True)) * 10 ** (-5 / 20)
+    x_q = ((x_db + amp * noise) * rng.uniform(0.5, 1.0, size=(len(x_db), 1, 1))).astype(np.float32)
+    w = _inputs.weights(seed=8)
+    m_pre, m_fp = nafp.get_melspec_layer(cfg), nafp.get_fingerprinter(cfg)
+    m_fp.set_weights(_inputs.weight_list(w))
+    tf = torch_ref.TorchFingerprinter(w)
+    embs = {}
+    for name, x in (('db', x_db), ('q', x_q)):
+        embs['gpu_' + name] = m_fp(m_pre(torch.from_numpy(x).cuda(), group_size=125)).cpu().numpy()
+        with torch.no_grad():
+            embs['cpu_' + name] = np.concatenate([tf(torch_ref.melspec_layer(torch.from_numpy(x[i:i + 125]))).numpy()
+                                                  for i in range(0, len(x), 125)])
+        assert (1 - (embs['gpu_' + name] * embs['cpu_' + name]).sum(1)).max() < 1e-5
+    hits = {}
+    for side in ('gpu', 'cpu'):
+        idx = E.FlatL2Index(128); idx.add(embs[side + '_db'])
+        hits[side] = idx.search(embs[side + '_q'], 1)[1][:, 0]
+    assert np.array_equal(hits['gpu'], hits['cpu'])
+    exact = (hits['gpu'] == np.arange(len(x_db))).mean()
+    near = (np.abs(hits['gpu'] - np.arange(len(x_db))) <= 1).mean()
+    print(f'top-1 exact {exact:.3f}, within one segment {near:.3f} (seeded glorot weights, untrained)')
+    assert near > 0.5
