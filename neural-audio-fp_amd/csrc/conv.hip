@@ -1480,6 +1480,10 @@ static int dgrad_tile_pt(const ConvGeom& g) {
     const int P = g.Fin * g.Tin;
     int pt = tile_pt(P);
     const int L = g.axis == 0 ? g.Tin : g.Fin;
+    if (g.stride == 1 && g.axis == 0 && L == 2 && g.pad == 1) {        // two frames, each with its own dead tap (perm 2)
+        while (pt > 1 && (P / 2) % pt != 0) pt >>= 1;
+        return pt;
+    }
     if (g.stride != 2 || L < 2) return pt;
     const int c0 = g.pad & 1, n0 = (L - c0 + 1) / 2;
     const int per = P / L;                                  // positions per coordinate value along the tap axis
@@ -1608,6 +1612,10 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
         if (g.stride == 2 && L >= 2) {
             p.perm_on = 1; p.perm_c0 = g.pad & 1;              // class 0: coordinate + pad even -> taps {0, 2}
             p.perm_n0 = (L - p.perm_c0 + 1) / 2;
+        } else if (g.stride == 1 && g.axis == 0 && L == 2 && g.pad == 1) {
+            // stride 1 on two frames (conv8 at the 1-s input): input frame 0 receives taps {0, 1}, frame 1 taps {1, 2}: the
+            // forward class order (last frame of every line last) separates them
+            p.perm_on = 2;
         }
         k_steps = dgrad_k_steps(g);
     }
