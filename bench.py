@@ -497,12 +497,15 @@ def main():
         conv0_ms = sum(p[0] for p in prof_fine) / len(prof_fine)
         tail_ms = sum(p[16] for p in prof_fine) / len(prof_fine)
         value = world * BSZ * args.steps / el
-        traffic, traffic_src, fe_traffic = None, None, None
+        traffic, traffic_src, fe_traffic, fe_kernel_us = None, None, None, None
         tp = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tp):          # PMC passes cannot run inside this process: profiles/ holds them
             tj = json.load(open(tp))
             traffic = tj.get('per_launch_bytes')
             fe_traffic = (tj.get('frontend') or {}).get('bytes_per_launch')
+            fe_k = ((tj.get('frontend') or {}).get('kernels') or {})
+            fe_k = fe_k.get('melspec_r16_kernel') or fe_k.get('melspec_kernel') or {}
+            fe_kernel_us = fe_k.get('mean_us_under_pmc')
             traffic_src = f"profiles/traffic.json ({tj.get('tag')}: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
         out = {
             'metric': 'fingerprint generation throughput (1-s segments/s)',
@@ -539,10 +542,15 @@ def main():
                                                    'stamps, split-K finish kernel included), conv0 / tail / melspec between recorded '
                                                    'events.  Stamping every launch still costs: these figures sum to ~10 % more than the '
                                                    'timed span; un-stamped kernel durations are in profiles/*_summary.md'},
-            'frontend_hbm': {'bound': 'hbm', 'kernel': 'melspec_kernel (STFT + mel + log; the max subtraction is applied by conv0 on load)',
+            'frontend_hbm': {'bound': 'hbm', 'kernel': 'melspec_r16_kernel (STFT + mel + log; the max subtraction is applied by conv0 on load)',
                              'algorithmic_bytes_per_segment': 32000 + 32768,
                              'achieved': round(BSZ * (32000 + 32768) / (mel_ms * 1e-3) / 1e9, 2), 'peak': 8000.0, 'unit': 'GB/s',
                              'frac': round(BSZ * (32000 + 32768) / (mel_ms * 1e-3) / 1e9 / 8000.0, 4),
+                             'kernel_us_rocprof': fe_kernel_us,
+                             'frac_at_kernel_time': round(BSZ * (32000 + 32768) / (fe_kernel_us * 1e-6) / 1e9 / 8000.0, 4) if fe_kernel_us else None,
+                             'note': '`achieved` divides by the time between two events around the whole stage (melspec_init_stats + the '
+                                     'kernel + launch gaps, measured in this run); kernel_us_rocprof is the kernel alone under rocprofv3 '
+                                     '(profiles/traffic.json)',
                              'traffic': fe_traffic, 'traffic_unit': 'bytes/launch (640 segments)',
                              'traffic_ratio_to_algorithmic': round(fe_traffic / (BSZ * (32000 + 32768)), 3) if fe_traffic else None},
         }

@@ -625,7 +625,7 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
     TailBwdArgs tb;
     tb.z = L.z[15]; tb.stats = L.stats + 2 * B * 15; tb.gamma = e->d_gamma[15]; tb.beta = e->d_beta[15];
     tb.w1 = e->d_w1k; tb.b1 = e->d_b1k; tb.w2 = e->d_w2k; tb.b2 = e->d_b2;
-    tb.d_emb = d_emb; tb.dy = L.dy; tb.dxh = L.dA;
+    tb.d_emb = d_emb; tb.dy = L.dy; tb.dxh = L.dA; tb.ln = L.sc;      // (L.sc is rewritten by the first ln_bwd_scalars launch, after the tail)
     tb.dw1 = grads[64]; tb.db1 = grads[65]; tb.dw2 = grads[66]; tb.db2 = grads[67];
     tb.D = (int)e->flat_dim; tb.Q = e->emb_sz; tb.S = e->S; tb.l2norm = l2norm;
     rc = launch_tail_bwd(tb, B, st);

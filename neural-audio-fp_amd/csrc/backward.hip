@@ -645,6 +645,7 @@ __global__ __launch_bounds__(256) void tail_bwd_a_kernel(const TailBwdArgs a) {
     var = var > 0.0 ? var : 0.0;
     const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
     const float lnA = (float)rstd, lnC = (float)(-mean * rstd);
+    if (q == 0) { a.ln[2 * b] = lnA; a.ln[2 * b + 1] = lnC; }     // kernel B reads them instead of redoing the double arithmetic per thread
     float x[S], act[32], y;
     tail_slice_forward<S>(a, b, q, lnA, lnC, x, act, y);
     float dyq = a.d_emb[b * Q + q];
@@ -685,11 +686,7 @@ __global__ __launch_bounds__(256) void tail_bwd_b_kernel(const TailBwdArgs a, in
 #pragma unroll
     for (int t = 0; t < NI; ++t) aw1[t] = 0.f;
     for (int64_t b = bb0; b < bb1; ++b) {
-        const double mean = a.stats[2 * b] / (double)a.D;
-        double var = a.stats[2 * b + 1] / (double)a.D - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
-        const float lnA = (float)rstd, lnC = (float)(-mean * rstd);
+        const float lnA = a.ln[2 * b], lnC = a.ln[2 * b + 1];     // (a double sqrt + divide per thread and sample were most of this kernel)
         float x[S];
 #pragma unroll
         for (int k = 0; k < S; ++k) {

@@ -160,6 +160,7 @@ struct TailBwdArgs {
     const float* w1; const float* b1; const float* w2; const float* b2;             // keras layouts
     const float* d_emb;                                                             // (B,Q)
     float* dy;            // (B,Q) scratch
+    float* ln;            // (B,2) scratch: the last conv's LayerNorm scalars (r_b, -mu_b r_b) per sample, written by kernel A for kernel B
     float* dxh;           // (B,D) out: dL/dxhat of the last conv
     float* dw1; float* db1; float* dw2; float* db2;                                 // keras layouts, out
     int D, Q, S, l2norm;

@@ -1,7 +1,7 @@
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-idx=[i for i,r in enumerate(rows) if 'melspec_kernel' in r['Kernel_Name']]
+idx=[i for i,r in enumerate(rows) if ('melspec_kernel' in r['Kernel_Name'] or 'melspec_r16_kernel' in r['Kernel_Name'])]
 a,b=idx[3],idx[4]
 for r in rows[a:b]:
     n=r['Kernel_Name'].split('(')[0].replace('nafp::','').replace('void ','')

@@ -107,7 +107,7 @@ def kernel_traffic(name_part):
 
 # front end (north star: "rocprof HBM GB/s on the STFT/mel path") and the Cin = 1 conv, per launch of 640 segments
 front = {}
-for key, part in (('melspec_kernel', 'melspec_kernel'), ('melspec_finalize_kernel', 'melspec_finalize'), ('conv0_kernel', 'conv0_kernel')):
+for key, part in (('melspec_kernel', 'melspec_kernel'), ('melspec_r16_kernel', 'melspec_r16_kernel'), ('melspec_finalize_kernel', 'melspec_finalize'), ('conv0_kernel', 'conv0_kernel')):
     kt = kernel_traffic(part)
     if kt:
         kt['bytes_per_segment'] = (kt['fetch_bytes_x2_corrected'] + kt['write_bytes']) / BSZ
@@ -118,7 +118,7 @@ json.dump({'tag': tag, 'kernel': 'conv_gemm_* (the 15 GEMM-conv launches of a st
                         'algorithmic_bytes_per_segment': 32000 + 32768,
                         'ratio_to_algorithmic': fe_total / BSZ / (32000 + 32768) if fe_total else None,
                         'note': 'f32 audio in (32,000 B) + log-mel out (32,768 B) per segment; the kernels of the front end '
-                                'that ran in the profiled bench (melspec_kernel, plus melspec_finalize_kernel when the '
+                                'that ran in the profiled bench (melspec_r16_kernel -- or melspec_kernel with NAFP_MELSPEC_R4=1 --, plus melspec_finalize_kernel when the '
                                 'log-mel tail is not deferred into conv0)'},
            'fetch_bytes_x2_corrected': fetch_bytes_per_launch, 'write_bytes': write_bytes_per_launch,
            'algorithmic_activation_bytes_per_launch': alg_bytes_per_launch,
@@ -150,7 +150,7 @@ with open(os.path.join(dst, f'{tag}_summary.md'), 'w') as f:
     # per bench step (from one melspec_kernel to the next): the durations of the GEMM-conv kernels and their split-K
     # finish kernels, summed; the timed region's HIP events give the SPAN from the first to the last of them
     tr = sorted(trace, key=lambda r: int(r['Start_Timestamp']))
-    marks = [i for i, r in enumerate(tr) if 'melspec_kernel' in r['Kernel_Name']]
+    marks = [i for i, r in enumerate(tr) if ('melspec_kernel' in r['Kernel_Name'] or 'melspec_r16_kernel' in r['Kernel_Name'])]
     per_step = []
     for a_, b_ in zip(marks[:-1], marks[1:]):
         ks = [r for r in tr[a_:b_] if GEMM in r['Kernel_Name'] or 'splitk_finish' in r['Kernel_Name']]
@@ -221,7 +221,7 @@ def train_section(dirname, probe_name, csv_name, title, cmd):
     shutil.copy(tt, os.path.join(dst, csv_name))
     ttrace = read_csv(os.path.join(src, dirname, 't_kernel_trace.csv'))
     ttrace.sort(key=lambda r: int(r['Start_Timestamp']))
-    idx = [i for i, r in enumerate(ttrace) if 'melspec_kernel' in r['Kernel_Name']]
+    idx = [i for i, r in enumerate(ttrace) if ('melspec_kernel' in r['Kernel_Name'] or 'melspec_r16_kernel' in r['Kernel_Name'])]
     a, b = idx[-2], idx[-1]
     agg2 = defaultdict(lambda: [0, 0.0])
     for r in ttrace[a:b]:

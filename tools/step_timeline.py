@@ -6,7 +6,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 min_us = float(sys.argv[2]) if len(sys.argv) > 2 else 6.0
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'melspec_kernel' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if ('melspec_kernel' in r['Kernel_Name'] or 'melspec_r16_kernel' in r['Kernel_Name'])]
 s, e = idx[-2], idx[-1]
 t0 = int(rows[s]['Start_Timestamp'])
 short = lambda n: n.replace('nafp::', '').replace('void ', '').split('(')[0][:28]
