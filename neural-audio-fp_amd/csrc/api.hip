@@ -108,6 +108,12 @@ struct nafp_encoder {
     int opt_bwd_overlap = []() { const char* v = getenv("NAFP_BWD_OVERLAP"); return v ? atoi(v) : 0; }();
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_main[16] = {}, ev_side[16] = {};
+    // set_weights: the 15 G / Hb images are small, latency-bound launches (2 "samples"; the late ones stream 6-12 MB of
+    // weights through a handful of workgroups): they run NAFP_SW_STREAMS abreast on helper streams of the handle, each
+    // with its own split-K slab, between a fork and a join on the caller's stream.
+    static constexpr int NAFP_SW_STREAMS = 4;
+    hipStream_t sw_streams[NAFP_SW_STREAMS] = {};
+    hipEvent_t sw_fork = nullptr, sw_join[NAFP_SW_STREAMS] = {};
 };
 
 // gradient group k = parameter tensors [kGroupFirst[k], kGroupLast[k]] in COMPLETION order of the backward pass
@@ -200,7 +206,7 @@ extern "C" int nafp_encoder_create(nafp_encoder** out, int in_f, int in_t, int e
     for (int j = 1; j < 16; ++j) total += (numel(e->shapes[4 * j]) + 63) / 64 * 64;               // dgrad weights
     total += (numel(e->shapes[64]) + 63) / 64 * 64 + 2 * ((numel(e->shapes[65]) + 63) / 64 * 64) + 64;   // keras div copies, inv_n
     for (int j = 1; j < 16; ++j) e->sw_slab_floats = std::max(e->sw_slab_floats, conv_gemm_slab_floats(2, e->geom[j]));
-    total += e->sw_slab_floats + 64;
+    total += nafp_encoder::NAFP_SW_STREAMS * (e->sw_slab_floats + 64);
     e->blob_floats = total;
     hipError_t err = hipMalloc(&e->d_blob, sizeof(float) * total);
     if (err != hipSuccess) { g_last_hip_error = (int)err; delete e; return NAFP_ERR_HIP; }
@@ -219,7 +225,7 @@ extern "C" int nafp_encoder_create(nafp_encoder** out, int in_f, int in_t, int e
     for (int j = 1; j < 16; ++j) e->d_wd.push_back(take(4 * j));
     e->d_w1k = take(64); e->d_b1k = take(65); e->d_w2k = take(65);
     e->d_inv_n = (double*)p; p += 64;
-    e->d_sw_slab = p; p += e->sw_slab_floats;
+    e->d_sw_slab = p; p += nafp_encoder::NAFP_SW_STREAMS * (e->sw_slab_floats + 64);      // one slab per helper stream, (sw_slab_floats + 64) apart
     // set_weights runs G_j and Hb_j as the two "samples" of one launch: the pairs must be adjacent
     for (int j = 0; j < 16; ++j) {
         const int64_t n = numel(e->shapes[4 * j + 2]);
@@ -251,6 +257,9 @@ extern "C" int nafp_encoder_destroy(nafp_encoder* e) {
     for (auto& ev : e->ev_main) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : e->ev_side) if (ev) (void)hipEventDestroy(ev);
     if (e->side_stream) (void)hipStreamDestroy(e->side_stream);
+    for (auto& q : e->sw_streams) if (q) (void)hipStreamDestroy(q);
+    for (auto& ev : e->sw_join) if (ev) (void)hipEventDestroy(ev);
+    if (e->sw_fork) (void)hipEventDestroy(e->sw_fork);
     delete e;
     return NAFP_OK;
 }
@@ -317,15 +326,30 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
     // positional epilogue terms of conv j: G = conv_j(gamma_{j-1}), Hb = conv_j(beta_{j-1}) + bias_j:
     // one 2-"sample" PLAIN launch per conv (gamma | beta adjacent in, G | Hb adjacent out), then all biases at once
     BiasTable bt; bt.count = 0;
+    constexpr int NS = nafp_encoder::NAFP_SW_STREAMS;
+    if (!e->sw_fork) {
+        NAFP_HIP_CHECK(hipEventCreateWithFlags(&e->sw_fork, hipEventDisableTiming));
+        for (int k = 0; k < NS; ++k) {
+            NAFP_HIP_CHECK(hipStreamCreateWithFlags(&e->sw_streams[k], hipStreamNonBlocking));
+            NAFP_HIP_CHECK(hipEventCreateWithFlags(&e->sw_join[k], hipEventDisableTiming));
+        }
+    }
+    NAFP_HIP_CHECK(hipEventRecord(e->sw_fork, st));                         // copies and re-packs above are done
+    for (int k = 0; k < NS; ++k) NAFP_HIP_CHECK(hipStreamWaitEvent(e->sw_streams[k], e->sw_fork, 0));
     for (int j = 1; j < 16; ++j) {
+        const int k = (j - 1) % NS;
         ConvGemmArgs a{};
         a.wp = e->d_w[j]; a.plain = true;
         a.x = e->d_gamma[j - 1]; a.bias = nullptr; a.y = e->d_G[j];
-        a.slab = e->sw_slab_floats ? e->d_sw_slab : nullptr; a.slab_floats = e->sw_slab_floats;
-        int rc = launch_conv_gemm(a, 2, e->geom[j], st);
+        a.slab = e->sw_slab_floats ? e->d_sw_slab + (int64_t)k * (e->sw_slab_floats + 64) : nullptr; a.slab_floats = e->sw_slab_floats;
+        int rc = launch_conv_gemm(a, 2, e->geom[j], e->sw_streams[k]);
         if (rc != NAFP_OK) return rc;
         bt.hb[bt.count] = e->d_Hb[j]; bt.bias[bt.count] = e->d_bias[j];
         bt.n[bt.count] = numel(e->shapes[4 * j + 2]); bt.cout[bt.count] = e->geom[j].Cout; ++bt.count;
+    }
+    for (int k = 0; k < NS; ++k) {
+        NAFP_HIP_CHECK(hipEventRecord(e->sw_join[k], e->sw_streams[k]));
+        NAFP_HIP_CHECK(hipStreamWaitEvent(st, e->sw_join[k], 0));
     }
     add_bias_kernel<<<dim3(32, bt.count), 256, 0, st>>>(bt);
     NAFP_LAUNCH_CHECK();

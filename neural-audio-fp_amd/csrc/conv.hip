@@ -2047,15 +2047,19 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ k3, float* __r
 // All convs' weight re-layouts of one set_weights call in ONE launch (training re-packs after every optimizer
 // step): entry e, blockIdx.y = e; forward operand (Cout, 3*Cin) by 32 x 32 LDS transposes and -- training only --
 // the transposed-conv operand (Cin, 3*Cout): Wd[c][k*Cout + n] = W[k][c][n].
+// Work units of 8 tiles (8192 elements) over all entries, one workgroup each (entry found in the unit prefix): the entries
+// range from 49 K to 3.1 M elements, and a fixed number of workgroups per entry made the launch as long as the largest one.
 __global__ __launch_bounds__(256) void multi_pack_kernel(const PackTable t) {
     __shared__ float tile[32][33];
-    const int e = blockIdx.y;
+    int e = 0;
+    while (e + 1 < t.count && t.unit0[e + 1] <= (int)blockIdx.x) ++e;
+    const int u = (int)blockIdx.x - t.unit0[e];
     const float* __restrict__ k3 = t.k3[e];
     float* __restrict__ wp = t.wp[e]; float* __restrict__ wd = t.wd[e];
     const int Cin = t.cin[e], Cout = t.cout[e], K = 3 * Cin;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int tiles_k = (K + 31) / 32, tiles_n = (Cout + 31) / 32;
-    for (int tl = blockIdx.x; tl < tiles_k * tiles_n; tl += gridDim.x) {
+    for (int tl = 8 * u; tl < 8 * u + 8 && tl < tiles_k * tiles_n; ++tl) {
         const int k0 = (tl % tiles_k) * 32, n0 = (tl / tiles_k) * 32;
         __syncthreads();
         for (int r = ty; r < 32; r += 8)
@@ -2066,7 +2070,7 @@ __global__ __launch_bounds__(256) void multi_pack_kernel(const PackTable t) {
     }
     if (wd) {
         const int64_t total = (int64_t)3 * Cin * Cout;
-        for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        for (int64_t i = (int64_t)u * 8192 + threadIdx.x; i < (int64_t)(u + 1) * 8192 && i < total; i += 256) {
             const int n = (int)(i % Cout);
             const int64_t r = i / Cout;
             const int c = (int)(r % Cin), k = (int)(r / Cin);
@@ -2075,9 +2079,16 @@ __global__ __launch_bounds__(256) void multi_pack_kernel(const PackTable t) {
     }
 }
 
-int launch_multi_pack(const PackTable& t, hipStream_t st) {
-    if (t.count <= 0) return NAFP_OK;
-    multi_pack_kernel<<<dim3(96, t.count), 256, 0, st>>>(t);
+int launch_multi_pack(const PackTable& t0, hipStream_t st) {
+    if (t0.count <= 0) return NAFP_OK;
+    PackTable t = t0;
+    t.unit0[0] = 0;
+    for (int e = 0; e < t.count; ++e) {
+        const int64_t tiles = (int64_t)((3 * t.cin[e] + 31) / 32) * ((t.cout[e] + 31) / 32);
+        // units of 8 tiles also cover the element-wise dgrad layout: 8 tiles x 1024 >= 8192 elements of the same entry
+        t.unit0[e + 1] = t.unit0[e] + (int)((std::max<int64_t>(tiles * 1024, (int64_t)3 * t.cin[e] * t.cout[e]) + 8191) / 8192);
+    }
+    multi_pack_kernel<<<dim3((unsigned)t.unit0[t.count]), 256, 0, st>>>(t);
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }

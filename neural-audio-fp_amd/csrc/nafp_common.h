@@ -186,7 +186,7 @@ int launch_conv0_bwd(const float* feat, const float* dt, float* dW0, float* dbia
 int launch_pack_dgrad_weight(const float* k3, float* wd, int Cin, int Cout, hipStream_t st);
 
 // weight packing
-struct PackTable { const float* k3[16]; float* wp[16]; float* wd[16]; int cin[16], cout[16]; int count; };
+struct PackTable { const float* k3[16]; float* wp[16]; float* wd[16]; int cin[16], cout[16]; int unit0[17]; int count; };
 int launch_multi_pack(const PackTable& t, hipStream_t st);
 int launch_pack_conv_weight(const float* k3, float* wp, int Cin, int Cout, hipStream_t st);
 int launch_pack_div(const float* w1, const float* b1, const float* w2, float* w1p, float* b1p,

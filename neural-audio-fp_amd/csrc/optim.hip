@@ -25,34 +25,70 @@ struct OptTable {
     long long numel[OPT_MAX_T];
     long long var_len[OPT_MAX_T];
     long long norm_off[OPT_MAX_T];       // first (w2, u2) pair of this tensor in the norm buffer
+    int blk0[OPT_MAX_T + 1];             // first work block of tensor i (blocks of OPT_BLK elements); blk0[n] = grid size
     int n;
 };
 
+// Work is cut into blocks of OPT_BLK elements over ALL tensors of a launch (one workgroup per block, tensor found by a
+// search in the block prefix): the tensors range from 128 to 3.1 M elements, and with a fixed number of workgroups per
+// tensor (round 1-2: 64) the launch lasted as long as 64 workgroups need for the largest one -- LAMB took 523 us per
+// step for 475 MB of traffic.
+constexpr int OPT_BLK = 4096;
+
+__device__ __forceinline__ int opt_find_tensor(const OptTable& t, int blk) {
+    int lo = 0, hi = t.n - 1;
+    while (lo < hi) {                                        // largest i with blk0[i] <= blk
+        const int mid = (lo + hi + 1) >> 1;
+        if (t.blk0[mid] <= blk) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(const OptTable t, float lr_t, float b1, float b2, float eps) {
-    const int ti = blockIdx.y;
+    const int ti = opt_find_tensor(t, blockIdx.x);
     float* __restrict__ p = t.p[ti]; const float* __restrict__ g = t.g[ti];
     float* __restrict__ m = t.m[ti]; float* __restrict__ v = t.v[ti];
     const long long n = t.numel[ti];
-    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const float gi = g[i];
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi; v[i] = vi;
-        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    const long long i0 = (long long)(blockIdx.x - t.blk0[ti]) * OPT_BLK;
+    const bool vec_ok = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;   // 16-B aligned tensors take float4
+#pragma unroll
+    for (int e = 0; e < OPT_BLK / 1024; ++e) {
+        const long long i = i0 + e * 1024 + 4 * threadIdx.x;
+        if (vec_ok && i + 3 < n) {
+            const float4 g4 = *(const float4*)(g + i), m4 = *(const float4*)(m + i), v4 = *(const float4*)(v + i);
+            float4 p4 = *(const float4*)(p + i), mo, vo;
+            mo.x = b1 * m4.x + (1.f - b1) * g4.x; vo.x = b2 * v4.x + (1.f - b2) * g4.x * g4.x; p4.x -= lr_t * mo.x / (sqrtf(vo.x) + eps);
+            mo.y = b1 * m4.y + (1.f - b1) * g4.y; vo.y = b2 * v4.y + (1.f - b2) * g4.y * g4.y; p4.y -= lr_t * mo.y / (sqrtf(vo.y) + eps);
+            mo.z = b1 * m4.z + (1.f - b1) * g4.z; vo.z = b2 * v4.z + (1.f - b2) * g4.z * g4.z; p4.z -= lr_t * mo.z / (sqrtf(vo.z) + eps);
+            mo.w = b1 * m4.w + (1.f - b1) * g4.w; vo.w = b2 * v4.w + (1.f - b2) * g4.w * g4.w; p4.w -= lr_t * mo.w / (sqrtf(vo.w) + eps);
+            *(float4*)(m + i) = mo; *(float4*)(v + i) = vo; *(float4*)(p + i) = p4;
+        } else {
+            for (long long k = i; k < n && k < i + 4; ++k) {
+                const float gi = g[k];
+                const float mi = b1 * m[k] + (1.f - b1) * gi;
+                const float vi = b2 * v[k] + (1.f - b2) * gi * gi;
+                m[k] = mi; v[k] = vi;
+                p[k] -= lr_t * mi / (sqrtf(vi) + eps);
+            }
+        }
     }
 }
 
 // LAMB phase 1: moments, and per-variable sum(w^2), sum(update^2) into `norms` (double pairs).
 __global__ __launch_bounds__(256) void lamb_moments_kernel(const OptTable t, float b1, float b2, float eps, float wd,
                                                            float inv_bc1, float inv_bc2, double* __restrict__ norms) {
-    const int ti = blockIdx.y;
+    const int ti = opt_find_tensor(t, blockIdx.x);
     const float* __restrict__ p = t.p[ti]; const float* __restrict__ g = t.g[ti];
     float* __restrict__ m = t.m[ti]; float* __restrict__ v = t.v[ti];
     const long long n = t.numel[ti], vl = t.var_len[ti];
     double* nb = norms + 2 * t.norm_off[ti];
     const bool one_var = vl == n;
+    const long long i0 = (long long)(blockIdx.x - t.blk0[ti]) * OPT_BLK;
     double w2 = 0.0, u2 = 0.0;
-    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+#pragma unroll
+    for (int e = 0; e < OPT_BLK / 256; ++e) {
+        const long long i = i0 + e * 256 + threadIdx.x;
+        if (i >= n) break;
         const float gi = g[i], wi = p[i];
         const float mi = b1 * m[i] + (1.f - b1) * gi;
         const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
@@ -81,15 +117,27 @@ __global__ __launch_bounds__(256) void lamb_moments_kernel(const OptTable t, flo
 // LAMB phase 2: w -= ratio * lr * update, ratio = ||w||/||update|| (1 if either norm is 0).
 __global__ __launch_bounds__(256) void lamb_apply_kernel(const OptTable t, float lr, float eps, float wd,
                                                          float inv_bc1, float inv_bc2, const double* __restrict__ norms) {
-    const int ti = blockIdx.y;
+    const int ti = opt_find_tensor(t, blockIdx.x);
     float* __restrict__ p = t.p[ti];
     const float* __restrict__ m = t.m[ti]; const float* __restrict__ v = t.v[ti];
     const long long n = t.numel[ti], vl = t.var_len[ti];
     const double* nb = norms + 2 * t.norm_off[ti];
-    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const long long s = i / vl;
-        const float wn = (float)sqrt(nb[2 * s]), un = (float)sqrt(nb[2 * s + 1]);
-        const float ratio = (wn > 0.f && un > 0.f) ? wn / un : 1.f;
+    const long long i0 = (long long)(blockIdx.x - t.blk0[ti]) * OPT_BLK;
+    float ratio1 = 1.f;                                        // the tensor is ONE variable: its ratio once per workgroup
+    if (vl == n) {
+        const float wn = (float)sqrt(nb[0]), un = (float)sqrt(nb[1]);
+        ratio1 = (wn > 0.f && un > 0.f) ? wn / un : 1.f;
+    }
+#pragma unroll
+    for (int e = 0; e < OPT_BLK / 256; ++e) {
+        const long long i = i0 + e * 256 + threadIdx.x;
+        if (i >= n) break;
+        float ratio = ratio1;
+        if (vl != n) {
+            const long long s = i / vl;
+            const float wn = (float)sqrt(nb[2 * s]), un = (float)sqrt(nb[2 * s + 1]);
+            ratio = (wn > 0.f && un > 0.f) ? wn / un : 1.f;
+        }
         const float wi = p[i];
         const float u = (m[i] * inv_bc1) / (sqrtf(v[i] * inv_bc2) + eps) + wd * wi;
         p[i] = wi - ratio * lr * u;
@@ -98,6 +146,7 @@ __global__ __launch_bounds__(256) void lamb_apply_kernel(const OptTable t, float
 
 static int fill_table(OptTable& tb, const nafp_opt_tensor* ts, int first, int n, long long& norm_cursor) {
     tb.n = n;
+    tb.blk0[0] = 0;
     for (int i = 0; i < n; ++i) {
         const nafp_opt_tensor& t = ts[first + i];
         if (!t.param || !t.grad || !t.m || !t.v || t.numel <= 0 || t.var_len <= 0 || t.numel % t.var_len != 0)
@@ -105,6 +154,9 @@ static int fill_table(OptTable& tb, const nafp_opt_tensor* ts, int first, int n,
         tb.p[i] = t.param; tb.g[i] = t.grad; tb.m[i] = t.m; tb.v[i] = t.v;
         tb.numel[i] = t.numel; tb.var_len[i] = t.var_len; tb.norm_off[i] = norm_cursor;
         norm_cursor += t.numel / t.var_len;
+        const long long nblk = (t.numel + OPT_BLK - 1) / OPT_BLK;
+        if ((long long)tb.blk0[i] + nblk > 0x7fffffffll) return NAFP_ERR_UNSUPPORTED;
+        tb.blk0[i + 1] = tb.blk0[i] + (int)nblk;
     }
     return NAFP_OK;
 }
@@ -151,7 +203,7 @@ extern "C" int nafp_adam_step(const nafp_opt_tensor* tensors_host, int n, float 
         const int cnt = n - first < OPT_MAX_T ? n - first : OPT_MAX_T;
         int rc = fill_table(tb, tensors_host, first, cnt, cursor);
         if (rc != NAFP_OK) return rc;
-        adam_kernel<<<dim3(64, cnt), 256, 0, st>>>(tb, lr_t, beta1, beta2, eps);
+        adam_kernel<<<dim3((unsigned)tb.blk0[cnt]), 256, 0, st>>>(tb, lr_t, beta1, beta2, eps);
         NAFP_LAUNCH_CHECK();
     }
     return NAFP_OK;
@@ -187,10 +239,10 @@ extern "C" int nafp_lamb_step(const nafp_opt_tensor* tensors_host, int n, float 
             int rc = fill_table(tb, tensors_host, first, cnt, cursor);
             if (rc != NAFP_OK) return rc;
             if (pass == 0)
-                lamb_moments_kernel<<<dim3(64, cnt), 256, 0, st>>>(tb, beta1, beta2, eps, weight_decay, inv_bc1,
+                lamb_moments_kernel<<<dim3((unsigned)tb.blk0[cnt]), 256, 0, st>>>(tb, beta1, beta2, eps, weight_decay, inv_bc1,
                                                                    inv_bc2, norms);
             else
-                lamb_apply_kernel<<<dim3(64, cnt), 256, 0, st>>>(tb, lr, eps, weight_decay, inv_bc1, inv_bc2, norms);
+                lamb_apply_kernel<<<dim3((unsigned)tb.blk0[cnt]), 256, 0, st>>>(tb, lr, eps, weight_decay, inv_bc1, inv_bc2, norms);
             NAFP_LAUNCH_CHECK();
         }
     }
