@@ -85,6 +85,30 @@ __global__ __launch_bounds__(256) void lamb_moments_kernel(const OptTable t, flo
     const bool one_var = vl == n;
     const long long i0 = (long long)(blockIdx.x - t.blk0[ti]) * OPT_BLK;
     double w2 = 0.0, u2 = 0.0;
+    const bool vec_ok = one_var && i0 + OPT_BLK <= n &&
+                        ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
+    if (vec_ok) {
+        // whole block of one variable, 16-B aligned: float4 loads, all four arrays of an iteration in flight together;
+        // the squares are summed in float per thread (16 terms) and in double from there on
+        float w2f = 0.f, u2f = 0.f;
+#pragma unroll
+        for (int e = 0; e < OPT_BLK / 1024; ++e) {
+            const long long i = i0 + e * 1024 + 4 * threadIdx.x;
+            const float4 g4 = *(const float4*)(g + i), p4 = *(const float4*)(p + i);
+            float4 m4 = *(const float4*)(m + i), v4 = *(const float4*)(v + i);
+#define NAFP_LAMB1(c_)                                                                       \
+            {                                                                                \
+                m4.c_ = b1 * m4.c_ + (1.f - b1) * g4.c_;                                     \
+                v4.c_ = b2 * v4.c_ + (1.f - b2) * g4.c_ * g4.c_;                             \
+                const float u_l = (m4.c_ * inv_bc1) / (sqrtf(v4.c_ * inv_bc2) + eps) + wd * p4.c_; \
+                w2f = fmaf(p4.c_, p4.c_, w2f); u2f = fmaf(u_l, u_l, u2f);                    \
+            }
+            NAFP_LAMB1(x) NAFP_LAMB1(y) NAFP_LAMB1(z) NAFP_LAMB1(w)
+#undef NAFP_LAMB1
+            *(float4*)(m + i) = m4; *(float4*)(v + i) = v4;
+        }
+        w2 = (double)w2f; u2 = (double)u2f;
+    } else
 #pragma unroll
     for (int e = 0; e < OPT_BLK / 256; ++e) {
         const long long i = i0 + e * 256 + threadIdx.x;
