@@ -25,6 +25,7 @@
 #include "nafp_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace nafp {
 
@@ -545,7 +546,8 @@ int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const Con
     const int col_tiles = (g.Cout / 128) * (p.n_live * g.Cin / 128);
     // one resident round: 256 CUs x 3 workgroups (each workgroup ends in 16 K atomics, so fewer is better;
     // measured at B = 1280: 768 / 1536 / 3072 / 6144 workgroups -> backward 22.3 / 22.5 / 22.9 / 24.3 ms)
-    long long chunks = std::max<long long>(1, 768 / col_tiles);
+    static const long long slots = []() { const char* e = getenv("NAFP_WGRAD_SLOTS"); return e ? atoll(e) : 768ll; }();
+    long long chunks = std::max<long long>(1, slots / col_tiles);
     long long rpw = (M + chunks - 1) / chunks;
     rpw = std::max<long long>(64, (rpw + 15) / 16 * 16);
     // the X descriptor of a workgroup spans (rows/P + 2) samples: keep it below 2 GiB
