@@ -20,6 +20,8 @@
 // operands), the row fragment of R stays in 64 registers for the whole kernel.
 #include "nafp_common.h"
 
+#include <algorithm>
+
 namespace nafp {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -31,7 +33,7 @@ __global__ __launch_bounds__(256) void ntxent_fwd_kernel(
         const float* __restrict__ org_l, const float* __restrict__ rep_l,
         const float* __restrict__ org_all, const float* __restrict__ rep_all,
         int n_local, int n_global, int rank_offset, float tau,
-        float* __restrict__ row_loss, float* __restrict__ row_lse, float* __restrict__ sim_mtx) {
+        float* __restrict__ fpart, float* __restrict__ sim_mtx) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, rl = lane & 31;
     const int n_rows = 2 * n_local, n_cols = 2 * n_global;
@@ -55,7 +57,10 @@ __global__ __launch_bounds__(256) void ntxent_fwd_kernel(
     }
     float run_m = -INFINITY, run_s = 0.f, pos_v = 0.f;
     const int n_tiles = (n_cols + 31) / 32;
-    for (int t = wave; t < n_tiles; t += 4) {
+    // blockIdx.y = column split: this workgroup's waves take tiles t = 4 y + wave, then + 4 gridDim.y (the sharded loss
+    // has few row blocks -- 20 per rank at BSZ 5120 over 8 ranks -- and 160 column tiles: without the split 20 workgroups
+    // walked all of them)
+    for (int t = blockIdx.y * 4 + wave; t < n_tiles; t += 4 * gridDim.y) {
         const int c = t * 32 + rl;                          // column this lane feeds into the A operand
         const bool cvalid = c < n_cols;
         const float* csrc = nullptr;
@@ -120,12 +125,36 @@ __global__ __launch_bounds__(256) void ntxent_fwd_kernel(
             pv += sp[w][tid];
         }
         const int rr = blockIdx.x * 32 + tid;
-        if (rr < n_rows) {
-            const float lse = m + __logf(s);
-            row_lse[rr] = lse;
-            row_loss[rr] = lse - pv;
+        if (rr < n_rows) {                                   // this split's (max, sum exp, positive logit): merged by ntxent_merge_kernel
+            float* o = fpart + ((int64_t)blockIdx.y * n_rows + rr) * 3;
+            o[0] = m; o[1] = s; o[2] = pv;
         }
     }
+}
+
+// Per row: merge the column splits' (max, sum exp, positive) in split order, lse and loss; then the sum of the row losses.
+// Single workgroup, fixed order: deterministic.
+__global__ void ntxent_merge_kernel(const float* __restrict__ fpart, int n_rows, int n_split,
+                                    float* __restrict__ row_lse, float* __restrict__ out) {
+    double acc = 0.0;
+    for (int r = threadIdx.x; r < n_rows; r += blockDim.x) {
+        float m = -INFINITY;
+        for (int k = 0; k < n_split; ++k) m = fmaxf(m, fpart[((int64_t)k * n_rows + r) * 3]);
+        float ssum = 0.f, pv = 0.f;
+        for (int k = 0; k < n_split; ++k) {
+            const float* q = fpart + ((int64_t)k * n_rows + r) * 3;
+            if (q[0] > -INFINITY) ssum += q[1] * __expf(q[0] - m);
+            pv += q[2];
+        }
+        const float lse = m + __logf(ssum);
+        row_lse[r] = lse;
+        acc += (double)(lse - pv);
+    }
+    acc = wave_sum(acc);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (float)(red[0] + red[1] + red[2] + red[3]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -147,7 +176,7 @@ __global__ __launch_bounds__(256) void ntxent_bwd_kernel(
         const float* __restrict__ org_all, const float* __restrict__ rep_all,
         const float* __restrict__ row_lse, int n_local, int n_global, int rank_offset,
         float tau, float scale,                 // scale = 1 / (tau * n_global)
-        float* __restrict__ part,               // [4 waves][n_owner][ND] partial sums over this wave's tiles
+        float* __restrict__ part,               // [4 gridDim.y (split, wave)][n_owner][ND] partial sums over this wave's tiles
         int n_owner_pad) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, jl = lane & 31;
@@ -183,7 +212,7 @@ __global__ __launch_bounds__(256) void ntxent_bwd_kernel(
         for (int q = 0; q < 16; ++q) out[nb][q] = 0.f;
 
     const int n_tiles = (n_other + 31) / 32;
-    for (int t = wave; t < n_tiles; t += 4) {
+    for (int t = blockIdx.y * 4 + wave; t < n_tiles; t += 4 * gridDim.y) {      // blockIdx.y: split over the other set's tiles
         const int ti = t * 32 + jl;                          // tile member this lane feeds (A operand)
         const bool tvalid = ti < n_other;
         const float* tsrc = tvalid ? (COL ? row_ptr(ti) : col_ptr(ti)) + HK * h : nullptr;
@@ -234,7 +263,7 @@ __global__ __launch_bounds__(256) void ntxent_bwd_kernel(
     }
     // D2[i' = feature (regs)][j' = owner (lane)]: feature = nb*32 + (q&3) + 8(q>>2) + 4h
     if (ovalid) {
-        float* dst = part + ((int64_t)wave * n_owner_pad + o) * ND;
+        float* dst = part + ((int64_t)(blockIdx.y * 4 + wave) * n_owner_pad + o) * ND;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -247,13 +276,13 @@ __global__ __launch_bounds__(256) void ntxent_bwd_kernel(
 // d_all[c] = sum_w partC[w][c] (+ sum_w partR[w][local row of c]); fixed order.
 __global__ void ntxent_bwd_combine_kernel(const float* __restrict__ partC, const float* __restrict__ partR,
                                           int n_local, int n_global, int rank_offset, int padC, int padR, int ND,
-                                          float* __restrict__ d_org_all, float* __restrict__ d_rep_all) {
+                                          int n_partC, int n_partR, float* __restrict__ d_org_all, float* __restrict__ d_rep_all) {
     const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;     // float4 index over (2*n_global, ND/4)
     const int64_t total = (int64_t)2 * n_global * (ND / 4);
     if (idx >= total) return;
     const int c = (int)(idx / (ND / 4)), f4 = (int)(idx % (ND / 4));
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < n_partC; ++w) {
         const float4 t = *(const float4*)(partC + ((int64_t)w * padC + c) * ND + 4 * f4);
         s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
@@ -261,7 +290,7 @@ __global__ void ntxent_bwd_combine_kernel(const float* __restrict__ partC, const
     const int li = gi - rank_offset;
     if (li >= 0 && li < n_local) {
         const int r = is_b ? n_local + li : li;
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < n_partR; ++w) {
             const float4 t = *(const float4*)(partR + ((int64_t)w * padR + r) * ND + 4 * f4);
             s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
         }
@@ -270,26 +299,25 @@ __global__ void ntxent_bwd_combine_kernel(const float* __restrict__ partC, const
     *(float4*)dst = s;
 }
 
-__global__ void ntxent_sum_kernel(const float* __restrict__ row_loss, int n, float* __restrict__ out) {
-    // single workgroup, fixed order: deterministic
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += (double)row_loss[i];
-    acc = wave_sum(acc);
-    __shared__ double red[4];
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) *out = (float)(red[0] + red[1] + red[2] + red[3]);
-}
-
 }  // namespace nafp
 
 using namespace nafp;
 
+// Splits of the "other" set per block of 32 owners: enough workgroups for the chip (about 320), at most 16.
+static int ntxent_splits(int64_t owners, int64_t others) {
+    const int64_t blocks = (owners + 31) / 32, tiles = (others + 31) / 32;
+    int64_t s = std::max<int64_t>(1, std::min<int64_t>(16, 320 / std::max<int64_t>(blocks, 1)));
+    s = std::min<int64_t>(s, std::max<int64_t>(1, tiles / 4));            // every wave of every split gets a tile
+    return (int)s;
+}
+
 extern "C" int64_t nafp_ntxent_workspace_bytes(int64_t n_local, int64_t n_global) {
     if (n_local < 0 || n_global < n_local) return -1;
-    // row_loss + row_lse, then the backward partials: [4][2*n_local padded][d] + [4][2*n_global padded][d], d <= 256
+    // forward partials (splits x rows x 3) + row_lse, then the backward partials:
+    // [4 splitsR][2*n_local padded][d] + [4 splitsC][2*n_global padded][d], d <= 256
     const int64_t padR = (2 * n_local + 31) / 32 * 32, padC = (2 * n_global + 31) / 32 * 32;
-    return (int64_t)sizeof(float) * (2 * (2 * n_local) + 64 + 4 * (padR + padC) * 256) + 256;
+    const int sR = ntxent_splits(2 * n_local, 2 * n_global), sC = ntxent_splits(2 * n_global, 2 * n_local);
+    return (int64_t)sizeof(float) * ((3 * sR + 1) * (2 * n_local) + 64 + 4 * (sR * padR + sC * padC) * 256) + 256;
 }
 
 namespace {
@@ -298,32 +326,33 @@ int ntxent_launch(const float* emb_org_local, const float* emb_rep_local, const 
                   const float* emb_rep_all, int64_t n_local, int64_t n_global, int64_t rank_offset, float tau,
                   float* loss_sum, float* sim_mtx, float* d_org_all, float* d_rep_all, void* workspace,
                   hipStream_t st) {
-    float* row_loss = (float*)workspace;
-    float* row_lse = row_loss + 2 * n_local;
     const int n_rows = (int)(2 * n_local);
-    ntxent_fwd_kernel<ND><<<(n_rows + 31) / 32, 256, 0, st>>>(
+    const int sR = ntxent_splits(2 * n_local, 2 * n_global), sC = ntxent_splits(2 * n_global, 2 * n_local);
+    float* fpart = (float*)workspace;                       // [sR][n_rows][3]
+    float* row_lse = fpart + (int64_t)3 * sR * n_rows;
+    ntxent_fwd_kernel<ND><<<dim3((n_rows + 31) / 32, sR), 256, 0, st>>>(
         emb_org_local, emb_rep_local, emb_org_all, emb_rep_all, (int)n_local, (int)n_global,
-        (int)rank_offset, tau, row_loss, row_lse, sim_mtx);
+        (int)rank_offset, tau, fpart, sim_mtx);
     NAFP_LAUNCH_CHECK();
-    ntxent_sum_kernel<<<1, 256, 0, st>>>(row_loss, n_rows, loss_sum);
+    ntxent_merge_kernel<<<1, 256, 0, st>>>(fpart, n_rows, sR, row_lse, loss_sum);
     NAFP_LAUNCH_CHECK();
     if (d_org_all) {
         const int padR = (n_rows + 31) / 32 * 32, padC = (int)((2 * n_global + 31) / 32 * 32);
-        float* partR = row_lse + 2 * n_local + 64;
+        float* partR = row_lse + n_rows + 64;
         partR = (float*)(((uintptr_t)partR + 15) & ~(uintptr_t)15);
-        float* partC = partR + (int64_t)4 * padR * ND;
+        float* partC = partR + (int64_t)4 * sR * padR * ND;
         const float scale = 1.0f / (tau * (float)n_global);
-        ntxent_bwd_kernel<ND, false><<<padR / 32, 256, 0, st>>>(emb_org_local, emb_rep_local, emb_org_all, emb_rep_all,
-                                                               row_lse, (int)n_local, (int)n_global, (int)rank_offset,
-                                                               tau, scale, partR, padR);
+        ntxent_bwd_kernel<ND, false><<<dim3(padR / 32, sR), 256, 0, st>>>(emb_org_local, emb_rep_local, emb_org_all, emb_rep_all,
+                                                                         row_lse, (int)n_local, (int)n_global, (int)rank_offset,
+                                                                         tau, scale, partR, padR);
         NAFP_LAUNCH_CHECK();
-        ntxent_bwd_kernel<ND, true><<<padC / 32, 256, 0, st>>>(emb_org_local, emb_rep_local, emb_org_all, emb_rep_all,
-                                                              row_lse, (int)n_local, (int)n_global, (int)rank_offset,
-                                                              tau, scale, partC, padC);
+        ntxent_bwd_kernel<ND, true><<<dim3(padC / 32, sC), 256, 0, st>>>(emb_org_local, emb_rep_local, emb_org_all, emb_rep_all,
+                                                                        row_lse, (int)n_local, (int)n_global, (int)rank_offset,
+                                                                        tau, scale, partC, padC);
         NAFP_LAUNCH_CHECK();
         const int64_t total = (int64_t)2 * n_global * (ND / 4);
         ntxent_bwd_combine_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
-            partC, partR, (int)n_local, (int)n_global, (int)rank_offset, padC, padR, ND, d_org_all, d_rep_all);
+            partC, partR, (int)n_local, (int)n_global, (int)rank_offset, padC, padR, ND, 4 * sC, 4 * sR, d_org_all, d_rep_all);
         NAFP_LAUNCH_CHECK();
     }
     return NAFP_OK;
