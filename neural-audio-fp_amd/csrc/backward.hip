@@ -25,7 +25,6 @@
 #include "nafp_common.h"
 
 #include <algorithm>
-#include <cstdlib>
 
 namespace nafp {
 
@@ -109,8 +108,7 @@ struct Conv0Regen { const float* feat; const float* w3; const float* bias; float
 template <bool CONV0>
 __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
         float* __restrict__ d, const float* __restrict__ tpre, const float* __restrict__ gamma,
-        const float* __restrict__ mr, const float* __restrict__ mr_prev, const double* __restrict__ lnsum, double inv_n,
-        float* __restrict__ dgamma, float* __restrict__ dbeta,
+        const float* __restrict__ sc, float* __restrict__ dgamma, float* __restrict__ dbeta,
         float* __restrict__ dbias, float* __restrict__ S1, float* __restrict__ S2, int64_t n, int64_t B, int C,
         const float* __restrict__ Gj, const float* __restrict__ Hbj, double* __restrict__ lnsum_below, const Conv0Regen c0) {
     extern __shared__ float s_q[];                                 // [per][2]: (s1, s2) of the layer below, this block's share
@@ -144,12 +142,8 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
     float4 gw0 = ag, gw1 = ag, gw2 = ag;                    // CONV0: dW0 taps 0..2 of this thread's 4 channels
 #pragma unroll 2
     for (int64_t b = b0; b < b1; ++b) {
-        // per-sample scalars (uniform: scalar loads): mean, rstd, s1/n, s2/n of this layer, r and -mu of the layer below
-        // (ln_bwd_scalars_kernel wrote the same record per layer until round 3: 16 launches of 3 workgroups per step)
-        const float mean = mr[2 * b], rstd = mr[2 * b + 1];
-        const float m1 = (float)(lnsum[2 * b] * inv_n), m2 = (float)(lnsum[2 * b + 1] * inv_n);
-        const float inv_r = 1.f / rstd;
-        const float rprev = mr_prev ? mr_prev[2 * b + 1] : 1.f, cprev = mr_prev ? -mr_prev[2 * b] : 0.f;
+        const float4 s0 = *(const float4*)(sc + 8 * b), s1 = *(const float4*)(sc + 8 * b + 4);
+        const float mean = s0.x, rstd = s0.y, m1 = s0.z, m2 = s0.w, inv_r = s1.x, rprev = s1.y, cprev = s1.z;
         float4* dp = (float4*)(d + b * n) + ii;
         const float4 dd = *dp;
         float4 tt;
@@ -546,8 +540,7 @@ int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const Con
     const int col_tiles = (g.Cout / 128) * (p.n_live * g.Cin / 128);
     // one resident round: 256 CUs x 3 workgroups (each workgroup ends in 16 K atomics, so fewer is better;
     // measured at B = 1280: 768 / 1536 / 3072 / 6144 workgroups -> backward 22.3 / 22.5 / 22.9 / 24.3 ms)
-    static const long long slots = []() { const char* e = getenv("NAFP_WGRAD_SLOTS"); return e ? atoll(e) : 768ll; }();
-    long long chunks = std::max<long long>(1, slots / col_tiles);
+    long long chunks = std::max<long long>(1, 768 / col_tiles);
     long long rpw = (M + chunks - 1) / chunks;
     rpw = std::max<long long>(64, (rpw + 15) / 16 * 16);
     // the X descriptor of a workgroup spans (rows/P + 2) samples: keep it below 2 GiB
@@ -775,7 +768,8 @@ int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* 
         ln_bwd_reduce_kernel<<<dim3(chunks, (unsigned)B), 256, 0, st>>>(d, tpre, gamma, mr, lnsum, n);
         NAFP_LAUNCH_CHECK();
     }
-    (void)sc;                                        // (the per-sample scalars are formed inside the fused kernel)
+    ln_bwd_scalars_kernel<<<(unsigned)((B + 255) / 256), 256, 0, st>>>(mr, lnsum, mr_prev, sc, B, 1.0 / (double)n);
+    NAFP_LAUNCH_CHECK();
     // batch chunks: every chunk ends in 5 atomics per element (~33 G atomics/s measured), which is what a
     // small layer pays for; 256..1024 workgroups keep the streaming layers at HBM speed
     const int64_t bx = n / 1024;
@@ -788,11 +782,11 @@ int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* 
         if (dW0 && C / 4 > 256) return NAFP_ERR_UNSUPPORTED;
         c0.feat = feat0; c0.w3 = w0; c0.bias = bias0; c0.dW0 = dW0; c0.F = g0->Fin; c0.Tin = g0->Tin; c0.Tout = g0->Tout;
         c0.stride = g0->stride; c0.pad = g0->pad;
-        ln_bwd_fused_kernel<true><<<dim3((unsigned)bx, by), 256, lds, st>>>(d, nullptr, gamma, mr, mr_prev, lnsum, 1.0 / (double)n, dgamma,
-                                                                          dbeta, dbias, S1, S2, n, B, C, Gj, Hbj, lnsum_below, c0);
+        ln_bwd_fused_kernel<true><<<dim3((unsigned)bx, by), 256, lds, st>>>(d, nullptr, gamma, sc, dgamma, dbeta, dbias, S1, S2, n, B,
+                                                                          C, Gj, Hbj, lnsum_below, c0);
     } else {
-        ln_bwd_fused_kernel<false><<<dim3((unsigned)bx, by), 256, lds, st>>>(d, tpre, gamma, mr, mr_prev, lnsum, 1.0 / (double)n, dgamma,
-                                                                           dbeta, dbias, S1, S2, n, B, C, Gj, Hbj, lnsum_below, c0);
+        ln_bwd_fused_kernel<false><<<dim3((unsigned)bx, by), 256, lds, st>>>(d, tpre, gamma, sc, dgamma, dbeta, dbias, S1, S2, n, B,
+                                                                           C, Gj, Hbj, lnsum_below, c0);
     }
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
