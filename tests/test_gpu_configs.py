@@ -5,8 +5,9 @@
   configs[2]  one whole contrastive train step at BSZ 1280, Adam
   configs[3]  one whole contrastive train step at BSZ 5120, LAMB (the per-rank shape 320 x 2560 of the sharded loss
               is in test_gpu_ntxent.py)
-  configs[4]  full-scale generate scaled down: 2 ranks (gloo, one GPU) each writing its slice of ONE >= 1 M-row
-              dummy_db.mm, then load_memmap_data + the exact search returns every probed row at its own id
+  configs[4]  full-scale generate: (i) ONE rank's full share of the 100 M-row / 8-rank job -- 12,500,000 rows through the
+              product's writer into one 6.4 GB dummy_db.mm, whole 125-groups against the ORACLE, load_memmap_data, exact-search
+              self hits; (ii) 2 ranks (gloo, one GPU) each writing its slice of ONE >= 1 M-row dummy_db.mm
 (configs[1], generate at BSZ 640, is test_gpu_generate.py / test_gpu_parity_forward.py / bench.py.)
 
 For the train steps: loss == the oracle's NT-Xent evaluated on the HIP embeddings; updated variables == the oracle's
@@ -216,5 +217,82 @@ def test_config4_two_ranks_write_one_million_row_memmap(nafp, cfg, tmp_path):
     index = FlatL2Index(128, capacity=n_rows)
     index.add(np.asarray(db))
     probe = np.unique(np.concatenate([np.arange(0, n_rows, 7919), [meta['0'][1] - 1, meta['0'][1], n_rows - 1]]))
+    _, ids = index.search(np.asarray(db[probe]), 1)
+    assert np.array_equal(ids[:, 0], probe)
+
+
+def test_config4_one_rank_full_share_12_5_million_rows(nafp, cfg, tmp_path):
+    """BASELINE.json configs[4] at ONE RANK'S FULL SIZE: 100 M segments sharded 8 ways = 12,500,000 rows = 6.4 GB of
+    fingerprints per GPU (generate.py:131-188: one np.memmap float32 (n, 128) + <key>_shape.npy).  The rows go through
+    the product's writer (`write_fingerprints_from_device_rows`: launches of 5 max-normalisation groups round-robin over
+    4 HIP streams, pinned downloads, memmap stores) from the seeded on-the-fly audio of tests/_fullscale_worker.py -- no
+    443 GB dataset exists on the box.  Checked: whole 125-groups against the float64 ORACLE (first, last, and the two
+    groups either side of a 625-row launch boundary in the middle of the file), every sampled row has unit norm, the
+    file opens through eval_faiss.load_memmap_data, and the exact index over all 12.5 M rows returns every probed row at
+    its own id.  The sustained rate (audio synthesis, D2H, memmap stores and the final flush included) is printed and
+    kept in gpurun_out/fullscale_r04.json.  NAFP_FULLSHARE_ROWS scales the test down for quick runs."""
+    import json
+    import shutil
+    import time
+    from neural_audio_fp_amd.model import generate as G
+    from neural_audio_fp_amd.eval.eval_faiss import FlatL2Index, load_memmap_data
+    import _fullscale_worker as FW
+    n_rows = int(os.environ.get('NAFP_FULLSHARE_ROWS', 12_500_000))
+    group, launch_groups = FW.GROUP, 5
+    assert cfg['BSZ']['TS_BATCH_SZ'] == group and n_rows % group == 0
+    need = n_rows * 128 * 4
+    free = shutil.disk_usage(str(tmp_path)).free
+    if free < need + (1 << 30):
+        pytest.skip(f'{free / 1e9:.1f} GB free under {tmp_path}: the 12.5 M-row file needs {need / 1e9:.1f} GB')
+    out_dir = str(tmp_path) + '/'
+    w = _inputs.weights(seed=23)
+    m_pre, m_fp = nafp.get_melspec_layer(cfg), nafp.get_fingerprinter(cfg)
+    m_fp.set_weights(_inputs.weight_list(w))
+    arr = np.memmap(out_dir + 'dummy_db.mm', dtype='float32', mode='w+', shape=(n_rows, 128))       # generate.py:157-161
+    np.save(out_dir + 'dummy_db_shape.npy', (n_rows, 128))
+    m_fp(m_pre(FW.synth_rows(0, launch_groups * group, 'cuda'), group_size=group, defer=True))      # warm-up: plans, workspaces
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r0, r1 = G.write_fingerprints_from_device_rows(lambda a, n: FW.synth_rows(a, n, 'cuda'), n_rows, m_pre, m_fp, arr, group,
+                                                   rank=0, world=1, launch_groups=launch_groups)
+    t_write = time.perf_counter() - t0
+    arr.flush()
+    t_all = time.perf_counter() - t0
+    assert (r0, r1) == (0, n_rows)
+    del arr
+    rate = n_rows / t_all
+    rec = {'rows': n_rows, 'bytes': need, 'seconds_incl_flush': round(t_all, 2), 'seconds_before_flush': round(t_write, 2),
+           'rows_per_s_incl_flush': round(rate, 1), 'launch_rows': launch_groups * group, 'streams': G.N_STREAMS,
+           'what': 'one rank\'s share of BASELINE configs[4] (100 M rows / 8 ranks) on one MI355X: seeded on-device audio -> '
+                   'log-mel -> encoder -> pinned D2H -> np.memmap stores -> flush'}
+    print('fullscale:', json.dumps(rec))
+    try:
+        os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(ROOT, 'gpurun_out', 'fullscale_r04.json'), 'w') as f:
+            json.dump(rec, f)
+    except OSError:
+        pass
+    db, shape = load_memmap_data(out_dir, 'dummy_db')                               # eval_faiss.py:18-62
+    assert tuple(shape) == (n_rows, 128) and db.shape == (n_rows, 128)
+    norms = np.linalg.norm(np.asarray(db[::4999]), axis=1)                          # no row left unwritten
+    assert np.abs(norms - 1).max() < 1e-5
+    # whole groups against the oracle: first, last, and the groups either side of a launch boundary in mid-file
+    launch = launch_groups * group
+    mid = (n_rows // 2) // launch * launch
+    worst_cos, worst_abs = 0.0, 0.0
+    for g0 in sorted({0, mid - group, mid, n_rows - group}):
+        x = FW.synth_rows(g0, group, 'cuda').cpu().numpy()
+        want = _oracle_fingerprints(x, w)                                            # one group = one m_pre batch (melspectrogram.py:108)
+        blk = np.asarray(db[g0:g0 + group])
+        worst_cos = max(worst_cos, float((1 - (blk * want).sum(1)).max()))
+        worst_abs = max(worst_abs, float(np.abs(blk - want).max()))
+        assert (1 - (blk * want).sum(1)).max() < 1e-5, g0                           # contract 1e-3
+        assert np.abs(blk - want).max() < 1e-4, g0
+    print(f'fullscale: worst 1 - cos vs oracle {worst_cos:.2e}, worst |diff| {worst_abs:.2e}; {rate:.0f} rows/s incl. flush')
+    # search: every probed row comes back at its own id out of ALL rows (eval_faiss.py:141-146, 209 with the exact index)
+    index = FlatL2Index(128, capacity=n_rows)
+    index.add(db)
+    assert index.ntotal == n_rows
+    probe = np.unique(np.concatenate([np.arange(0, n_rows, 104_729), [mid - 1, mid, n_rows - 1]]))
     _, ids = index.search(np.asarray(db[probe]), 1)
     assert np.array_equal(ids[:, 0], probe)
