@@ -207,6 +207,64 @@ def train_region(cfg, world, rank, dist, global_bsz, steps, torch, warmup=2, opt
             'data': 'synthetic (seeded noise anchors, replicas = anchors + noise at 5 dB SNR), resident in HBM'}
 
 
+def train_rank640(cfg, torch, steps=20, warmup=4):
+    """The operating point of the metric's 8-GPU entry, on ONE GPU: a rank's share of the global batch of 5120 is 640
+    segments (320 anchors + 320 replicas), LAMB.  The step runs through a process group of ONE rank on RCCL (legal for
+    RCCL), so every collective of `train_step` executes -- all-gather of the embeddings, reduce-scatter of their
+    gradient, the 4 gradient pieces on the communication stream -- but each moves data only inside this GPU:
+    a ONE-GPU COMPUTE BOUND of the 8-rank step, NOT a scaling measurement (no xGMI traffic, a 640 x 640 loss instead of
+    one rank's 640 x 5120 share).  `stage_ms` = the same step's pieces between device events (the split of
+    tools/train_probe.py), taken without the process group."""
+    import copy
+    import socket
+    import torch.distributed as dist
+    from neural_audio_fp_amd.model import trainer as T
+    import neural_audio_fp_amd as nafp
+    bsz = 640
+    # ---- stage split (no process group) ----
+    c = copy.deepcopy(cfg)
+    c['BSZ']['TR_BATCH_SZ'], c['BSZ']['TR_N_ANCHOR'] = bsz, bsz // 2
+    c['TRAIN']['OPTIMIZER'], c['TRAIN']['LR'] = 'LAMB', 1e-4
+    m_pre, m_specaug, m_fp, opt, loss_obj, bucket = T.setup(c, 1000)
+    X = next(iter(T.synthetic_batches(c, 1)(1)))
+    names = ['melspec+aug', 'forward_train', 'ntxent', 'backward', 'optimizer', 'set_weights(next fwd)']
+    tot = [0.0] * len(names)
+
+    def ev():
+        e = torch.cuda.Event(enable_timing=True); e.record(); return e
+    n_split = 8
+    for it in range(n_split + 3):
+        e = [ev()]
+        feat = m_specaug(m_pre(torch.cat(X, 0))); e.append(ev())
+        emb = m_fp.forward_train(feat); e.append(ev())
+        _, da, db = loss_obj.loss_and_grad(emb[:bsz // 2], emb[bsz // 2:]); e.append(ev())
+        grads = m_fp.backward(torch.cat([da, db])); e.append(ev())
+        opt.apply_gradients(zip(grads, m_fp.trainable_variables), var_lens=m_fp.variable_lengths()); m_fp.mark_dirty(); e.append(ev())
+        m_fp._sync(); e.append(ev())
+        torch.cuda.synchronize()
+        if it >= 3:
+            for k in range(len(names)):
+                tot[k] += e[k].elapsed_time(e[k + 1])
+    stage = {n: round(t / n_split, 4) for n, t in zip(names, tot)}
+    del m_pre, m_specaug, m_fp, opt, loss_obj, bucket
+    # ---- the step itself, through a 1-rank RCCL group ----
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1,
+                            device_id=torch.device('cuda', torch.cuda.current_device()))
+    try:
+        r = train_region(cfg, 1, 0, dist, bsz, steps, torch, warmup=warmup, optimizer='LAMB')
+    finally:
+        dist.destroy_process_group()
+    r['stage_ms'] = stage
+    r['what'] = ('one rank\'s share (640 of 5120 segments) of the 8-GPU train step on ONE GPU through a 1-rank RCCL group: every '
+                 'collective of the step executes, none crosses xGMI -- a one-GPU compute bound of the 8-rank step, not a scaling '
+                 'measurement')
+    r['scaling'] = 'none (single GPU)'
+    return r
+
+
 def e2e_generate(cfg, torch, n_small=100, n_large=600):
     """SURVEY.md 8d config 2, second figure: DISK -> .mm through the product's own `write_fingerprints` (whole-file
     upload into pinned arenas, device-side windows, 4 HIP streams, pinned download, memmap store), on the config-1 set
@@ -265,6 +323,49 @@ def e2e_generate(cfg, torch, n_small=100, n_large=600):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def fullscale_generate(cfg, torch, rows):
+    """BASELINE.json configs[4] in the bench line, scaled: `rows` (default 1,250,000 = a tenth of ONE rank's
+    12,500,000-row share of the 100 M-row / 8-rank job; --fullscale-rows 12500000 runs the whole share) through the
+    product's writer `write_fingerprints_from_device_rows` -- seeded on-device audio (no 443 GB dataset exists on the box)
+    -> log-mel -> encoder -> pinned D2H on 4 HIP streams -> np.memmap stores -> flush.  The whole share at full size is
+    tests/test_gpu_configs.py::test_config4_one_rank_full_share_12_5_million_rows (oracle-checked groups, search self
+    hits); its record of a run is kept in profiles/."""
+    import shutil
+    import tempfile
+    import numpy as np
+    from neural_audio_fp_amd.model import generate as g
+    group = int(cfg['BSZ']['TS_BATCH_SZ'])
+    rows = rows // group * group
+    d = tempfile.mkdtemp(prefix='nafp_full_')
+    try:
+        if shutil.disk_usage(d).free < rows * 512 + (1 << 30):
+            return {'skipped': f'not enough room under {d} for {rows * 512 / 1e9:.2f} GB'}
+        m_pre, m_fp = g.build_fp(cfg)
+        t_ax = torch.arange(8000, device='cuda', dtype=torch.float32) / 8000.0
+        gen = torch.Generator(device='cuda')
+
+        def synth(row0, n):                      # a launch of whole groups: seeded noise + one tone per row
+            gen.manual_seed(row0)
+            f = 300.0 + (torch.arange(row0, row0 + n, device='cuda') % 3500).float()
+            return 0.1 * torch.randn((n, 1, 8000), generator=gen, device='cuda') + 0.2 * torch.sin(2 * torch.pi * f[:, None, None] * t_ax)
+        m_fp(m_pre(synth(0, 5 * group), group_size=group, defer=True))
+        arr = np.memmap(os.path.join(d, 'dummy_db.mm'), dtype='float32', mode='w+', shape=(rows, 128))
+        np.save(os.path.join(d, 'dummy_db_shape.npy'), (rows, 128))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        g.write_fingerprints_from_device_rows(synth, rows, m_pre, m_fp, arr, group)
+        t1 = time.perf_counter()
+        arr.flush()
+        t2 = time.perf_counter()
+        ok = bool(np.isfinite(arr[-1]).all()) and abs(float(np.linalg.norm(arr[rows // 2])) - 1.0) < 1e-4
+        del arr
+        return {'rows': rows, 'bytes': rows * 512, 'value': round(rows / (t2 - t0), 1), 'unit': 'segments/s incl. audio synthesis, D2H, memmap stores and flush',
+                'seconds': round(t2 - t0, 3), 'flush_seconds': round(t2 - t1, 3), 'launch_rows': 5 * group, 'streams': g.N_STREAMS,
+                'share_of_one_rank': round(rows / 12_500_000, 4), 'rows_ok': ok}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as ONE child process tree
     (`python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>`), relay rank 0's JSON line, return
@@ -307,6 +408,8 @@ def main():
     ap.add_argument('--no-train', action='store_true', help='skip the contrastive-train region (reported as "train")')
     ap.add_argument('--train-steps', type=int, default=6)
     ap.add_argument('--train-bsz', type=int, default=5120, help='GLOBAL train batch (BASELINE.json configs[3])')
+    ap.add_argument('--fullscale-rows', type=int, default=1_250_000,
+                    help='rows of the configs[4] stand-in (reported as "fullscale_generate"); 12500000 = one rank\'s whole share; 0 = skip')
     ap.add_argument('--no-pipelined', action='store_true',
                     help='skip the extra 4-stream region (used under rocprofv3 so that its per-kernel '
                          'averages cover the single-stream launches only)')
@@ -472,15 +575,18 @@ def main():
                   'min_cosine_vs_f32_path': float((got_emb * ref_emb).sum(1).min()),
                   'note': 'experimental option NAFP_OPT_BF16X3 on the unsplit GEMM convs (convs 1-6, 8 at BSZ 640); NOT the '
                           "reference's arithmetic, not part of `value`"}
-    train, train_1280 = None, None
+    train, train_1280, train_r640 = None, None, None
     if not args.no_train:
         train = train_region(cfg, world, rank, dist, args.train_bsz, args.train_steps, torch)
         if world == 1:                                  # BSZ 1280, Adam, one GPU
             train_1280 = train_region(cfg, world, rank, dist, min(1280, args.train_bsz), max(args.train_steps, 12), torch,
                                       warmup=3, optimizer='Adam')
-    e2e = None
+            train_r640 = train_rank640(cfg, torch)      # the 8-GPU operating point (per-rank batch 640) as a one-GPU compute bound
+    e2e, fullscale = None, None
     if world == 1 and not args.no_e2e:
         e2e = e2e_generate(cfg, torch)
+        if args.fullscale_rows > 0:
+            fullscale = fullscale_generate(cfg, torch, args.fullscale_rows)
     iso = None
     if n_str > 1:
         m_fp.profile_enable(6)
@@ -563,8 +669,12 @@ def main():
             out['train'] = train
         if train_1280:
             out['train_1280'] = train_1280
+        if train_r640:
+            out['train_rank640'] = train_r640
         if e2e:
             out['e2e_generate'] = e2e
+        if fullscale:
+            out['fullscale_generate'] = fullscale
         if iso:
             iso_ms = sum(sum(p[1:16]) for p in iso) / len(iso)
             iso_ach = gemm_flops_per_step / (iso_ms * 1e-3) / 1e12

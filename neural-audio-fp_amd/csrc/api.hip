@@ -335,22 +335,31 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
         }
     }
     NAFP_HIP_CHECK(hipEventRecord(e->sw_fork, st));                         // copies and re-packs above are done
-    for (int k = 0; k < NS; ++k) NAFP_HIP_CHECK(hipStreamWaitEvent(e->sw_streams[k], e->sw_fork, 0));
-    for (int j = 1; j < 16; ++j) {
+    // Between the fork and the join nothing returns early: whatever fails, the helper streams are joined back into the
+    // caller's stream first -- otherwise later work on `st` would race G / Hb launches still running on the helpers, and the
+    // next call would reuse their slabs under them.  The first error is kept and returned after the join.
+    int fork_rc = NAFP_OK;
+    int forked = 0;
+    for (int k = 0; k < NS && fork_rc == NAFP_OK; ++k) {
+        if (hipStreamWaitEvent(e->sw_streams[k], e->sw_fork, 0) != hipSuccess) fork_rc = NAFP_ERR_HIP; else ++forked;
+    }
+    for (int j = 1; j < 16 && fork_rc == NAFP_OK; ++j) {
         const int k = (j - 1) % NS;
         ConvGemmArgs a{};
         a.wp = e->d_w[j]; a.plain = true;
         a.x = e->d_gamma[j - 1]; a.bias = nullptr; a.y = e->d_G[j];
         a.slab = e->sw_slab_floats ? e->d_sw_slab + (int64_t)k * (e->sw_slab_floats + 64) : nullptr; a.slab_floats = e->sw_slab_floats;
-        int rc = launch_conv_gemm(a, 2, e->geom[j], e->sw_streams[k]);
-        if (rc != NAFP_OK) return rc;
+        fork_rc = launch_conv_gemm(a, 2, e->geom[j], e->sw_streams[k]);
         bt.hb[bt.count] = e->d_Hb[j]; bt.bias[bt.count] = e->d_bias[j];
         bt.n[bt.count] = numel(e->shapes[4 * j + 2]); bt.cout[bt.count] = e->geom[j].Cout; ++bt.count;
     }
-    for (int k = 0; k < NS; ++k) {
-        NAFP_HIP_CHECK(hipEventRecord(e->sw_join[k], e->sw_streams[k]));
-        NAFP_HIP_CHECK(hipStreamWaitEvent(st, e->sw_join[k], 0));
+    for (int k = 0; k < forked; ++k) {
+        if (hipEventRecord(e->sw_join[k], e->sw_streams[k]) != hipSuccess || hipStreamWaitEvent(st, e->sw_join[k], 0) != hipSuccess) {
+            (void)hipStreamSynchronize(e->sw_streams[k]);                   // cannot order it on the device: drain it on the host
+            if (fork_rc == NAFP_OK) fork_rc = NAFP_ERR_HIP;
+        }
     }
+    if (fork_rc != NAFP_OK) return fork_rc;
     add_bias_kernel<<<dim3(32, bt.count), 256, 0, st>>>(bt);
     NAFP_LAUNCH_CHECK();
     int rc = launch_pack_div(t[64], t[65], t[66], e->d_w1p, e->d_b1p, e->d_w2p, e->emb_sz, e->S, st);

@@ -1531,10 +1531,30 @@ static int pick_bn(int64_t n_tiles128, int Cout, int k_steps = 0) {
     return (n_tiles128 < thr && n_tiles128 >= lo) ? 64 : 128;
 }
 
+// Tile plan of a FORWARD launch (rows x position slots x class order): ONE decision, shared by the launcher and by the
+// workspace sizing below -- the slab is sized for the tile count and split factor of the plan that actually runs.
+struct FwdPlan { int BM, pt, perm; };
+static FwdPlan fwd_plan(int64_t B, const ConvGeom& g, bool full_epilogue, bool fuse0) {
+    const int P = g.Fout * g.Tout;
+    FwdPlan r{fuse0 ? 128 : pick_bm(B, P, g.Cout), tile_pt(P), 0};
+    if (r.BM == 256 && full_epilogue && 256 / r.pt != 8) r.BM = 128;      // FULL mode on 256 rows keeps its statistics in registers: 8 samples per position
+    if (full_epilogue && !fuse0) {
+        FwdTile ft = fwd_tile(g, r.BM);
+        if (r.BM == 256 && ft.saved == 0.0) {
+            // the 256-row tile cannot hold one class with 8 samples per position (conv8 at large batches: 16 positions
+            // per class), the 128-row tile can: a third of the K-steps outweighs the larger tile's few per cent
+            const FwdTile f2 = fwd_tile(g, 128);
+            if (f2.saved >= 0.10) { r.BM = 128; ft = f2; }
+        }
+        r.pt = ft.pt; r.perm = ft.perm;
+    }
+    return r;
+}
+
 int64_t conv_gemm_slab_floats(int64_t B, const ConvGeom& g, bool with_dgrad) {
     const int P = g.Fout * g.Tout;
-    const int BM = pick_bm(B, P, g.Cout);
-    const int pt = tile_pt(P), ST = BM / pt;
+    const FwdPlan fp = fwd_plan(B, g, true, false);
+    const int BM = fp.BM, pt = fp.pt, ST = BM / pt;
     const int64_t n_tiles = ((B + ST - 1) / ST) * ((P + pt - 1) / pt) * (g.Cout / BN);
     const int bn = BM == 256 ? 128 : pick_bn(n_tiles, g.Cout, live_k_steps(g));
     int S = BM == 256 ? 1 : choose_split(n_tiles * (BN / bn), live_k_steps(g), B * P * g.Cout, bn == 64 ? (n64_two_stage() ? 1280.0 : 1024.0) : 768.0);
@@ -1567,20 +1587,11 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     p.Fin = g.Fin; p.Tin = g.Tin; p.Cin = g.Cin; p.Tout = g.Tout; p.Cout = g.Cout;
     p.axis = g.axis; p.stride = g.stride; p.pad = g.pad;
     p.B = (int)B; p.P = g.Fout * g.Tout;
-    int BM = a.f0_feat ? 128 : pick_bm(B, a.dgrad ? g.Fin * g.Tin : p.P, a.dgrad ? g.Cin : g.Cout);
-    int pt = tile_pt(p.P);
-    if (BM == 256 && !a.plain && !a.dgrad && 256 / pt != 8) BM = 128;      // FULL mode on 256 rows keeps its statistics in registers: 8 samples per position
-    int fwd_perm = 0;
-    if (!a.plain && !a.dgrad && !a.f0_feat) {
-        FwdTile ft = fwd_tile(g, BM);
-        if (BM == 256 && ft.saved == 0.0) {
-            // the 256-row tile cannot hold one class with 8 samples per position (conv8 at large batches: 16 positions
-            // per class), the 128-row tile can: a third of the K-steps outweighs the larger tile's few per cent
-            const FwdTile f2 = fwd_tile(g, 128);
-            if (f2.saved >= 0.10) { BM = 128; ft = f2; }
-        }
-        pt = ft.pt; fwd_perm = ft.perm;
-    }
+    // forward launches: fwd_plan() (shared with conv_gemm_slab_floats); the transposed conv picks its rows from ITS output
+    const FwdPlan fp = fwd_plan(B, g, !a.plain && !a.dgrad, a.f0_feat != nullptr);
+    int BM = a.dgrad ? pick_bm(B, g.Fin * g.Tin, g.Cin) : fp.BM;
+    int pt = fp.pt;
+    const int fwd_perm = a.dgrad ? 0 : fp.perm;
     p.PT = pt; p.ST = BM / pt;
     p.log2ST = 0;
     while ((1 << p.log2ST) < p.ST) ++p.log2ST;

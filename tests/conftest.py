@@ -46,3 +46,36 @@ def golden():
     reference: it cannot run here; see oracle/__init__.py)."""
     import numpy as np
     return dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'hotpath_v1.npz')))
+
+
+# ---- observed maxima next to their tolerances (VERDICT r3 item 9): printed in the terminal summary even under -q, so the
+# driver's GPUTEST tail carries them, and kept in gpurun_out/observed_tolerances.json ----
+_OBSERVED = {}
+
+
+@pytest.fixture
+def observe(request):
+    """observe(what, value, tol): records max(value) per (test, what) and asserts value < tol."""
+    def rec(what, value, tol):
+        key = f'{request.node.name}::{what}'
+        value = float(value)
+        cur = _OBSERVED.get(key)
+        _OBSERVED[key] = (max(value, cur[0]) if cur else value, float(tol))
+        assert value < tol, (what, value, tol)
+    return rec
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not _OBSERVED:
+        return
+    terminalreporter.write_line('observed error maxima (value / tolerance):')
+    for k in sorted(_OBSERVED):
+        v, t = _OBSERVED[k]
+        terminalreporter.write_line(f'  {k}: {v:.3e} / {t:.1e}  ({t / max(v, 1e-300):.0f}x headroom)')
+    try:
+        import json
+        os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(ROOT, 'gpurun_out', 'observed_tolerances.json'), 'w') as f:
+            json.dump({k: {'observed': v, 'tolerance': t} for k, (v, t) in _OBSERVED.items()}, f, indent=1, sort_keys=True)
+    except OSError:
+        pass

@@ -19,7 +19,7 @@ def _reference(feat, w, d_emb):
 
 @pytest.mark.parametrize('fused_ln', [1, 0, 2])
 @pytest.mark.parametrize('B', [2, 5])
-def test_encoder_backward_matches_autograd(nafp, B, fused_ln):
+def test_encoder_backward_matches_autograd(nafp, B, fused_ln, observe):
     """fused_ln = NAFP_OPT_FUSED_LN_BWD: 2 runs the LayerNorm backward of every eligible layer inside the transposed
     conv that produces its gradient (dgrad_ln_kernel: one position x 128 samples per tile, here mostly empty rows),
     0 never, 1 the default policy (at this batch size: never)."""
@@ -42,9 +42,8 @@ def test_encoder_backward_matches_autograd(nafp, B, fused_ln):
         scale = np.abs(wg).max() + 1e-12
         err = np.abs(g - wg).max() / scale
         worst = max(worst, err)
-        # fp32 through 16 layers of forward + backward vs float64 autograd: 2e-3 of the largest entry
-        assert err < 2e-3, (names[i], err, scale)
-    print('worst relative gradient error', worst)
+    # fp32 through 16 layers of forward + backward vs float64 autograd: 1e-4 of each tensor's largest entry (observed ~5e-6)
+    observe('gradient, rel. to the tensor max', worst, 1e-4)
 
 
 def test_backward_is_additive_over_the_batch_at_bsz_5120(nafp):
@@ -73,7 +72,7 @@ def test_backward_is_additive_over_the_batch_at_bsz_5120(nafp):
 
 
 @pytest.mark.parametrize('emb_sz', [64, 256])
-def test_other_fingerprint_dimensions_forward_and_backward(nafp, emb_sz):
+def test_other_fingerprint_dimensions_forward_and_backward(nafp, emb_sz, observe):
     """EMB_SZ 64 / 256 (divide-and-encode slices of 16 / 4 of the 1024-wide flatten)."""
     from oracle import nnfp as o_nnfp
     B = 3
@@ -92,11 +91,11 @@ def test_other_fingerprint_dimensions_forward_and_backward(nafp, emb_sz):
     assert np.abs(emb_t.cpu().numpy() - want_emb).max() < 2e-5
     for i, (g, wg) in enumerate(zip(grads, want)):
         err = np.abs(g.cpu().numpy() - wg).max() / (np.abs(wg).max() + 1e-12)
-        assert err < 2e-3, (i, err)
+        observe('gradient, rel. to the tensor max', err, 1e-4)
     assert m_fp.variable_lengths()[64] == w['div.w1'].size // emb_sz
 
 
-def test_two_second_segments_forward_and_backward(nafp):
+def test_two_second_segments_forward_and_backward(nafp, observe):
     """input (256, 63, 1) (2-s segments: the shape behind the reference's `Total params: 19,224,576`,
     nnfp.py:262-271): odd extents exercise the asymmetric SAME padding and the parity classes of the
     transposed conv with an odd number of positions."""
@@ -117,7 +116,7 @@ def test_two_second_segments_forward_and_backward(nafp):
     assert np.abs(emb.cpu().numpy() - e.detach().numpy()).max() < 2e-5
     for i, (g, p) in enumerate(zip(grads, tf.params)):
         wg = p.grad.numpy()
-        assert np.abs(g.cpu().numpy() - wg).max() / (np.abs(wg).max() + 1e-12) < 2e-3, i
+        observe('gradient, rel. to the tensor max', np.abs(g.cpu().numpy() - wg).max() / (np.abs(wg).max() + 1e-12), 1e-4)
 
 
 @pytest.mark.parametrize('B', [64, 130, 257])
@@ -140,3 +139,41 @@ def test_fused_ln_backward_equals_the_separate_pass(nafp, B):
         for i, (a, b) in enumerate(zip(out[mode], out[0])):
             scale = float(b.abs().max()) + 1e-20
             assert float((a - b).abs().max()) / scale < 2e-4, (mode, i)
+
+
+@pytest.mark.parametrize('B', [5, 130])
+def test_weight_gradients_on_the_side_stream_equal_the_single_stream_pass(nafp, B, observe):
+    """NAFP_OPT_BWD_OVERLAP (option 4; measured slower and off by default): the weight gradients run on a
+    second stream of the handle behind per-layer events, over the same dA / dB ping-pong buffers the main chain keeps
+    rewriting.  Same kernels, same operands: the gradients must agree with the single-stream pass to the order of the
+    fp32 atomics, twice in a row (the second pass reuses the buffers the side stream read), and a consumer that waits on
+    the per-group events (`grad_group_wait`, what GradientBucket.all_reduce does) must see finished gradients."""
+    g = torch.Generator(device='cuda').manual_seed(40 + B)
+    feat = -1.2 * torch.rand((B, 256, 32, 1), generator=g, device='cuda')
+    d_emb = torch.randn((B, 128), generator=g, device='cuda')
+    w = _inputs.weight_list(_inputs.weights(seed=15))
+    out = {}
+    for mode in (0, 1):
+        m_fp = nafp.FingerPrinter(seed=0)
+        m_fp.set_option(4, mode)
+        m_fp.set_weights(w)
+        runs = []
+        for rep in range(2):
+            m_fp.forward_train(feat)
+            grads = m_fp.backward(d_emb)
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):                       # the communication stream's view: wait per group, then read
+                for k in range(len(m_fp.grad_groups())):
+                    m_fp.grad_group_wait(k)
+                seen = [t.clone() for t in grads]
+            side.synchronize()
+            torch.cuda.synchronize()
+            for a, b in zip(seen, grads):
+                assert torch.equal(a, b)                        # nothing was still being written behind the events
+            runs.append([t.clone() for t in grads])
+        out[mode] = runs
+    worst = 0.0
+    for rep in range(2):
+        for i, (a, b) in enumerate(zip(out[1][rep], out[0][rep])):
+            worst = max(worst, float((a - b).abs().max()) / (float(b.abs().max()) + 1e-20))
+    observe('side-stream vs single-stream gradients, rel. to the tensor max', worst, 2e-5)

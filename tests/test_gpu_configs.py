@@ -118,7 +118,7 @@ def _oracle_update(which, w0, g, lr, var_len):
 
 
 @pytest.mark.parametrize('bsz,which', [(1280, 'adam'), (5120, 'lamb')])
-def test_whole_train_step_at_baseline_batch(nafp, cfg, bsz, which):
+def test_whole_train_step_at_baseline_batch(nafp, cfg, bsz, which, observe):
     from neural_audio_fp_amd.model import trainer as T
     from neural_audio_fp_amd.model.fp.lamb_optimizer import Adam, LAMB
     from neural_audio_fp_amd.model.fp.specaug_chain.specaug_chain import get_specaug_chain_layer
@@ -149,8 +149,10 @@ def test_whole_train_step_at_baseline_batch(nafp, cfg, bsz, which):
     for i, (v, vl) in enumerate(zip(m_fp.trainable_variables, m_fp.variable_lengths())):
         want = _oracle_update(which, w0[i], grads[i], lr, vl)
         got = v.detach().cpu().numpy().astype(np.float64)
-        # one step of size <= lr (Adam) / <= lr * |w| / |u| * |u| (LAMB): float32 arithmetic vs float64
-        assert np.abs(got - want).max() < 2e-3 * lr + 2e-7 * (np.abs(w0[i]).max() + 1e-30), i
+        # one step of size <= lr (Adam) / <= lr * |w| / |u| * |u| (LAMB): float32 arithmetic vs float64.  The error is the
+        # rounding of the float32 variable itself (half an ulp of |w|) plus 1e-4 of the step
+        observe('updated variable, excess over ulp(|w|)/2, in units of lr',
+                max(0.0, np.abs(got - want).max() - 6e-8 * (np.abs(w0[i]).max() + 1e-30)) / lr, 1e-4)
     assert opt.iterations == 1
     # (3) the gradients: 16 samples spread over the batch (anchors and replicas, first / last tiles) vs float64 autograd
     d_a, d_b = o_nt.grad_embeddings(e[:n], e[n:], cfg['LOSS']['TAU'])
@@ -173,7 +175,7 @@ def test_whole_train_step_at_baseline_batch(nafp, cfg, bsz, which):
         wg = p.grad.numpy()
         err = np.abs(gs - wg).max() / (np.abs(wg).max() + 1e-30)
         worst = max(worst, err)
-        assert err < 2e-3, (i, err)
+    observe('gradient of 16 samples, rel. to the tensor max', worst, 1e-4)
     print(f'BSZ {bsz} {which}: loss {float(loss):.5f} (oracle {wl:.5f}); worst relative gradient error {worst:.2e}')
 
 

@@ -14,20 +14,20 @@ import _inputs
 pytestmark = pytest.mark.gpu
 
 
-def test_golden_fixtures_on_gpu(nafp, cfg, golden):
+def test_golden_fixtures_on_gpu(nafp, cfg, golden, observe):
     x = _inputs.audio(4, seed=11)
     m_pre, m_fp = nafp.get_melspec_layer(cfg), nafp.get_fingerprinter(cfg)
     m_fp.set_weights(_inputs.weight_list(_inputs.weights(seed=3)))
     xt = torch.from_numpy(x).cuda()
     feat = m_pre(xt)
-    assert np.abs(feat.cpu().numpy() - golden['mel_seed11']).max() < 2e-5
-    assert np.abs(m_pre(xt, group_size=2).cpu().numpy() - golden['mel_seed11_group2']).max() < 2e-5
+    observe('|d log-mel|', np.abs(feat.cpu().numpy() - golden['mel_seed11']).max(), 2e-5)
+    observe('|d log-mel|', np.abs(m_pre(xt, group_size=2).cpu().numpy() - golden['mel_seed11_group2']).max(), 2e-5)
     # encoder on the GOLDEN features (isolates the encoder from front-end rounding)
     gfeat = torch.from_numpy(golden['mel_seed11']).cuda()
-    assert np.abs(m_fp.front_conv(gfeat).cpu().numpy() - golden['flat_seed11_w3']).max() < 2e-4
+    observe('|d flat|', np.abs(m_fp.front_conv(gfeat).cpu().numpy() - golden['flat_seed11_w3']).max(), 5e-5)
     emb = m_fp(gfeat).cpu().numpy()
-    assert np.abs(emb - golden['emb_seed11_w3']).max() < 2e-5
-    assert (1 - (emb * golden['emb_seed11_w3']).sum(1)).max() < 1e-6      # contract 1e-3
+    observe('|d emb|', np.abs(emb - golden['emb_seed11_w3']).max(), 5e-6)
+    observe('1 - cos', (1 - (emb * golden['emb_seed11_w3']).sum(1)).max(), 1e-6)      # contract 1e-3
 
 
 def test_batch_independence_and_ragged_sizes(nafp, cfg):

@@ -64,7 +64,7 @@ def _load_oracle_weights(m_fp, w):
 
 
 @pytest.mark.parametrize('B', [1, 5])
-def test_encoder_matches_oracle(nafp, cfg, B):
+def test_encoder_matches_oracle(nafp, cfg, B, observe):
     rng = np.random.default_rng(10 + B)
     feat = (-rng.uniform(0, 1.2, size=(B, 256, 32, 1))).astype(np.float32)
     w = o_nnfp.init_weights(seed=3, randomize_affine=True)
@@ -76,11 +76,11 @@ def test_encoder_matches_oracle(nafp, cfg, B):
     want_flat = o_nnfp.front_conv(feat, w, dtype=np.float64)
     want_emb = o_nnfp.fingerprinter(feat, w, dtype=np.float64)
     assert flat.shape == (B, 1024) and emb.shape == (B, 128)
-    # fp32 through 16 conv+LN layers vs float64 oracle: abs 2e-4 on O(1) activations
-    assert np.abs(flat - want_flat).max() < 2e-4
-    assert np.abs(emb - want_emb).max() < 2e-5
+    # fp32 through 16 conv+LN layers vs float64 oracle: abs 5e-5 on O(1) activations
+    observe('|d flat|', np.abs(flat - want_flat).max(), 5e-5)
+    observe('|d emb|', np.abs(emb - want_emb).max(), 5e-6)
     cos = (emb * want_emb).sum(1) / np.linalg.norm(emb, axis=1) / np.linalg.norm(want_emb, axis=1)
-    assert (1 - cos).max() < 1e-6                  # contract: 1e-3
+    observe('1 - cos', (1 - cos).max(), 1e-6)      # contract: 1e-3
     # div_enc alone (trainer.py:73-76 calls the halves separately), no L2
     de = m_fp.div_enc(torch.from_numpy(want_flat.astype(np.float32)).cuda()).cpu().numpy()
     assert np.abs(de - o_nnfp.div_enc(want_flat, w)).max() < 1e-5

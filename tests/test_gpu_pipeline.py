@@ -70,6 +70,9 @@ def test_train_generate_evaluate_cli(tmp_path):
     out = run('evaluate', 'EXP', '2', '-c', 'tiny', '-t', str(work / 'ids.npy'), '--test_seq_len', '1 3')
     raw = np.load(emb / 'raw_score.npy')
     assert raw.shape == (len(ids), 8) and np.array_equal(np.load(emb / 'test_ids.npy'), ids)
+    import json
+    used = json.load(open(emb / 'index_used.json'))              # default -i ivfpq is served by the exact search: recorded next to the scores
+    assert used['index_type_requested'].lower() == 'ivfpq' and used['substituted'] is True and used['index_type_used'].startswith('L2')
     top1_exact = raw[:, :2].mean(0)
     print(out[-600:], top1_exact)
     assert top1_exact[1] > 0.8 and top1_exact[1] >= top1_exact[0] - 0.05       # noisy copies are found; longer queries do not hurt
