@@ -418,6 +418,13 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args.gpus))                # nothing above has touched the GPU
 
+    # stdout carries ONE JSON line and nothing else: RCCL prints a version banner to fd 1 when a communicator is created
+    # (rank 0, every init), libraries chat -- all of that is sent to stderr for the rest of the run, the line is written to
+    # the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import yaml
     import __graft_entry__
@@ -684,7 +691,8 @@ def main():
                 'per_conv_ms': [round(sum(p[k] for p in iso) / len(iso), 4) for k in range(17)]}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     if dist:
         dist.barrier()
         dist.destroy_process_group()

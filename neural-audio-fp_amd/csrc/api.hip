@@ -411,7 +411,7 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
     char* ws = (char*)align_up((int64_t)(uintptr_t)workspace, 256);
     const int64_t stats_only = align_up((int64_t)sizeof(double) * 2 * 16 * n_seg, 256);
     const int64_t stats_bytes = stats_only + NAFP_TICKET_SLOTS * (int64_t)sizeof(unsigned);
-    double* stats = (double*)ws;
+    stat_t* stats = (stat_t*)ws;
     unsigned* tickets = (unsigned*)(ws + stats_only);       // arrival counters of the split-K launches (zero between launches)
     float* bufA = (float*)(ws + stats_bytes);
     float* bufB = (float*)(ws + stats_bytes + align_up((int64_t)sizeof(float) * e->bufA_per_seg * n_seg, 256));
@@ -541,7 +541,7 @@ extern "C" int nafp_encoder_div_enc(nafp_encoder* e, const float* flat, int64_t 
 namespace {
 struct TrainLayout {
     int64_t B;
-    double* stats; unsigned* tickets; float* mr; float* sc;
+    stat_t* stats; unsigned* tickets; float* mr; float* sc;
     // zeroed together at the start of the backward pass: per-layer LN sums, S1/S2 of every layer
     char* zero_begin; int64_t zero_bytes;
     double* lnsum[16]; float* S1[16]; float* S2[16];
@@ -556,7 +556,7 @@ TrainLayout train_layout(const nafp_encoder* e, int64_t B, void* ws) {
     char* p = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     char* p0 = p;
     auto take = [&](int64_t bytes) { char* r = p; p += (bytes + 255) / 256 * 256; return r; };
-    L.stats = (double*)take((int64_t)sizeof(double) * 2 * 16 * B);
+    L.stats = (stat_t*)take((int64_t)sizeof(stat_t) * 2 * 16 * B);
     L.tickets = (unsigned*)take(NAFP_TICKET_SLOTS * (int64_t)sizeof(unsigned));      // directly behind the statistics: one fill covers both
     L.mr = (float*)take((int64_t)sizeof(float) * 2 * 16 * B);
     L.sc = (float*)take((int64_t)sizeof(float) * 8 * B);

@@ -31,13 +31,13 @@ namespace nafp {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 // (mean, rstd) per sample and layer from the double (sum, sumsq) statistics.
-__global__ void stats_to_mr_kernel(const double* __restrict__ stats, float* __restrict__ mr, int64_t n_pairs,
+__global__ void stats_to_mr_kernel(const stat_t* __restrict__ stats, float* __restrict__ mr, int64_t n_pairs,
                                    const double* __restrict__ inv_n_per_layer, int64_t B) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n_pairs) return;
     const double inv_n = inv_n_per_layer[i / B];
-    const double mean = stats[2 * i] * inv_n;
-    double var = stats[2 * i + 1] * inv_n - mean * mean;
+    const double mean = stat_get(stats + 2 * i) * inv_n;
+    double var = stat_get(stats + 2 * i + 1) * inv_n - mean * mean;
     var = var > 0.0 ? var : 0.0;
     mr[2 * i] = (float)mean;
     mr[2 * i + 1] = (float)(1.0 / sqrt(var + (double)LN_EPS));
@@ -660,8 +660,8 @@ template <int S>
 __global__ __launch_bounds__(256) void tail_bwd_a_kernel(const TailBwdArgs a) {
     const int q = threadIdx.x, Q = a.Q;
     const int64_t b = blockIdx.x;
-    const double mean = a.stats[2 * b] / (double)a.D;
-    double var = a.stats[2 * b + 1] / (double)a.D - mean * mean;
+    const double mean = stat_get(a.stats + 2 * b) / (double)a.D;
+    double var = stat_get(a.stats + 2 * b + 1) / (double)a.D - mean * mean;
     var = var > 0.0 ? var : 0.0;
     const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
     const float lnA = (float)rstd, lnC = (float)(-mean * rstd);
@@ -769,7 +769,7 @@ __global__ void pack_dgrad_weight_kernel(const float* __restrict__ k3, float* __
 }
 
 // ---- host launch helpers used by api.hip -------------------------------------------------
-int launch_stats_to_mr(const double* stats, float* mr, const double* inv_n_dev, int64_t B, int n_layers, hipStream_t st) {
+int launch_stats_to_mr(const stat_t* stats, float* mr, const double* inv_n_dev, int64_t B, int n_layers, hipStream_t st) {
     const int64_t n = (int64_t)n_layers * B;
     stats_to_mr_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(stats, mr, n, inv_n_dev, B);
     NAFP_LAUNCH_CHECK();

@@ -73,7 +73,7 @@ template <bool STORE, int ROWS0>
 __global__ __launch_bounds__(256) void conv0_kernel(
         const float* __restrict__ feat, const float* __restrict__ w3, const float* __restrict__ bias,
         const float* __restrict__ gamma, float* __restrict__ y, float* __restrict__ v_out,
-        double* __restrict__ stats, int F, int Tin, int Tout, int Cout, int stride, int pad,
+        stat_t* __restrict__ stats, int F, int Tin, int Tout, int Cout, int stride, int pad,
         const float* __restrict__ gstat, int group_size, int segment_norm) {
     constexpr int NP = 4;                           // positions per thread and batch
     __shared__ float s_x[ROWS0 * 64 + 8];           // rows of the input, Tin <= 64, with one zero in front (index -1)
@@ -172,13 +172,13 @@ __global__ __launch_bounds__(256) void conv0_kernel(
     if (lane == 0) { red[wave] = ds; red[4 + wave] = dq; }
     __syncthreads();
     if (tid == 0) {
-        atomicAdd(stats + 2 * b, red[0] + red[1] + red[2] + red[3]);
-        atomicAdd(stats + 2 * b + 1, red[4] + red[5] + red[6] + red[7]);
+        stat_add(stats + 2 * b, red[0] + red[1] + red[2] + red[3]);
+        stat_add(stats + 2 * b + 1, red[4] + red[5] + red[6] + red[7]);
     }
 }
 
 int launch_conv0(const float* feat, const float* w3, const float* bias, const float* gamma, float* y,
-                 float* v_out, double* stats, int64_t B, const ConvGeom& g, hipStream_t st, const float* gstat,
+                 float* v_out, stat_t* stats, int64_t B, const ConvGeom& g, hipStream_t st, const float* gstat,
                  int group_size, int segment_norm) {
     if (g.Cin != 1 || g.axis != 0 || (g.Cout % 4) != 0 || 256 % (g.Cout / 4) != 0 || g.Tin > 64) return NAFP_ERR_UNSUPPORTED;
     // rows per workgroup, measured at B = 640 on one box (ms): 4 -> 0.339, 8 -> 0.291, 16 -> 0.272 (the plain per-position
@@ -205,7 +205,7 @@ int launch_conv0(const float* feat, const float* w3, const float* bias, const fl
     return NAFP_OK;
 }
 
-int launch_conv0_stats(const float* feat, const float* w3, const float* bias, double* stats, int64_t B,
+int launch_conv0_stats(const float* feat, const float* w3, const float* bias, stat_t* stats, int64_t B,
                        const ConvGeom& g, hipStream_t st) {
     if (g.Cin != 1 || g.axis != 0 || (g.Cout % 4) != 0 || 256 % (g.Cout / 4) != 0 || g.Tin > 64) return NAFP_ERR_UNSUPPORTED;
     constexpr int R = 32;
@@ -275,8 +275,8 @@ struct ConvKernelParams {
     const float* Hb;          // (P, Cout)      FULL
     const float* gamma_out;   // (P, Cout)      FULL
     const float* bias;        // (Cout) or null PLAIN
-    const double* stats_in;   // (B, 2)         FULL
-    double* stats_out;        // (B, 2)         FULL
+    const stat_t* stats_in;   // (B, 2)         FULL   (64-bit fixed point: stat_add() / stat_get(), nafp_common.h)
+    stat_t* stats_out;        // (B, 2)         FULL
     float* y;                 // (B, P, Cout)
     float* v_out;             // (B, P, Cout) or null: the ELU output itself (kept for the backward pass)
     int Fin, Tin, Cin, Tout, Cout;
@@ -517,8 +517,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     const bool stat_thread = tid >= 64 && tid < 64 + p.ST;
     double st_sum = 0.0, st_sq = 0.0;             // loaded here, turned into (r, c) after the first DMAs are on their way
     if (stat_thread && p.mode != 1 && b0 + tid - 64 < p.B) {
-        st_sum = p.stats_in[2 * (int64_t)(b0 + tid - 64)];
-        st_sq = p.stats_in[2 * (int64_t)(b0 + tid - 64) + 1];
+        st_sum = stat_get(p.stats_in + 2 * (int64_t)(b0 + tid - 64));
+        st_sq = stat_get(p.stats_in + 2 * (int64_t)(b0 + tid - 64) + 1);
     }
     if (tid < 32) {
         int pos = p.P, inner = 0; unsigned mask = 0;
@@ -1183,7 +1183,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
 #pragma unroll
                     for (int w = 0; w < NW; ++w) t += red[w * 16 + which * 4 + sl] + red[w * 16 + 8 + which * 4 + sl];
                 }
-                atomicAdd(p.stats_out + 2 * (int64_t)b + which, t);
+                stat_add(p.stats_out + 2 * (int64_t)b + which, t);
             }
         }
     } else {
@@ -1193,8 +1193,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
             if (b < p.B) {
                 double ds = 0.0, dq = 0.0;
                 for (int pl = 0; pl < p.PT; ++pl) { ds += (double)rowS[pl * p.ST + tid]; dq += (double)rowQ[pl * p.ST + tid]; }
-                atomicAdd(p.stats_out + 2 * (int64_t)b, ds);
-                atomicAdd(p.stats_out + 2 * (int64_t)b + 1, dq);
+                stat_add(p.stats_out + 2 * (int64_t)b, ds);
+                stat_add(p.stats_out + 2 * (int64_t)b + 1, dq);
             }
         }
     }
@@ -1283,8 +1283,8 @@ constexpr int FIN_MAXS = 64;            // samples a workgroup may touch (4096 /
 template <int FIN_F4>                   // float4 per workgroup: 1024, 512 or 256 (the launch wants >= 1024 workgroups)
 __global__ __launch_bounds__(256) void splitk_finish_kernel(
         const float* __restrict__ slab, int S, const float* __restrict__ G, const float* __restrict__ Hb,
-        const float* __restrict__ gamma_out, const double* __restrict__ stats_in,
-        double* __restrict__ stats_out, float* __restrict__ y, float* __restrict__ v_out, int B, int P, int Cout,
+        const float* __restrict__ gamma_out, const stat_t* __restrict__ stats_in,
+        stat_t* __restrict__ stats_out, float* __restrict__ y, float* __restrict__ v_out, int B, int P, int Cout,
         double inv_n_in) {
     __shared__ float sR[FIN_MAXS], sC[FIN_MAXS];
     __shared__ float sPart[4][FIN_F4 / 256][2][2];     // [wave][pass][first / last sample of the wave][sum, sumsq]
@@ -1297,8 +1297,8 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(
     const int b_first = (int)((i0 / c4) / P), b_last = (int)((i_last / c4) / P);
     if (tid <= b_last - b_first) {
         const int b = b_first + tid;
-        const double mean = stats_in[2 * (int64_t)b] * inv_n_in;
-        double var = stats_in[2 * (int64_t)b + 1] * inv_n_in - mean * mean;
+        const double mean = stat_get(stats_in + 2 * (int64_t)b) * inv_n_in;
+        double var = stat_get(stats_in + 2 * (int64_t)b + 1) * inv_n_in - mean * mean;
         var = var > 0.0 ? var : 0.0;
         const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
         sR[tid] = (float)rstd; sC[tid] = (float)(-mean * rstd);
@@ -1354,8 +1354,8 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(
             for (int e = 0; e < FIN_F4 / 256; ++e)
                 for (int h = 0; h < 2; ++h)
                     if (sPartB[w][e][h] == b) { ds += (double)sPart[w][e][h][0]; dq += (double)sPart[w][e][h][1]; }
-        atomicAdd(stats_out + 2 * (int64_t)b, ds);
-        atomicAdd(stats_out + 2 * (int64_t)b + 1, dq);
+        stat_add(stats_out + 2 * (int64_t)b, ds);
+        stat_add(stats_out + 2 * (int64_t)b + 1, dq);
     }
 }
 

@@ -51,6 +51,23 @@ __device__ __forceinline__ float elu1(float v) {
     return v > 0.f ? v : e;
 }
 
+// Per-sample LayerNorm statistics (sum, sum of squares of a conv's ELU output) are accumulated as 64-bit FIXED-POINT
+// integers with STAT_FRAC_BITS fractional bits.  Integer addition is associative, so the totals do not depend on the
+// order in which tiles, workgroups or split-K finishers arrive: the forward pass -- and with it every fingerprint -- is
+// BIT-REPRODUCIBLE run to run (the double atomicAdd used before made two generate runs differ by ~1e-6).  Each partial is
+// a double formed in a fixed order inside its workgroup and rounded once to the grid: <= 2^-21 absolute per partial
+// (at most a few thousand partials per sample), against sums that are divided by n >= 1024 and compared with the
+// LayerNorm epsilon 1e-3 -- far below float32 rounding of the activations themselves.  Range: |sum| < 2^43 ~ 8.8e12,
+// i.e. an RMS activation below 4096 at the largest layer (n = 2^19); LayerNorm keeps activations O(1).
+typedef long long stat_t;
+constexpr int STAT_FRAC_BITS = 20;
+#ifdef __HIPCC__
+__device__ __forceinline__ void stat_add(stat_t* slot, double v) {
+    atomicAdd((unsigned long long*)slot, (unsigned long long)__double2ll_rn(v * (double)(1 << STAT_FRAC_BITS)));
+}
+__device__ __forceinline__ double stat_get(const stat_t* slot) { return (double)(*slot) * (1.0 / (double)(1 << STAT_FRAC_BITS)); }
+#endif
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -89,7 +106,7 @@ __device__ __forceinline__ void atomic_min_float(float* addr, float v) {
 // gstat != nullptr: `feat` is the raw log-mel and (max, min) per group of `group_size` samples; the batch-max
 // subtraction / clamp / segment normalisation of melspectrogram.py:108-111 is applied on load.
 int launch_conv0(const float* feat, const float* w3, const float* bias, const float* gamma, float* y,
-                 float* v_out, double* stats, int64_t B, const ConvGeom& g, hipStream_t st,
+                 float* v_out, stat_t* stats, int64_t B, const ConvGeom& g, hipStream_t st,
                  const float* gstat = nullptr, int group_size = 0, int segment_norm = 0);
 
 // implicit-GEMM conv (see conv.hip for the LayerNorm folding).
@@ -101,8 +118,8 @@ struct ConvGemmArgs {
     const float* Hb;         // (P,Cout) conv(beta_in) + bias      FULL
     const float* gamma_out;  // (P,Cout) LN scale of THIS conv     FULL
     const float* bias;       // (Cout) or nullptr                  PLAIN
-    const double* stats_in;  // (B,2): sum, sumsq of the previous conv's ELU output   FULL
-    double* stats_out;       // (B,2), must be zero on entry                          FULL
+    const stat_t* stats_in;  // (B,2): sum, sumsq of the previous conv's ELU output (fixed point, stat_get())   FULL
+    stat_t* stats_out;       // (B,2), must be zero on entry                          FULL
     float* y;                // (B,Fout,Tout,Cout): z = gamma_out . v (FULL) or acc + bias (PLAIN)
     float* v_out;            // optional (FULL): the pre-activation t (v = ELU(t)), kept for the backward pass
     bool plain;
@@ -118,7 +135,7 @@ struct ConvGemmArgs {
     const ConvGeom* f0_geom;
 };
 // statistics (sum, sum of squares of ELU(conv0 + bias) per sample) without storing the activation
-int launch_conv0_stats(const float* feat, const float* w3, const float* bias, double* stats, int64_t B,
+int launch_conv0_stats(const float* feat, const float* w3, const float* bias, stat_t* stats, int64_t B,
                        const ConvGeom& g, hipStream_t st);
 int64_t conv_gemm_slab_floats(int64_t B, const ConvGeom& g, bool with_dgrad = false);   // workspace the split-K policy wants
 int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStream_t st);
@@ -141,7 +158,7 @@ int launch_ln_bwd_scalars(const float* mr, const double* lnsum, const float* mr_
 // tail: LN of the last conv + flatten + divide-and-encode + optional L2 norm.
 struct TailArgs {
     const float* x;          // (B, D): z = gamma . v of the last conv, or already-normalised flat
-    const double* stats;     // (B,2) or nullptr when x is already the LN output
+    const stat_t* stats;     // (B,2) or nullptr when x is already the LN output
     const float* gamma;      // (D) or nullptr
     const float* beta;       // (D) or nullptr
     const float* w1p;        // (S,32,Q)
@@ -156,7 +173,7 @@ int launch_tail(const TailArgs& a, int64_t B, hipStream_t st);
 
 // ---- backward pass (backward.hip) ----------------------------------------------------------
 struct TailBwdArgs {
-    const float* z; const double* stats; const float* gamma; const float* beta;     // last conv (z = gamma . v)
+    const float* z; const stat_t* stats; const float* gamma; const float* beta;     // last conv (z = gamma . v)
     const float* w1; const float* b1; const float* w2; const float* b2;             // keras layouts
     const float* d_emb;                                                             // (B,Q)
     float* dy;            // (B,Q) scratch
@@ -166,7 +183,7 @@ struct TailBwdArgs {
     int D, Q, S, l2norm;
 };
 int launch_tail_bwd(const TailBwdArgs& a, int64_t B, hipStream_t st);
-int launch_stats_to_mr(const double* stats, float* mr, const double* inv_n_dev, int64_t B, int n_layers, hipStream_t st);
+int launch_stats_to_mr(const stat_t* stats, float* mr, const double* inv_n_dev, int64_t B, int n_layers, hipStream_t st);
 // LayerNorm + ELU backward of one layer (backward.hip): d = r_j * dL/dxhat_j -> dts = r_{j-1} * dL/dt_j in place;
 // dgamma/dbeta/dbias/S1/S2 accumulate (zeroed by the caller, like lnsum); sc = (B, 8) scratch.
 // tpre = the layer's stored PRE-activation t (v = ELU(t) is recomputed).  reduce_here: compute this layer's (s1, s2)

@@ -50,8 +50,8 @@ __global__ __launch_bounds__(512) void tail_kernel(const TailArgs a, int64_t B) 
     for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
         float lnA = 1.f, lnC = 0.f;
         if (a.stats) {
-            const double mean = a.stats[2 * b] / (double)a.D;
-            double var = a.stats[2 * b + 1] / (double)a.D - mean * mean;
+            const double mean = stat_get(a.stats + 2 * b) / (double)a.D;
+            double var = stat_get(a.stats + 2 * b + 1) / (double)a.D - mean * mean;
             var = var > 0.0 ? var : 0.0;
             const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
             lnA = (float)rstd; lnC = (float)(-mean * rstd);

@@ -71,7 +71,7 @@ def pytest_terminal_summary(terminalreporter):
     terminalreporter.write_line('observed error maxima (value / tolerance):')
     for k in sorted(_OBSERVED):
         v, t = _OBSERVED[k]
-        terminalreporter.write_line(f'  {k}: {v:.3e} / {t:.1e}  ({t / max(v, 1e-300):.0f}x headroom)')
+        terminalreporter.write_line(f'  {k}: {v:.3e} / {t:.1e}' + (f'  ({t / v:.0f}x headroom)' if v > 1e-30 else ''))
     try:
         import json
         os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)

@@ -94,6 +94,47 @@ def test_config0_generate_100_clips_ts_batch_125(nafp, cfg, tmp_path):
         blk = got[gi * 125:gi * 125 + len(rows)]
         assert (1 - (blk * want).sum(1)).max() < 1e-5, gi                       # contract 1e-3
         assert np.abs(blk - want).max() < 1e-4, gi
+    # ---- bit-reproducible generate ----
+    # (a) the same command again: byte-identical custom_source.mm (the per-sample LayerNorm statistics are accumulated as
+    #     64-bit fixed-point integers -- order-free -- and every other sum of the forward pass is taken in a fixed order)
+    import hashlib
+    first = open(out_dir + 'custom_source.mm', 'rb').read()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'run.py'), 'generate', 'c0', '1', '-c', 'c0', '-s', str(src)],
+                       cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    again = open(out_dir + 'custom_source.mm', 'rb').read()
+    assert first == again, 'two runs of run.py generate differ'
+    # (b) other launch sizes through the product's writer, each twice: 125 (one group per launch), 750, 1000 (8 groups; the
+    #     last launch ragged): run-to-run identical bytes at every size.  ACROSS sizes the tile plan and the split-K factors
+    #     -- the fp32 summation order -- differ, so those agree to rounding: 1 - cos < 1e-6.
+    from neural_audio_fp_amd.model.utils.audio_utils import SegmentSource
+    m_pre = nafp.get_melspec_layer(c)
+    source = SegmentSource(paths, bsz=125)
+    by_size = {}
+    for launch_rows in (125, 750, 1000):
+        runs = []
+        for rep in range(2):
+            arr = np.zeros((5900, 128), np.float32)
+            g.write_fingerprints(source, g.StreamedEmbedder(m_pre, m_fp), arr, 125, launch_rows=launch_rows)
+            runs.append(arr)
+        assert runs[0].tobytes() == runs[1].tobytes(), launch_rows
+        by_size[launch_rows] = runs[0]
+    assert by_size[750].tobytes() == first                                        # run.py's own launch size (6 groups: LAUNCH_SEGMENTS 640 rounded up)
+    for launch_rows in (125, 1000):
+        assert (1 - (by_size[launch_rows] * got).sum(1)).max() < 1e-6, launch_rows
+    # (c) the committed hash of this output (seeded weights, seeded clips, this kernel generation): tests/golden/
+    #     hip_generate_sha256.json.  A change of any forward kernel's summation order legitimately changes it -- then
+    #     re-record it from gpurun_out/hip_generate_sha256.json of a run and say so in the commit.
+    import json
+    sha = hashlib.sha256(first).hexdigest()
+    try:
+        os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+        json.dump({'config0_custom_source_mm_sha256': sha}, open(os.path.join(ROOT, 'gpurun_out', 'hip_generate_sha256.json'), 'w'))
+    except OSError:
+        pass
+    want_sha = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'hip_generate_sha256.json'))).get('config0_custom_source_mm_sha256')
+    if want_sha:
+        assert sha == want_sha, f'custom_source.mm of config 0 hashes to {sha}; tests/golden/hip_generate_sha256.json holds {want_sha}'
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -213,7 +254,9 @@ def test_config4_two_ranks_write_one_million_row_memmap(nafp, cfg, tmp_path):
         want = m_fp(m_pre(x, group_size=125)).cpu().numpy()
         # (the ranks ran launches of 625 rows, this is one of 125: tile shapes and split-K factors -- the fp32 summation
         # order -- depend on the launch size, so the two agree to rounding, not bit for bit)
-        assert np.abs(np.asarray(db[g0:g0 + 125]) - want).max() < 3e-6, g0
+        blk = np.asarray(db[g0:g0 + 125])
+        assert np.abs(blk - want).max() < 3e-6, g0
+        assert (1 - (blk * want).sum(1)).max() < 1e-6, g0                        # what a search sees: the cosine
     # search: every probed row comes back at its own id (eval_faiss.py:141-146, 209 with the exact index)
     from neural_audio_fp_amd.eval.eval_faiss import FlatL2Index
     index = FlatL2Index(128, capacity=n_rows)
