@@ -576,7 +576,8 @@ TrainLayout train_layout(const nafp_encoder* e, int64_t B, void* ws) {
         L.v[j] = j == 0 ? nullptr : (float*)take((int64_t)sizeof(float) * n * B);     // layer 0: regenerated, not stored
     }
     L.slab_floats = 0;
-    for (int j = 1; j < 16; ++j) L.slab_floats = std::max(L.slab_floats, conv_gemm_slab_floats(B, e->geom[j], true));
+    for (int j = 1; j < 16; ++j)
+        L.slab_floats = std::max(L.slab_floats, std::max(conv_gemm_slab_floats(B, e->geom[j], true), wgrad_slab_floats(B, e->geom[j])));
     L.slab = (float*)take((int64_t)sizeof(float) * L.slab_floats);
     L.dA = (float*)take((int64_t)sizeof(float) * max_n * B);
     L.dB = (float*)take((int64_t)sizeof(float) * max_n * B);
@@ -666,15 +667,18 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
     // `cur` holds r_j * dL/dxhat_j on entry of iteration j and r_{j-1} * dL/dt_j (dts) after launch_ln_bwd
     float* cur = L.dA; float* other = L.dB;
     bool ln_done = false;       // `cur` already holds dts_j (the LayerNorm backward of layer j ran inside dgrad_{j+1})
+    bool sc_ready = false;      // L.sc already holds the scalar records of layer j (side job of wgrad_{j+1})
     for (int j = 15; j >= 1; --j) {
         const ConvGeom& g = e->geom[j];
         const int P = g.Fout * g.Tout;
         const float* mr_j = L.mr + 2 * B * j; const float* mr_p = L.mr + 2 * B * (j - 1);
         if (!ln_done) {
             rc = launch_ln_bwd(cur, L.v[j], e->d_gamma[j], mr_j, mr_p, L.lnsum[j], L.sc, grads[4 * j + 2], grads[4 * j + 3],
-                               grads[4 * j + 1], L.S1[j], L.S2[j], B, P, g.Cout, st, j == 15, e->d_G[j], e->d_Hb[j], L.lnsum[j - 1]);
+                               grads[4 * j + 1], L.S1[j], L.S2[j], B, P, g.Cout, st, j == 15, e->d_G[j], e->d_Hb[j], L.lnsum[j - 1],
+                               nullptr, nullptr, nullptr, nullptr, nullptr, sc_ready);
             if (rc != NAFP_OK) return rc;
         }
+        sc_ready = false;
         // the transposed conv below writes `other`, which still holds dts_{j+1}: wgrad(j+1), on the weight-gradient stream,
         // must be done with it
         if (overlap && j < 15) NAFP_HIP_CHECK(hipStreamWaitEvent(st, e->ev_side[j + 1], 0));
@@ -706,12 +710,27 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
             NAFP_HIP_CHECK(hipEventRecord(e->ev_main[j], st));
             NAFP_HIP_CHECK(hipStreamWaitEvent(sw, e->ev_main[j], 0));
         }
-        rc = launch_wgrad(L.z[j - 1], cur, grads[4 * j], B, g, sw);
-        if (rc != NAFP_OK) return rc;
-        rc = launch_wgrad(e->d_gamma[j - 1], L.S1[j], grads[4 * j], 1, g, sw);
-        if (rc != NAFP_OK) return rc;
-        rc = launch_wgrad(e->d_beta[j - 1], L.S2[j], grads[4 * j], 1, g, sw);
-        if (rc != NAFP_OK) return rc;
+        // (the two rank-one terms ride in the main launch as two aux samples: [gamma | beta] and [S1 | S2] are adjacent pairs.)
+        // Side job of that launch, single-stream mode only: the scalar records the LayerNorm backward of layer j - 1 starts from
+        // (its sums are final since ln_bwd of layer j; the fused dgrad path and the side stream keep the separate launch)
+        const ConvGeom& gp1 = e->geom[j - 1];
+        ScalarsJob sj{L.mr + 2 * B * (j - 1), L.lnsum[j - 1], j >= 2 ? L.mr + 2 * B * (j - 2) : nullptr, L.sc, (long long)B,
+                      1.0 / ((double)gp1.Fout * gp1.Tout * gp1.Cout)};
+        const bool fold_sc = !overlap && !ln_done;
+        const bool pairs = L.S2[j] == L.S1[j] + (int64_t)P * g.Cout;
+        if (pairs) {
+            rc = launch_wgrad(L.z[j - 1], cur, grads[4 * j], B, g, sw, e->d_gamma[j - 1], L.S1[j], overlap ? nullptr : L.slab,
+                              overlap ? 0 : L.slab_floats, overlap ? nullptr : L.tickets, fold_sc ? &sj : nullptr);
+            if (rc != NAFP_OK) return rc;
+        } else {
+            rc = launch_wgrad(L.z[j - 1], cur, grads[4 * j], B, g, sw, nullptr, nullptr, nullptr, 0, nullptr, fold_sc ? &sj : nullptr);
+            if (rc != NAFP_OK) return rc;
+            rc = launch_wgrad(e->d_gamma[j - 1], L.S1[j], grads[4 * j], 1, g, sw);
+            if (rc != NAFP_OK) return rc;
+            rc = launch_wgrad(e->d_beta[j - 1], L.S2[j], grads[4 * j], 1, g, sw);
+            if (rc != NAFP_OK) return rc;
+        }
+        sc_ready = fold_sc;
         if (overlap) NAFP_HIP_CHECK(hipEventRecord(e->ev_side[j], sw));
         std::swap(cur, other);
         // layers j .. 15 (and the divide-and-encode tensors) are final from here on (when the LayerNorm backward of layer
@@ -726,7 +745,7 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
         if (!ln_done) {
             rc = launch_ln_bwd(cur, nullptr, e->d_gamma[0], L.mr, nullptr, L.lnsum[0], L.sc, grads[2], grads[3], grads[1],
                                nullptr, nullptr, B, g.Fout * g.Tout, g.Cout, st, false, nullptr, nullptr, nullptr,
-                               feat, e->d_w[0], e->d_bias[0], &g, grads[0]);     // ... and dW0 in the same pass
+                               feat, e->d_w[0], e->d_bias[0], &g, grads[0], sc_ready);     // ... and dW0 in the same pass
             if (rc != NAFP_OK) return rc;
         } else {
             rc = launch_conv0_bwd(feat, cur, grads[0], nullptr, B, g, st);

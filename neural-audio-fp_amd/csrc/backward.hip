@@ -278,13 +278,41 @@ __device__ __forceinline__ void lds_dma16_b(unsigned lds_addr, unsigned voff, u3
                  : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 
+// (ScalarsJob, nafp_common.h: side job of a wgrad launch -- the per-sample scalar records of the LayerNorm backward of the
+// layer BELOW, what ln_bwd_scalars_kernel computes: its inputs are final once ln_bwd_fused of this layer has run, its consumer
+// is the next ln_bwd_fused launch; 15 three-workgroup launches of ~10 us each on the serial chain of the backward pass otherwise.)
 struct WgradParams {
     const float* X; const float* D; float* dW;
     int B, P, Tout, Fin, Tin, Cin, Cout, axis, stride, pad;
     long long sample_in;
     int rows_per_wg;
     int tap_pack, n_live;          // live taps, 2 bits each: taps that read real data for at least one output position
+    // n_aux = 2 "samples" appended BEHIND the batch (rows B*P ... (B+2)*P - 1 of the same GEMM): X2 = [gamma_{j-1} ; beta_{j-1}]
+    // (2 x sample_in, adjacent), D2 = [S1_j ; S2_j] (2 x P x Cout, adjacent): the two rank-one terms of dW_j,
+    //   dW_j = wgrad(z_{j-1}, r dt) + wgrad(gamma_{j-1}, sum_b c_b dt) + wgrad(beta_{j-1}, sum_b dt),
+    // ride in the main launch instead of two launches of their own (30 launches of ~13 us per backward pass).
+    const float* X2; const float* D2; int n_aux; long long M_main;
+    // small-P kernel: the row chunks of an output tile meet through a slab + an arrival ticket per tile; the LAST arriver adds
+    // the parts in chunk order and stores dW (no atomics: deterministic, and dW is written once)
+    float* slab; unsigned* tickets; int n_chunks;
+    ScalarsJob sj;
 };
+
+__device__ __forceinline__ void wgrad_scalars_side_job(const ScalarsJob& j) {
+    if (!j.sc) return;
+    const long long wg = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z);
+    const long long n_wg = (long long)gridDim.x * gridDim.y * gridDim.z;
+    for (long long b = wg * 256 + threadIdx.x; b < j.B; b += n_wg * 256) {
+        const float mean = j.mr[2 * b], rstd = j.mr[2 * b + 1];
+        float* o = j.sc + 8 * b;
+        o[0] = mean; o[1] = rstd;
+        o[2] = (float)(j.lnsum[2 * b] * j.inv_n); o[3] = (float)(j.lnsum[2 * b + 1] * j.inv_n);
+        o[4] = 1.f / rstd;
+        o[5] = j.mr_prev ? j.mr_prev[2 * b + 1] : 1.f;
+        o[6] = j.mr_prev ? -j.mr_prev[2 * b] : 0.f;
+        o[7] = 0.f;
+    }
+}
 
 __global__ __launch_bounds__(256, 3) void wgrad_kernel(const WgradParams p) {
     constexpr int NST = 3, KR = 16;
@@ -298,6 +326,7 @@ __global__ __launch_bounds__(256, 3) void wgrad_kernel(const WgradParams p) {
     // blockIdx.z enumerates (live tap, c-tile): a tap that only ever sees zero padding (b5-b7 at the 1-s input) has a
     // zero gradient, which the zeroed dW already holds
     const int tap = (p.tap_pack >> (2 * (blockIdx.z / ctiles))) & 3, c0 = (blockIdx.z % ctiles) * 128, n0 = blockIdx.y * 128;
+    wgrad_scalars_side_job(p.sj);
     const long long M = (long long)p.B * p.P;
     const long long m0 = (long long)blockIdx.x * p.rows_per_wg;
     const long long m_end = std::min<long long>(M, m0 + p.rows_per_wg);
@@ -409,9 +438,14 @@ __global__ __launch_bounds__(256, 3) void wgrad_fast_kernel(const WgradParams p,
     const int wc = wave >> 1, wn = wave & 1;
     const int ctiles = p.Cin / 128;
     const int tap = (p.tap_pack >> (2 * (blockIdx.z / ctiles))) & 3, c0 = (blockIdx.z % ctiles) * 128, n0 = blockIdx.y * 128;
-    const long long M = (long long)p.B * p.P;
-    const long long m0 = (long long)blockIdx.x * p.rows_per_wg;               // multiple of 16
+    wgrad_scalars_side_job(p.sj);
+    // rows [0, M_main) are the batch, rows [M_main, M) the aux samples (X2 / D2): the launcher makes M_main and every chunk
+    // start multiples of the rows a K-step consumes, so a K-step lies entirely on one side and only its buffer descriptors
+    // and scalar offsets change (the per-lane address parts are linear in the row index across sample boundaries)
+    const long long M = (long long)(p.B + p.n_aux) * p.P;
+    const long long m0 = (long long)blockIdx.x * p.rows_per_wg;               // multiple of 16 (32 with aux rows)
     const long long m_end = std::min<long long>(M, m0 + p.rows_per_wg);
+    const long long main_end = std::min<long long>(m_end, p.M_main);
     // Two output frames per line (Tout = 2) and a tap that reads real data for only ONE of them -- conv8's taps 0 and 2
     // (stride 1 on two frames), conv6's tap 2 (its last frame hangs over the end): every second row of this tap's GEMM is
     // zero padding.  Such a tap walks only the live rows: a K-step takes 16 LINES at the live frame instead of 8 lines x 2
@@ -426,9 +460,13 @@ __global__ __launch_bounds__(256, 3) void wgrad_fast_kernel(const WgradParams p,
     const int n_steps = (int)((m_end - m0 + rows_per_step - 1) / rows_per_step);
     const int b_first = (int)(m0 / p.P);
     const int chunk = lane & 31, hh = lane >> 5;
-    const long long x_bytes = ((long long)(m_end - 1) / p.P - b_first + 1) * p.sample_in * 4;
+    const long long x_bytes = main_end > m0 ? ((long long)(main_end - 1) / p.P - b_first + 1) * p.sample_in * 4 : 0;
     const u32x4b rsX = make_rsrc_b(p.X + (long long)b_first * p.sample_in, (unsigned)std::min<long long>(x_bytes, 0x7fffffffll));
-    const u32x4b rsD = make_rsrc_b(p.D + m0 * p.Cout, (unsigned)((m_end - m0) * p.Cout * 4));
+    const u32x4b rsD = make_rsrc_b(p.D + m0 * p.Cout, (unsigned)(std::max<long long>(main_end - m0, 0) * p.Cout * 4));
+    const u32x4b rsX2 = make_rsrc_b(p.X2, (unsigned)(p.n_aux * p.sample_in * 4));
+    const u32x4b rsD2 = make_rsrc_b(p.D2, (unsigned)(std::max<long long>(m_end - p.M_main, 0) * p.Cout * 4));   // rows beyond this chunk: out of range
+    const unsigned x_shift = (unsigned)(((long long)p.B - b_first) * p.sample_in * 4);      // (modular: b_first > B for a chunk inside the aux rows)
+    const unsigned d_shift = (unsigned)((p.M_main - m0) * p.Cout * 4);
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
 
     // per-lane bases of the two DMA instructions of this wave (rows r = 4 wave + 2 i + hh of every step)
@@ -468,15 +506,20 @@ __global__ __launch_bounds__(256, 3) void wgrad_fast_kernel(const WgradParams p,
     const int Fout = 1 << lfo;
 
 #define NAFP_WGF_DMA(s_, slot_)                                                                        \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                    \
-        bool ok_l = okc[i];                                                                            \
-        if (p.axis == 1) {                                     /* padding rows at the edge of a sample */ \
-            const int f_l = ((fo0[i] + (s_) * dl) & fmask) * p.stride - p.pad + tap;                   \
-            ok_l = f_l >= 0 && f_l < p.stride * Fout;                                                  \
+    {                                                                                                  \
+        const bool aux_l = p.n_aux && m0 + (long long)(s_) * rows_per_step >= p.M_main;   /* wave-uniform */ \
+        const u32x4b rx_l = aux_l ? rsX2 : rsX, rd_l = aux_l ? rsD2 : rsD;                             \
+        const unsigned sx_l = (unsigned)(s_) * dX - (aux_l ? x_shift : 0u), sd_l = (unsigned)(s_) * dD - (aux_l ? d_shift : 0u); \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                \
+            bool ok_l = okc[i];                                                                        \
+            if (p.axis == 1) {                                 /* padding rows at the edge of a sample */ \
+                const int f_l = ((fo0[i] + (s_) * dl) & fmask) * p.stride - p.pad + tap;               \
+                ok_l = f_l >= 0 && f_l < p.stride * Fout;                                              \
+            }                                                                                          \
+            const unsigned la_l = lds0 + (unsigned)(((slot_) * STAGE + (4 * wave + 2 * i) * 128) * 4); \
+            lds_dma16_b(la_l, ok_l ? vxb[i] : OOB, rx_l, sx_l);                                        \
+            lds_dma16_b(la_l + TILE * 4, vdb[i], rd_l, sd_l);                                          \
         }                                                                                              \
-        const unsigned la_l = lds0 + (unsigned)(((slot_) * STAGE + (4 * wave + 2 * i) * 128) * 4);     \
-        lds_dma16_b(la_l, ok_l ? vxb[i] : OOB, rsX, (unsigned)(s_) * dX);                              \
-        lds_dma16_b(la_l + TILE * 4, vdb[i], rsD, (unsigned)(s_) * dD);                                \
     }
 
     f32x16 acc[2][2];
@@ -541,49 +584,311 @@ __global__ __launch_bounds__(256, 3) void wgrad_fast_kernel(const WgradParams p,
             }
 }
 
-int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const ConvGeom& g, hipStream_t st) {
+// wgrad for the SMALL layers: P = Fout * Tout a power of two below 16 (every layer from b5 on at the 1-s input: P = 8, 4, 4, 2,
+// 2, 1).  There the GEMM's reduction dimension -- rows m = (sample, position) -- is short (640 ... 5120 rows at a batch of
+// 640) and its output, the weight tensor, is the large side (0.5 ... 3.1 M elements): what the generic kernel paid for was
+// (i) ~160 vector instructions of row bookkeeping per K-step, (ii) 16 K fp32 atomics per workgroup -- 6 ... 23 row chunks
+// each adding a full 128 x 128 tile into dW --, (iii) the two rank-one terms as launches of their own.  Here:
+//   * 16 rows of a K-step are 16 / P whole samples, so a lane's DMA row keeps its position (hence its tap geometry and
+//     padding test) for the whole loop and moves 16 / P samples per step: per-lane base + scalar offset, no vector
+//     instruction in the loop besides the MFMAs (as wgrad_fast_kernel);
+//   * the tile is 128 c x BNT n (BNT = 64 doubles the tiles of the layers with few of them), the row chunks are as few as
+//     fill the chip (n_chunks, often 1 or 2), and they meet through a slab: every chunk writes its partial tile through
+//     the caches, draws an arrival ticket for the tile, and the LAST arriver adds the parts in chunk order and stores dW
+//     once (n_chunks == 1: straight from the accumulators).  No atomics: the gradient is bit-reproducible;
+//   * the aux samples (gamma | beta against S1 | S2) are rows B*P ... of the same loop.
+template <int BNT>
+__global__ __launch_bounds__(256, 3) void wgrad_smallp_kernel(const WgradParams p, const int lp) {
+    constexpr int NST = 3, KR = 16;
+    constexpr int TX = KR * 128, TD = KR * BNT, STAGE = TX + TD;   // X rows | D rows
+    constexpr int NIW = BNT / 64;                                  // n-tiles (32 columns) per wave: wave = 64 c x BNT / 2 n
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave >> 1, wn = wave & 1;
+    const int ctiles = p.Cin / 128;
+    const int tap = (p.tap_pack >> (2 * (blockIdx.z / ctiles))) & 3, c0 = (blockIdx.z % ctiles) * 128, n0 = blockIdx.y * BNT;
+    wgrad_scalars_side_job(p.sj);
+    const long long M = (long long)(p.B + p.n_aux) * p.P;
+    const long long m0 = (long long)blockIdx.x * p.rows_per_wg;               // multiple of 16
+    const long long m_end = std::min<long long>(M, m0 + p.rows_per_wg);
+    const long long main_end = std::min<long long>(m_end, p.M_main);
+    const int n_steps = (int)((m_end - m0 + KR - 1) / KR);
+    const int b_first = (int)(m0 >> lp);
+    const int chunk = lane & 31, hh = lane >> 5;
+    const long long x_bytes = main_end > m0 ? (((main_end - 1) >> lp) - b_first + 1) * p.sample_in * 4 : 0;
+    const u32x4b rsX = make_rsrc_b(p.X + (long long)b_first * p.sample_in, (unsigned)std::min<long long>(x_bytes, 0x7fffffffll));
+    const u32x4b rsD = make_rsrc_b(p.D + m0 * p.Cout, (unsigned)(std::max<long long>(main_end - m0, 0) * p.Cout * 4));
+    const u32x4b rsX2 = make_rsrc_b(p.X2, (unsigned)(p.n_aux * p.sample_in * 4));
+    const u32x4b rsD2 = make_rsrc_b(p.D2, (unsigned)(std::max<long long>(m_end - p.M_main, 0) * p.Cout * 4));
+    const unsigned x_shift = (unsigned)(((long long)p.B - b_first) * p.sample_in * 4);
+    const unsigned d_shift = (unsigned)((p.M_main - m0) * p.Cout * 4);
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
+
+    // X: instruction i of wave w stages rows r = 4 w + 2 i + hh (32 lanes x 16 B = the 128 channels of a row)
+    unsigned vxb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 4 * wave + 2 * i + hh;
+        const int pos = r & (p.P - 1);
+        const int fo = pos / p.Tout, to = pos - fo * p.Tout;
+        int src; bool ok;
+        if (p.axis == 0) { const int t = to * p.stride - p.pad + tap; ok = t >= 0 && t < p.Tin; src = (fo * p.Tin + t) * p.Cin; }
+        else             { const int f = fo * p.stride - p.pad + tap; ok = f >= 0 && f < p.Fin; src = (f * p.Tin + to) * p.Cin; }
+        vxb[i] = ok ? (unsigned)(((long long)(r >> lp) * p.sample_in + src + c0 + 4 * chunk) * 4) : OOB;
+    }
+    const unsigned dX = (unsigned)((KR >> lp) * p.sample_in * 4);             // bytes per K-step: 16 / P samples
+    // D: BNT = 128: the same row mapping; BNT = 64: one instruction covers 4 rows of 16 lanes
+    unsigned vdb[NIW];
+#pragma unroll
+    for (int i = 0; i < NIW; ++i) {
+        const int r = BNT == 128 ? 4 * wave + 2 * i + hh : 4 * wave + (lane >> 4);
+        const int ch = BNT == 128 ? chunk : (lane & 15);
+        vdb[i] = (unsigned)(((long long)r * p.Cout + n0 + 4 * ch) * 4);
+    }
+    const unsigned dD = (unsigned)(KR * p.Cout * 4);
+
+#define NAFP_WSP_DMA(s_, slot_)                                                                        \
+    {                                                                                                  \
+        const bool aux_l = p.n_aux && m0 + (long long)(s_) * KR >= p.M_main;              /* wave-uniform */ \
+        const u32x4b rx_l = aux_l ? rsX2 : rsX, rd_l = aux_l ? rsD2 : rsD;                             \
+        const unsigned sx_l = (unsigned)(s_) * dX - (aux_l ? x_shift : 0u), sd_l = (unsigned)(s_) * dD - (aux_l ? d_shift : 0u); \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                  \
+            lds_dma16_b(lds0 + (unsigned)(((slot_) * STAGE + (4 * wave + 2 * i) * 128) * 4), vxb[i], rx_l, sx_l); \
+        _Pragma("unroll") for (int i = 0; i < NIW; ++i)                                                \
+            lds_dma16_b(lds0 + (unsigned)(((slot_) * STAGE + TX + (4 * wave + 2 * i) * BNT) * 4), vdb[i], rd_l, sd_l); \
+    }
+
+    f32x16 acc[2][NIW];
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+        for (int ni = 0; ni < NIW; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ci][ni][r] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < n_steps) NAFP_WSP_DMA(s, s)
+
+    // MFMA operands: lane (rl, hh) owns the channel pair 2 rl, 2 rl + 1 of its wave's 64 channels (tiles ci = 0, 1 = even /
+    // odd channels) and -- BNT = 128 -- the column pair 2 rl, 2 rl + 1 of its wave's 64 columns, or -- BNT = 64 -- column rl of 32
+    const int rl = lane & 31;
+    typedef float f32x2w __attribute__((ext_vector_type(2)));
+    const float* Xl = smem + hh * 128 + wc * 64 + 2 * rl;
+    const float* Dl = smem + TX + hh * BNT + wn * (BNT / 2) + (BNT == 128 ? 2 * rl : rl);
+    int slot = 0;
+    for (int s = 0; s < n_steps; ++s) {
+        if (s + NST - 2 >= n_steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 + NIW) : "memory");      // one younger step may stay in flight
+        __builtin_amdgcn_s_barrier();
+        const float* Xs = Xl + slot * STAGE;
+        const float* Ds = Dl + slot * STAGE;
+        f32x2w a[KR / 2], bq[KR / 2];
+#pragma unroll
+        for (int kp = 0; kp < KR / 2; ++kp) {
+            a[kp] = *(const f32x2w*)(Xs + 2 * kp * 128);
+            if (BNT == 128) bq[kp] = *(const f32x2w*)(Ds + 2 * kp * BNT);
+            else { bq[kp].x = Ds[2 * kp * BNT]; bq[kp].y = 0.f; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        int nslot = slot + NST - 1; if (nslot >= NST) nslot -= NST;
+#pragma unroll
+        for (int kp = 0; kp < KR / 2; ++kp) {
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                for (int ni = 0; ni < NIW; ++ni)
+                    acc[ci][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp][ci], bq[kp][ni], acc[ci][ni], 0, 0, 0);
+            if (kp == 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + NST - 1 < n_steps) { NAFP_WSP_DMA(s + NST - 1, nslot) }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (++slot == NST) slot = 0;
+    }
+#undef NAFP_WSP_DMA
+    // C/D layout: lane holds column n_l (+ ni for BNT = 128), rows c_l(r) = 2 ((r&3) + 8 (r>>2) + 4 hh) + ci of its wave's block
+    const int n_l = wn * (BNT / 2) + (BNT == 128 ? 2 * rl : rl);
+    const int tile_id = blockIdx.y + gridDim.y * blockIdx.z;
+    if (p.n_chunks > 1) {
+        // my partial tile -> slab[tile][chunk] (row-major 128 x BNT) THROUGH the caches (sc0 sc1: the XCDs' L2s are not
+        // coherent with each other), wait for the write acknowledgements, then draw the tile's arrival ticket (device-scope
+        // atomic) -- the protocol of conv_gemm's in-kernel split-K finish (conv.hip, EPI 4)
+        const int part_bytes = 128 * BNT * 4;
+        const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(
+            p.slab + ((long long)tile_id * p.n_chunks + blockIdx.x) * (128 * BNT), 0, part_bytes, 0x00020000);
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c_l = wc * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * hh) + ci;
+#pragma unroll
+                for (int ni = 0; ni < NIW; ++ni)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (float)acc[ci][ni][r]), rsP, (c_l * BNT + n_l + ni) * 4, 0, 17);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // my part is in memory
+        __syncthreads();                                              // ... and so is every wave's of this workgroup
+        __shared__ unsigned s_ticket;
+        if (tid == 0) s_ticket = __hip_atomic_fetch_add(p.tickets + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_ticket != (unsigned)(p.n_chunks - 1)) return;
+        if (tid == 0) __hip_atomic_store(p.tickets + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        // last arriver: all parts -- its own included -- from memory, in chunk order (the sum does not depend on who arrives last)
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int ni = 0; ni < NIW; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ci][ni][r] = 0.f;
+        for (int k = 0; k < p.n_chunks; ++k) {
+            const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(
+                p.slab + ((long long)tile_id * p.n_chunks + k) * (128 * BNT), 0, part_bytes, 0x00020000);
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c_l = wc * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * hh) + ci;
+#pragma unroll
+                    for (int ni = 0; ni < NIW; ++ni)
+                        acc[ci][ni][r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsK, (c_l * BNT + n_l + ni) * 4, 0, 17));
+                }
+        }
+    }
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = c0 + wc * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * hh) + ci;
+            float* o = p.dW + ((long long)tap * p.Cin + c) * p.Cout + n0 + n_l;
+            if (BNT == 128) { f32x2w v2; v2.x = acc[ci][0][r]; v2.y = acc[ci][NIW - 1][r]; *(f32x2w*)o = v2; }
+            else *o = acc[ci][0][r];
+        }
+}
+
+static int wgrad_live_taps(const ConvGeom& g, int* tap_pack) {
+    const int n_in = g.axis == 0 ? g.Tin : g.Fin, n_out = g.axis == 0 ? g.Tout : g.Fout;
+    int n_live = 0; *tap_pack = 0;
+    for (int t = 0; t < 3; ++t) {
+        bool live = false;
+        for (int o = 0; o < n_out && !live; ++o) { const int i = o * g.stride - g.pad + t; live = i >= 0 && i < n_in; }
+        if (live) { *tap_pack |= t << (2 * n_live); ++n_live; }
+    }
+    return n_live;
+}
+
+// Plan of the small-P kernel for a batch of B samples (+ 2 aux samples): tile width, row chunks, slab need.
+struct WgradSmallPlan { bool ok; int bnt, chunks, rows_per_wg, lp; int64_t tiles, slab_floats; };
+static WgradSmallPlan wgrad_small_plan(int64_t B, const ConvGeom& g) {
+    WgradSmallPlan r{false, 128, 1, 0, 0, 0, 0};
+    static const int on = []() { const char* e = getenv("NAFP_WGRAD_SMALLP"); return e ? atoi(e) : 1; }();
+    const int P = g.Fout * g.Tout;
+    if (!on || g.Cin % 128 != 0 || g.Cout % 128 != 0 || P >= 16 || (P & (P - 1)) != 0 || (B * P) % 16 != 0) return r;
+    while ((1 << r.lp) < P) ++r.lp;
+    int tp; const int n_live = wgrad_live_taps(g, &tp);
+    if (n_live == 0) return r;
+    const int64_t tiles128 = (int64_t)(g.Cout / 128) * (n_live * g.Cin / 128);
+    r.bnt = tiles128 < 192 ? 64 : 128;
+    r.tiles = (int64_t)(g.Cout / r.bnt) * (n_live * g.Cin / 128);
+    if (r.tiles > NAFP_TICKET_SLOTS) return r;
+    const int64_t M = (B + 2) * P, steps = (M + 15) / 16;
+    // enough workgroups for two per CU, but at least 12 K-steps each (NAFP_WGRAD_SP_TARGET: workgroups aimed at)
+    static const int64_t target = []() { const char* e = getenv("NAFP_WGRAD_SP_TARGET"); return e ? atoll(e) : (int64_t)512; }();
+    int64_t chunks = std::max<int64_t>(1, (target + r.tiles - 1) / r.tiles);
+    chunks = std::min<int64_t>(chunks, std::max<int64_t>(1, steps / 12));
+    int64_t rpw = ((steps + chunks - 1) / chunks) * 16;
+    chunks = (M + rpw - 1) / rpw;
+    r.chunks = (int)chunks; r.rows_per_wg = (int)rpw;
+    r.slab_floats = chunks > 1 ? r.tiles * chunks * 128 * r.bnt : 0;
+    r.ok = true;
+    return r;
+}
+
+int64_t wgrad_slab_floats(int64_t B, const ConvGeom& g) {
+    const WgradSmallPlan pl = wgrad_small_plan(B, g);
+    return pl.ok ? pl.slab_floats : 0;
+}
+
+// dW (keras (3,Cin,Cout)) of one layer.  X2 / D2 (both or neither): the two aux samples [gamma | beta] resp. [S1 | S2],
+// each pair adjacent in memory, folded into the main launch where the shape allows (else two more launches, as before).
+// slab / tickets (or null): workspace of the small-P kernel (null: it is not used).  sj: optional side job (see ScalarsJob).
+int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const ConvGeom& g, hipStream_t st,
+                 const float* X2, const float* D2, float* slab, int64_t slab_floats, unsigned* tickets, const ScalarsJob* sj) {
     if (g.Cin % 128 != 0 || g.Cout % 128 != 0) return NAFP_ERR_UNSUPPORTED;
     WgradParams p;
     p.X = X; p.D = D; p.dW = dW; p.B = (int)B; p.P = g.Fout * g.Tout; p.Tout = g.Tout;
     p.Fin = g.Fin; p.Tin = g.Tin; p.Cin = g.Cin; p.Cout = g.Cout; p.axis = g.axis; p.stride = g.stride; p.pad = g.pad;
     p.sample_in = (long long)g.Fin * g.Tin * g.Cin;
-    const long long M = (long long)B * p.P;
-    p.tap_pack = 0; p.n_live = 0;
-    {
-        const int n_in = g.axis == 0 ? g.Tin : g.Fin, n_out = g.axis == 0 ? g.Tout : g.Fout;
-        for (int t = 0; t < 3; ++t) {
-            bool live = false;
-            for (int o = 0; o < n_out && !live; ++o) { const int i = o * g.stride - g.pad + t; live = i >= 0 && i < n_in; }
-            if (live) { p.tap_pack |= t << (2 * p.n_live); ++p.n_live; }
+    p.X2 = X; p.D2 = D; p.n_aux = 0; p.M_main = (long long)B * p.P;
+    p.slab = nullptr; p.tickets = nullptr; p.n_chunks = 1;
+    p.sj = sj ? *sj : ScalarsJob{nullptr, nullptr, nullptr, nullptr, 0, 0.0};
+    p.n_live = wgrad_live_taps(g, &p.tap_pack);
+    if (p.n_live == 0) {                                   // nothing to add; the side job still has to run
+        if (sj && sj->sc) {
+            ln_bwd_scalars_kernel<<<(unsigned)((sj->B + 255) / 256), 256, 0, st>>>(sj->mr, sj->lnsum, sj->mr_prev, sj->sc, sj->B, sj->inv_n);
+            NAFP_LAUNCH_CHECK();
         }
+        return NAFP_OK;
     }
-    const int col_tiles = (g.Cout / 128) * (p.n_live * g.Cin / 128);
-    // one resident round: 256 CUs x 3 workgroups (each workgroup ends in 16 K atomics, so fewer is better;
-    // measured at B = 1280: 768 / 1536 / 3072 / 6144 workgroups -> backward 22.3 / 22.5 / 22.9 / 24.3 ms)
-    long long chunks = std::max<long long>(1, 768 / col_tiles);
-    long long rpw = (M + chunks - 1) / chunks;
-    rpw = std::max<long long>(64, (rpw + 15) / 16 * 16);
-    // the X descriptor of a workgroup spans (rows/P + 2) samples: keep it below 2 GiB
-    while (rpw > 64 && (rpw / p.P + 2) * p.sample_in * 4 >= (1ll << 31)) rpw = std::max<long long>(64, rpw / 2 / 16 * 16);
-    p.rows_per_wg = (int)rpw;
-    const unsigned gx = (unsigned)((M + rpw - 1) / rpw);
     static bool attr = false;
     const int lds = 3 * 2 * 16 * 128 * (int)sizeof(float);
     if (!attr) {
         NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_smallp_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_smallp_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr = true;
     }
+    const bool have_aux = X2 && D2;
+    // ---- small layers (P < 16) ----
+    const WgradSmallPlan sp = wgrad_small_plan(B, g);
+    if (sp.ok && have_aux && (sp.chunks == 1 || (slab && tickets && sp.slab_floats <= slab_floats))) {
+        p.X2 = X2; p.D2 = D2; p.n_aux = 2;
+        p.rows_per_wg = sp.rows_per_wg; p.n_chunks = sp.chunks; p.slab = slab; p.tickets = tickets;
+        const dim3 grid((unsigned)sp.chunks, (unsigned)(g.Cout / sp.bnt), (unsigned)(p.n_live * g.Cin / 128));
+        if (sp.bnt == 64) wgrad_smallp_kernel<64><<<grid, 256, 3 * (16 * 128 + 16 * 64) * sizeof(float), st>>>(p, sp.lp);
+        else wgrad_smallp_kernel<128><<<grid, 256, lds, st>>>(p, sp.lp);
+        NAFP_LAUNCH_CHECK();
+        return NAFP_OK;
+    }
+    const int col_tiles = (g.Cout / 128) * (p.n_live * g.Cin / 128);
     // regular shapes take the kernel whose K-steps are (nearly) free of vector instructions
     auto log2_exact = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
     const int lt = log2_exact(g.Tout), lfo = log2_exact(g.Fout);
     static const bool fast_on = []() { const char* e = getenv("NAFP_WGRAD_FAST"); return !e || e[0] != '0'; }();
     const bool fast = fast_on && lt >= 0 && lt <= 4 && lfo >= 0 && p.P % 16 == 0 && (g.stride == 1 || g.stride == 2) &&
                       (g.axis == 0 ? (g.Fin == g.Fout) : (g.Fin == g.stride * g.Fout && g.Tin == g.Tout));
-    if (fast) wgrad_fast_kernel<<<dim3(gx, g.Cout / 128, p.n_live * g.Cin / 128), 256, lds, st>>>(p, lt, lfo);
-    else wgrad_kernel<<<dim3(gx, g.Cout / 128, p.n_live * g.Cin / 128), 256, lds, st>>>(p);
-    NAFP_LAUNCH_CHECK();
-    return NAFP_OK;
+    static const bool aux_fold = []() { const char* e = getenv("NAFP_WGRAD_AUXFOLD"); return !e || e[0] != '0'; }();
+    // aux rows ride in the fast kernel when every K-step stays on one side of row B * P (a K-step takes 16 rows, 32 for the
+    // half-dead taps of the two-frame layers)
+    const bool fold = fast && have_aux && aux_fold && p.P % 32 == 0;
+    auto launch_one = [&](const float* Xq, const float* Dq, int64_t Bq, bool with_aux, const ScalarsJob* job) -> int {
+        WgradParams q = p;
+        q.X = Xq; q.D = Dq; q.B = (int)Bq; q.M_main = (long long)Bq * q.P;
+        q.n_aux = with_aux ? 2 : 0; q.X2 = with_aux ? X2 : Xq; q.D2 = with_aux ? D2 : Dq;
+        q.sj = job ? *job : ScalarsJob{nullptr, nullptr, nullptr, nullptr, 0, 0.0};
+        const long long M = (long long)(Bq + q.n_aux) * q.P;
+        // one resident round: 256 CUs x 3 workgroups (each workgroup ends in 16 K atomics, so fewer is better;
+        // measured at B = 1280: 768 / 1536 / 3072 / 6144 workgroups -> backward 22.3 / 22.5 / 22.9 / 24.3 ms)
+        long long chunks = std::max<long long>(1, 768 / col_tiles);
+        long long rpw = (M + chunks - 1) / chunks;
+        rpw = std::max<long long>(64, (rpw + 31) / 32 * 32);
+        // the X descriptor of a workgroup spans (rows/P + 2) samples: keep it below 2 GiB
+        while (rpw > 64 && (rpw / q.P + 2) * q.sample_in * 4 >= (1ll << 31)) rpw = std::max<long long>(64, rpw / 2 / 32 * 32);
+        q.rows_per_wg = (int)rpw;
+        const unsigned gx = (unsigned)((M + rpw - 1) / rpw);
+        if (fast) wgrad_fast_kernel<<<dim3(gx, g.Cout / 128, q.n_live * g.Cin / 128), 256, lds, st>>>(q, lt, lfo);
+        else wgrad_kernel<<<dim3(gx, g.Cout / 128, q.n_live * g.Cin / 128), 256, lds, st>>>(q);
+        NAFP_LAUNCH_CHECK();
+        return NAFP_OK;
+    };
+    int rc = launch_one(X, D, B, fold, sj);
+    if (rc != NAFP_OK || !have_aux || fold) return rc;
+    rc = launch_one(X2, D2, 1, false, nullptr);                                   // gamma_{j-1} against S1_j
+    if (rc != NAFP_OK) return rc;
+    return launch_one(X2 + p.sample_in, D2 + (long long)p.P * p.Cout, 1, false, nullptr);   // beta_{j-1} against S2_j
 }
 
 // ============================================================================
@@ -779,7 +1084,8 @@ int launch_stats_to_mr(const stat_t* stats, float* mr, const double* inv_n_dev, 
 int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* mr, const float* mr_prev,
                   double* lnsum, float* sc, float* dgamma, float* dbeta, float* dbias, float* S1, float* S2,
                   int64_t B, int P, int C, hipStream_t st, bool reduce_here, const float* Gj, const float* Hbj,
-                  double* lnsum_below, const float* feat0, const float* w0, const float* bias0, const ConvGeom* g0, float* dW0) {
+                  double* lnsum_below, const float* feat0, const float* w0, const float* bias0, const ConvGeom* g0, float* dW0,
+                  bool scalars_done) {
     const int64_t n = (int64_t)P * C;
     if (C % 4 != 0 || (256 % (C / 4) != 0 && (C / 4) % 256 != 0) || n % 1024 != 0 || 1024 % C != 0) return NAFP_ERR_UNSUPPORTED;
     if (reduce_here) {
@@ -788,8 +1094,10 @@ int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* 
         ln_bwd_reduce_kernel<<<dim3(chunks, (unsigned)B), 256, 0, st>>>(d, tpre, gamma, mr, lnsum, n);
         NAFP_LAUNCH_CHECK();
     }
-    ln_bwd_scalars_kernel<<<(unsigned)((B + 255) / 256), 256, 0, st>>>(mr, lnsum, mr_prev, sc, B, 1.0 / (double)n);
-    NAFP_LAUNCH_CHECK();
+    if (!scalars_done) {                  // (else: written by the side job of the wgrad launch of the layer above)
+        ln_bwd_scalars_kernel<<<(unsigned)((B + 255) / 256), 256, 0, st>>>(mr, lnsum, mr_prev, sc, B, 1.0 / (double)n);
+        NAFP_LAUNCH_CHECK();
+    }
     // batch chunks: every chunk ends in 5 atomics per element (~33 G atomics/s measured), which is what a
     // small layer pays for; 256..1024 workgroups keep the streaming layers at HBM speed
     const int64_t bx = n / 1024;

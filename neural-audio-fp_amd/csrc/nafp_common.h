@@ -193,11 +193,17 @@ int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* 
                   double* lnsum, float* sc, float* dgamma, float* dbeta, float* dbias, float* S1, float* S2,
                   int64_t B, int P, int C, hipStream_t st, bool reduce_here, const float* Gj, const float* Hbj,
                   double* lnsum_below, const float* feat0 = nullptr, const float* w0 = nullptr, const float* bias0 = nullptr,
-                  const ConvGeom* g0 = nullptr, float* dW0 = nullptr);
+                  const ConvGeom* g0 = nullptr, float* dW0 = nullptr, bool scalars_done = false);
 // feat0 (layer 0 only): regenerate the pre-activation instead of reading tpre; dW0: also accumulate conv0's weight gradient
 // (keras (1,3,1,C) layout) and leave `d` unwritten
 // dW (keras (3,Cin,Cout), accumulated) += sum_rows X[b, in(pos,tap), :] (x) D[b,pos,:]
-int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const ConvGeom& g, hipStream_t st);
+// X2 / D2 (both or neither): the aux samples [gamma_{j-1} | beta_{j-1}] resp. [S1_j | S2_j] (each pair adjacent), i.e. the two
+// rank-one terms of dW_j; slab / tickets: workspace of the small-layer kernel (or null); sj: optional side job.
+struct ScalarsJob { const float* mr; const double* lnsum; const float* mr_prev; float* sc; long long B; double inv_n; };   // sc == null: none
+int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const ConvGeom& g, hipStream_t st,
+                 const float* X2 = nullptr, const float* D2 = nullptr, float* slab = nullptr, int64_t slab_floats = 0,
+                 unsigned* tickets = nullptr, const ScalarsJob* sj = nullptr);
+int64_t wgrad_slab_floats(int64_t B, const ConvGeom& g);
 int launch_conv0_bwd(const float* feat, const float* dt, float* dW0, float* dbias0, int64_t B, const ConvGeom& g,
                      hipStream_t st);
 int launch_pack_dgrad_weight(const float* k3, float* wd, int Cin, int Cout, hipStream_t st);

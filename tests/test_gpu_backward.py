@@ -177,3 +177,33 @@ def test_weight_gradients_on_the_side_stream_equal_the_single_stream_pass(nafp, 
         for i, (a, b) in enumerate(zip(out[1][rep], out[0][rep])):
             worst = max(worst, float((a - b).abs().max()) / (float(b.abs().max()) + 1e-20))
     observe('side-stream vs single-stream gradients, rel. to the tensor max', worst, 2e-5)
+
+
+def test_backward_with_aux_rows_and_small_layer_kernel(nafp, observe):
+    """B = 32: B * P is a multiple of 16 for every layer, so the weight gradients take the round-4 paths -- the two rank-one
+    terms (gamma | beta against S1 | S2) as aux rows of the main launch, the small-layer kernel (P < 16: plain stores or
+    slab + last-arriver, no atomics) and the scalar records of the next layer as a side job of the wgrad launch -- where
+    B = 2 / 5 above take the fallbacks (separate launches).  All 68 gradients against float64 autograd."""
+    B = 32
+    rng = np.random.default_rng(77)
+    feat = (-rng.uniform(0, 1.2, size=(B, 256, 32, 1))).astype(np.float32)
+    w = _inputs.weights(seed=13)
+    d_emb = rng.normal(size=(B, 128)).astype(np.float32)
+    m_fp = nafp.FingerPrinter(seed=0)
+    m_fp.set_weights(_inputs.weight_list(w))
+    emb = m_fp.forward_train(torch.from_numpy(feat).cuda())
+    grads = [g.clone() for g in m_fp.backward(torch.from_numpy(d_emb).cuda())]
+    torch.set_num_threads(min(32, __import__('os').cpu_count() or 1))
+    want_emb, want = _reference(feat, w, d_emb)
+    assert np.abs(emb.cpu().numpy() - want_emb).max() < 2e-5
+    names = __import__('neural_audio_fp_amd').model.fp.nnfp.tensor_names()
+    worst = 0.0
+    for i, (g, wg) in enumerate(zip(grads, want)):
+        err = np.abs(g.cpu().numpy() - wg).max() / (np.abs(wg).max() + 1e-12)
+        assert err < 1e-4, (names[i], err)
+        worst = max(worst, err)
+    observe('gradient, rel. to the tensor max', worst, 1e-4)
+    # a second pass over the same activations: the slab / ticket protocol leaves its counters at zero
+    again = m_fp.backward(torch.from_numpy(d_emb).cuda())
+    for i, (a, b) in enumerate(zip(again, grads)):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12, names[i]
