@@ -465,14 +465,20 @@ __global__ __launch_bounds__(256, 3) void wgrad_fast_kernel(const WgradParams p,
     const u32x4b rsD = make_rsrc_b(p.D + m0 * p.Cout, (unsigned)(std::max<long long>(main_end - m0, 0) * p.Cout * 4));
     const u32x4b rsX2 = make_rsrc_b(p.X2, (unsigned)(p.n_aux * p.sample_in * 4));
     const u32x4b rsD2 = make_rsrc_b(p.D2, (unsigned)(std::max<long long>(m_end - p.M_main, 0) * p.Cout * 4));   // rows beyond this chunk: out of range
-    const unsigned x_shift = (unsigned)(((long long)p.B - b_first) * p.sample_in * 4);      // (modular: b_first > B for a chunk inside the aux rows)
-    const unsigned d_shift = (unsigned)((p.M_main - m0) * p.Cout * 4);
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
 
     // per-lane bases of the two DMA instructions of this wave (rows r = 4 wave + 2 i + hh of every step)
     const int dl = to_sel >= 0 ? KR : (KR >> lt);              // source/output lines per step
     const int fmask = (1 << lfo) - 1;
-    unsigned vxb[2], vdb[2]; int fo0[2];
+    // The aux rows start at K-step s_aux of this chunk (INT_MAX: none).  From there on the lane parts are re-based on X2 / D2
+    // (vxa / vda = the lane's offsets at step s_aux) and the scalar part counts steps from s_aux: both parts stay
+    // non-negative -- the hardware adds voffset and soffset without wrapping, so a "negative" scalar part is out of range.
+    const unsigned dX = (unsigned)((p.axis == 0 ? dl : dl * p.stride) * p.Tin * p.Cin * 4);   // bytes per step
+    const unsigned dD = (unsigned)(rows_per_step * p.Cout * 4);
+    const int s_aux = (p.n_aux && m_end > p.M_main) ? (int)(std::max<long long>(p.M_main - m0, 0) / rows_per_step) : 0x7fffffff;
+    const long long x_rebase = s_aux == 0x7fffffff ? 0 : (long long)s_aux * dX - ((long long)p.B - b_first) * p.sample_in * 4;
+    const long long d_rebase = s_aux == 0x7fffffff ? 0 : (long long)s_aux * dD - (p.M_main - m0) * p.Cout * 4;
+    unsigned vxb[2], vdb[2], vxa[2], vda[2]; int fo0[2];
     bool okc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -482,8 +488,10 @@ __global__ __launch_bounds__(256, 3) void wgrad_fast_kernel(const WgradParams p,
             const int t = to_sel * p.stride - p.pad + tap;
             const long long src = (line * p.Tin + t) * p.Cin;
             okc[i] = true; fo0[i] = (int)(line & fmask);
-            vxb[i] = (unsigned)((src - (long long)b_first * p.sample_in + c0 + 4 * chunk) * 4);
-            vdb[i] = (unsigned)(((long long)(2 * r + to_sel) * p.Cout + n0 + 4 * chunk) * 4);
+            const long long vx = (src - (long long)b_first * p.sample_in + c0 + 4 * chunk) * 4;
+            const long long vd = ((long long)(2 * r + to_sel) * p.Cout + n0 + 4 * chunk) * 4;
+            vxb[i] = (unsigned)vx; vdb[i] = (unsigned)vd;
+            vxa[i] = (unsigned)(vx + x_rebase); vda[i] = (unsigned)(vd + d_rebase);
             continue;
         }
         const long long line = ((m0 + r) >> lt);               // = b * Fout + fo of step 0
@@ -498,18 +506,18 @@ __global__ __launch_bounds__(256, 3) void wgrad_fast_kernel(const WgradParams p,
             src = (((long long)p.stride * line - p.pad + tap) * p.Tin + to) * p.Cin;
         }
         fo0[i] = (int)(line & fmask);
-        vxb[i] = (unsigned)((src - (long long)b_first * p.sample_in + c0 + 4 * chunk) * 4);
-        vdb[i] = (unsigned)(((long long)r * p.Cout + n0 + 4 * chunk) * 4);
+        const long long vx = (src - (long long)b_first * p.sample_in + c0 + 4 * chunk) * 4;
+        const long long vd = ((long long)r * p.Cout + n0 + 4 * chunk) * 4;
+        vxb[i] = (unsigned)vx; vdb[i] = (unsigned)vd;
+        vxa[i] = (unsigned)(vx + x_rebase); vda[i] = (unsigned)(vd + d_rebase);      // (a padding row may wrap: it is masked)
     }
-    const unsigned dX = (unsigned)((p.axis == 0 ? dl : dl * p.stride) * p.Tin * p.Cin * 4);   // bytes per step
-    const unsigned dD = (unsigned)(rows_per_step * p.Cout * 4);
     const int Fout = 1 << lfo;
 
 #define NAFP_WGF_DMA(s_, slot_)                                                                        \
     {                                                                                                  \
-        const bool aux_l = p.n_aux && m0 + (long long)(s_) * rows_per_step >= p.M_main;   /* wave-uniform */ \
+        const bool aux_l = (s_) >= s_aux;                                                  /* wave-uniform */ \
         const u32x4b rx_l = aux_l ? rsX2 : rsX, rd_l = aux_l ? rsD2 : rsD;                             \
-        const unsigned sx_l = (unsigned)(s_) * dX - (aux_l ? x_shift : 0u), sd_l = (unsigned)(s_) * dD - (aux_l ? d_shift : 0u); \
+        const unsigned srel_l = (unsigned)(aux_l ? (s_) - s_aux : (s_));                               \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                \
             bool ok_l = okc[i];                                                                        \
             if (p.axis == 1) {                                 /* padding rows at the edge of a sample */ \
@@ -517,8 +525,8 @@ __global__ __launch_bounds__(256, 3) void wgrad_fast_kernel(const WgradParams p,
                 ok_l = f_l >= 0 && f_l < p.stride * Fout;                                              \
             }                                                                                          \
             const unsigned la_l = lds0 + (unsigned)(((slot_) * STAGE + (4 * wave + 2 * i) * 128) * 4); \
-            lds_dma16_b(la_l, ok_l ? vxb[i] : OOB, rx_l, sx_l);                                        \
-            lds_dma16_b(la_l + TILE * 4, vdb[i], rd_l, sd_l);                                          \
+            lds_dma16_b(la_l, ok_l ? (aux_l ? vxa[i] : vxb[i]) : OOB, rx_l, srel_l * dX);              \
+            lds_dma16_b(la_l + TILE * 4, aux_l ? vda[i] : vdb[i], rd_l, srel_l * dD);                  \
         }                                                                                              \
     }
 
@@ -622,12 +630,16 @@ __global__ __launch_bounds__(256, 3) void wgrad_smallp_kernel(const WgradParams 
     const u32x4b rsD = make_rsrc_b(p.D + m0 * p.Cout, (unsigned)(std::max<long long>(main_end - m0, 0) * p.Cout * 4));
     const u32x4b rsX2 = make_rsrc_b(p.X2, (unsigned)(p.n_aux * p.sample_in * 4));
     const u32x4b rsD2 = make_rsrc_b(p.D2, (unsigned)(std::max<long long>(m_end - p.M_main, 0) * p.Cout * 4));
-    const unsigned x_shift = (unsigned)(((long long)p.B - b_first) * p.sample_in * 4);
-    const unsigned d_shift = (unsigned)((p.M_main - m0) * p.Cout * 4);
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
+    const unsigned dX = (unsigned)((KR >> lp) * p.sample_in * 4);             // bytes per K-step: 16 / P samples
+    const unsigned dD = (unsigned)(KR * p.Cout * 4);
+    // aux rows from K-step s_aux on: lane parts re-based on X2 / D2, scalar part counted from s_aux (see wgrad_fast_kernel)
+    const int s_aux = (p.n_aux && m_end > p.M_main) ? (int)(std::max<long long>(p.M_main - m0, 0) / KR) : 0x7fffffff;
+    const long long x_rebase = s_aux == 0x7fffffff ? 0 : (long long)s_aux * dX - ((long long)p.B - b_first) * p.sample_in * 4;
+    const long long d_rebase = s_aux == 0x7fffffff ? 0 : (long long)s_aux * dD - (p.M_main - m0) * p.Cout * 4;
 
     // X: instruction i of wave w stages rows r = 4 w + 2 i + hh (32 lanes x 16 B = the 128 channels of a row)
-    unsigned vxb[2];
+    unsigned vxb[2], vxa[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int r = 4 * wave + 2 * i + hh;
@@ -636,28 +648,29 @@ __global__ __launch_bounds__(256, 3) void wgrad_smallp_kernel(const WgradParams 
         int src; bool ok;
         if (p.axis == 0) { const int t = to * p.stride - p.pad + tap; ok = t >= 0 && t < p.Tin; src = (fo * p.Tin + t) * p.Cin; }
         else             { const int f = fo * p.stride - p.pad + tap; ok = f >= 0 && f < p.Fin; src = (f * p.Tin + to) * p.Cin; }
-        vxb[i] = ok ? (unsigned)(((long long)(r >> lp) * p.sample_in + src + c0 + 4 * chunk) * 4) : OOB;
+        const long long vx = ((long long)(r >> lp) * p.sample_in + src + c0 + 4 * chunk) * 4;
+        vxb[i] = ok ? (unsigned)vx : OOB;
+        vxa[i] = ok ? (unsigned)(vx + x_rebase) : OOB;
     }
-    const unsigned dX = (unsigned)((KR >> lp) * p.sample_in * 4);             // bytes per K-step: 16 / P samples
     // D: BNT = 128: the same row mapping; BNT = 64: one instruction covers 4 rows of 16 lanes
-    unsigned vdb[NIW];
+    unsigned vdb[NIW], vda[NIW];
 #pragma unroll
     for (int i = 0; i < NIW; ++i) {
         const int r = BNT == 128 ? 4 * wave + 2 * i + hh : 4 * wave + (lane >> 4);
         const int ch = BNT == 128 ? chunk : (lane & 15);
-        vdb[i] = (unsigned)(((long long)r * p.Cout + n0 + 4 * ch) * 4);
+        const long long vd = ((long long)r * p.Cout + n0 + 4 * ch) * 4;
+        vdb[i] = (unsigned)vd; vda[i] = (unsigned)(vd + d_rebase);
     }
-    const unsigned dD = (unsigned)(KR * p.Cout * 4);
 
 #define NAFP_WSP_DMA(s_, slot_)                                                                        \
     {                                                                                                  \
-        const bool aux_l = p.n_aux && m0 + (long long)(s_) * KR >= p.M_main;              /* wave-uniform */ \
+        const bool aux_l = (s_) >= s_aux;                                                  /* wave-uniform */ \
         const u32x4b rx_l = aux_l ? rsX2 : rsX, rd_l = aux_l ? rsD2 : rsD;                             \
-        const unsigned sx_l = (unsigned)(s_) * dX - (aux_l ? x_shift : 0u), sd_l = (unsigned)(s_) * dD - (aux_l ? d_shift : 0u); \
+        const unsigned srel_l = (unsigned)(aux_l ? (s_) - s_aux : (s_));                               \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                  \
-            lds_dma16_b(lds0 + (unsigned)(((slot_) * STAGE + (4 * wave + 2 * i) * 128) * 4), vxb[i], rx_l, sx_l); \
+            lds_dma16_b(lds0 + (unsigned)(((slot_) * STAGE + (4 * wave + 2 * i) * 128) * 4), aux_l ? vxa[i] : vxb[i], rx_l, srel_l * dX); \
         _Pragma("unroll") for (int i = 0; i < NIW; ++i)                                                \
-            lds_dma16_b(lds0 + (unsigned)(((slot_) * STAGE + TX + (4 * wave + 2 * i) * BNT) * 4), vdb[i], rd_l, sd_l); \
+            lds_dma16_b(lds0 + (unsigned)(((slot_) * STAGE + TX + (4 * wave + 2 * i) * BNT) * 4), aux_l ? vda[i] : vdb[i], rd_l, srel_l * dD); \
     }
 
     f32x16 acc[2][NIW];
