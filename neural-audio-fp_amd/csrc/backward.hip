@@ -580,6 +580,22 @@ __global__ __launch_bounds__(256, 3) void wgrad_fast_kernel(const WgradParams p,
     }
 #undef NAFP_WGF_DMA
     // D[i = c][j = n]: lane holds n = 2 (lane & 31) + ni, rows c = 2 ((r&3) + 8(r>>2) + 4*hh) + ci
+    if (p.slab) {
+        // the row chunks of a tile meet in wgrad_reduce_kernel (next launch): partial tile -> slab[tile][chunk], row-major
+        // 128 x 128, plain coalesced 8-byte stores.  (fp32 atomics straight into dW run at ONE element per clock and L2
+        // channel -- 768 workgroups x 16 K of them were ~47 us of every layer, whatever its size -- and made the sum
+        // depend on the arrival order.)
+        float* part = p.slab + ((long long)(blockIdx.y + gridDim.y * blockIdx.z) * gridDim.x + blockIdx.x) * (128 * 128);
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c_l = wc * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * hh) + ci;
+                f32x2w v2; v2.x = acc[ci][0][r]; v2.y = acc[ci][1][r];
+                *(f32x2w*)(part + c_l * 128 + wn * 64 + 2 * rl) = v2;
+            }
+        return;
+    }
 #pragma unroll
     for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
@@ -590,6 +606,29 @@ __global__ __launch_bounds__(256, 3) void wgrad_fast_kernel(const WgradParams p,
                 const int n = n0 + wn * 64 + 2 * rl + ni;
                 atomicAdd(p.dW + ((long long)tap * p.Cin + c) * p.Cout + n, acc[ci][ni][r]);
             }
+}
+
+// dW tile = sum over the row chunks of its partial tiles, in chunk order (deterministic), stored once.
+// grid = (32 slices of 512 elements, n-tiles, live taps x c-tiles) -- the wgrad grid's y / z; 256 threads x 2 floats.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dW, int n_chunks,
+                                                           int Cin, int Cout, int tap_pack) {
+    typedef float f32x2w __attribute__((ext_vector_type(2)));
+    const int ctiles = Cin / 128;
+    const int tap = (tap_pack >> (2 * (blockIdx.z / ctiles))) & 3, c0 = (blockIdx.z % ctiles) * 128, n0 = blockIdx.y * 128;
+    const int e = blockIdx.x * 512 + threadIdx.x * 2;               // element of the 128 x 128 tile
+    const f32x2w* src = (const f32x2w*)(slab + ((long long)(blockIdx.y + gridDim.y * blockIdx.z) * n_chunks) * (128 * 128) + e);
+    f32x2w t = {0.f, 0.f};
+    int k = 0;
+    for (; k + 8 <= n_chunks; k += 8) {
+        f32x2w v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + (long long)(k + u) * (128 * 128 / 2));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += v[u];
+    }
+    for (; k < n_chunks; ++k) t += __builtin_nontemporal_load(src + (long long)k * (128 * 128 / 2));
+    const int c = c0 + (e >> 7), n = n0 + (e & 127);
+    *(f32x2w*)(dW + ((long long)tap * Cin + c) * Cout + n) = t;
 }
 
 // wgrad for the SMALL layers: P = Fout * Tout a power of two below 16 (every layer from b5 on at the 1-s input: P = 8, 4, 4, 2,
@@ -802,26 +841,47 @@ static WgradSmallPlan wgrad_small_plan(int64_t B, const ConvGeom& g) {
     while ((1 << r.lp) < P) ++r.lp;
     int tp; const int n_live = wgrad_live_taps(g, &tp);
     if (n_live == 0) return r;
-    const int64_t tiles128 = (int64_t)(g.Cout / 128) * (n_live * g.Cin / 128);
-    r.bnt = tiles128 < 192 ? 64 : 128;
-    r.tiles = (int64_t)(g.Cout / r.bnt) * (n_live * g.Cin / 128);
-    if (r.tiles > NAFP_TICKET_SLOTS) return r;
     const int64_t M = (B + 2) * P, steps = (M + 15) / 16;
-    // enough workgroups for two per CU, but at least 12 K-steps each (NAFP_WGRAD_SP_TARGET: workgroups aimed at)
-    static const int64_t target = []() { const char* e = getenv("NAFP_WGRAD_SP_TARGET"); return e ? atoll(e) : (int64_t)512; }();
-    int64_t chunks = std::max<int64_t>(1, (target + r.tiles - 1) / r.tiles);
-    chunks = std::min<int64_t>(chunks, std::max<int64_t>(1, steps / 12));
-    int64_t rpw = ((steps + chunks - 1) / chunks) * 16;
-    chunks = (M + rpw - 1) / rpw;
-    r.chunks = (int)chunks; r.rows_per_wg = (int)rpw;
-    r.slab_floats = chunks > 1 ? r.tiles * chunks * 128 * r.bnt : 0;
+    // Tile width and row chunks by a makespan model: W = tiles x chunks workgroups go round-robin over 256 CUs, a CU works
+    // through ceil(W / 256) of them (co-resident workgroups share its SIMDs), each steps / chunks K-steps long plus ~`ov`
+    // K-steps of prologue / epilogue; a 64-column tile's K-step costs half a 128-column one's; a CU holding a single
+    // workgroup (one wave per SIMD) leaves the LDS round trip of every K-step exposed (`eff1`).  Sweep knobs:
+    // NAFP_WGRAD_SP_OV, NAFP_WGRAD_SP_EFF1 (per cent), NAFP_WGRAD_SP_FORCE="bnt:chunks".
+    static const double ov = []() { const char* e = getenv("NAFP_WGRAD_SP_OV"); return e ? atof(e) : 5.0; }();
+    static const double eff1 = []() { const char* e = getenv("NAFP_WGRAD_SP_EFF1"); return e ? atof(e) / 100.0 : 0.8; }();
+    struct Force { int bnt, chunks; };
+    static const Force force = []() {
+        Force f{0, 0}; const char* e = getenv("NAFP_WGRAD_SP_FORCE");
+        if (e) sscanf(e, "%d:%d", &f.bnt, &f.chunks);
+        return f;
+    }();
+    double best = 1e30;
+    for (int bnt = 64; bnt <= 128; bnt += 64) {
+        if (force.bnt && bnt != force.bnt) continue;
+        const int64_t tiles = (int64_t)(g.Cout / bnt) * (n_live * g.Cin / 128);
+        if (tiles > NAFP_TICKET_SLOTS) continue;
+        for (int64_t c = 1; c <= std::max<int64_t>(1, steps / 8) && c <= 64; ++c) {
+            if (force.chunks && c != std::min<int64_t>(force.chunks, std::max<int64_t>(1, steps / 8))) continue;
+            const int64_t spw = (steps + c - 1) / c, cc = (steps + spw - 1) / spw;      // chunks actually used
+            const int64_t per_cu = (tiles * cc + 255) / 256;
+            double cost = (double)per_cu * ((double)spw + ov) * (bnt == 64 ? 0.5 : 1.0) / (per_cu == 1 ? eff1 : 1.0);
+            if (cc > 1) cost += 1.0;                                                   // slab write + last-arriver pass
+            if (cost < best - 1e-9) { best = cost; r.bnt = bnt; r.chunks = (int)cc; r.rows_per_wg = (int)(spw * 16); r.tiles = tiles; }
+        }
+    }
+    if (best >= 1e30) return r;
+    r.slab_floats = r.chunks > 1 ? r.tiles * r.chunks * 128 * r.bnt : 0;
     r.ok = true;
     return r;
 }
 
 int64_t wgrad_slab_floats(int64_t B, const ConvGeom& g) {
     const WgradSmallPlan pl = wgrad_small_plan(B, g);
-    return pl.ok ? pl.slab_floats : 0;
+    if (pl.ok) return pl.slab_floats;
+    // fast kernel: <= 768 workgroups (+ the rounding of the chunk count) x one 128 x 128 partial tile each
+    int tp; const int n_live = wgrad_live_taps(g, &tp);
+    const int64_t col_tiles = (int64_t)(g.Cout / 128) * (n_live * g.Cin / 128);
+    return col_tiles == 0 ? 0 : (768 + 2 * col_tiles) * (int64_t)(128 * 128);
 }
 
 // dW (keras (3,Cin,Cout)) of one layer.  X2 / D2 (both or neither): the two aux samples [gamma | beta] resp. [S1 | S2],
@@ -892,9 +952,17 @@ int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const Con
         while (rpw > 64 && (rpw / q.P + 2) * q.sample_in * 4 >= (1ll << 31)) rpw = std::max<long long>(64, rpw / 2 / 32 * 32);
         q.rows_per_wg = (int)rpw;
         const unsigned gx = (unsigned)((M + rpw - 1) / rpw);
+        // the main launch of the fast kernel leaves its partial tiles in the slab; wgrad_reduce_kernel sums them into dW
+        static const bool slab_on = []() { const char* e = getenv("NAFP_WGRAD_SLAB"); return !e || e[0] != '0'; }();
+        const bool use_slab = slab_on && fast && Bq == B && slab && (int64_t)col_tiles * gx * 128 * 128 <= slab_floats;
+        q.slab = use_slab ? slab : nullptr; q.n_chunks = (int)gx;
         if (fast) wgrad_fast_kernel<<<dim3(gx, g.Cout / 128, q.n_live * g.Cin / 128), 256, lds, st>>>(q, lt, lfo);
         else wgrad_kernel<<<dim3(gx, g.Cout / 128, q.n_live * g.Cin / 128), 256, lds, st>>>(q);
         NAFP_LAUNCH_CHECK();
+        if (use_slab) {
+            wgrad_reduce_kernel<<<dim3(32, g.Cout / 128, q.n_live * g.Cin / 128), 256, 0, st>>>(slab, dW, (int)gx, g.Cin, g.Cout, q.tap_pack);
+            NAFP_LAUNCH_CHECK();
+        }
         return NAFP_OK;
     };
     int rc = launch_one(X, D, B, fold, sj);
