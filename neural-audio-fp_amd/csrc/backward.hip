@@ -140,30 +140,29 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
     }
     float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag, a1 = ag, a2 = ag;
     float4 gw0 = ag, gw1 = ag, gw2 = ag;                    // CONV0: dW0 taps 0..2 of this thread's 4 channels
-#pragma unroll 2
-    for (int64_t b = b0; b < b1; ++b) {
-        const float4 s0 = *(const float4*)(sc + 8 * b), s1 = *(const float4*)(sc + 8 * b + 4);
-        const float mean = s0.x, rstd = s0.y, m1 = s0.z, m2 = s0.w, inv_r = s1.x, rprev = s1.y, cprev = s1.z;
-        float4* dp = (float4*)(d + b * n) + ii;
-        const float4 dd = *dp;
-        float4 tt;
-        float x0 = 0.f, x1 = 0.f, x2 = 0.f;
-        if (CONV0) {
-            const float* xr = c0.feat + b * (int64_t)c0.F * c0.Tin + x_off;
-            x0 = x_ok[0] ? xr[0] : 0.f; x1 = x_ok[1] ? xr[1] : 0.f; x2 = x_ok[2] ? xr[2] : 0.f;
-            tt.x = fmaf(x2, k2.x, fmaf(x1, k1.x, fmaf(x0, k0.x, kb.x)));
-            tt.y = fmaf(x2, k2.y, fmaf(x1, k1.y, fmaf(x0, k0.y, kb.y)));
-            tt.z = fmaf(x2, k2.z, fmaf(x1, k1.z, fmaf(x0, k0.z, kb.z)));
-            tt.w = fmaf(x2, k2.w, fmaf(x1, k1.w, fmaf(x0, k0.w, kb.w)));
-        } else {
-#ifdef NAFP_LNB_NT_LOAD
-            { typedef float f4nt __attribute__((ext_vector_type(4))); const f4nt q = __builtin_nontemporal_load((const f4nt*)(tpre + b * n) + ii); tt = make_float4(q.x, q.y, q.z, q.w); }
-#else
-            tt = ((const float4*)(tpre + b * n))[ii];
-#endif
-        }
-        float4 o;
-        float q1 = 0.f, q2 = 0.f;
+    // Samples are taken UNR at a time, and the loads of the NEXT group are issued before the current group is worked on
+    // (two register sets, ping-pong).  The in-place store of a sample orders every later load of `d` behind it (same
+    // pointer), so a plain loop keeps ONE sample's 32 bytes per thread in flight, and a group without the look-ahead pays one
+    // memory round trip per group: at a per-rank batch of 640 the mid layers (256 workgroups, 160 samples each) ran at
+    // 1.5 - 2.5 TB/s on latency alone.  (More batch chunks instead cost more than they gain: every chunk ends in 5 atomics
+    // per element -- NAFP_LNB_WGS 512 / 1024 / 2048 measured slower.)
+    constexpr int UNR = 4;
+    struct Grp { float4 dd[UNR], tt[UNR], s0[UNR], s1[UNR]; float x[UNR][3]; };
+    Grp ga, gb;
+#define NAFP_LN_LOAD(G_, bq_)                                                                                  \
+    _Pragma("unroll") for (int u = 0; u < UNR; ++u) {                                                          \
+        const int64_t b_l = std::min<int64_t>((bq_) + u, b1 - 1);        /* (a clamped duplicate is loaded, not used) */ \
+        G_.s0[u] = *(const float4*)(sc + 8 * b_l); G_.s1[u] = *(const float4*)(sc + 8 * b_l + 4);             \
+        G_.dd[u] = *((const float4*)(d + b_l * n) + ii);                                                       \
+        G_.x[u][0] = 0.f; G_.x[u][1] = 0.f; G_.x[u][2] = 0.f;                                                  \
+        if (CONV0) {                                                                                           \
+            const float* xr = c0.feat + b_l * (int64_t)c0.F * c0.Tin + x_off;                                  \
+            G_.x[u][0] = x_ok[0] ? xr[0] : 0.f; G_.x[u][1] = x_ok[1] ? xr[1] : 0.f; G_.x[u][2] = x_ok[2] ? xr[2] : 0.f; \
+            G_.tt[u] = make_float4(0.f, 0.f, 0.f, 0.f);                                                        \
+        } else {                                                                                               \
+            G_.tt[u] = ((const float4*)(tpre + b_l * n))[ii];                                                  \
+        }                                                                                                      \
+    }
 #define NAFP_LN_ONE(c_)                                                                     \
         {                                                                                   \
             const float vv_l = elu1(tt.c_);                                                 \
@@ -175,28 +174,60 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
             a1.c_ = fmaf(cprev, o.c_, a1.c_); a2.c_ += dt;                                  \
             q1 = fmaf(o.c_, Gq.c_, q1); q2 = fmaf(o.c_, tt.c_ - Hq.c_, q2);                 \
         }
-        NAFP_LN_ONE(x) NAFP_LN_ONE(y) NAFP_LN_ONE(z) NAFP_LN_ONE(w)
-#undef NAFP_LN_ONE
-        if (CONV0 && live) {                                   // o = dt here (no layer below: rprev = 1)
-            gw0.x = fmaf(x0, o.x, gw0.x); gw0.y = fmaf(x0, o.y, gw0.y); gw0.z = fmaf(x0, o.z, gw0.z); gw0.w = fmaf(x0, o.w, gw0.w);
-            gw1.x = fmaf(x1, o.x, gw1.x); gw1.y = fmaf(x1, o.y, gw1.y); gw1.z = fmaf(x1, o.z, gw1.z); gw1.w = fmaf(x1, o.w, gw1.w);
-            gw2.x = fmaf(x2, o.x, gw2.x); gw2.y = fmaf(x2, o.y, gw2.y); gw2.z = fmaf(x2, o.z, gw2.z); gw2.w = fmaf(x2, o.w, gw2.w);
+#define NAFP_LN_WORK(G_, bq_)                                                                                  \
+    _Pragma("unroll") for (int u = 0; u < UNR; ++u) {                                                          \
+        const int64_t b = (bq_) + u;                                                                           \
+        if (b >= b1) break;                                                                                    \
+        const float4 s0 = G_.s0[u], s1 = G_.s1[u];                                                             \
+        const float mean = s0.x, rstd = s0.y, m1 = s0.z, m2 = s0.w, inv_r = s1.x, rprev = s1.y, cprev = s1.z;  \
+        float4* dp = (float4*)(d + b * n) + ii;                                                                \
+        const float4 dd = G_.dd[u];                                                                            \
+        float4 tt = G_.tt[u];                                                                                  \
+        const float x0 = G_.x[u][0], x1 = G_.x[u][1], x2 = G_.x[u][2];                                         \
+        if (CONV0) {                                                                                           \
+            tt.x = fmaf(x2, k2.x, fmaf(x1, k1.x, fmaf(x0, k0.x, kb.x)));                                       \
+            tt.y = fmaf(x2, k2.y, fmaf(x1, k1.y, fmaf(x0, k0.y, kb.y)));                                       \
+            tt.z = fmaf(x2, k2.z, fmaf(x1, k1.z, fmaf(x0, k0.z, kb.z)));                                       \
+            tt.w = fmaf(x2, k2.w, fmaf(x1, k1.w, fmaf(x0, k0.w, kb.w)));                                       \
+        }                                                                                                      \
+        float4 o;                                                                                              \
+        float q1 = 0.f, q2 = 0.f;                                                                              \
+        NAFP_LN_ONE(x) NAFP_LN_ONE(y) NAFP_LN_ONE(z) NAFP_LN_ONE(w)                                            \
+        if (CONV0 && live) {                                   /* o = dt here (no layer below: rprev = 1) */   \
+            gw0.x = fmaf(x0, o.x, gw0.x); gw0.y = fmaf(x0, o.y, gw0.y); gw0.z = fmaf(x0, o.z, gw0.z); gw0.w = fmaf(x0, o.w, gw0.w); \
+            gw1.x = fmaf(x1, o.x, gw1.x); gw1.y = fmaf(x1, o.y, gw1.y); gw1.z = fmaf(x1, o.z, gw1.z); gw1.w = fmaf(x1, o.w, gw1.w); \
+            gw2.x = fmaf(x2, o.x, gw2.x); gw2.y = fmaf(x2, o.y, gw2.y); gw2.z = fmaf(x2, o.z, gw2.z); gw2.w = fmaf(x2, o.w, gw2.w); \
+        }                                                                                                      \
+        if (live && !(CONV0 && c0.dW0)) *dp = o;               /* (nothing reads dts_0 once dW0 is formed here) */ \
+        if (lnsum_below) {                                                                                     \
+            /* wave sums of (q1, q2) in 7 shuffles: fold the halves, then q1 lives in lanes 0..31 and q2 in 32..63 */ \
+            if (!live) { q1 = 0.f; q2 = 0.f; }                                                                 \
+            q1 += __shfl_xor(q1, 32, 64); q2 += __shfl_xor(q2, 32, 64);                                        \
+            float x = lane < 32 ? q1 : q2;                                                                     \
+            _Pragma("unroll") for (int o2 = 16; o2 > 0; o2 >>= 1) x += __shfl_xor(x, o2, 64);                  \
+            if ((lane & 31) == 0) atomicAdd(s_q + 2 * (b - b0) + (lane >> 5), x);                              \
+        }                                                                                                      \
+    }
+    if (CONV0) {
+        // (layer 0 regenerates its pre-activation and forms dW0: at 229 registers the look-ahead cost it its occupancy --
+        // 385 -> 467 us at a batch of 640 -- so it keeps the plain groups)
+        for (int64_t bq = b0; bq < b1; bq += UNR) {
+            NAFP_LN_LOAD(ga, bq)
+            NAFP_LN_WORK(ga, bq)
         }
-#ifdef NAFP_LNB_NT_STORE
-        if (live && !(CONV0 && c0.dW0)) { typedef float f4nt __attribute__((ext_vector_type(4))); const f4nt q = {o.x, o.y, o.z, o.w}; __builtin_nontemporal_store(q, (f4nt*)dp); }
-#else
-        if (live && !(CONV0 && c0.dW0)) *dp = o;               // (nothing reads dts_0 once dW0 is formed here)
-#endif
-        if (lnsum_below) {
-            // wave sums of (q1, q2) in 7 shuffles: fold the halves, then q1 lives in lanes 0..31 and q2 in 32..63
-            if (!live) { q1 = 0.f; q2 = 0.f; }
-            q1 += __shfl_xor(q1, 32, 64); q2 += __shfl_xor(q2, 32, 64);
-            float x = lane < 32 ? q1 : q2;
-#pragma unroll
-            for (int o2 = 16; o2 > 0; o2 >>= 1) x += __shfl_xor(x, o2, 64);
-            if ((lane & 31) == 0) atomicAdd(s_q + 2 * (b - b0) + (lane >> 5), x);
+    } else {
+        if (b0 < b1) { NAFP_LN_LOAD(ga, b0) }
+        for (int64_t bq = b0; bq < b1; bq += 2 * UNR) {
+            if (bq + UNR < b1) { NAFP_LN_LOAD(gb, bq + UNR) }
+            NAFP_LN_WORK(ga, bq)
+            if (bq + UNR >= b1) break;
+            if (bq + 2 * UNR < b1) { NAFP_LN_LOAD(ga, bq + 2 * UNR) }
+            NAFP_LN_WORK(gb, bq + UNR)
         }
     }
+#undef NAFP_LN_ONE
+#undef NAFP_LN_WORK
+#undef NAFP_LN_LOAD
     if (lnsum_below) {
         __syncthreads();
         for (int64_t k = threadIdx.x; k < 2 * (b1 - b0); k += 256)
@@ -1182,7 +1213,8 @@ int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* 
     // batch chunks: every chunk ends in 5 atomics per element (~33 G atomics/s measured), which is what a
     // small layer pays for; 256..1024 workgroups keep the streaming layers at HBM speed
     const int64_t bx = n / 1024;
-    int by = (int)std::min<int64_t>(B, std::min<int64_t>(64, std::max<int64_t>(4, 256 / bx)));
+    static const int64_t wg_target = []() { const char* e = getenv("NAFP_LNB_WGS"); return e ? atoll(e) : (int64_t)256; }();
+    int by = (int)std::min<int64_t>(B, std::min<int64_t>(64, std::max<int64_t>(4, wg_target / bx)));
     while (lnsum_below && (B + by - 1) / by * 8 > 32768 && by < B) by *= 2;      // LDS share of the sums below: 8 B per sample
     const size_t lds = lnsum_below ? (size_t)((B + by - 1) / by) * 2 * sizeof(float) : 0;
     Conv0Regen c0{};
