@@ -912,7 +912,7 @@ int64_t wgrad_slab_floats(int64_t B, const ConvGeom& g) {
     // fast kernel: <= 768 workgroups (+ the rounding of the chunk count) x one 128 x 128 partial tile each
     int tp; const int n_live = wgrad_live_taps(g, &tp);
     const int64_t col_tiles = (int64_t)(g.Cout / 128) * (n_live * g.Cin / 128);
-    return col_tiles == 0 ? 0 : (768 + 2 * col_tiles) * (int64_t)(128 * 128);
+    return col_tiles == 0 ? 0 : (1536 + 2 * col_tiles) * (int64_t)(128 * 128);      // (room for NAFP_WGRAD_WGS up to 1536)
 }
 
 // dW (keras (3,Cin,Cout)) of one layer.  X2 / D2 (both or neither): the two aux samples [gamma | beta] resp. [S1 | S2],
@@ -976,7 +976,8 @@ int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const Con
         const long long M = (long long)(Bq + q.n_aux) * q.P;
         // one resident round: 256 CUs x 3 workgroups (each workgroup ends in 16 K atomics, so fewer is better;
         // measured at B = 1280: 768 / 1536 / 3072 / 6144 workgroups -> backward 22.3 / 22.5 / 22.9 / 24.3 ms)
-        long long chunks = std::max<long long>(1, 768 / col_tiles);
+        static const long long wg_target = []() { const char* e = getenv("NAFP_WGRAD_WGS"); return e ? atoll(e) : 768ll; }();
+        long long chunks = std::max<long long>(1, wg_target / col_tiles);
         long long rpw = (M + chunks - 1) / chunks;
         rpw = std::max<long long>(64, (rpw + 31) / 32 * 32);
         // the X descriptor of a workgroup spans (rows/P + 2) samples: keep it below 2 GiB
