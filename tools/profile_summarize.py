@@ -198,8 +198,55 @@ with open(os.path.join(dst, f'{tag}_summary.md'), 'w') as f:
             tot = kt['fetch_bytes_x2_corrected'] + kt['write_bytes']
             f.write(f'| `{k}` | {kt["fetch_bytes_x2_corrected"] / 1e6:.2f} | {kt["write_bytes"] / 1e6:.2f} | '
                     f'{kt["bytes_per_segment"]:.0f} | {kt["mean_us_under_pmc"]:.1f} | {tot / kt["mean_us_under_pmc"] / 1e3:.0f} |\n')
+
         f.write(f'\nFront end (STFT/mel path) total: {fe_total / BSZ:.0f} B per segment vs 64,768 B algorithmic '
                 f'(32,000 B f32 audio + 32,768 B log-mel) = {fe_total / BSZ / 64768:.2f}x.\n\n')
+
+    # ---- the front end in SQ counters (two passes: pmc_sq and pmc_sq2) ----
+    fe = defaultdict(list)
+    for d_ in ('pmc_sq', 'pmc_sq2'):
+        pth = os.path.join(src, d_, 'p_counter_collection.csv')
+        if not os.path.exists(pth):
+            continue
+        for r in read_csv(pth):
+            if 'melspec_r16_kernel' in r['Kernel_Name']:
+                fe[r['Counter_Name']].append(float(r['Counter_Value']))
+                fe['_dur_' + d_].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+    if fe.get('SQ_WAVE_CYCLES'):
+        m = {k: sum(v) / len(v) for k, v in fe.items()}
+        dur_us = m.get('_dur_pmc_sq2', m.get('_dur_pmc_sq', 0.0)) / 1e3
+        wc = m['SQ_WAVE_CYCLES']                       # quad-cycles summed over waves
+        f.write('\n## The front end (`melspec_r16_kernel`, 640 segments per launch) in SQ counters\n\n')
+        f.write('Separate `--pmc` passes of the bench command (`pmc_sq`, `pmc_sq2`); SQ_* cycle counters are in quad-cycles summed over '
+                'all waves (MI355X_MICROARCH.md), shares are of SQ_WAVE_CYCLES.\n\n| quantity | value |\n|---|---|\n')
+        f.write(f'| kernel duration under PMC | {dur_us:.1f} us |\n')
+        if 'SQ_WAVES' in m:
+            f.write(f'| waves launched | {m["SQ_WAVES"]:.0f} (= {m["SQ_WAVES"] / 4:.0f} workgroups of 4 waves) |\n')
+        if 'GRBM_GUI_ACTIVE' in m and m.get('_dur_pmc_sq'):
+            cyc = m['GRBM_GUI_ACTIVE'] / 8.0               # the counter is summed over the 8 XCDs
+            clk = cyc / m['_dur_pmc_sq']
+            f.write(f'| shader clock (GRBM_GUI_ACTIVE / 8 XCDs / duration) | {clk:.2f} GHz |\n')
+            occ = wc * 4 / (cyc * 256)
+            f.write(f'| mean resident waves per CU (SQ_WAVE_CYCLES x 4 / (cycles x 256 CUs)) | {occ:.1f} of 8 possible at 200 VGPRs / 80.9 KB LDS (2 workgroups) |\n')
+        for name, label in (('SQ_ACTIVE_INST_ANY', 'issuing an instruction (ACTIVE_INST_ANY)'),
+                            ('SQ_ACTIVE_INST_VALU', '... a vector ALU instruction (ACTIVE_INST_VALU)'),
+                            ('SQ_ACTIVE_INST_LDS', '... an LDS instruction (ACTIVE_INST_LDS)'),
+                            ('SQ_WAIT_INST_ANY', 'waiting to issue (WAIT_INST_ANY: dependency / pipe busy)'),
+                            ('SQ_WAIT_INST_LDS', '... of which on the LDS pipe (WAIT_INST_LDS)'),
+                            ('SQ_WAIT_ANY', 'parked on s_waitcnt / barrier (WAIT_ANY)')):
+            if name in m:
+                f.write(f'| wave time {label} | {m[name] / wc * 100:.1f} % |\n')
+        if 'SQ_INSTS_VALU' in m and 'SQ_WAVES' in m:
+            f.write(f'| vector ALU instructions per wave | {m["SQ_INSTS_VALU"] / m["SQ_WAVES"]:.0f} |\n')
+        if 'SQ_INSTS_LDS' in m and 'SQ_WAVES' in m:
+            f.write(f'| LDS instructions per wave | {m["SQ_INSTS_LDS"] / m["SQ_WAVES"]:.0f} |\n')
+        if 'SQ_LDS_BANK_CONFLICT' in m and 'SQ_LDS_IDX_ACTIVE' in m and m['SQ_LDS_IDX_ACTIVE']:
+            f.write(f'| LDS bank-conflict cycles / LDS active cycles | {m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"] * 100:.1f} % |\n')
+        if 'SQ_INSTS_VALU' in m and dur_us:
+            # a wave64 VALU instruction occupies its SIMD for 4 cycles (2 for the packed-rate ones): issue-time floor of the kernel
+            floor_us = m['SQ_INSTS_VALU'] * 4 / (256 * 4) / 2.1e3
+            f.write(f'| VALU issue-time floor (instructions x 4 cycles / 1024 SIMDs at 2.1 GHz) | {floor_us:.1f} us = {floor_us / dur_us * 100:.0f} % of the kernel |\n')
+        f.write('\n')
     f.write('## SQ counters per GEMM-conv shape (grid threads -> mean over launches)\n\n')
     f.write('| grid threads | dur us | clock GHz | MFMA busy % | wave occupancy/CU | WAIT_ANY % | WAIT_INST % | LDS bank conflicts |\n|---|---|---|---|---|---|---|---|\n')
     for g in sorted(agg, reverse=True):
@@ -214,7 +261,7 @@ with open(os.path.join(dst, f'{tag}_summary.md'), 'w') as f:
                 f'{a["SQ_WAIT_ANY"] / a["SQ_WAVE_CYCLES"] * 100:.1f} | {a["SQ_WAIT_INST_ANY"] / a["SQ_WAVE_CYCLES"] * 100:.1f} | '
                 f'{a.get("SQ_LDS_BANK_CONFLICT", 0):.0f} |\n')
 # ---- train steps (tools/train_probe.py under --kernel-trace --stats) ----
-def train_section(dirname, probe_name, csv_name, title, cmd):
+def train_section(dirname, probe_name, csv_name, title, cmd, layers_b=None):
     tt = os.path.join(src, dirname, 't_kernel_stats.csv')
     if not os.path.exists(tt):
         return
@@ -240,14 +287,23 @@ def train_section(dirname, probe_name, csv_name, title, cmd):
             f.write(f'| `{n[:60]}` | {c} | {d:.0f} |\n')
         if probe:
             f.write('\nUn-profiled stage timing of the same script (torch events):\n\n```\n' + probe.strip() + '\n```\n')
+        lt = os.path.join(src, f'layers_{layers_b}.txt') if layers_b else None
+        if lt and os.path.exists(lt):
+            f.write('\nPer layer of that step (tools/train_layer_table.py: kernel durations from the trace, useful TFLOP/s on the '
+                    'effective MACs of SURVEY appendix A; wgrad includes its reduce kernel, dgrad its split-K finish):\n\n```\n' +
+                    open(lt).read().strip() + '\n```\n')
 
 
 train_section('train_trace', 'train_probe.txt', f'{tag}_train_kernel_stats.csv',
               'Train step (SURVEY 8d config 3: BSZ 1280 = 640 anchors + 640 replicas, Adam, 1 GPU)',
-              'python tools/train_probe.py 1280 adam 5')
+              'python tools/train_probe.py 1280 adam 5', 1280)
 train_section('train5120_trace', 'train5120_probe.txt', f'{tag}_train5120_kernel_stats.csv',
               'Train step at the headline batch (BASELINE configs[3] on ONE GPU: global BSZ 5120, LAMB)',
-              'python tools/train_probe.py 5120 lamb 3')
+              'python tools/train_probe.py 5120 lamb 3', 5120)
+train_section('train640_trace', 'train640_probe.txt', f'{tag}_train640_kernel_stats.csv',
+              'Train step at the 8-GPU operating point on ONE GPU (per-rank batch 640 of the global 5120, LAMB; no process group here: '
+              'the bench object `train_rank640` runs the same step through a 1-rank RCCL group)',
+              'python tools/train_probe.py 640 lamb 5', 640)
 for name, title in (('search', 'Exact search (eval side): `python tools/search_bench.py 10000000 38000 2`'),
                     ('loader', 'Training loader + augmentation: `python tools/loader_bench.py 300`')):
     st = os.path.join(src, f'{name}_trace', 't_kernel_stats.csv')
@@ -261,4 +317,14 @@ for name, title in (('search', 'Exact search (eval side): `python tools/search_b
         for r in read_csv(st)[:5]:
             f.write(f'| `{r["Name"][:70]}` | {r["Calls"]} | {float(r["AverageNs"]) / 1e3:.1f} | {float(r["TotalDurationNs"]) / 1e6:.2f} |\n')
         f.write('\n```\n' + '\n'.join(txt) + '\n```\n')
+fs = os.path.join(ROOT, 'gpurun_out', 'fullscale_r04.json')
+if os.path.exists(fs):
+    rec = json.load(open(fs))
+    with open(os.path.join(dst, f'{tag}_summary.md'), 'a') as f:
+        f.write('\n## BASELINE configs[4] at one rank\'s full share (tests/test_gpu_configs.py::test_config4_one_rank_full_share_12_5_million_rows)\n\n')
+        f.write(f'{rec["rows"]:,} rows ({rec["bytes"] / 1e9:.1f} GB of fingerprints) through `write_fingerprints_from_device_rows` '
+                f'(launches of {rec["launch_rows"]} rows on {rec["streams"]} HIP streams, pinned D2H, np.memmap stores): '
+                f'**{rec["seconds_incl_flush"]} s including the final flush = {rec["rows_per_s_incl_flush"]:,.0f} rows/s sustained** '
+                f'({rec["seconds_before_flush"]} s before the flush); whole 125-groups (first, last, either side of a launch boundary '
+                'in mid-file) equal the float64 oracle (1 - cos < 1e-5), the exact index over all rows returns every probed row at its own id.\n')
 print(open(os.path.join(dst, f'{tag}_summary.md')).read())
