@@ -343,8 +343,23 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
     for (int k = 0; k < NS && fork_rc == NAFP_OK; ++k) {
         if (hipStreamWaitEvent(e->sw_streams[k], e->sw_fork, 0) != hipSuccess) fork_rc = NAFP_ERR_HIP; else ++forked;
     }
+    // the small layers (P <= 8): ONE weight-streaming launch (conv.hip, gh_gemv_kernel), first in line on the last helper stream
+    GhTable gh; gh.count = 0;
+    bool by_gemv[16] = {};
+    for (int j = 1; j < 16; ++j)
+        if (gh.count < GH_MAX_LAYERS && gh_gemv_eligible(e->geom[j])) {
+            gh_table_add(gh, e->geom[j], e->d_w[j], e->d_gamma[j - 1], e->d_G[j]);
+            by_gemv[j] = true;
+            bt.hb[bt.count] = e->d_Hb[j]; bt.bias[bt.count] = e->d_bias[j];
+            bt.n[bt.count] = numel(e->shapes[4 * j + 2]); bt.cout[bt.count] = e->geom[j].Cout; ++bt.count;
+        }
+    if (fork_rc == NAFP_OK && forked == NS) fork_rc = launch_gh_gemv(gh, e->sw_streams[NS - 1]);
+    else for (int j = 1; j < 16; ++j) by_gemv[j] = false;              // (could not fork: everything through the tiled launches, bt rebuilt below)
+    if (forked != NS) bt.count = 0;
+    int n_tiled = 0;
     for (int j = 1; j < 16 && fork_rc == NAFP_OK; ++j) {
-        const int k = (j - 1) % NS;
+        if (by_gemv[j]) continue;
+        const int k = (n_tiled++) % NS;
         ConvGemmArgs a{};
         a.wp = e->d_w[j]; a.plain = true;
         a.x = e->d_gamma[j - 1]; a.bias = nullptr; a.y = e->d_G[j];
@@ -700,6 +715,7 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
             ConvGemmArgs a{};
             a.x = cur; a.wp = e->d_wd[j]; a.y = other; a.plain = true; a.dgrad = true;
             a.slab = L.slab_floats ? L.slab : nullptr; a.slab_floats = L.slab_floats;
+            a.tickets = overlap ? nullptr : L.tickets;      // split-K finished in-kernel (the side stream's wgrad shares the counters: not then)
             rc = launch_conv_gemm(a, B, g, st);
             if (rc != NAFP_OK) return rc;
         }

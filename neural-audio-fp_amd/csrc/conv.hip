@@ -1015,8 +1015,9 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         return;
     }
 
-    if (EPI == 4) {
-        // Split-K finished in-kernel.  Every part writes its partial sums to its slab THROUGH the caches (sc0 sc1: the
+    if (EPI == 4 || EPI == 5) {
+        // Split-K finished in-kernel (EPI 5: of a PLAIN launch -- the transposed convs of the backward pass: the total, plus
+        // bias, is stored as it is; no separate plain_finish_kernel and no second trip of the partial sums through a launch).  Every part writes its partial sums to its slab THROUGH the caches (sc0 sc1: the
         // XCDs' L2s are not coherent with each other), waits for the write acknowledgements, and draws an arrival ticket
         // for its output tile (device-scope atomic).  The workgroup that draws the last ticket re-reads all parts --
         // its own included, from memory, in part order: the sum does not depend on who arrives last -- and runs the FULL
@@ -1069,6 +1070,25 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
                         for (int ni = 0; ni < NIW; ++ni)
                             acc[mi][ni][rg * 4 + q] += __builtin_bit_cast(
                                 float, __builtin_amdgcn_raw_buffer_load_b32(rsZ, voffs[mi][rg], q * ystep_b + ni * 128, 17));
+        }
+        if (EPI == 5) {
+            float bv[NIW];
+#pragma unroll
+            for (int ni = 0; ni < NIW; ++ni) bv[ni] = p.bias ? p.bias[n_base + ni * 32] : 0.f;
+#pragma unroll
+            for (int ni = 0; ni < NIW; ++ni) asm volatile("" : "+v"(bv[ni]));
+            const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc(
+                p.y_final + (int64_t)b0 * p.P * p.Cout, 0, (int)((unsigned)nb * (unsigned)ystep_b), 0x00020000);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int ni = 0; ni < NIW; ++ni)
+                            __builtin_amdgcn_raw_buffer_store_b32(f2i(acc[mi][ni][rg * 4 + q] + bv[ni]), rsF, voffs[mi][rg], q * ystep_b + ni * 128, 0);
+            return;
         }
     }
 
@@ -1229,6 +1249,8 @@ NAFP_GEMM_KERNEL(conv_gemm_n64k16s3_train, 128, 64, 16, 3, 4, false, 1)
 NAFP_GEMM_KERNEL(conv_gemm_n64k16s3_any, 128, 64, 16, 3, 4, false, 2)
 NAFP_GEMM_KERNEL(conv_gemm_n64k16s3_plain, 128, 64, 16, 3, 4, false, 3)
 NAFP_GEMM_KERNEL(conv_gemm_n64k16s3_splitfin, 128, 64, 16, 3, 4, false, 4)      // split-K part + in-kernel finish by the last arriver
+NAFP_GEMM_KERNEL(conv_gemm_n64k16s3_plainfin, 128, 64, 16, 3, 4, false, 5)      // ... of a PLAIN launch (transposed conv)
+NAFP_GEMM_KERNEL(conv_gemm_k16s3_plainfin, 128, 128, 16, 3, 3, false, 5)
 // 128 x 64 tile on a 2-stage ring (24 KB): 5 workgroups per CU = 1280 slots -- the mid convs' 640 / 1280 tiles (x split-K) then
 // fill exactly one round instead of leaving a last round with one workgroup per CU (which runs at half the pipe rate)
 NAFP_GEMM_KERNEL(conv_gemm_n64k16s2_infer, 128, 64, 16, 2, 5, false, 0)
@@ -1659,7 +1681,12 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     // conv7 0.119 -> 0.104 ms, conv9 0.193 -> 0.178 --, with 160 or fewer the finish kernel's finer split wins by 2-8 %)
     static const int fin_min = []() { const char* e = getenv("NAFP_SPLIT_INKERNEL"); return e ? atoi(e) : 320; }();
     const bool in_kernel_finish = fin_min > 0 && S > 1 && !a.plain && bn == 64 && a.tickets && n_tiles >= fin_min && n_tiles <= NAFP_TICKET_SLOTS;
-    p.tickets = in_kernel_finish ? a.tickets : nullptr; p.y_final = a.y;
+    // PLAIN split launches (the transposed convs) with arrival counters: the last arriver adds the parts and stores the result
+    // (its epilogue is a sum: nothing like the FULL epilogue's serial tail) -- NAFP_PLAIN_INKERNEL=0 restores slab + plain_finish_kernel
+    static const int plain_fin = []() { const char* e = getenv("NAFP_PLAIN_INKERNEL"); return e ? atoi(e) : 1; }();
+    const bool plain_in_kernel = plain_fin > 0 && S > 1 && a.plain && a.tickets && n_tiles <= NAFP_TICKET_SLOTS;
+    p.tickets = (in_kernel_finish || plain_in_kernel) ? a.tickets : nullptr; p.y_final = a.y;
+    if (plain_in_kernel) p.bias = a.bias;
     static const int grid3d = []() { const char* e = getenv("NAFP_GRID3D"); return e ? atoi(e) : 1; }();
     // NAFP_XCDMAP: 0 = the plain 3-D grids, 1 (default) = 1-D grid in XCD-aware order, the operand to keep inside one L2 chosen
     // by size (column-fastest unless the live weights outweigh the activations read), 2 / 3 = force column- / row-fastest
@@ -1669,7 +1696,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     while ((1 << p.log2_ncol) < n_col) ++p.log2_ncol;
     const int64_t total_wg = (int64_t)p.n_sg * n_pb * n_col * S;
     // (launches that finish their split-K in-kernel keep the plain grid: measured at B = 640 the map costs convs 7 and 9 5 us each)
-    bool xm = xcdmap != 0 && !a.f0_feat && !in_kernel_finish && (1 << p.log2_ncol) == n_col && total_wg < ((int64_t)1 << 31);
+    bool xm = xcdmap != 0 && !a.f0_feat && !in_kernel_finish && !plain_in_kernel && (1 << p.log2_ncol) == n_col && total_wg < ((int64_t)1 << 31);
     if (xm) {
         const double a_bytes = (double)B * (double)p.sample_in * 4.0, w_bytes = (double)k_steps * 16.0 * p.Cout * 4.0;
         const bool row_fast = xcdmap == 3 || (xcdmap == 1 && w_bytes > a_bytes);
@@ -1693,7 +1720,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
         g_timeline.last_grid[3] = BM; g_timeline.last_grid[4] = bn;
     }
     int rc;
-    const bool finish_follows = S > 1 && !in_kernel_finish;
+    const bool finish_follows = S > 1 && !in_kernel_finish && !plain_in_kernel;
     g_ev_start = a.ev_start; g_ev_stop = finish_follows ? nullptr : a.ev_stop;
     p.f0_feat = nullptr; p.f0_w = nullptr; p.f0_bias = nullptr; p.f0_gamma = nullptr;
     p.f0_T = 0; p.f0_stride = 1; p.f0_pad = 0;
@@ -1708,6 +1735,9 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
         return launch_variant(conv_gemm_k16s3_fuse0, 128, 128, 16, 3, p, grid, st);
     }
     const bool fast_st = p.ST == 4 || p.ST == 8;
+    if (plain_in_kernel)
+        return bn == 64 ? launch_variant(conv_gemm_n64k16s3_plainfin, 128, 64, 16, 3, p, grid, st)
+                        : launch_variant(conv_gemm_k16s3_plainfin, 128, 128, 16, 3, p, grid, st);
     const int epi = in_kernel_finish ? 4 : p.mode != 0 ? 3 : (!fast_st ? 2 : (p.v_out ? 1 : 0));
     const bool two_stage = n64_two_stage() && bn == 64 && (epi == 0 || epi == 1 || epi == 4);
     if (a.bf16x3 && epi == 0 && (bn == 128 || two_stage))
@@ -2100,6 +2130,92 @@ int launch_multi_pack(const PackTable& t0, hipStream_t st) {
         t.unit0[e + 1] = t.unit0[e] + (int)((std::max<int64_t>(tiles * 1024, (int64_t)3 * t.cin[e] * t.cout[e]) + 8191) / 8192);
     }
     multi_pack_kernel<<<dim3((unsigned)t.unit0[t.count]), 256, 0, st>>>(t);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}
+
+// ============================================================================
+// G_j / Hb_j of the small layers (set_weights; every train step re-runs it).  conv_j of the two "samples" gamma_{j-1}, beta_{j-1}
+// is a GEMM of 2 P <= 16 rows against the whole weight tensor: through the tiled kernel that was 15 - 46 us per layer of pure
+// latency (a handful of workgroups stream 2 - 12 MB behind a 3-stage ring); here it is a weight-streaming pass: a wave owns 4
+// output columns, its lanes split K (float4 each, the rows of W are k-contiguous), the <= 16 input rows come from L1 / L2,
+// the 64 partial sums per wave meet by butterfly.  One launch for all small layers.
+// ============================================================================
+__global__ __launch_bounds__(256) void gh_gemv_kernel(const GhTable t) {
+    int e = 0;
+    while (e + 1 < t.count && t.wg0[e + 1] <= (int)blockIdx.x) ++e;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Cin = t.cin[e], Cout = t.cout[e], P = t.P[e], K3 = 3 * Cin;
+    const int n0 = ((int)blockIdx.x - t.wg0[e]) * 16 + wave * 4;
+    const float* __restrict__ wp = t.wp[e];
+    const float* __restrict__ x = t.x[e];
+    float acc[4][16];
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+        for (int m = 0; m < 16; ++m) acc[nn][m] = 0.f;
+    for (int tap = 0; tap < 3; ++tap) {
+        bool any = false;
+        for (int pos = 0; pos < P; ++pos) any = any || t.src[e][pos][tap] >= 0;
+        if (!any) continue;                                         // a tap that only ever reads zero padding
+        for (int c0 = 0; c0 < Cin; c0 += 256) {
+            const int c = c0 + 4 * lane;
+            float4 w4[4];
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn) w4[nn] = *(const float4*)(wp + (int64_t)(n0 + nn) * K3 + tap * Cin + c);
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                if (m >= 2 * P) break;                              // rows m = s * P + pos, s = 0 (gamma), 1 (beta)
+                const int s = m >= P ? 1 : 0, pos = m - s * P;
+                const int off = t.src[e][pos][tap];
+                if (off < 0) continue;
+                const float4 x4 = *(const float4*)(x + (int64_t)s * t.sample_in[e] + off + c);
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn)
+                    acc[nn][m] = fmaf(w4[nn].x, x4.x, fmaf(w4[nn].y, x4.y, fmaf(w4[nn].z, x4.z, fmaf(w4[nn].w, x4.w, acc[nn][m]))));
+            }
+        }
+    }
+    float* __restrict__ y = t.y[e];
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            if (m >= 2 * P) break;
+            float v = acc[nn][m];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == ((nn * 16 + m) & 63)) y[(int64_t)m * Cout + n0 + nn] = v;      // row m of [G ; Hb] (adjacent, P rows each)
+        }
+}
+
+bool gh_gemv_eligible(const ConvGeom& g) {
+    static const bool on = []() { const char* e = getenv("NAFP_GH_GEMV"); return !e || e[0] != '0'; }();
+    const int P = g.Fout * g.Tout;
+    return on && P <= 8 && g.Cin % 256 == 0 && g.Cout % 16 == 0 && (int64_t)g.Fin * g.Tin * g.Cin < ((int64_t)1 << 30);
+}
+
+void gh_table_add(GhTable& t, const ConvGeom& g, const float* wp, const float* x, float* y) {
+    const int e = t.count++;
+    if (e == 0) t.wg0[0] = 0;
+    t.wp[e] = wp; t.x[e] = x; t.y[e] = y;
+    t.cin[e] = g.Cin; t.cout[e] = g.Cout; t.P[e] = g.Fout * g.Tout; t.sample_in[e] = g.Fin * g.Tin * g.Cin;
+    for (int pos = 0; pos < 8; ++pos)
+        for (int tap = 0; tap < 3; ++tap) {
+            int off = -1;
+            if (pos < t.P[e]) {
+                const int fo = pos / g.Tout, to = pos - fo * g.Tout;
+                if (g.axis == 0) { const int ti = to * g.stride - g.pad + tap; if (ti >= 0 && ti < g.Tin) off = (fo * g.Tin + ti) * g.Cin; }
+                else             { const int fi = fo * g.stride - g.pad + tap; if (fi >= 0 && fi < g.Fin) off = (fi * g.Tin + to) * g.Cin; }
+            }
+            t.src[e][pos][tap] = off;
+        }
+    t.wg0[e + 1] = t.wg0[e] + g.Cout / 16;
+}
+
+int launch_gh_gemv(const GhTable& t, hipStream_t st) {
+    if (t.count <= 0) return NAFP_OK;
+    gh_gemv_kernel<<<dim3((unsigned)t.wg0[t.count]), 256, 0, st>>>(t);
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }

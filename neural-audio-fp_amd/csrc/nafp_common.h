@@ -212,6 +212,21 @@ int launch_pack_dgrad_weight(const float* k3, float* wd, int Cin, int Cout, hipS
 struct PackTable { const float* k3[16]; float* wp[16]; float* wd[16]; int cin[16], cout[16]; int unit0[17]; int count; };
 int launch_multi_pack(const PackTable& t, hipStream_t st);
 int launch_pack_conv_weight(const float* k3, float* wp, int Cin, int Cout, hipStream_t st);
+// Positional epilogue tensors G_j = conv_j(gamma_{j-1}), Hb_j = conv_j(beta_{j-1}) (bias added later) of the SMALL layers
+// (P <= 8 output positions: 2 P <= 16 GEMM rows against a 2 - 12 MB weight tensor) in ONE weight-streaming launch.
+constexpr int GH_MAX_LAYERS = 8;
+struct GhTable {
+    const float* wp[GH_MAX_LAYERS];      // (Cout, 3 * Cin) packed weights
+    const float* x[GH_MAX_LAYERS];       // gamma_{j-1} (Fin, Tin, Cin); beta_{j-1} follows at + sample_in
+    float* y[GH_MAX_LAYERS];             // G_j (P, Cout); Hb_j follows at + P * Cout
+    int cin[GH_MAX_LAYERS], cout[GH_MAX_LAYERS], P[GH_MAX_LAYERS], sample_in[GH_MAX_LAYERS];
+    int src[GH_MAX_LAYERS][8][3];        // per output position and tap: float offset of the source row inside a sample, -1 = zero padding
+    int wg0[GH_MAX_LAYERS + 1];          // first workgroup of each layer (16 output columns per workgroup)
+    int count;
+};
+bool gh_gemv_eligible(const ConvGeom& g);
+void gh_table_add(GhTable& t, const ConvGeom& g, const float* wp, const float* x, float* y);
+int launch_gh_gemv(const GhTable& t, hipStream_t st);
 int launch_pack_div(const float* w1, const float* b1, const float* w2, float* w1p, float* b1p,
                     float* w2p, int Q, int S, hipStream_t st);
 
