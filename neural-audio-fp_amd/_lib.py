@@ -68,6 +68,7 @@ PROTOTYPES = {
     'nafp_specaug_mean_workspace_bytes': (c_i64, []),
     'nafp_specaug_mean': (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p]),
     'nafp_l2_normalize_rows': (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p]),
+    'nafp_pack_embedding_grads': (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     'nafp_cosine_decay_lr_host': (c_float, [c_float, c_i64, c_i64, c_float]),
     'nafp_cosine_decay_restarts_lr_host': (c_float, [c_float, c_i64, c_i64, c_float, c_float, c_float]),
     'nafp_adam_step': (c_int, [c_void_p, c_int, c_float, c_float, c_float, c_float, c_i64, c_void_p]),

@@ -153,6 +153,27 @@ int launch_pack_div(const float* w1, const float* b1, const float* w2, float* w1
 
 }  // namespace nafp
 
+namespace nafp {
+__global__ __launch_bounds__(256) void pack_embedding_grads_kernel(const float* __restrict__ da, const float* __restrict__ db,
+                                                                   const float* __restrict__ loss_sum, float loss_scale,
+                                                                   int64_t half, float* __restrict__ send) {
+    const int64_t r = blockIdx.y, chunk = 2 * half + 4;
+    float* o = send + r * chunk;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < chunk; i += (int64_t)gridDim.x * 256)
+        o[i] = i < half ? da[r * half + i] : i < 2 * half ? db[r * half + (i - half)] : loss_sum[0] * loss_scale;
+}
+}  // namespace nafp
+
+extern "C" int nafp_pack_embedding_grads(const float* d_a_all, const float* d_b_all, const float* loss_sum, float loss_scale,
+                                         int64_t world, int64_t n_anchors, int dim, float* send, void* stream) {
+    if (!d_a_all || !d_b_all || !loss_sum || !send || world <= 0 || n_anchors <= 0 || dim <= 0 || world > 65535) return NAFP_ERR_INVALID_ARG;
+    const int64_t half = n_anchors * dim;
+    const unsigned gx = (unsigned)std::min<int64_t>((2 * half + 4 + 255) / 256, 1024);
+    nafp::pack_embedding_grads_kernel<<<dim3(gx, (unsigned)world), 256, 0, (hipStream_t)stream>>>(d_a_all, d_b_all, loss_sum, loss_scale, half, send);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}
+
 extern "C" int nafp_l2_normalize_rows(const float* x, int64_t n_rows, int dim, float* out, void* stream) {
     if (!x || !out || n_rows < 0 || dim <= 0) return NAFP_ERR_INVALID_ARG;
     if (n_rows == 0) return NAFP_OK;

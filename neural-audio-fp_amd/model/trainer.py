@@ -133,7 +133,8 @@ def train_step(X, m_pre, m_specaug, m_fp, loss_obj, opt, bucket=None, timers=Non
         loss_sum, _, d_a_all, d_b_all = _ntxent_call(loss_obj._lib, ha, hb, a_all, b_all, rank * n_anchors,
                                                      loss_obj.tau, False, True)
         t0 = _mark(timers)
-        loss, d_emb = scatter_embedding_gradients(dist, loss_sum / n_g, d_a_all, d_b_all, n_anchors)
+        loss, d_emb = scatter_embedding_gradients(dist, loss_sum, d_a_all, d_b_all, n_anchors, loss_scale=1.0 / n_g,
+                                                  lib=loss_obj._lib)
         _mark(timers, 'reduce_scatter(d emb)', t0)
     grads = m_fp.backward(d_emb)
     if dist is not None:
@@ -155,7 +156,7 @@ def _mark(timers, name=None, start=None):
     return e
 
 
-def scatter_embedding_gradients(dist, loss_local, d_a_all, d_b_all, n_anchors):
+def scatter_embedding_gradients(dist, loss_local, d_a_all, d_b_all, n_anchors, loss_scale=1.0, lib=None):
     """The backward of the embedding all-gather.  Every rank holds its contribution to the gradient w.r.t. ALL gathered
     embeddings (d_a_all, d_b_all: (world * n_anchors, d)) and its share `loss_local` of the global loss; it needs the sum
     over ranks of only ITS rows.  ONE reduce-scatter of [d/d a | d/d b | loss] laid out per destination rank; the loss
@@ -164,9 +165,19 @@ def scatter_embedding_gradients(dist, loss_local, d_a_all, d_b_all, n_anchors):
     world, d = dist.get_world_size(), d_a_all.shape[1]
     chunk = 2 * n_anchors * d
     send = torch.empty((world, chunk + 4), dtype=torch.float32, device=d_a_all.device)
-    send[:, :n_anchors * d] = d_a_all.reshape(world, n_anchors * d)
-    send[:, n_anchors * d:chunk] = d_b_all.reshape(world, n_anchors * d)
-    send[:, chunk:] = loss_local
+    if lib is not None and d_a_all.is_cuda:
+        # one library launch packs [d/d a | d/d b | loss * loss_scale] per destination rank (three strided torch copies, a
+        # fill and a division before: five small launches on the latency-bound per-rank-640 step)
+        from .. import _lib
+        loss_t = loss_local if torch.is_tensor(loss_local) else torch.tensor([float(loss_local)], device=d_a_all.device)
+        with torch.cuda.device(d_a_all.device):
+            _lib.check(lib.nafp_pack_embedding_grads(_lib.ptr(d_a_all.contiguous()), _lib.ptr(d_b_all.contiguous()),
+                                                     _lib.ptr(loss_t.reshape(-1).float().contiguous()), float(loss_scale), world,
+                                                     n_anchors, d, _lib.ptr(send), _lib.current_stream()), 'pack_embedding_grads')
+    else:                                           # (the CPU-side gloo harness of the tests)
+        send[:, :n_anchors * d] = d_a_all.reshape(world, n_anchors * d)
+        send[:, n_anchors * d:chunk] = d_b_all.reshape(world, n_anchors * d)
+        send[:, chunk:] = loss_local * loss_scale
     recv = torch.empty((chunk + 4,), dtype=torch.float32, device=d_a_all.device)
     _reduce_scatter(dist, recv, send)
     return recv[chunk], recv[:chunk].view(2 * n_anchors, d)

@@ -121,3 +121,19 @@ def test_weights_marked_dirty_then_four_streams(nafp):
         torch.cuda.synchronize()
         for k in range(4):
             assert float((outs[k] - want[tag][k]).abs().max()) < 1e-6, (rep, k)
+
+
+def test_pack_embedding_grads_kernel_equals_the_torch_packing(nafp):
+    """nafp_pack_embedding_grads: send[r] = [d/d a rows of rank r | d/d b rows of rank r | loss * scale x 4]."""
+    from neural_audio_fp_amd import _lib
+    lib = _lib.load()
+    world, n_a, d = 8, 320, 128
+    g = torch.Generator(device='cuda').manual_seed(1)
+    da = torch.randn((world * n_a, d), generator=g, device='cuda')
+    db = torch.randn((world * n_a, d), generator=g, device='cuda')
+    loss = torch.tensor([3.25], device='cuda')
+    send = torch.full((world, 2 * n_a * d + 4), float('nan'), device='cuda')
+    _lib.check(lib.nafp_pack_embedding_grads(_lib.ptr(da), _lib.ptr(db), _lib.ptr(loss), 0.5, world, n_a, d, _lib.ptr(send),
+                                             _lib.current_stream()), 'pack_embedding_grads')
+    want = torch.cat([da.reshape(world, -1), db.reshape(world, -1), torch.full((world, 4), 1.625, device='cuda')], dim=1)
+    assert torch.equal(send, want)
