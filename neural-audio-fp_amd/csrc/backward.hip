@@ -1215,7 +1215,11 @@ int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* 
     // small layer pays for; 256..1024 workgroups keep the streaming layers at HBM speed
     const int64_t bx = n / 1024;
     static const int64_t wg_target = []() { const char* e = getenv("NAFP_LNB_WGS"); return e ? atoll(e) : (int64_t)256; }();
-    int by = (int)std::min<int64_t>(B, std::min<int64_t>(64, std::max<int64_t>(4, wg_target / bx)));
+    // at least 4 batch chunks -- 2 for the two largest layers at a small batch (>= 512 workgroups either way; measured at
+    // B = 640: layer 0 377 -> 321 us, layer 1 422 -> 402; at B = 5120 the halved chunk count costs layer 0 4 %): NAFP_LNB_MINBY overrides
+    static const int64_t min_by_env = []() { const char* e = getenv("NAFP_LNB_MINBY"); return e ? atoll(e) : (int64_t)0; }();
+    const int64_t min_by = min_by_env > 0 ? min_by_env : ((bx >= 256 && B <= 1024) ? 2 : 4);
+    int by = (int)std::min<int64_t>(B, std::min<int64_t>(64, std::max<int64_t>(min_by, wg_target / bx)));
     while (lnsum_below && (B + by - 1) / by * 8 > 32768 && by < B) by *= 2;      // LDS share of the sums below: 8 B per sample
     const size_t lds = lnsum_below ? (size_t)((B + by - 1) / by) * 2 * sizeof(float) : 0;
     Conv0Regen c0{};
