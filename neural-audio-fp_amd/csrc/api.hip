@@ -77,9 +77,11 @@ struct nafp_encoder {
     double* d_inv_n = nullptr;
     float* d_sw_slab = nullptr; int64_t sw_slab_floats = 0;      // split-K slab of the G/Hb launches in set_weights
     bool has_weights = false;
-    // NAFP_OPT_FUSE_CONV0 (default: NAFP_FUSE0 env, else off).  Measured at B = 640: conv0 0.35 ms +
-    // conv1 1.17 ms materialised vs 0.17 ms (statistics pass) + 1.38 ms fused: the ELU evaluation is
-    // VALU-bound, so re-generating z0 in conv1 costs what the store saved.
+    // NAFP_OPT_FUSE_CONV0 (default: NAFP_FUSE0 env, else off).  Re-measured in round 4 on the current kernels (B = 640, same
+    // box, tools/ab_bench.sh, two rounds): materialised conv0 0.257 ms + conv1 1.118 ms = 1.375 ms (187.2 k segments/s) vs
+    // fused 0.172 ms (statistics pass) + 1.436 ms = 1.608 ms (179.3 k): the f32 MFMAs share the SIMDs' issue time with the
+    // vector ALU, so re-generating z0 (3 FMAs + an exponential per element, per K-step) inside conv1 costs the matrix pipe
+    // more than the 1.34 GB store + re-read costs the bus.  (Round 1: 0.35 + 1.17 vs 0.17 + 1.38.)
     bool opt_fuse_conv0 = []() { const char* v = getenv("NAFP_FUSE0"); return v && v[0] == '1'; }();
     // NAFP_OPT_FUSED_LN_BWD (default NAFP_DGRAD_LN env, else 1)
     // Measured (B = 1280, same box, ms per backward pass): 20.9 with the separate LayerNorm-backward pass, 23.3 with the

@@ -69,13 +69,29 @@ def per_step_sum(d, name_part, min_grid=0):
 
 
 macs = bench.conv_effective_macs()
-n_steps_pmc = 7            # profile_round.sh: --steps 5 --warmup 2
-f_sum, f_n = per_step_sum(fetch, GEMM, min_grid=256 * 8)
-w_sum, w_n = per_step_sum(write, GEMM, min_grid=256 * 8)
-# launches of the bench steps only: 15 per step
-n_full = 15 * n_steps_pmc
-fetch_bytes_per_launch = 2.0 * f_sum * 1024 / f_n if f_n else None       # gfx950 x2 correction
-write_bytes_per_launch = w_sum * 1024 / w_n if w_n else None
+
+
+def per_bench_step(dirname, counter):
+    """Mean over the bench steps of the pass (a step = the dispatches from one front-end kernel to the next) of the counter
+    summed over the step's GEMM-conv kernels AND their split-K finish kernels; the one-off launches of set_weights (G / Hb
+    images) and anything before the first step are left out.  Returns (mean KiB per step, steps)."""
+    rows = [r for r in read_csv(os.path.join(src, dirname, 'p_counter_collection.csv')) if r['Counter_Name'] == counter]
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    marks = [i for i, r in enumerate(rows) if 'melspec_r16_kernel' in r['Kernel_Name'] or 'melspec_kernel' in r['Kernel_Name']]
+    per = []
+    for a_, b_ in zip(marks, marks[1:] + [len(rows)]):
+        ks = [float(r['Counter_Value']) for r in rows[a_:b_] if GEMM in r['Kernel_Name'] or 'splitk_finish' in r['Kernel_Name']]
+        n_gemm = sum(1 for r in rows[a_:b_] if GEMM in r['Kernel_Name'])
+        if n_gemm == 15:                          # a whole forward step (the per-conv pass and partial tails are dropped)
+            per.append(sum(ks))
+    return (sum(per) / len(per) if per else None), len(per)
+
+
+f_step, f_n = per_bench_step('pmc_fetch', 'FETCH_SIZE')
+w_step, w_n = per_bench_step('pmc_write', 'WRITE_SIZE')
+# per launch = per step / 15 (the 15 GEMM-conv launches of a step, their split-K finish kernels included)
+fetch_bytes_per_launch = 2.0 * f_step * 1024 / 15 if f_step else None       # gfx950 x2 correction
+write_bytes_per_launch = w_step * 1024 / 15 if w_step else None
 alg_bytes_per_launch = None
 # algorithmic HBM bytes of the 15 convs per step: each activation read once + written once (z tensors)
 geo_out = []
@@ -187,8 +203,8 @@ with open(os.path.join(dst, f'{tag}_summary.md'), 'w') as f:
         f.write('\n')
     f.write('## HBM traffic of the dominant kernel (separate PMC passes)\n\n')
     if traffic:
-        f.write(f'* FETCH_SIZE (x2 gfx950 correction): {fetch_bytes_per_launch / 1e6:.1f} MB per launch (mean of {f_n})\n')
-        f.write(f'* WRITE_SIZE: {write_bytes_per_launch / 1e6:.1f} MB per launch (mean of {w_n})\n')
+        f.write(f'* FETCH_SIZE (x2 gfx950 correction): {fetch_bytes_per_launch / 1e6:.1f} MB per launch (mean of {f_n} bench steps, 15 launches + split-K finish kernels each)\n')
+        f.write(f'* WRITE_SIZE: {write_bytes_per_launch / 1e6:.1f} MB per launch (mean of {w_n} bench steps)\n')
         f.write(f'* total {traffic / 1e6:.1f} MB per launch vs {alg_bytes_per_launch / 1e6:.1f} MB algorithmic '
                 f'activation bytes (each z tensor read once + written once; weights/G/Hb/gamma not counted)\n\n')
     if front:
@@ -244,8 +260,9 @@ with open(os.path.join(dst, f'{tag}_summary.md'), 'w') as f:
             f.write(f'| LDS bank-conflict cycles / LDS active cycles | {m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"] * 100:.1f} % |\n')
         if 'SQ_INSTS_VALU' in m and dur_us:
             # a wave64 VALU instruction occupies its SIMD for 4 cycles (2 for the packed-rate ones): issue-time floor of the kernel
-            floor_us = m['SQ_INSTS_VALU'] * 4 / (256 * 4) / 2.1e3
-            f.write(f'| VALU issue-time floor (instructions x 4 cycles / 1024 SIMDs at 2.1 GHz) | {floor_us:.1f} us = {floor_us / dur_us * 100:.0f} % of the kernel |\n')
+            ghz = (m['GRBM_GUI_ACTIVE'] / 8.0 / m['_dur_pmc_sq']) if ('GRBM_GUI_ACTIVE' in m and m.get('_dur_pmc_sq')) else 2.1
+            floor_us = m['SQ_INSTS_VALU'] * 4 / (256 * 4) / (ghz * 1e3)
+            f.write(f'| VALU issue-time floor (instructions x 4 cycles / 1024 SIMDs at {ghz:.2f} GHz) | {floor_us:.1f} us = {floor_us / dur_us * 100:.0f} % of the kernel |\n')
         f.write('\n')
     f.write('## SQ counters per GEMM-conv shape (grid threads -> mean over launches)\n\n')
     f.write('| grid threads | dur us | clock GHz | MFMA busy % | wave occupancy/CU | WAIT_ANY % | WAIT_INST % | LDS bank conflicts |\n|---|---|---|---|---|---|---|---|\n')
