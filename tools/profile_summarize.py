@@ -334,6 +334,15 @@ for name, title in (('search', 'Exact search (eval side): `python tools/search_b
         for r in read_csv(st)[:5]:
             f.write(f'| `{r["Name"][:70]}` | {r["Calls"]} | {float(r["AverageNs"]) / 1e3:.1f} | {float(r["TotalDurationNs"]) / 1e6:.2f} |\n')
         f.write('\n```\n' + '\n'.join(txt) + '\n```\n')
+for b_, title_ in ((5120, 'Global batch 5120, LAMB'), (640, 'Per-rank batch 640, LAMB')):
+    sqp = os.path.join(dst, f'{tag}_train{b_}_sq.txt')
+    if os.path.exists(sqp):
+        with open(os.path.join(dst, f'{tag}_summary.md'), 'a') as f:
+            if b_ == 5120:
+                f.write('\n## SQ counters of the train step\'s kernels (one `--pmc` pass over `tools/train_probe.py`, `tools/pmc_train_sq.sh`)\n\n'
+                        'MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x shader cycles); GHz = GRBM_GUI_ACTIVE / 8 XCDs / duration; sums over the '
+                        'kernel\'s launches in the run.  Useful TFLOP/s of an MFMA kernel ~ 157.3 x (GHz / 2.4) x busy.\n')
+            f.write(f'\n{title_}:\n\n```\n' + open(sqp).read().strip() + '\n```\n')
 fs = os.path.join(ROOT, 'gpurun_out', 'fullscale_r04.json')
 if os.path.exists(fs):
     rec = json.load(open(fs))
