@@ -1219,7 +1219,12 @@ int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* 
     // B = 640: layer 0 377 -> 321 us, layer 1 422 -> 402; at B = 5120 the halved chunk count costs layer 0 4 %): NAFP_LNB_MINBY overrides
     static const int64_t min_by_env = []() { const char* e = getenv("NAFP_LNB_MINBY"); return e ? atoll(e) : (int64_t)0; }();
     const int64_t min_by = min_by_env > 0 ? min_by_env : ((bx >= 256 && B <= 1024) ? 2 : 4);
-    int by = (int)std::min<int64_t>(B, std::min<int64_t>(64, std::max<int64_t>(min_by, wg_target / bx)));
+    // at most 64 chunks, and at least ~20 samples per chunk: every chunk ends in 5 atomics per element onto the same addresses,
+    // which is what the small layers' launches consist of (B = 640: 64 -> 32 chunks takes layers 10-15 from 221 to 174 us;
+    // at B = 5120 fewer chunks than 64 only lengthen the sample loops).  NAFP_LNB_MAXBY overrides.
+    static const int64_t max_by_env = []() { const char* e = getenv("NAFP_LNB_MAXBY"); return e ? atoll(e) : (int64_t)0; }();
+    const int64_t max_by = max_by_env > 0 ? max_by_env : std::min<int64_t>(64, std::max<int64_t>(8, B / 20));
+    int by = (int)std::min<int64_t>(B, std::min<int64_t>(max_by, std::max<int64_t>(min_by, wg_target / bx)));
     while (lnsum_below && (B + by - 1) / by * 8 > 32768 && by < B) by *= 2;      // LDS share of the sums below: 8 B per sample
     const size_t lds = lnsum_below ? (size_t)((B + by - 1) / by) * 2 * sizeof(float) : 0;
     Conv0Regen c0{};
