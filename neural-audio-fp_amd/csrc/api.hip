@@ -692,7 +692,8 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
         if (!ln_done) {
             rc = launch_ln_bwd(cur, L.v[j], e->d_gamma[j], mr_j, mr_p, L.lnsum[j], L.sc, grads[4 * j + 2], grads[4 * j + 3],
                                grads[4 * j + 1], L.S1[j], L.S2[j], B, P, g.Cout, st, j == 15, e->d_G[j], e->d_Hb[j], L.lnsum[j - 1],
-                               nullptr, nullptr, nullptr, nullptr, nullptr, sc_ready);
+                               nullptr, nullptr, nullptr, nullptr, nullptr, sc_ready, L.slab_floats ? L.slab : nullptr, L.slab_floats,
+                               L.tickets);
             if (rc != NAFP_OK) return rc;
         }
         sc_ready = false;
@@ -763,7 +764,8 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
         if (!ln_done) {
             rc = launch_ln_bwd(cur, nullptr, e->d_gamma[0], L.mr, nullptr, L.lnsum[0], L.sc, grads[2], grads[3], grads[1],
                                nullptr, nullptr, B, g.Fout * g.Tout, g.Cout, st, false, nullptr, nullptr, nullptr,
-                               feat, e->d_w[0], e->d_bias[0], &g, grads[0], sc_ready);     // ... and dW0 in the same pass
+                               feat, e->d_w[0], e->d_bias[0], &g, grads[0], sc_ready,     // ... and dW0 in the same pass
+                               L.slab_floats ? L.slab : nullptr, L.slab_floats, L.tickets);
             if (rc != NAFP_OK) return rc;
         } else {
             rc = launch_conv0_bwd(feat, cur, grads[0], nullptr, B, g, st);

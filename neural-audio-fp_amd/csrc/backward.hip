@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
         float* __restrict__ d, const float* __restrict__ tpre, const float* __restrict__ gamma,
         const float* __restrict__ sc, float* __restrict__ dgamma, float* __restrict__ dbeta,
         float* __restrict__ dbias, float* __restrict__ S1, float* __restrict__ S2, int64_t n, int64_t B, int C,
-        const float* __restrict__ Gj, const float* __restrict__ Hbj, double* __restrict__ lnsum_below, const Conv0Regen c0) {
+        const float* __restrict__ Gj, const float* __restrict__ Hbj, double* __restrict__ lnsum_below, const Conv0Regen c0,
+        float* __restrict__ part_slab, unsigned* __restrict__ tickets) {
     extern __shared__ float s_q[];                                 // [per][2]: (s1, s2) of the layer below, this block's share
     const int64_t i = blockIdx.x * 256ll + threadIdx.x;
     const bool live = i < n / 4;
@@ -233,7 +234,46 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
         for (int64_t k = threadIdx.x; k < 2 * (b1 - b0); k += 256)
             atomicAdd(lnsum_below + 2 * b0 + k, (double)s_q[k]);
     }
-    if (live) {
+    if (part_slab) {
+        // The batch chunks (blockIdx.y) of a block of 1024 elements meet through a slab instead of 4 fp32 atomics per element
+        // and chunk onto the same addresses (~33 G contended atomics/s: 15 - 28 % of this kernel at a batch of 640): every
+        // chunk writes its (dgamma, dbeta, S1, S2) partials through the caches, draws the block's arrival ticket, and the
+        // LAST arriver adds the parts in chunk order and stores the four tensors once -- deterministic as a by-product.
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        const int n_arr = S1 ? 4 : 2;
+        const int64_t blk_floats = (int64_t)gridDim.y * n_arr * 1024;                   // per x-block: [chunk][array][1024]
+        float* base = part_slab + (int64_t)blockIdx.x * blk_floats;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(blk_floats * 4), 0x00020000);
+        const int my = ((int)blockIdx.y * n_arr * 1024 + 4 * (int)threadIdx.x) * 4;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, ag), rs, my, 0, 17);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, ab), rs, my + 4096, 0, 17);
+        if (S1) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, a1), rs, my + 8192, 0, 17);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, a2), rs, my + 12288, 0, 17);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __shared__ unsigned s_tk;
+        if (threadIdx.x == 0) s_tk = __hip_atomic_fetch_add(tickets + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_tk == gridDim.y - 1) {
+            if (threadIdx.x == 0) __hip_atomic_store(tickets + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float4 t4[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) t4[a] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int y = 0; y < (int)gridDim.y; ++y) {
+                const int off = (y * n_arr * 1024 + 4 * (int)threadIdx.x) * 4;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    if (a >= n_arr) break;
+                    const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + a * 4096, 0, 17));
+                    t4[a].x += v.x; t4[a].y += v.y; t4[a].z += v.z; t4[a].w += v.w;
+                }
+            }
+            *(float4*)(dgamma + 4 * i) = t4[0]; *(float4*)(dbeta + 4 * i) = t4[1];
+            if (S1) { *(float4*)(S1 + 4 * i) = t4[2]; *(float4*)(S2 + 4 * i) = t4[3]; }
+        }
+    } else if (live) {
         float* g = dgamma + 4 * i; float* bt = dbeta + 4 * i;
         atomicAdd(g, ag.x); atomicAdd(g + 1, ag.y); atomicAdd(g + 2, ag.z); atomicAdd(g + 3, ag.w);
         atomicAdd(bt, ab.x); atomicAdd(bt + 1, ab.y); atomicAdd(bt + 2, ab.z); atomicAdd(bt + 3, ab.w);
@@ -1198,7 +1238,7 @@ int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* 
                   double* lnsum, float* sc, float* dgamma, float* dbeta, float* dbias, float* S1, float* S2,
                   int64_t B, int P, int C, hipStream_t st, bool reduce_here, const float* Gj, const float* Hbj,
                   double* lnsum_below, const float* feat0, const float* w0, const float* bias0, const ConvGeom* g0, float* dW0,
-                  bool scalars_done) {
+                  bool scalars_done, float* part_slab, int64_t part_slab_floats, unsigned* tickets) {
     const int64_t n = (int64_t)P * C;
     if (C % 4 != 0 || (256 % (C / 4) != 0 && (C / 4) % 256 != 0) || n % 1024 != 0 || 1024 % C != 0) return NAFP_ERR_UNSUPPORTED;
     if (reduce_here) {
@@ -1227,6 +1267,12 @@ int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* 
     int by = (int)std::min<int64_t>(B, std::min<int64_t>(max_by, std::max<int64_t>(min_by, wg_target / bx)));
     while (lnsum_below && (B + by - 1) / by * 8 > 32768 && by < B) by *= 2;      // LDS share of the sums below: 8 B per sample
     const size_t lds = lnsum_below ? (size_t)((B + by - 1) / by) * 2 * sizeof(float) : 0;
+    // slab + last-arriver in place of the per-element atomics (needs whole 1024-element blocks: n % 1024 == 0, checked above)
+    static const bool slab_on = []() { const char* e = getenv("NAFP_LNB_SLAB"); return !e || e[0] != '0'; }();
+    // (taken for the layers with >= 8 blocks of 1024 elements: there it is faster -- B = 640: layers 0-9 lose 5-25 us each --; on the
+    // small layers the 1-4 last arrivers add 32 chunks each on their own, +8-12 us per launch, so those keep the atomics)
+    if (!(slab_on && bx >= 8 && part_slab && tickets && bx <= NAFP_TICKET_SLOTS && bx * by * 4 * 1024 <= part_slab_floats &&
+          bx * by * 4 * 1024 * 4 < ((int64_t)1 << 31))) { part_slab = nullptr; tickets = nullptr; }
     Conv0Regen c0{};
     if (feat0) {
         if (!g0 || g0->Cin != 1 || g0->axis != 0 || g0->Cout != C || g0->Fout * g0->Tout != P || reduce_here) return NAFP_ERR_INVALID_ARG;
@@ -1234,10 +1280,10 @@ int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* 
         c0.feat = feat0; c0.w3 = w0; c0.bias = bias0; c0.dW0 = dW0; c0.F = g0->Fin; c0.Tin = g0->Tin; c0.Tout = g0->Tout;
         c0.stride = g0->stride; c0.pad = g0->pad;
         ln_bwd_fused_kernel<true><<<dim3((unsigned)bx, by), 256, lds, st>>>(d, nullptr, gamma, sc, dgamma, dbeta, dbias, S1, S2, n, B,
-                                                                          C, Gj, Hbj, lnsum_below, c0);
+                                                                          C, Gj, Hbj, lnsum_below, c0, part_slab, tickets);
     } else {
         ln_bwd_fused_kernel<false><<<dim3((unsigned)bx, by), 256, lds, st>>>(d, tpre, gamma, sc, dgamma, dbeta, dbias, S1, S2, n, B,
-                                                                           C, Gj, Hbj, lnsum_below, c0);
+                                                                           C, Gj, Hbj, lnsum_below, c0, part_slab, tickets);
     }
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
