@@ -27,6 +27,12 @@ Prints ONE JSON line (rank 0).  Extra objects:
                600-clip set (second figure), with the ingest / launch split
   train, train_1280   contrastive train steps/s at global BSZ 5120 / LAMB (configs[3]) and
                BSZ 1280 / Adam (configs[2])
+  train_rank640       the 8-GPU operating point of configs[3] on ONE GPU: per-rank batch 640, LAMB, through a
+               1-rank RCCL group (every collective executes, none crosses xGMI): a one-GPU compute bound, not scaling
+  fullscale_generate  configs[4] through the product's writer on seeded on-device audio, --fullscale-rows rows
+               (default 1.25 M = a tenth of one rank's share; the full 12.5 M-row share is a pytest -m gpu test)
+stdout carries the JSON line only: fd 1 is pointed at stderr for the run (RCCL prints a banner there), the line is
+written to the saved descriptor.
 """
 import argparse
 import json
