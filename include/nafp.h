@@ -214,10 +214,11 @@ int nafp_encoder_grad_group_wait(nafp_encoder* enc, int group, void* stream);
  *                        separate pass that re-reads and re-writes the gradient).  0 (default): never -- measured slower
  *                        than the separate pass; 1: for the layers of >= 32768 elements per sample at
  *                        batches >= 64; 2: wherever the geometry permits.
- *   NAFP_OPT_BWD_OVERLAP  training, 1: the weight gradients of nafp_encoder_backward run on a second, low-priority
- *                        stream owned by the handle, next to the HBM-bound LayerNorm backward of the layer below;
- *                        `stream` is made to wait for them before the last event of the call, so callers see the same
- *                        ordering as with 0 (default: everything on `stream`; the overlap measured slower). */
+ *   NAFP_OPT_BWD_OVERLAP  training: weight gradients of nafp_encoder_backward on a second stream owned by the handle; `stream` is
+ *                        made to wait for them before the last event of the call, so callers see the same ordering as with 0.
+ *                        2 (default): those of the SMALL layers (fewer than 16 output positions), next to the LayerNorm backward
+ *                        and transposed conv of the layer below; 1: every layer's (measured slower); 0: everything on
+ *                        `stream`. */
 #define NAFP_OPT_FUSE_CONV0 1
 #define NAFP_OPT_FUSED_LN_BWD 2
 #define NAFP_OPT_BWD_OVERLAP 4

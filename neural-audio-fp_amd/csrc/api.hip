@@ -99,15 +99,19 @@ struct nafp_encoder {
     // communication stream can start reducing a group while the rest of the backward pass still runs
     hipEvent_t grad_events[NAFP_GRAD_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
     bool grad_events_valid = false;
-    // NAFP_OPT_BWD_OVERLAP (default NAFP_BWD_OVERLAP env, else 0): the weight gradients of the backward pass run on a
-    // second, low-priority stream of the handle.  The chain  LayerNorm backward(j) -> transposed conv(j) -> LayerNorm
-    // backward(j-1) ...  is the critical path and alternates between an HBM-bound pass and an MFMA-bound one; wgrad(j) only
-    // needs dts_j and is needed at the very end, so it can fill the matrix pipes while the LayerNorm pass of the layer
-    // below streams (12 of 94 ms per step at BSZ 5120 are that pass running alone).  MEASURED SLOWER, hence off: side by
-    // side both kernels stretch to the sum of their solo times or beyond (BSZ 5120: wgrad_2 3.96 -> 6.67 ms next to
-    // ln_bwd_1 3.0 -> 6.6 ms; wgrad_1 8.85 -> 15.1 ms next to ln_bwd_0 2.45 -> 6.2 ms; step 93.3 -> 96.7 ms) -- the
-    // streaming pass starves wgrad's operand ring and its VALU work shares the SIMDs' issue slots with the f32 MFMAs.
-    int opt_bwd_overlap = []() { const char* v = getenv("NAFP_BWD_OVERLAP"); return v ? atoi(v) : 0; }();
+    // NAFP_OPT_BWD_OVERLAP (default NAFP_BWD_OVERLAP env, else 2): weight gradients on a second stream of the handle.  The chain
+    // LayerNorm backward(j) -> transposed conv(j) -> LayerNorm backward(j-1) ... is the critical path; wgrad(j) only needs dts_j
+    // and is needed at the very end.
+    //   1 = every layer's: MEASURED SLOWER.  Side by side with the HBM-bound LayerNorm pass both kernels stretch to the sum of
+    //       their solo times or beyond (BSZ 5120: wgrad_2 3.96 -> 6.67 ms next to ln_bwd_1 3.0 -> 6.6 ms; step 93.3 -> 96.7 ms):
+    //       the streaming pass starves wgrad's operand ring and its VALU work shares the SIMDs' issue slots with the f32 MFMAs.
+    //   2 = only the SMALL layers' (P < 16 output positions: b5 ... b7).  Their launches -- weight gradient, LayerNorm backward and
+    //       transposed conv alike -- are 250-750 short workgroups that fill a quarter of the chip, so wgrad(j) runs next to the
+    //       LayerNorm backward of layer j-1 for free; it has a slab and arrival counters of its own (TrainLayout::slab2).
+    //       Same-box A/B, ms per step: B = 640 13.04 -> 12.83, 1280 24.11 -> 24.07, 5120 88.1 -> 87.4.
+    // The side stream has the DEFAULT priority: with a lowest- or highest-priority stream every hand-over between the two
+    // queues cost ~0.4 ms (B = 640: 13.0 -> 18.0-18.2 ms per step for twelve of them).
+    int opt_bwd_overlap = []() { const char* v = getenv("NAFP_BWD_OVERLAP"); return v ? atoi(v) : 2; }();
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_main[16] = {}, ev_side[16] = {};
     // set_weights: the 15 G / Hb images are small, latency-bound launches (2 "samples"; the late ones stream 6-12 MB of
@@ -274,7 +278,7 @@ extern "C" int nafp_encoder_set_option(nafp_encoder* e, int option, int value) {
         case NAFP_OPT_FUSED_LN_BWD:
             if (value < 0 || value > 2) return NAFP_ERR_INVALID_ARG;
             e->opt_fused_ln_bwd = value; return NAFP_OK;
-        case NAFP_OPT_BWD_OVERLAP: e->opt_bwd_overlap = value != 0; return NAFP_OK;
+        case NAFP_OPT_BWD_OVERLAP: e->opt_bwd_overlap = value < 0 ? 0 : (value > 2 ? 1 : value); return NAFP_OK;
         default: return NAFP_ERR_INVALID_ARG;
     }
 }
@@ -564,6 +568,7 @@ struct TrainLayout {
     double* lnsum[16]; float* S1[16]; float* S2[16];
     float* z[16]; float* v[16];          // z = gamma . ELU(t) (operand of the next conv), v = the pre-activation t
     float* slab; int64_t slab_floats;
+    float* slab2; int64_t slab2_floats; unsigned* tickets2;     // the weight-gradient stream's own slab and arrival counters (opt_bwd_overlap 2)
     float* dA; float* dB; float* dy;
     int64_t bytes;
 };
@@ -574,7 +579,8 @@ TrainLayout train_layout(const nafp_encoder* e, int64_t B, void* ws) {
     char* p0 = p;
     auto take = [&](int64_t bytes) { char* r = p; p += (bytes + 255) / 256 * 256; return r; };
     L.stats = (stat_t*)take((int64_t)sizeof(stat_t) * 2 * 16 * B);
-    L.tickets = (unsigned*)take(NAFP_TICKET_SLOTS * (int64_t)sizeof(unsigned));      // directly behind the statistics: one fill covers both
+    L.tickets = (unsigned*)take(2 * NAFP_TICKET_SLOTS * (int64_t)sizeof(unsigned));  // directly behind the statistics: one fill covers both
+    L.tickets2 = L.tickets + NAFP_TICKET_SLOTS;                                       // (second half: the weight-gradient stream's counters)
     L.mr = (float*)take((int64_t)sizeof(float) * 2 * 16 * B);
     L.sc = (float*)take((int64_t)sizeof(float) * 8 * B);
     L.zero_begin = p;
@@ -596,6 +602,10 @@ TrainLayout train_layout(const nafp_encoder* e, int64_t B, void* ws) {
     for (int j = 1; j < 16; ++j)
         L.slab_floats = std::max(L.slab_floats, std::max(conv_gemm_slab_floats(B, e->geom[j], true), wgrad_slab_floats(B, e->geom[j])));
     L.slab = (float*)take((int64_t)sizeof(float) * L.slab_floats);
+    L.slab2_floats = 0;
+    for (int j = 1; j < 16; ++j)
+        if (e->geom[j].Fout * e->geom[j].Tout < 16) L.slab2_floats = std::max(L.slab2_floats, wgrad_slab_floats(B, e->geom[j]));
+    L.slab2 = (float*)take((int64_t)sizeof(float) * L.slab2_floats);
     L.dA = (float*)take((int64_t)sizeof(float) * max_n * B);
     L.dB = (float*)take((int64_t)sizeof(float) * max_n * B);
     L.dy = (float*)take((int64_t)sizeof(float) * e->emb_sz * B);
@@ -616,7 +626,7 @@ extern "C" int nafp_encoder_forward_train(nafp_encoder* e, const float* feat, in
     if (workspace_bytes < nafp_encoder_train_workspace_bytes(e, n_seg)) return NAFP_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     TrainLayout L = train_layout(e, n_seg, workspace);
-    NAFP_HIP_CHECK(hipMemsetAsync(L.stats, 0, (char*)(L.tickets + NAFP_TICKET_SLOTS) - (char*)L.stats, st));
+    NAFP_HIP_CHECK(hipMemsetAsync(L.stats, 0, (char*)(L.tickets + 2 * NAFP_TICKET_SLOTS) - (char*)L.stats, st));
     // (layer 0 keeps no pre-activation: the backward pass regenerates it from `feat`, 3 FMAs per element)
     int rc = launch_conv0(feat, e->d_w[0], e->d_bias[0], e->d_gamma[0], L.z[0], nullptr, L.stats, n_seg, e->geom[0], st);
     if (rc != NAFP_OK) return rc;
@@ -660,16 +670,21 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
     for (auto& ev : e->grad_events)
         if (!ev) NAFP_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     e->grad_events_valid = false;
-    // the weight-gradient stream (see opt_bwd_overlap): lowest priority, so that the critical path keeps the right of way
-    const bool overlap = e->opt_bwd_overlap != 0;
-    if (overlap && !e->side_stream) {
+    // the weight-gradient stream (see opt_bwd_overlap)
+    // opt_bwd_overlap: 1 = every layer's weight gradient on the side stream (measured slower, see the struct), 2 = only the SMALL
+    // layers' (P < 16 positions)
+    const int ov_mode = e->opt_bwd_overlap;
+    const bool overlap = ov_mode == 1;
+    auto side_layer = [&](int j) { return ov_mode == 1 || (ov_mode == 2 && j >= 1 && j <= 15 && e->geom[j].Fout * e->geom[j].Tout < 16); };
+    if (ov_mode != 0 && !e->side_stream) {
         int pr_least = 0, pr_greatest = 0;
         NAFP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
-        NAFP_HIP_CHECK(hipStreamCreateWithPriority(&e->side_stream, hipStreamNonBlocking, pr_least));
+        static const int side_prio = []() { const char* v = getenv("NAFP_SIDE_PRIO"); return v ? atoi(v) : 1; }();   // 0: lowest, 1: default (see opt_bwd_overlap), 2: highest
+        if (side_prio == 1) NAFP_HIP_CHECK(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
+        else NAFP_HIP_CHECK(hipStreamCreateWithPriority(&e->side_stream, hipStreamNonBlocking, side_prio == 2 ? pr_greatest : pr_least));
         for (auto& ev : e->ev_main) NAFP_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         for (auto& ev : e->ev_side) NAFP_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
-    hipStream_t sw = overlap ? e->side_stream : st;
     int rc = launch_stats_to_mr(L.stats, L.mr, e->d_inv_n, B, 16, st);
     if (rc != NAFP_OK) return rc;
     // tail: d_emb -> r * dxhat of the last conv + divide-and-encode gradients
@@ -696,10 +711,15 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
                                L.tickets);
             if (rc != NAFP_OK) return rc;
         }
-        sc_ready = false;
         // the transposed conv below writes `other`, which still holds dts_{j+1}: wgrad(j+1), on the weight-gradient stream,
         // must be done with it
-        if (overlap && j < 15) NAFP_HIP_CHECK(hipStreamWaitEvent(st, e->ev_side[j + 1], 0));
+        if (j < 15 && side_layer(j + 1)) NAFP_HIP_CHECK(hipStreamWaitEvent(st, e->ev_side[j + 1], 0));
+        const bool on_side = side_layer(j);
+        hipStream_t sw = on_side ? e->side_stream : st;
+        const ConvGeom& gp1 = e->geom[j - 1];
+        ScalarsJob sj{L.mr + 2 * B * (j - 1), L.lnsum[j - 1], j >= 2 ? L.mr + 2 * B * (j - 2) : nullptr, L.sc, (long long)B,
+                      1.0 / ((double)gp1.Fout * gp1.Tout * gp1.Cout)};
+        sc_ready = false;
         ln_done = j >= 2 && dgrad_ln_eligible(B, g, e->opt_fused_ln_bwd);   // (layer 0 keeps no pre-activation: see conv0 below)
         if (ln_done) {
             // transposed conv of dts_j with the LayerNorm + ELU backward of layer j-1 in its epilogue: `other` <- dts_{j-1}
@@ -718,39 +738,38 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
             ConvGemmArgs a{};
             a.x = cur; a.wp = e->d_wd[j]; a.y = other; a.plain = true; a.dgrad = true;
             a.slab = L.slab_floats ? L.slab : nullptr; a.slab_floats = L.slab_floats;
-            a.tickets = overlap ? nullptr : L.tickets;      // split-K finished in-kernel (the side stream's wgrad shares the counters: not then)
+            a.tickets = overlap ? nullptr : L.tickets;      // split-K finished in-kernel (mode 1: the side stream's wgrad shares the counters)
+            a.sj = &sj;                                     // side job: the scalar records of layer j - 1
             rc = launch_conv_gemm(a, B, g, st);
             if (rc != NAFP_OK) return rc;
+            sc_ready = true;
         }
         // dW_j = wgrad(z_{j-1}, r dt) + wgrad(gamma_{j-1}, sum_b c_b dt) + wgrad(beta_{j-1}, sum_b dt).  On the weight-gradient
         // stream it starts BEHIND the transposed conv of this layer (two MFMA-bound kernels side by side only share the
         // pipes) and so runs next to the LayerNorm backward of layer j-1, which is HBM-bound and next on the main stream.
-        if (overlap) {
+        if (on_side) {
             NAFP_HIP_CHECK(hipEventRecord(e->ev_main[j], st));
             NAFP_HIP_CHECK(hipStreamWaitEvent(sw, e->ev_main[j], 0));
         }
+        float* w_slab = !on_side ? L.slab : (ov_mode == 2 ? L.slab2 : nullptr);
+        const int64_t w_slab_floats = !on_side ? L.slab_floats : (ov_mode == 2 ? L.slab2_floats : 0);
+        unsigned* w_tickets = !on_side ? L.tickets : (ov_mode == 2 ? L.tickets2 : nullptr);
         // (the two rank-one terms ride in the main launch as two aux samples: [gamma | beta] and [S1 | S2] are adjacent pairs.)
         // Side job of that launch, single-stream mode only: the scalar records the LayerNorm backward of layer j - 1 starts from
         // (its sums are final since ln_bwd of layer j; the fused dgrad path and the side stream keep the separate launch)
-        const ConvGeom& gp1 = e->geom[j - 1];
-        ScalarsJob sj{L.mr + 2 * B * (j - 1), L.lnsum[j - 1], j >= 2 ? L.mr + 2 * B * (j - 2) : nullptr, L.sc, (long long)B,
-                      1.0 / ((double)gp1.Fout * gp1.Tout * gp1.Cout)};
-        const bool fold_sc = !overlap && !ln_done;
         const bool pairs = L.S2[j] == L.S1[j] + (int64_t)P * g.Cout;
         if (pairs) {
-            rc = launch_wgrad(L.z[j - 1], cur, grads[4 * j], B, g, sw, e->d_gamma[j - 1], L.S1[j], overlap ? nullptr : L.slab,
-                              overlap ? 0 : L.slab_floats, overlap ? nullptr : L.tickets, fold_sc ? &sj : nullptr);
+            rc = launch_wgrad(L.z[j - 1], cur, grads[4 * j], B, g, sw, e->d_gamma[j - 1], L.S1[j], w_slab, w_slab_floats, w_tickets, nullptr);
             if (rc != NAFP_OK) return rc;
         } else {
-            rc = launch_wgrad(L.z[j - 1], cur, grads[4 * j], B, g, sw, nullptr, nullptr, nullptr, 0, nullptr, fold_sc ? &sj : nullptr);
+            rc = launch_wgrad(L.z[j - 1], cur, grads[4 * j], B, g, sw, nullptr, nullptr, nullptr, 0, nullptr, nullptr);
             if (rc != NAFP_OK) return rc;
             rc = launch_wgrad(e->d_gamma[j - 1], L.S1[j], grads[4 * j], 1, g, sw);
             if (rc != NAFP_OK) return rc;
             rc = launch_wgrad(e->d_beta[j - 1], L.S2[j], grads[4 * j], 1, g, sw);
             if (rc != NAFP_OK) return rc;
         }
-        sc_ready = fold_sc;
-        if (overlap) NAFP_HIP_CHECK(hipEventRecord(e->ev_side[j], sw));
+        if (on_side) NAFP_HIP_CHECK(hipEventRecord(e->ev_side[j], sw));
         std::swap(cur, other);
         // layers j .. 15 (and the divide-and-encode tensors) are final from here on (when the LayerNorm backward of layer
         // j-1 ran fused, its dgamma / dbeta / dbias are final too: they belong to the next group or are simply early)
@@ -772,7 +791,8 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
             if (rc != NAFP_OK) return rc;
         }
     }
-    if (overlap) NAFP_HIP_CHECK(hipStreamWaitEvent(st, e->ev_side[1], 0));      // every wgrad is done (the side stream runs them in order)
+    for (int j = 1; j <= 15; ++j)                       // every side-stream wgrad is done (in order: the last is the lowest side layer)
+        if (side_layer(j)) { NAFP_HIP_CHECK(hipStreamWaitEvent(st, e->ev_side[j], 0)); break; }
     NAFP_HIP_CHECK(hipEventRecord(e->grad_events[NAFP_GRAD_GROUPS - 1], st));
     e->grad_events_valid = true;
     return NAFP_OK;

@@ -308,6 +308,7 @@ struct ConvKernelParams {
     const float* f0_bias;     // (Cin)
     const float* f0_gamma;    // (F0, Tin, Cin) = LN scale of conv0 = layout of z0
     int f0_T, f0_stride, f0_pad;   // conv0: input frames, stride and pad-before along T
+    ScalarsJob sj;            // PLAIN launches of the backward pass: side job (sc == null: none)
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -491,6 +492,22 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         pb = (int)(rt / (unsigned)p.n_sg); sg = (int)(rt - (unsigned)pb * (unsigned)p.n_sg);
     } else
     if (!(p.opt & 4)) { pb = blockIdx.x / p.n_sg; sg = blockIdx.x - pb * p.n_sg; colz = blockIdx.y; zsp = blockIdx.z; }
+    if ((EPI == 3 || EPI == 5) && p.sj.sc) {
+        // side job of a transposed conv of the backward pass: the scalar records the LayerNorm backward of the layer below
+        // starts from (their inputs are final since the LayerNorm backward of this layer; NT samples per workgroup)
+        const long long wg = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z);
+        const long long n_wg = (long long)gridDim.x * gridDim.y * gridDim.z;
+        for (long long b = wg * NT + tid; b < p.sj.B; b += n_wg * NT) {
+            const float mean = p.sj.mr[2 * b], rstd = p.sj.mr[2 * b + 1];
+            float* o = p.sj.sc + 8 * b;
+            o[0] = mean; o[1] = rstd;
+            o[2] = (float)(p.sj.lnsum[2 * b] * p.sj.inv_n); o[3] = (float)(p.sj.lnsum[2 * b + 1] * p.sj.inv_n);
+            o[4] = 1.f / rstd;
+            o[5] = p.sj.mr_prev ? p.sj.mr_prev[2 * b + 1] : 1.f;
+            o[6] = p.sj.mr_prev ? -p.sj.mr_prev[2 * b] : 0.f;
+            o[7] = 0.f;
+        }
+    }
     const int tile_n0 = colz * BNT;
     const int K = 3 * p.Cin;
     // diagnostic timeline: lane 0 of every wave stamps the shader clock at the phase boundaries of its tile
@@ -1724,6 +1741,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     g_ev_start = a.ev_start; g_ev_stop = finish_follows ? nullptr : a.ev_stop;
     p.f0_feat = nullptr; p.f0_w = nullptr; p.f0_bias = nullptr; p.f0_gamma = nullptr;
     p.f0_T = 0; p.f0_stride = 1; p.f0_pad = 0;
+    p.sj = (a.sj && a.plain) ? *a.sj : ScalarsJob{nullptr, nullptr, nullptr, nullptr, 0, 0.0};
     if (a.f0_feat) {
         // conv0 generated in-kernel: this conv must be the 3x1 conv that consumes conv0's output
         if (a.plain || S != 1 || !a.f0_geom || g.axis != 1 || a.f0_geom->Cout != g.Cin || a.f0_geom->Tout != g.Tin ||
@@ -2048,6 +2066,7 @@ int launch_dgrad_ln(const DgradLnArgs& a, int64_t B, const ConvGeom& g, hipStrea
     const int S = g.axis == 0 ? g.Cout : g.Tout * g.Cout;
     p.tap_stride = -(S / g.stride);
     p.inv_n_in = 1.0; p.mode = 1; p.n_split = 1; p.abl = 0; p.tl = nullptr; p.opt = 0; p.tickets = nullptr; p.y_final = nullptr;
+    p.sj = ScalarsJob{nullptr, nullptr, nullptr, nullptr, 0, 0.0};
     p.perm_on = 0; p.perm_n0 = 0; p.perm_c0 = 0;        // one position per workgroup: no class ordering needed
     p.wp_bytes = (unsigned)((int64_t)g.Cout * 3 * g.Cin * 4);
     p.f0_feat = nullptr; p.f0_w = nullptr; p.f0_bias = nullptr; p.f0_gamma = nullptr; p.f0_T = 0; p.f0_stride = 1; p.f0_pad = 0;

@@ -111,6 +111,9 @@ int launch_conv0(const float* feat, const float* w3, const float* bias, const fl
 
 // implicit-GEMM conv (see conv.hip for the LayerNorm folding).
 constexpr int NAFP_TICKET_SLOTS = 4096;      // output tiles of a split-K launch that finishes in-kernel
+// Side job a launch of the backward pass can carry: the per-sample scalar records of the LayerNorm backward of the layer below
+// (what ln_bwd_scalars_kernel computes; backward.hip).  sc == null: none.
+struct ScalarsJob { const float* mr; const double* lnsum; const float* mr_prev; float* sc; long long B; double inv_n; };   // sc == null: none
 struct ConvGemmArgs {
     const float* x;          // (B,Fin,Tin,Cin): z of the previous conv (FULL) or a raw image (PLAIN)
     const float* wp;         // packed (Cout, 3*Cin), k = tap*Cin + cin
@@ -133,6 +136,7 @@ struct ConvGemmArgs {
     // `x` is then unused.  f0_geom = geometry of conv0.
     const float* f0_feat; const float* f0_w; const float* f0_bias; const float* f0_gamma;
     const ConvGeom* f0_geom;
+    const ScalarsJob* sj;    // optional (PLAIN launches of the backward pass): side job, see ScalarsJob
 };
 // statistics (sum, sum of squares of ELU(conv0 + bias) per sample) without storing the activation
 int launch_conv0_stats(const float* feat, const float* w3, const float* bias, stat_t* stats, int64_t B,
@@ -202,7 +206,6 @@ int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* 
 // dW (keras (3,Cin,Cout), accumulated) += sum_rows X[b, in(pos,tap), :] (x) D[b,pos,:]
 // X2 / D2 (both or neither): the aux samples [gamma_{j-1} | beta_{j-1}] resp. [S1_j | S2_j] (each pair adjacent), i.e. the two
 // rank-one terms of dW_j; slab / tickets: workspace of the small-layer kernel (or null); sj: optional side job.
-struct ScalarsJob { const float* mr; const double* lnsum; const float* mr_prev; float* sc; long long B; double inv_n; };   // sc == null: none
 int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const ConvGeom& g, hipStream_t st,
                  const float* X2 = nullptr, const float* D2 = nullptr, float* slab = nullptr, int64_t slab_floats = 0,
                  unsigned* tickets = nullptr, const ScalarsJob* sj = nullptr);

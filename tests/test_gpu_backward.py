@@ -141,11 +141,13 @@ def test_fused_ln_backward_equals_the_separate_pass(nafp, B):
             assert float((a - b).abs().max()) / scale < 2e-4, (mode, i)
 
 
-@pytest.mark.parametrize('B', [5, 130])
-def test_weight_gradients_on_the_side_stream_equal_the_single_stream_pass(nafp, B, observe):
-    """NAFP_OPT_BWD_OVERLAP (option 4; measured slower and off by default): the weight gradients run on a
-    second stream of the handle behind per-layer events, over the same dA / dB ping-pong buffers the main chain keeps
-    rewriting.  Same kernels, same operands: the gradients must agree with the single-stream pass to the order of the
+@pytest.mark.parametrize('side_mode', [1, 2])
+@pytest.mark.parametrize('B', [5, 130, 160])
+def test_weight_gradients_on_the_side_stream_equal_the_single_stream_pass(nafp, B, side_mode, observe):
+    """NAFP_OPT_BWD_OVERLAP (option 4; 2 = the small layers' weight gradients, the default; 1 = every layer's, measured slower;
+    0 = single stream): the weight gradients run on a second stream of the handle behind per-layer events, over the same
+    dA / dB ping-pong buffers the main chain keeps rewriting (B = 160: B * P is a multiple of 16 for every layer, so the small
+    layers take their slab kernel with the side stream's own slab and counters).  Same kernels, same operands: the gradients must agree with the single-stream pass to the order of the
     fp32 atomics, twice in a row (the second pass reuses the buffers the side stream read), and a consumer that waits on
     the per-group events (`grad_group_wait`, what GradientBucket.all_reduce does) must see finished gradients."""
     g = torch.Generator(device='cuda').manual_seed(40 + B)
@@ -153,7 +155,7 @@ def test_weight_gradients_on_the_side_stream_equal_the_single_stream_pass(nafp, 
     d_emb = torch.randn((B, 128), generator=g, device='cuda')
     w = _inputs.weight_list(_inputs.weights(seed=15))
     out = {}
-    for mode in (0, 1):
+    for mode in (0, side_mode):
         m_fp = nafp.FingerPrinter(seed=0)
         m_fp.set_option(4, mode)
         m_fp.set_weights(w)
@@ -174,7 +176,7 @@ def test_weight_gradients_on_the_side_stream_equal_the_single_stream_pass(nafp, 
         out[mode] = runs
     worst = 0.0
     for rep in range(2):
-        for i, (a, b) in enumerate(zip(out[1][rep], out[0][rep])):
+        for i, (a, b) in enumerate(zip(out[side_mode][rep], out[0][rep])):
             worst = max(worst, float((a - b).abs().max()) / (float(b.abs().max()) + 1e-20))
     observe('side-stream vs single-stream gradients, rel. to the tensor max', worst, 2e-5)
 
