@@ -675,7 +675,8 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
     // layers' (P < 16 positions)
     const int ov_mode = e->opt_bwd_overlap;
     const bool overlap = ov_mode == 1;
-    auto side_layer = [&](int j) { return ov_mode == 1 || (ov_mode == 2 && j >= 1 && j <= 15 && e->geom[j].Fout * e->geom[j].Tout < 16); };
+    static const int side_max_p = []() { const char* v = getenv("NAFP_SIDE_MAXP"); return v ? atoi(v) : 16; }();      // (sweep knob: 16 = the small layers)
+    auto side_layer = [&](int j) { return ov_mode == 1 || (ov_mode == 2 && j >= 1 && j <= 15 && e->geom[j].Fout * e->geom[j].Tout < side_max_p); };
     if (ov_mode != 0 && !e->side_stream) {
         int pr_least = 0, pr_greatest = 0;
         NAFP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));

@@ -152,6 +152,22 @@ class FingerPrinter:
         self._use_events = {}
         self._dirty = False
 
+    def prefetch_weights(self):
+        """Start the re-pack of modified variables NOW, on a stream of the handle's own (default priority), instead of on the
+        caller's stream at the next forward: `nafp_encoder_set_weights` (copies, re-layouts, the G / Hb images: ~0.3 ms) then
+        runs next to whatever the caller enqueues before that forward -- in `train_step` the front end of the next batch
+        (concatenation, log-mel, spec-augment).  Ordered like `_sync`: behind everything the current stream has enqueued
+        (the optimizer step that modified the variables, the backward pass that read the packed weights), and every later
+        forward waits for its completion event."""
+        if not self._dirty:
+            return
+        cur = torch.cuda.current_stream(self.device)
+        if getattr(self, '_prep_stream', None) is None:
+            self._prep_stream = torch.cuda.Stream(device=self.device)
+        self._prep_stream.wait_stream(cur)
+        with torch.cuda.stream(self._prep_stream):
+            self._sync()
+
     def _wait_weights(self):
         ev = self._weights_event
         if ev is not None:

@@ -35,6 +35,9 @@ from .fp.specaug_chain.specaug_chain import get_specaug_chain_layer
 from . import generate as _gen
 
 
+_PREFETCH_WEIGHTS = __import__('os').environ.get('NAFP_PREFETCH_WEIGHTS', '1') != '0'
+
+
 def build_fp(cfg):
     """trainer.py:19-30."""
     m_pre = get_melspec_layer(cfg, trainable=False)
@@ -143,6 +146,8 @@ def train_step(X, m_pre, m_specaug, m_fp, loss_obj, opt, bucket=None, timers=Non
         bucket.all_reduce(dist)
     opt.apply_gradients(zip(grads, m_fp.trainable_variables), var_lens=m_fp.variable_lengths())
     m_fp.mark_dirty()
+    if _PREFETCH_WEIGHTS and hasattr(m_fp, 'prefetch_weights'):
+        m_fp.prefetch_weights()                 # the re-pack for the next forward starts now, next to the next batch's front end
     return loss, None
 
 
