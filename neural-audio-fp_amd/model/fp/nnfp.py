@@ -139,6 +139,7 @@ class FingerPrinter:
             self._wait_weights()
             return
         cur = torch.cuda.current_stream(self.device)
+        self._wait_weights()               # a re-pack still in flight on another stream (prefetch_weights) writes the same blob: behind it
         for key, ev in list(self._use_events.items()):
             if key != cur.cuda_stream:
                 cur.wait_event(ev)
