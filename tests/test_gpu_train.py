@@ -182,3 +182,44 @@ def test_train_step_with_other_embedding_widths(nafp, cfg, emb_sz):
     want = o_nt.compute_loss(emb0[:16], emb0[16:], c['LOSS']['TAU'])[0]
     assert abs(losses[0] - want) < 1e-4 * max(1.0, abs(want))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_prefetched_weight_repack_equals_the_lazy_one(nafp, cfg, monkeypatch):
+    """`train_step` starts the re-pack of the updated weights on a stream of the handle's own right after the optimizer
+    (`FingerPrinter.prefetch_weights`); the next forward only waits for its completion event.  Five steps with the
+    prefetch and five with the lazy re-pack at the next forward (same seeded data, no spec-augment) must give the same
+    losses and variables to the rounding of the backward pass's atomics -- and a forward issued on ANOTHER stream right
+    after a step must see the new weights, not the old blob."""
+    from neural_audio_fp_amd.model import trainer as T
+    from neural_audio_fp_amd.model.fp.lamb_optimizer import LAMB
+    from neural_audio_fp_amd.model.fp.NTxent_loss_single_gpu import NTxentLoss
+    n = 16
+    xa, xp = _pairs(n, 9)
+    X = (torch.from_numpy(xa).cuda(), torch.from_numpy(xp).cuda())
+    m_pre = nafp.get_melspec_layer(cfg)
+    feat = m_pre(torch.cat(X, 0))
+    runs = {}
+    for prefetch in (True, False):
+        monkeypatch.setattr(T, '_PREFETCH_WEIGHTS', prefetch)
+        m_fp = nafp.FingerPrinter(seed=0)
+        m_fp.set_weights(_inputs.weight_list(_inputs.weights(seed=22)))
+        opt = LAMB(learning_rate=1e-3)
+        loss_obj = NTxentLoss(n_org=n, n_rep=n, tau=0.05)
+        losses = []
+        for step in range(5):
+            loss, _ = T.train_step(X, m_pre, _NoAug(), m_fp, loss_obj, opt)
+            losses.append(float(loss))
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):                     # straight after the step, on another stream
+            emb_side = m_fp(feat).clone()
+        side.synchronize()
+        torch.cuda.synchronize()
+        emb_main = m_fp(feat)
+        assert torch.equal(emb_side, emb_main)            # the side-stream forward waited for the re-pack
+        runs[prefetch] = (losses, [v.detach().clone() for v in m_fp.trainable_variables], emb_main.clone())
+    la, lb = runs[True][0], runs[False][0]
+    assert lb[-1] < lb[0]
+    assert max(abs(a - b) for a, b in zip(la, lb)) < 1e-4 * max(1.0, abs(lb[0]))
+    for a, b in zip(runs[True][1], runs[False][1]):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7
+    assert float((runs[True][2] - runs[False][2]).abs().max()) < 1e-4
