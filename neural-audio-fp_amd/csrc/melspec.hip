@@ -25,8 +25,11 @@ constexpr int HOP = 256;
 constexpr int NBIN = NFFT / 2 + 1;          // 513
 constexpr int MAX_TAPS = 8;
 constexpr int MAX_SEG = 1 << 22;             // LDS use no longer depends on the segment length
-constexpr int CHUNK_FRAMES = 16;             // frames per LDS-resident chunk
-constexpr int TILE_LD = 20;                 // LDS leading dimension of the (n_mels, <=16) tile chunk
+#ifndef NAFP_MEL_CHUNK
+#define NAFP_MEL_CHUNK 16                    // (8 = twice the workgroups of half the frames: measured, DESIGN.md 4.1 [r4])
+#endif
+constexpr int CHUNK_FRAMES = NAFP_MEL_CHUNK; // frames per LDS-resident chunk
+constexpr int TILE_LD = CHUNK_FRAMES + 4;   // LDS leading dimension of the (n_mels, <= CHUNK_FRAMES) tile chunk
 constexpr int SIG_CHUNK = (CHUNK_FRAMES - 1) * HOP + NFFT;  // 4864 samples feed 16 consecutive frames
 constexpr int N_TW = 768;                   // twiddles used by the radix-4 passes (index < 3 * 256)
 
