@@ -31,17 +31,27 @@ std::vector<ConvGeom> encoder_geometry(int in_f, int in_t) {
 }
 
 // set_weights helpers: all plain tensor copies in ONE launch, and bias_j added to every Hb_j in one launch.
-struct CopyTable { const float* src[64]; float* dst[64]; int64_t n[64]; int count; };
+// `nz` entries (the LayerNorm scales): the library's WORKING copy never holds a value of magnitude below 1e-30 -- an exact zero
+// becomes +1e-30.  Every conv stores z = gamma . v; the backward pass recovers v = z / gamma from it instead of keeping a second
+// tensor (the pre-activation) per layer, which needs gamma != 0.  Against activations of O(1) a scale of 1e-30 IS zero in
+// float32 (its contribution vanishes in the first addition it meets), so the forward result does not change; the variable
+// the caller sees is not touched.
+struct CopyTable { const float* src[64]; float* dst[64]; int64_t n[64]; int nz[64]; int count; };
+__device__ __forceinline__ float nz_scale(float g) { return fabsf(g) < 1e-30f ? copysignf(1e-30f, g) : g; }
 __global__ __launch_bounds__(256) void multi_copy_kernel(const CopyTable t) {
     const int e = blockIdx.y;
     const float* __restrict__ s = t.src[e]; float* __restrict__ d = t.dst[e];
     const int64_t n = t.n[e];
+    const bool nz = t.nz[e] != 0;
     if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) {
-        for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n / 4; i += (int64_t)gridDim.x * 256)
-            ((float4*)d)[i] = ((const float4*)s)[i];
-        for (int64_t i = n / 4 * 4 + blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+        for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n / 4; i += (int64_t)gridDim.x * 256) {
+            float4 v = ((const float4*)s)[i];
+            if (nz) { v.x = nz_scale(v.x); v.y = nz_scale(v.y); v.z = nz_scale(v.z); v.w = nz_scale(v.w); }
+            ((float4*)d)[i] = v;
+        }
+        for (int64_t i = n / 4 * 4 + blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = nz ? nz_scale(s[i]) : s[i];
     } else {
-        for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+        for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = nz ? nz_scale(s[i]) : s[i];
     }
 }
 struct BiasTable { float* hb[16]; const float* bias[16]; int64_t n[16]; int cout[16]; int count; };
@@ -112,6 +122,12 @@ struct nafp_encoder {
     // The side stream has the DEFAULT priority: with a lowest- or highest-priority stream every hand-over between the two
     // queues cost ~0.4 ms (B = 640: 13.0 -> 18.0-18.2 ms per step for twelve of them).
     int opt_bwd_overlap = []() { const char* v = getenv("NAFP_BWD_OVERLAP"); return v ? atoi(v) : 2; }();
+    // NAFP_KEEP_T=1: the training forward also stores every conv's pre-activation t (rounds 1-3).  Default 0: only z = gamma . v
+    // is kept and the LayerNorm backward recovers what it needs of t from v = z / gamma (ln_bwd_fused_kernel<.., FROMZ>): the
+    // forward convs lose their second store stream and the workspace 4.6 MB per segment.  The fused transposed-conv +
+    // LayerNorm-backward path (opt_fused_ln_bwd) reads t and therefore implies keeping it.
+    bool keep_t_env = []() { const char* v = getenv("NAFP_KEEP_T"); return v && v[0] == '1'; }();
+    bool keep_t() const { return keep_t_env || opt_fused_ln_bwd != 0; }
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_main[16] = {}, ev_side[16] = {};
     // set_weights: the 15 G / Hb images are small, latency-bound launches (2 "samples"; the late ones stream 6-12 MB of
@@ -305,13 +321,13 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
         if (!t[i]) return NAFP_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     CopyTable ct; ct.count = 0;
-    auto add_copy = [&](const float* src, float* dst, int64_t n) { ct.src[ct.count] = src; ct.dst[ct.count] = dst; ct.n[ct.count] = n; ++ct.count; };
+    auto add_copy = [&](const float* src, float* dst, int64_t n, int nz = 0) { ct.src[ct.count] = src; ct.dst[ct.count] = dst; ct.n[ct.count] = n; ct.nz[ct.count] = nz; ++ct.count; };
     add_copy(t[0], e->d_w[0], 3 * e->geom[0].Cout);
     for (int j = 0; j < 16; ++j) {
         const ConvGeom& g = e->geom[j];
         const int64_t nln = (int64_t)g.Fout * g.Tout * g.Cout;
         add_copy(t[4 * j + 1], e->d_bias[j], g.Cout);
-        add_copy(t[4 * j + 2], e->d_gamma[j], nln);
+        add_copy(t[4 * j + 2], e->d_gamma[j], nln, 1);          // LayerNorm scale: kept away from exact zero (multi_copy_kernel)
         add_copy(t[4 * j + 3], e->d_beta[j], nln);
     }
     add_copy(t[64], e->d_w1k, numel(e->shapes[64]));
@@ -596,7 +612,7 @@ TrainLayout train_layout(const nafp_encoder* e, int64_t B, void* ws) {
         const int64_t n = (int64_t)e->geom[j].Fout * e->geom[j].Tout * e->geom[j].Cout;
         max_n = std::max(max_n, n);
         L.z[j] = (float*)take((int64_t)sizeof(float) * n * B);
-        L.v[j] = j == 0 ? nullptr : (float*)take((int64_t)sizeof(float) * n * B);     // layer 0: regenerated, not stored
+        L.v[j] = (j == 0 || !e->keep_t()) ? nullptr : (float*)take((int64_t)sizeof(float) * n * B);   // layer 0: regenerated; else only with keep_t()
     }
     L.slab_floats = 0;
     for (int j = 1; j < 16; ++j)
@@ -706,10 +722,10 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
         const int P = g.Fout * g.Tout;
         const float* mr_j = L.mr + 2 * B * j; const float* mr_p = L.mr + 2 * B * (j - 1);
         if (!ln_done) {
-            rc = launch_ln_bwd(cur, L.v[j], e->d_gamma[j], mr_j, mr_p, L.lnsum[j], L.sc, grads[4 * j + 2], grads[4 * j + 3],
+            rc = launch_ln_bwd(cur, L.v[j] ? L.v[j] : L.z[j], e->d_gamma[j], mr_j, mr_p, L.lnsum[j], L.sc, grads[4 * j + 2], grads[4 * j + 3],
                                grads[4 * j + 1], L.S1[j], L.S2[j], B, P, g.Cout, st, j == 15, e->d_G[j], e->d_Hb[j], L.lnsum[j - 1],
                                nullptr, nullptr, nullptr, nullptr, nullptr, sc_ready, L.slab_floats ? L.slab : nullptr, L.slab_floats,
-                               L.tickets);
+                               L.tickets, L.v[j] == nullptr);
             if (rc != NAFP_OK) return rc;
         }
         // the transposed conv below writes `other`, which still holds dts_{j+1}: wgrad(j+1), on the weight-gradient stream,

@@ -198,7 +198,8 @@ int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* 
                   int64_t B, int P, int C, hipStream_t st, bool reduce_here, const float* Gj, const float* Hbj,
                   double* lnsum_below, const float* feat0 = nullptr, const float* w0 = nullptr, const float* bias0 = nullptr,
                   const ConvGeom* g0 = nullptr, float* dW0 = nullptr, bool scalars_done = false,
-                  float* part_slab = nullptr, int64_t part_slab_floats = 0, unsigned* tickets = nullptr);
+                  float* part_slab = nullptr, int64_t part_slab_floats = 0, unsigned* tickets = nullptr, bool tpre_is_z = false);
+// tpre_is_z: `tpre` is the layer's stored z = gamma . v instead of its pre-activation (v = z / gamma; gamma = the working copy)
 // part_slab / tickets (or null): the batch chunks' (dgamma, dbeta, S1, S2) partials meet through the slab, summed in chunk
 // order by the last arriver of each 1024-element block, instead of through atomics
 // feat0 (layer 0 only): regenerate the pre-activation instead of reading tpre; dW0: also accumulate conv0's weight gradient
