@@ -87,6 +87,16 @@ struct nafp_encoder {
     double* d_inv_n = nullptr;
     float* d_sw_slab = nullptr; int64_t sw_slab_floats = 0;      // split-K slab of the G/Hb launches in set_weights
     bool has_weights = false;
+    // Ordering of set_weights against the passes that read what it writes, when they run on DIFFERENT streams (a trainer
+    // starts the re-pack of the updated variables on a stream of its own while the next batch's front end runs, nnfp.py
+    // prefetch_weights): `sw_copied` = the plain copies are done (conv0 reads nothing else: its kernel, bias and gamma_0),
+    // `sw_done` = everything is (packed kernels, G / Hb, the divide-and-encode re-layout).  A pass on another stream waits for
+    // the event it needs right before the first launch that needs it (wait_weights): the training forward starts conv0 behind
+    // `sw_copied` and conv1 behind `sw_done`, so the ~0.3 ms chain of small G / Hb launches runs under conv0 instead of in front
+    // of it (B = 640: the main stream sat idle for 0.19 ms per step waiting for it).  Same stream: no wait is enqueued.
+    hipEvent_t sw_copied = nullptr, sw_done = nullptr;
+    hipStream_t sw_stream = nullptr;
+    bool sw_recorded = false;
     // NAFP_OPT_FUSE_CONV0 (default: NAFP_FUSE0 env, else off).  Re-measured in round 4 on the current kernels (B = 640, same
     // box, tools/ab_bench.sh, two rounds): materialised conv0 0.257 ms + conv1 1.118 ms = 1.375 ms (187.2 k segments/s) vs
     // fused 0.172 ms (statistics pass) + 1.436 ms = 1.608 ms (179.3 k): the f32 MFMAs share the SIMDs' issue time with the
@@ -282,6 +292,8 @@ extern "C" int nafp_encoder_destroy(nafp_encoder* e) {
     for (auto& q : e->sw_streams) if (q) (void)hipStreamDestroy(q);
     for (auto& ev : e->sw_join) if (ev) (void)hipEventDestroy(ev);
     if (e->sw_fork) (void)hipEventDestroy(e->sw_fork);
+    if (e->sw_copied) (void)hipEventDestroy(e->sw_copied);
+    if (e->sw_done) (void)hipEventDestroy(e->sw_done);
     delete e;
     return NAFP_OK;
 }
@@ -334,8 +346,14 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
     add_copy(t[65], e->d_b1k, numel(e->shapes[65]));
     add_copy(t[66], e->d_w2k, numel(e->shapes[66]));
     add_copy(t[67], e->d_b2, e->emb_sz);
+    if (!e->sw_copied) {
+        NAFP_HIP_CHECK(hipEventCreateWithFlags(&e->sw_copied, hipEventDisableTiming));
+        NAFP_HIP_CHECK(hipEventCreateWithFlags(&e->sw_done, hipEventDisableTiming));
+    }
+    e->sw_recorded = false;                 // (an early return below leaves the passes without events to wait for: the caller got an error)
     multi_copy_kernel<<<dim3(32, ct.count), 256, 0, st>>>(ct);
     NAFP_LAUNCH_CHECK();
+    NAFP_HIP_CHECK(hipEventRecord(e->sw_copied, st));
     {
         PackTable pt; pt.count = 0;
         for (int j = 1; j < 16; ++j) {
@@ -401,7 +419,16 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
     NAFP_LAUNCH_CHECK();
     int rc = launch_pack_div(t[64], t[65], t[66], e->d_w1p, e->d_b1p, e->d_w2p, e->emb_sz, e->S, st);
     if (rc != NAFP_OK) return rc;
+    NAFP_HIP_CHECK(hipEventRecord(e->sw_done, st));
+    e->sw_stream = st; e->sw_recorded = true;
     e->has_weights = true;
+    return NAFP_OK;
+}
+
+// A pass on stream `st` is about to read what the last set_weights wrote (all of it, or only the plain copies): see sw_copied / sw_done.
+static int wait_weights(nafp_encoder* e, hipStream_t st, bool all) {
+    if (!e->sw_recorded || st == e->sw_stream) return NAFP_OK;
+    NAFP_HIP_CHECK(hipStreamWaitEvent(st, all ? e->sw_done : e->sw_copied, 0));
     return NAFP_OK;
 }
 
@@ -455,6 +482,7 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
     float* slab = (float*)((char*)bufB + align_up((int64_t)sizeof(float) * e->bufB_per_seg * n_seg, 256));
     int64_t slab_floats = 0;
     for (int j = 1; j < 16; ++j) slab_floats = std::max(slab_floats, conv_gemm_slab_floats(n_seg, e->geom[j]));
+    { int wrc = wait_weights(e, st, true); if (wrc != NAFP_OK) return wrc; }
     NAFP_HIP_CHECK(hipMemsetAsync(stats, 0, stats_bytes, st));        // statistics + counters, one fill
     hipEvent_t* ev = nullptr;
     if (e->prof_max > 0 && e->prof_count < e->prof_max) ev = e->prof_events.data() + (size_t)NAFP_PROF_EV * e->prof_count++;
@@ -568,6 +596,7 @@ extern "C" int nafp_encoder_div_enc(nafp_encoder* e, const float* flat, int64_t 
     t.w1p = e->d_w1p; t.b1p = e->d_b1p; t.w2p = e->d_w2p; t.b2 = e->d_b2;
     t.out_flat = nullptr; t.out_emb = out_emb;
     t.D = (int)e->flat_dim; t.Q = e->emb_sz; t.S = e->S; t.l2norm = l2norm;
+    { int wrc = wait_weights(e, (hipStream_t)stream, true); if (wrc != NAFP_OK) return wrc; }
     return launch_tail(t, n_seg, (hipStream_t)stream);
 }
 
@@ -586,6 +615,7 @@ struct TrainLayout {
     float* slab; int64_t slab_floats;
     float* slab2; int64_t slab2_floats; unsigned* tickets2;     // the weight-gradient stream's own slab and arrival counters (opt_bwd_overlap 2)
     float* dA; float* dB; float* dy;
+    float* dts[16];                      // the small layers' gradients in buffers of their own (opt_bwd_overlap 2), else nullptr
     int64_t bytes;
 };
 
@@ -625,6 +655,14 @@ TrainLayout train_layout(const nafp_encoder* e, int64_t B, void* ws) {
     L.dA = (float*)take((int64_t)sizeof(float) * max_n * B);
     L.dB = (float*)take((int64_t)sizeof(float) * max_n * B);
     L.dy = (float*)take((int64_t)sizeof(float) * e->emb_sz * B);
+    // The layers whose weight gradient runs on the second stream (P < 16: 61 KB per sample together) keep their incoming gradient /
+    // dts in a buffer of their own instead of the dA / dB pair: nothing overwrites it during the pass, so the main stream never
+    // has to wait for the weight-gradient stream before a transposed conv (a wait is a barrier packet in its queue: ~14 us of
+    // idle each, six per step).
+    for (int j = 0; j < 16; ++j) {
+        const int64_t n = (int64_t)e->geom[j].Fout * e->geom[j].Tout * e->geom[j].Cout;
+        L.dts[j] = (j >= 1 && e->geom[j].Fout * e->geom[j].Tout < 16) ? (float*)take((int64_t)sizeof(float) * n * B) : nullptr;
+    }
     L.bytes = (p - p0) + 256;
     return L;
 }
@@ -643,9 +681,12 @@ extern "C" int nafp_encoder_forward_train(nafp_encoder* e, const float* feat, in
     hipStream_t st = (hipStream_t)stream;
     TrainLayout L = train_layout(e, n_seg, workspace);
     NAFP_HIP_CHECK(hipMemsetAsync(L.stats, 0, (char*)(L.tickets + 2 * NAFP_TICKET_SLOTS) - (char*)L.stats, st));
+    static const bool split_wait = []() { const char* v = getenv("NAFP_SW_SPLIT_WAIT"); return !v || v[0] != '0'; }();
+    { int wrc = wait_weights(e, st, !split_wait); if (wrc != NAFP_OK) return wrc; }
     // (layer 0 keeps no pre-activation: the backward pass regenerates it from `feat`, 3 FMAs per element)
     int rc = launch_conv0(feat, e->d_w[0], e->d_bias[0], e->d_gamma[0], L.z[0], nullptr, L.stats, n_seg, e->geom[0], st);
     if (rc != NAFP_OK) return rc;
+    if (split_wait) { int wrc = wait_weights(e, st, true); if (wrc != NAFP_OK) return wrc; }
     for (int j = 1; j < 16; ++j) {
         ConvGemmArgs a{};
         a.x = L.z[j - 1]; a.stats_in = L.stats + 2 * n_seg * (j - 1);
@@ -674,6 +715,7 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
     TrainLayout L = train_layout(e, B, workspace);
     for (size_t i = 0; i < e->shapes.size(); ++i)
         if (!grads[i]) return NAFP_ERR_INVALID_ARG;
+    { int wrc = wait_weights(e, st, true); if (wrc != NAFP_OK) return wrc; }
     // every gradient accumulates through atomics: zero them (adjacent tensors -- e.g. views into one flat
     // all-reduce bucket -- in one memset) together with the LN sums and S1/S2
     for (size_t i = 0; i < e->shapes.size();) {
@@ -708,19 +750,27 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
     TailBwdArgs tb;
     tb.z = L.z[15]; tb.stats = L.stats + 2 * B * 15; tb.gamma = e->d_gamma[15]; tb.beta = e->d_beta[15];
     tb.w1 = e->d_w1k; tb.b1 = e->d_b1k; tb.w2 = e->d_w2k; tb.b2 = e->d_b2;
-    tb.d_emb = d_emb; tb.dy = L.dy; tb.dxh = L.dA; tb.ln = L.sc;      // (L.sc is rewritten by the first ln_bwd_scalars launch, after the tail)
+    tb.w1p = e->d_w1p; tb.b1p = e->d_b1p; tb.w2p = e->d_w2p;
+    // gradient buffers: layer j's incoming gradient (then dts_j, in place) lives in its own buffer when its weight gradient runs on
+    // the second stream (mode 2), else in dA / dB by parity
+    static const bool own_bufs = []() { const char* v = getenv("NAFP_SIDE_OWNBUF"); return !v || v[0] != '0'; }();
+    auto own = [&](int j) { return own_bufs && ov_mode == 2 && j >= 1 && side_layer(j) && L.dts[j] != nullptr; };
+    auto gbuf = [&](int j) { return own(j) ? L.dts[j] : ((j & 1) ? L.dA : L.dB); };
+    tb.d_emb = d_emb; tb.dy = L.dy; tb.dxh = gbuf(15); tb.ln = L.sc;      // (L.sc is rewritten by the first ln_bwd_scalars launch, after the tail)
     tb.dw1 = grads[64]; tb.db1 = grads[65]; tb.dw2 = grads[66]; tb.db2 = grads[67];
     tb.D = (int)e->flat_dim; tb.Q = e->emb_sz; tb.S = e->S; tb.l2norm = l2norm;
     rc = launch_tail_bwd(tb, B, st);
     if (rc != NAFP_OK) return rc;
     // `cur` holds r_j * dL/dxhat_j on entry of iteration j and r_{j-1} * dL/dt_j (dts) after launch_ln_bwd
-    float* cur = L.dA; float* other = L.dB;
+    float* cur = gbuf(15); float* other = nullptr;
+    static const bool ride = []() { const char* v = getenv("NAFP_SIDE_RIDE"); return !v || v[0] != '0'; }();
     bool ln_done = false;       // `cur` already holds dts_j (the LayerNorm backward of layer j ran inside dgrad_{j+1})
     bool sc_ready = false;      // L.sc already holds the scalar records of layer j (side job of wgrad_{j+1})
     for (int j = 15; j >= 1; --j) {
         const ConvGeom& g = e->geom[j];
         const int P = g.Fout * g.Tout;
         const float* mr_j = L.mr + 2 * B * j; const float* mr_p = L.mr + 2 * B * (j - 1);
+        other = gbuf(j - 1);
         if (!ln_done) {
             rc = launch_ln_bwd(cur, L.v[j] ? L.v[j] : L.z[j], e->d_gamma[j], mr_j, mr_p, L.lnsum[j], L.sc, grads[4 * j + 2], grads[4 * j + 3],
                                grads[4 * j + 1], L.S1[j], L.S2[j], B, P, g.Cout, st, j == 15, e->d_G[j], e->d_Hb[j], L.lnsum[j - 1],
@@ -728,9 +778,9 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
                                L.tickets, L.v[j] == nullptr);
             if (rc != NAFP_OK) return rc;
         }
-        // the transposed conv below writes `other`, which still holds dts_{j+1}: wgrad(j+1), on the weight-gradient stream,
-        // must be done with it
-        if (j < 15 && side_layer(j + 1)) NAFP_HIP_CHECK(hipStreamWaitEvent(st, e->ev_side[j + 1], 0));
+        // the transposed conv below writes `other`; where that is the dA / dB buffer that still holds dts_{j+1}, wgrad(j+1), on the
+        // weight-gradient stream, must be done with it (not with buffers of their own: see TrainLayout::dts)
+        if (j < 15 && side_layer(j + 1) && !own(j + 1)) NAFP_HIP_CHECK(hipStreamWaitEvent(st, e->ev_side[j + 1], 0));
         const bool on_side = side_layer(j);
         hipStream_t sw = on_side ? e->side_stream : st;
         const ConvGeom& gp1 = e->geom[j - 1];
@@ -757,6 +807,9 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
             a.slab = L.slab_floats ? L.slab : nullptr; a.slab_floats = L.slab_floats;
             a.tickets = overlap ? nullptr : L.tickets;      // split-K finished in-kernel (mode 1: the side stream's wgrad shares the counters)
             a.sj = &sj;                                     // side job: the scalar records of layer j - 1
+            // the weight-gradient stream starts behind this launch: its event rides on the launch's last dispatch packet
+            // (hipExtLaunchKernel) instead of a record of its own in the queue (~7 us of idle each)
+            if (on_side && ride) a.ev_stop = e->ev_main[j];
             rc = launch_conv_gemm(a, B, g, st);
             if (rc != NAFP_OK) return rc;
             sc_ready = true;
@@ -765,7 +818,7 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
         // stream it starts BEHIND the transposed conv of this layer (two MFMA-bound kernels side by side only share the
         // pipes) and so runs next to the LayerNorm backward of layer j-1, which is HBM-bound and next on the main stream.
         if (on_side) {
-            NAFP_HIP_CHECK(hipEventRecord(e->ev_main[j], st));
+            if (ln_done || !ride) NAFP_HIP_CHECK(hipEventRecord(e->ev_main[j], st));
             NAFP_HIP_CHECK(hipStreamWaitEvent(sw, e->ev_main[j], 0));
         }
         float* w_slab = !on_side ? L.slab : (ov_mode == 2 ? L.slab2 : nullptr);
@@ -787,7 +840,7 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
             if (rc != NAFP_OK) return rc;
         }
         if (on_side) NAFP_HIP_CHECK(hipEventRecord(e->ev_side[j], sw));
-        std::swap(cur, other);
+        cur = other;
         // layers j .. 15 (and the divide-and-encode tensors) are final from here on (when the LayerNorm backward of layer
         // j-1 ran fused, its dgamma / dbeta / dbias are final too: they belong to the next group or are simply early)
         // (with the weight-gradient stream the event is recorded THERE: behind wgrad(j), and -- through ev_main[j] -- behind

@@ -114,7 +114,11 @@ struct Conv0Regen { const float* feat; const float* w3; const float* bias; float
 // t = v (v > 0) or log(v + 1) for the adjoint-identity sum of the layer below -- there t only ever appears multiplied by
 // dts, which carries the factor v + 1, so the saturated end (v -> -1, t -> -inf) contributes (v+1) log(v+1) -> 0.
 // Saves the second store stream of every training forward conv (~10 % of its time) and 4.6 MB per segment of workspace.
-template <bool CONV0, bool FROMZ = false>
+// WAVE (the small layers, n <= 4096 elements per sample): a workgroup covers 64 float4 columns instead of 256, and its four
+// waves take a quarter each of the workgroup's batch chunk.  Same number of threads, same samples per thread, but the four waves'
+// sums meet in LDS first, so a launch ends in a quarter of the atomics (they are what such a launch mostly consists of: 32
+// chunks x 5 atomics per element onto the same addresses at ~33 G/s).
+template <bool CONV0, bool FROMZ = false, bool WAVE = false>
 __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
         float* __restrict__ d, const float* __restrict__ tpre, const float* __restrict__ gamma,
         const float* __restrict__ sc, float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -122,20 +126,23 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
         const float* __restrict__ Gj, const float* __restrict__ Hbj, double* __restrict__ lnsum_below, const Conv0Regen c0,
         float* __restrict__ part_slab, unsigned* __restrict__ tickets) {
     extern __shared__ float s_q[];                                 // [per][2]: (s1, s2) of the layer below, this block's share
-    const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = WAVE ? blockIdx.x * 64ll + lane : blockIdx.x * 256ll + threadIdx.x;
     const bool live = i < n / 4;
     const int64_t ii = live ? i : 0;
     const int64_t per = (B + gridDim.y - 1) / gridDim.y;
-    const int64_t b0 = blockIdx.y * per, b1 = std::min<int64_t>(B, b0 + per);
+    const int64_t B0 = blockIdx.y * per, B1 = std::min<int64_t>(B, B0 + per);           // the workgroup's batch chunk
+    const int64_t per_w = WAVE ? (B1 - B0 + 3) / 4 : 0;                                   // WAVE: this wave's quarter of it
+    const int64_t b0 = WAVE ? std::min<int64_t>(B1, B0 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * per_w) : B0;   // (wave-uniform: scalar loads of the sample records)
+    const int64_t b1 = WAVE ? std::min<int64_t>(B1, b0 + per_w) : B1;
     const float4 gg = ((const float4*)gamma)[ii];
     const float4 rgg = FROMZ ? make_float4(1.f / gg.x, 1.f / gg.y, 1.f / gg.z, 1.f / gg.w) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 Gq = make_float4(0.f, 0.f, 0.f, 0.f), Hq = Gq;
-    if (lnsum_below) {
+    if (!CONV0 && lnsum_below) {
         Gq = ((const float4*)Gj)[ii]; Hq = ((const float4*)Hbj)[ii];
         for (int64_t k = threadIdx.x; k < 2 * per; k += 256) s_q[k] = 0.f;
         __syncthreads();
     }
-    const int lane = threadIdx.x & 63;
     // CONV0: this thread's position (f, to), its 4 channels' kernel taps and bias
     float4 k0 = make_float4(0.f, 0.f, 0.f, 0.f), k1 = k0, k2 = k0, kb = k0;
     int x_off = 0; bool x_ok[3] = {false, false, false};
@@ -185,8 +192,11 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
             const float du = dd.c_ * inv_r;                                                 \
             ag.c_ = fmaf(du, xt, ag.c_); ab.c_ += du;                                       \
             o.c_ = dt * rprev;                                                              \
-            a1.c_ = fmaf(cprev, o.c_, a1.c_); a2.c_ += dt;                                  \
-            q1 = fmaf(o.c_, Gq.c_, q1); q2 = fmaf(o.c_, tv_l - Hq.c_, q2);                  \
+            a2.c_ += dt;                                                                    \
+            if constexpr (!CONV0) {                    /* (layer 0 has no layer below: S1, the sums below and G / Hb are not formed) */ \
+                a1.c_ = fmaf(cprev, o.c_, a1.c_);                                           \
+                q1 = fmaf(o.c_, Gq.c_, q1); q2 = fmaf(o.c_, tv_l - Hq.c_, q2);              \
+            }                                                                               \
         }
 #define NAFP_LN_WORK(G_, bq_)                                                                                  \
     _Pragma("unroll") for (int u = 0; u < UNR; ++u) {                                                          \
@@ -213,13 +223,13 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
             gw2.x = fmaf(x2, o.x, gw2.x); gw2.y = fmaf(x2, o.y, gw2.y); gw2.z = fmaf(x2, o.z, gw2.z); gw2.w = fmaf(x2, o.w, gw2.w); \
         }                                                                                                      \
         if (live && !(CONV0 && c0.dW0)) *dp = o;               /* (nothing reads dts_0 once dW0 is formed here) */ \
-        if (lnsum_below) {                                                                                     \
+        if (!CONV0 && lnsum_below) {                                                                           \
             /* wave sums of (q1, q2) in 7 shuffles: fold the halves, then q1 lives in lanes 0..31 and q2 in 32..63 */ \
             if (!live) { q1 = 0.f; q2 = 0.f; }                                                                 \
             q1 += __shfl_xor(q1, 32, 64); q2 += __shfl_xor(q2, 32, 64);                                        \
             float x = lane < 32 ? q1 : q2;                                                                     \
             _Pragma("unroll") for (int o2 = 16; o2 > 0; o2 >>= 1) x += __shfl_xor(x, o2, 64);                  \
-            if ((lane & 31) == 0) atomicAdd(s_q + 2 * (b - b0) + (lane >> 5), x);                              \
+            if ((lane & 31) == 0) atomicAdd(s_q + 2 * (b - B0) + (lane >> 5), x);                              \
         }                                                                                                      \
     }
     if (CONV0) {
@@ -242,10 +252,33 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
 #undef NAFP_LN_ONE
 #undef NAFP_LN_WORK
 #undef NAFP_LN_LOAD
-    if (lnsum_below) {
+    if (!CONV0 && lnsum_below) {
         __syncthreads();
-        for (int64_t k = threadIdx.x; k < 2 * (b1 - b0); k += 256)
-            atomicAdd(lnsum_below + 2 * b0 + k, (double)s_q[k]);
+        for (int64_t k = threadIdx.x; k < 2 * (B1 - B0); k += 256)
+            atomicAdd(lnsum_below + 2 * B0 + k, (double)s_q[k]);
+    }
+    if constexpr (WAVE) {
+        // wave w adds up array w (dgamma, dbeta, S1, S2) of this block's 64 columns over the four waves; the S2 sums are also the
+        // block's share of dbias (a block of 256 consecutive elements lies in one position: C % 256 == 0, distinct channels per lane)
+        __shared__ float4 wred[4][256];
+        wred[0][threadIdx.x] = ag; wred[1][threadIdx.x] = ab; wred[2][threadIdx.x] = a1; wred[3][threadIdx.x] = a2;
+        __syncthreads();
+        const int wv = threadIdx.x >> 6;
+        if (live) {
+            float4 t = wred[wv][lane];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                const float4 u = wred[wv][64 * k + lane];
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            float* o = (wv == 0 ? dgamma : (wv == 1 ? dbeta : (wv == 2 ? S1 : S2))) + 4 * i;
+            atomicAdd(o, t.x); atomicAdd(o + 1, t.y); atomicAdd(o + 2, t.z); atomicAdd(o + 3, t.w);
+            if (wv == 3) {
+                float* ob = dbias + (4 * i) % C;
+                atomicAdd(ob, t.x); atomicAdd(ob + 1, t.y); atomicAdd(ob + 2, t.z); atomicAdd(ob + 3, t.w);
+            }
+        }
+        return;
     }
     if (part_slab) {
         // The batch chunks (blockIdx.y) of a block of 1024 elements meet through a slab instead of 4 fp32 atomics per element
@@ -253,14 +286,14 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
         // chunk writes its (dgamma, dbeta, S1, S2) partials through the caches, draws the block's arrival ticket, and the
         // LAST arriver adds the parts in chunk order and stores the four tensors once -- deterministic as a by-product.
         typedef int v4i __attribute__((ext_vector_type(4)));
-        const int n_arr = S1 ? 4 : 2;
+        const int n_arr = (!CONV0 && S1) ? 4 : 2;
         const int64_t blk_floats = (int64_t)gridDim.y * n_arr * 1024;                   // per x-block: [chunk][array][1024]
         float* base = part_slab + (int64_t)blockIdx.x * blk_floats;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(blk_floats * 4), 0x00020000);
         const int my = ((int)blockIdx.y * n_arr * 1024 + 4 * (int)threadIdx.x) * 4;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, ag), rs, my, 0, 17);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, ab), rs, my + 4096, 0, 17);
-        if (S1) {
+        if (!CONV0 && S1) {
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, a1), rs, my + 8192, 0, 17);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, a2), rs, my + 12288, 0, 17);
         }
@@ -284,13 +317,13 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
                 }
             }
             *(float4*)(dgamma + 4 * i) = t4[0]; *(float4*)(dbeta + 4 * i) = t4[1];
-            if (S1) { *(float4*)(S1 + 4 * i) = t4[2]; *(float4*)(S2 + 4 * i) = t4[3]; }
+            if (!CONV0 && S1) { *(float4*)(S1 + 4 * i) = t4[2]; *(float4*)(S2 + 4 * i) = t4[3]; }
         }
     } else if (live) {
         float* g = dgamma + 4 * i; float* bt = dbeta + 4 * i;
         atomicAdd(g, ag.x); atomicAdd(g + 1, ag.y); atomicAdd(g + 2, ag.z); atomicAdd(g + 3, ag.w);
         atomicAdd(bt, ab.x); atomicAdd(bt + 1, ab.y); atomicAdd(bt + 2, ab.z); atomicAdd(bt + 3, ab.w);
-        if (S1) {
+        if (!CONV0 && S1) {
             float* o1 = S1 + 4 * i; float* o2 = S2 + 4 * i;
             atomicAdd(o1, a1.x); atomicAdd(o1 + 1, a1.y); atomicAdd(o1 + 2, a1.z); atomicAdd(o1 + 3, a1.w);
             atomicAdd(o2, a2.x); atomicAdd(o2 + 1, a2.y); atomicAdd(o2 + 2, a2.z); atomicAdd(o2 + 3, a2.w);
@@ -1117,13 +1150,15 @@ __device__ __forceinline__ void tail_slice_forward(const TailBwdArgs& a, int64_t
         x[i] = fmaf(lnA, a.z[b * a.D + d], fmaf(lnC, a.gamma[d], a.beta[d]));
     }
     y = a.b2[q];
+    // (thread <-> slice q: the packed layouts put the Q slices of one (i, j) side by side -- with the keras layout every
+    // load touched 64 cache lines, which is what this kernel's time consisted of)
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
-        float h = a.b1[q * 32 + j];
+        float h = a.b1p[j * a.Q + q];
 #pragma unroll
-        for (int i = 0; i < S; ++i) h = fmaf(x[i], a.w1[(q * S + i) * 32 + j], h);
+        for (int i = 0; i < S; ++i) h = fmaf(x[i], a.w1p[(i * 32 + j) * a.Q + q], h);
         act[j] = h;                                              // pre-activation
-        y = fmaf(elu1(h), a.w2[q * 32 + j], y);
+        y = fmaf(elu1(h), a.w2p[j * a.Q + q], y);
     }
 }
 
@@ -1158,9 +1193,9 @@ __global__ __launch_bounds__(256) void tail_bwd_a_kernel(const TailBwdArgs a) {
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
         const float h = act[j];
-        const float da = dyq * a.w2[q * 32 + j] * (h > 0.f ? 1.f : __expf(h));
+        const float da = dyq * a.w2p[j * Q + q] * (h > 0.f ? 1.f : __expf(h));
 #pragma unroll
-        for (int i = 0; i < S; ++i) dx[i] = fmaf(a.w1[(q * S + i) * 32 + j], da, dx[i]);
+        for (int i = 0; i < S; ++i) dx[i] = fmaf(a.w1p[(i * 32 + j) * Q + q], da, dx[i]);
     }
 #pragma unroll
     for (int i = 0; i < S; ++i) a.dxh[b * a.D + q * S + i] = lnA * dx[i];      // r_b * dL/dxhat: ln_bwd_fused's convention
@@ -1176,6 +1211,7 @@ __global__ __launch_bounds__(256) void tail_bwd_b_kernel(const TailBwdArgs a, in
     float aw1[NI], ab1 = 0.f, aw2 = 0.f, ab2 = 0.f;
 #pragma unroll
     for (int t = 0; t < NI; ++t) aw1[t] = 0.f;
+#pragma unroll 4
     for (int64_t b = bb0; b < bb1; ++b) {
         const float lnA = a.ln[2 * b], lnC = a.ln[2 * b + 1];     // (a double sqrt + divide per thread and sample were most of this kernel)
         float x[S];
@@ -1268,7 +1304,10 @@ int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* 
     // batch chunks: every chunk ends in 5 atomics per element (~33 G atomics/s measured), which is what a
     // small layer pays for; 256..1024 workgroups keep the streaming layers at HBM speed
     const int64_t bx = n / 1024;
-    static const int64_t wg_target = []() { const char* e = getenv("NAFP_LNB_WGS"); return e ? atoll(e) : (int64_t)256; }();
+    // (B >= 4096: the chunks are >= 64 samples long whatever their number, and layers 2-5 at 256-512 workgroups ran one wave per
+    // SIMD: 2048 measured 86.5 -> 86.2 ms per step at B = 5120; at B = 640 / 1280 more chunks cost more than they gain)
+    static const int64_t wg_env = []() { const char* e = getenv("NAFP_LNB_WGS"); return e ? atoll(e) : (int64_t)0; }();
+    const int64_t wg_target = wg_env > 0 ? wg_env : (B >= 4096 ? 2048 : 256);
     // at least 4 batch chunks -- 2 for the two largest layers at a small batch (>= 512 workgroups either way; measured at
     // B = 640: layer 0 377 -> 321 us, layer 1 422 -> 402; at B = 5120 the halved chunk count costs layer 0 4 %): NAFP_LNB_MINBY overrides
     static const int64_t min_by_env = []() { const char* e = getenv("NAFP_LNB_MINBY"); return e ? atoll(e) : (int64_t)0; }();
@@ -1288,6 +1327,18 @@ int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* 
     if (!(slab_on && bx >= 8 && part_slab && tickets && bx <= NAFP_TICKET_SLOTS && bx * by * 4 * 1024 <= part_slab_floats &&
           bx * by * 4 * 1024 * 4 < ((int64_t)1 << 31))) { part_slab = nullptr; tickets = nullptr; }
     Conv0Regen c0{};
+    // the small layers: four waves of a workgroup share its batch chunk (ln_bwd_fused_kernel<.., WAVE>); NAFP_LNB_WAVE_MAXN=0 turns it off
+    static const int64_t wave_maxn = []() { const char* e = getenv("NAFP_LNB_WAVE_MAXN"); return e ? atoll(e) : (int64_t)4096; }();
+    static const int64_t wave_spw = []() { const char* e = getenv("NAFP_LNB_WAVE_SPW"); return e && atoll(e) > 0 ? atoll(e) : (int64_t)20; }();
+    if (!feat0 && tpre_is_z && S1 && S2 && n <= wave_maxn && C % 256 == 0) {
+        int byw = (int)std::max<int64_t>(1, std::min<int64_t>(64, B / (4 * wave_spw)));
+        while (lnsum_below && (B + byw - 1) / byw * 8 > 32768 && byw < B) byw *= 2;
+        const size_t ldsw = lnsum_below ? (size_t)((B + byw - 1) / byw) * 2 * sizeof(float) : 0;
+        ln_bwd_fused_kernel<false, true, true><<<dim3((unsigned)(n / 256), byw), 256, ldsw, st>>>(d, tpre, gamma, sc, dgamma, dbeta, dbias, S1, S2, n, B,
+                                                                                            C, Gj, Hbj, lnsum_below, c0, nullptr, nullptr);
+        NAFP_LAUNCH_CHECK();
+        return NAFP_OK;
+    }
     if (feat0) {
         if (!g0 || g0->Cin != 1 || g0->axis != 0 || g0->Cout != C || g0->Fout * g0->Tout != P || reduce_here) return NAFP_ERR_INVALID_ARG;
         if (dW0 && C / 4 > 256) return NAFP_ERR_UNSUPPORTED;

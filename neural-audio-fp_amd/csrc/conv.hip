@@ -1769,8 +1769,9 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     if (rc != NAFP_OK || S == 1 || in_kernel_finish) return rc;
     if (a.plain) {
         const int64_t n4 = out_floats / 4;
-        plain_finish_kernel<<<dim3((unsigned)std::min<int64_t>((n4 + 255) / 256, 8192)), 256, 0, st>>>(a.slab, S, a.bias, a.y, n4,
-                                                                                                    p.Cout);
+        const dim3 fgrid((unsigned)std::min<int64_t>((n4 + 255) / 256, 8192));
+        if (a.ev_stop) hipExtLaunchKernelGGL(plain_finish_kernel, fgrid, dim3(256), 0, st, nullptr, a.ev_stop, 0, (const float*)a.slab, S, a.bias, a.y, n4, p.Cout);
+        else plain_finish_kernel<<<fgrid, 256, 0, st>>>(a.slab, S, a.bias, a.y, n4, p.Cout);
         NAFP_LAUNCH_CHECK();
         return NAFP_OK;
     }

@@ -179,6 +179,7 @@ int launch_tail(const TailArgs& a, int64_t B, hipStream_t st);
 struct TailBwdArgs {
     const float* z; const stat_t* stats; const float* gamma; const float* beta;     // last conv (z = gamma . v)
     const float* w1; const float* b1; const float* w2; const float* b2;             // keras layouts
+    const float* w1p; const float* b1p; const float* w2p;                           // the forward tail's layouts (S,32,Q) / (32,Q): kernel A, thread <-> q, reads them coalesced
     const float* d_emb;                                                             // (B,Q)
     float* dy;            // (B,Q) scratch
     float* ln;            // (B,2) scratch: the last conv's LayerNorm scalars (r_b, -mu_b r_b) per sample, written by kernel A for kernel B

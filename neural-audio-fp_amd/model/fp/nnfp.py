@@ -134,9 +134,10 @@ class FingerPrinter:
         """Push replaced / modified variables to the library, ordered against every stream that uses
         the handle: the re-pack (copy, pack, G/Hb launches) writes the handle's shared packed-weight
         blob, so (i) it first waits for the forwards still running on OTHER streams, and (ii) every later
-        forward waits for its completion event before it reads the blob (`_wait_weights`)."""
+        pass on another stream waits for it INSIDE the library (`nafp_encoder_set_weights` records an event
+        after its plain copies and one at its end; the passes wait for the one they need right before the
+        first launch that needs it -- the training forward starts its first conv behind the copies only)."""
         if not self._dirty:
-            self._wait_weights()
             return
         cur = torch.cuda.current_stream(self.device)
         self._wait_weights()               # a re-pack still in flight on another stream (prefetch_weights) writes the same blob: behind it

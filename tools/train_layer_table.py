@@ -26,11 +26,18 @@ for r in step[c0 + 1:tail]:
     elif 'splitk_finish' in n and fwd:
         fwd[-1][1] += us(r)
 print('forward:  ' + '  '.join(f'c{j}:{t:.0f}us/{2 * macs[j] * B / t / 1e6:.0f}TF' for j, t in fwd))
+# weight gradients of the small layers run on a side stream (NAFP_OPT_BWD_OVERLAP=2), one layer behind the main
+# stream's LayerNorm backward: they are attributed by their own launch order (15, 14, ...) and marked '*' -- their
+# durations overlap the main stream's kernels and are not additive
+main = next(r.get('Stream_Id') for r in step[tail + 1:] if 'ln_bwd_fused' in r['Kernel_Name'])
+side = [us(r) for r in step[tail + 1:] if 'wgrad' in r['Kernel_Name'] and r.get('Stream_Id') != main]
 layer, cur, out = 15, {'ln': 0.0, 'wg': 0.0, 'dg': 0.0}, []
 for r in step[tail + 1:]:
     n = r['Kernel_Name']
+    if 'wgrad' in n and r.get('Stream_Id') != main:
+        continue
     if 'ln_bwd_fused' in n:
-        if cur['ln'] or cur['wg']:
+        if cur['ln']:
             out.append((layer, cur)); layer -= 1; cur = {'ln': 0.0, 'wg': 0.0, 'dg': 0.0}
         cur['ln'] += us(r)
     elif 'wgrad' in n:
@@ -44,4 +51,7 @@ for l, c in out:
         print(f'  {l:2d}  {c["ln"]:9.1f}')
         continue
     m = 2 * macs[l] * B / 1e6
-    print(f'  {l:2d}  {c["ln"]:9.1f}  {c["wg"]:9.1f} ({m / max(c["wg"], 1e-9):5.0f})  {c["dg"]:9.1f} ({m / max(c["dg"], 1e-9):5.0f})')
+    star = ' '
+    if 15 - l < len(side) and not c['wg']:
+        c['wg'], star = side[15 - l], '*'
+    print(f'  {l:2d}  {c["ln"]:9.1f}  {c["wg"]:9.1f}{star}({m / max(c["wg"], 1e-9):5.0f})  {c["dg"]:9.1f} ({m / max(c["dg"], 1e-9):5.0f})')
