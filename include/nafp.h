@@ -136,8 +136,8 @@ int64_t nafp_encoder_flat_dim(const nafp_encoder* enc);    /* F'*T'*C of front_c
  * Ordering: the call may be given a stream of its own.  Every later pass of this handle on a
  * DIFFERENT stream (forward*, div_enc, forward_train, backward) waits on the device for what it
  * reads of this call's output -- the training forward starts its first conv as soon as the plain
- * copies are done and only its second conv behind the whole re-pack --, so the caller does not
- * order them.  What the caller still orders: this call behind the passes enqueued EARLIER on
+ * copies are done, its second behind layer 1's share (formed first) and only its third behind the
+ * whole re-pack --, so the caller does not order them.  What the caller still orders: this call behind the passes enqueued EARLIER on
  * other streams (they read the blob it overwrites), and behind whatever produced `tensors`. */
 int nafp_encoder_set_weights(nafp_encoder* enc, const float* const* tensors_host_array,
                              void* stream);

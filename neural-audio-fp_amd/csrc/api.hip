@@ -92,9 +92,11 @@ struct nafp_encoder {
     // prefetch_weights): `sw_copied` = the plain copies are done (conv0 reads nothing else: its kernel, bias and gamma_0),
     // `sw_done` = everything is (packed kernels, G / Hb, the divide-and-encode re-layout).  A pass on another stream waits for
     // the event it needs right before the first launch that needs it (wait_weights): the training forward starts conv0 behind
-    // `sw_copied` and conv1 behind `sw_done`, so the ~0.3 ms chain of small G / Hb launches runs under conv0 instead of in front
-    // of it (B = 640: the main stream sat idle for 0.19 ms per step waiting for it).  Same stream: no wait is enqueued.
-    hipEvent_t sw_copied = nullptr, sw_done = nullptr;
+    // `sw_copied`, conv1 behind `sw_l1` (set_weights forms layer 1's G / Hb first, on its own stream) and conv2 behind `sw_done`,
+    // so the ~0.3 ms chain of small G / Hb launches runs under conv0 and conv1 instead of in front of them (B = 640: the main
+    // stream sat idle for 0.19 ms per step waiting for it; next to conv0, which saturates the HBM write path, the chain stretches
+    // to 0.4 ms, hence the third event).  Same stream: no wait is enqueued.
+    hipEvent_t sw_copied = nullptr, sw_l1 = nullptr, sw_done = nullptr;      // (sw_l1: conv1's packed kernel and G / Hb are done too)
     hipStream_t sw_stream = nullptr;
     bool sw_recorded = false;
     // NAFP_OPT_FUSE_CONV0 (default: NAFP_FUSE0 env, else off).  Re-measured in round 4 on the current kernels (B = 640, same
@@ -293,6 +295,7 @@ extern "C" int nafp_encoder_destroy(nafp_encoder* e) {
     for (auto& ev : e->sw_join) if (ev) (void)hipEventDestroy(ev);
     if (e->sw_fork) (void)hipEventDestroy(e->sw_fork);
     if (e->sw_copied) (void)hipEventDestroy(e->sw_copied);
+    if (e->sw_l1) (void)hipEventDestroy(e->sw_l1);
     if (e->sw_done) (void)hipEventDestroy(e->sw_done);
     delete e;
     return NAFP_OK;
@@ -349,6 +352,7 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
     if (!e->sw_copied) {
         NAFP_HIP_CHECK(hipEventCreateWithFlags(&e->sw_copied, hipEventDisableTiming));
         NAFP_HIP_CHECK(hipEventCreateWithFlags(&e->sw_done, hipEventDisableTiming));
+        NAFP_HIP_CHECK(hipEventCreateWithFlags(&e->sw_l1, hipEventDisableTiming));
     }
     e->sw_recorded = false;                 // (an early return below leaves the passes without events to wait for: the caller got an error)
     multi_copy_kernel<<<dim3(32, ct.count), 256, 0, st>>>(ct);
@@ -366,13 +370,32 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
     // positional epilogue terms of conv j: G = conv_j(gamma_{j-1}), Hb = conv_j(beta_{j-1}) + bias_j:
     // one 2-"sample" PLAIN launch per conv (gamma | beta adjacent in, G | Hb adjacent out), then all biases at once
     BiasTable bt; bt.count = 0;
-    constexpr int NS = nafp_encoder::NAFP_SW_STREAMS;
+    // (NAFP_SW_NSTREAMS: how many of the helper streams are used, 1..4; NAFP_SW_GEMV_OWN=1: the weight-streaming launch on the
+    // caller's stream itself instead of the last helper)
+    static const int ns_env = []() { const char* v = getenv("NAFP_SW_NSTREAMS"); return v ? atoi(v) : nafp_encoder::NAFP_SW_STREAMS; }();
+    static const bool gemv_own = []() { const char* v = getenv("NAFP_SW_GEMV_OWN"); return v && v[0] == '1'; }();
+    const int NS = std::max(1, std::min<int>(nafp_encoder::NAFP_SW_STREAMS, ns_env));
     if (!e->sw_fork) {
         NAFP_HIP_CHECK(hipEventCreateWithFlags(&e->sw_fork, hipEventDisableTiming));
         for (int k = 0; k < NS; ++k) {
             NAFP_HIP_CHECK(hipStreamCreateWithFlags(&e->sw_streams[k], hipStreamNonBlocking));
             NAFP_HIP_CHECK(hipEventCreateWithFlags(&e->sw_join[k], hipEventDisableTiming));
         }
+    }
+    // layer 1 first, on the caller's stream: the training forward's conv1 waits for this much only (sw_l1)
+    bool l1_done = false;
+    if (!gh_gemv_eligible(e->geom[1])) {
+        ConvGemmArgs a{};
+        a.wp = e->d_w[1]; a.plain = true; a.x = e->d_gamma[0]; a.bias = nullptr; a.y = e->d_G[1];
+        a.slab = e->sw_slab_floats ? e->d_sw_slab : nullptr; a.slab_floats = e->sw_slab_floats;
+        int rc1 = launch_conv_gemm(a, 2, e->geom[1], st);
+        if (rc1 != NAFP_OK) return rc1;
+        BiasTable b1; b1.count = 1;
+        b1.hb[0] = e->d_Hb[1]; b1.bias[0] = e->d_bias[1]; b1.n[0] = numel(e->shapes[4 * 1 + 2]); b1.cout[0] = e->geom[1].Cout;
+        add_bias_kernel<<<dim3(32, 1), 256, 0, st>>>(b1);
+        NAFP_LAUNCH_CHECK();
+        l1_done = true;
+        NAFP_HIP_CHECK(hipEventRecord(e->sw_l1, st));
     }
     NAFP_HIP_CHECK(hipEventRecord(e->sw_fork, st));                         // copies and re-packs above are done
     // Between the fork and the join nothing returns early: whatever fails, the helper streams are joined back into the
@@ -393,12 +416,12 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
             bt.hb[bt.count] = e->d_Hb[j]; bt.bias[bt.count] = e->d_bias[j];
             bt.n[bt.count] = numel(e->shapes[4 * j + 2]); bt.cout[bt.count] = e->geom[j].Cout; ++bt.count;
         }
-    if (fork_rc == NAFP_OK && forked == NS) fork_rc = launch_gh_gemv(gh, e->sw_streams[NS - 1]);
+    if (fork_rc == NAFP_OK && forked == NS) fork_rc = launch_gh_gemv(gh, gemv_own ? st : e->sw_streams[NS - 1]);
     else for (int j = 1; j < 16; ++j) by_gemv[j] = false;              // (could not fork: everything through the tiled launches, bt rebuilt below)
     if (forked != NS) bt.count = 0;
     int n_tiled = 0;
     for (int j = 1; j < 16 && fork_rc == NAFP_OK; ++j) {
-        if (by_gemv[j]) continue;
+        if (by_gemv[j] || (j == 1 && l1_done)) continue;
         const int k = (n_tiled++) % NS;
         ConvGemmArgs a{};
         a.wp = e->d_w[j]; a.plain = true;
@@ -419,6 +442,7 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
     NAFP_LAUNCH_CHECK();
     int rc = launch_pack_div(t[64], t[65], t[66], e->d_w1p, e->d_b1p, e->d_w2p, e->emb_sz, e->S, st);
     if (rc != NAFP_OK) return rc;
+    if (!l1_done) NAFP_HIP_CHECK(hipEventRecord(e->sw_l1, st));
     NAFP_HIP_CHECK(hipEventRecord(e->sw_done, st));
     e->sw_stream = st; e->sw_recorded = true;
     e->has_weights = true;
@@ -426,9 +450,9 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
 }
 
 // A pass on stream `st` is about to read what the last set_weights wrote (all of it, or only the plain copies): see sw_copied / sw_done.
-static int wait_weights(nafp_encoder* e, hipStream_t st, bool all) {
+static int wait_weights(nafp_encoder* e, hipStream_t st, int stage = 2) {          // 0: the plain copies, 1: + layer 1, 2: everything
     if (!e->sw_recorded || st == e->sw_stream) return NAFP_OK;
-    NAFP_HIP_CHECK(hipStreamWaitEvent(st, all ? e->sw_done : e->sw_copied, 0));
+    NAFP_HIP_CHECK(hipStreamWaitEvent(st, stage == 0 ? e->sw_copied : (stage == 1 ? e->sw_l1 : e->sw_done), 0));
     return NAFP_OK;
 }
 
@@ -482,7 +506,7 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
     float* slab = (float*)((char*)bufB + align_up((int64_t)sizeof(float) * e->bufB_per_seg * n_seg, 256));
     int64_t slab_floats = 0;
     for (int j = 1; j < 16; ++j) slab_floats = std::max(slab_floats, conv_gemm_slab_floats(n_seg, e->geom[j]));
-    { int wrc = wait_weights(e, st, true); if (wrc != NAFP_OK) return wrc; }
+    { int wrc = wait_weights(e, st); if (wrc != NAFP_OK) return wrc; }
     NAFP_HIP_CHECK(hipMemsetAsync(stats, 0, stats_bytes, st));        // statistics + counters, one fill
     hipEvent_t* ev = nullptr;
     if (e->prof_max > 0 && e->prof_count < e->prof_max) ev = e->prof_events.data() + (size_t)NAFP_PROF_EV * e->prof_count++;
@@ -596,7 +620,7 @@ extern "C" int nafp_encoder_div_enc(nafp_encoder* e, const float* flat, int64_t 
     t.w1p = e->d_w1p; t.b1p = e->d_b1p; t.w2p = e->d_w2p; t.b2 = e->d_b2;
     t.out_flat = nullptr; t.out_emb = out_emb;
     t.D = (int)e->flat_dim; t.Q = e->emb_sz; t.S = e->S; t.l2norm = l2norm;
-    { int wrc = wait_weights(e, (hipStream_t)stream, true); if (wrc != NAFP_OK) return wrc; }
+    { int wrc = wait_weights(e, (hipStream_t)stream); if (wrc != NAFP_OK) return wrc; }
     return launch_tail(t, n_seg, (hipStream_t)stream);
 }
 
@@ -682,12 +706,12 @@ extern "C" int nafp_encoder_forward_train(nafp_encoder* e, const float* feat, in
     TrainLayout L = train_layout(e, n_seg, workspace);
     NAFP_HIP_CHECK(hipMemsetAsync(L.stats, 0, (char*)(L.tickets + 2 * NAFP_TICKET_SLOTS) - (char*)L.stats, st));
     static const bool split_wait = []() { const char* v = getenv("NAFP_SW_SPLIT_WAIT"); return !v || v[0] != '0'; }();
-    { int wrc = wait_weights(e, st, !split_wait); if (wrc != NAFP_OK) return wrc; }
+    { int wrc = wait_weights(e, st, split_wait ? 0 : 2); if (wrc != NAFP_OK) return wrc; }
     // (layer 0 keeps no pre-activation: the backward pass regenerates it from `feat`, 3 FMAs per element)
     int rc = launch_conv0(feat, e->d_w[0], e->d_bias[0], e->d_gamma[0], L.z[0], nullptr, L.stats, n_seg, e->geom[0], st);
     if (rc != NAFP_OK) return rc;
-    if (split_wait) { int wrc = wait_weights(e, st, true); if (wrc != NAFP_OK) return wrc; }
     for (int j = 1; j < 16; ++j) {
+        if (split_wait && j <= 2) { int wrc = wait_weights(e, st, j); if (wrc != NAFP_OK) return wrc; }
         ConvGemmArgs a{};
         a.x = L.z[j - 1]; a.stats_in = L.stats + 2 * n_seg * (j - 1);
         a.wp = e->d_w[j]; a.G = e->d_G[j]; a.Hb = e->d_Hb[j]; a.gamma_out = e->d_gamma[j];
@@ -715,7 +739,7 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
     TrainLayout L = train_layout(e, B, workspace);
     for (size_t i = 0; i < e->shapes.size(); ++i)
         if (!grads[i]) return NAFP_ERR_INVALID_ARG;
-    { int wrc = wait_weights(e, st, true); if (wrc != NAFP_OK) return wrc; }
+    { int wrc = wait_weights(e, st); if (wrc != NAFP_OK) return wrc; }
     // every gradient accumulates through atomics: zero them (adjacent tensors -- e.g. views into one flat
     // all-reduce bucket -- in one memset) together with the LN sums and S1/S2
     for (size_t i = 0; i < e->shapes.size();) {

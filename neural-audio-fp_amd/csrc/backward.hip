@@ -1142,27 +1142,6 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(
 //   kernel B (workgroup = slice x batch chunk, thread <-> (i, j)): batch-reduced weight gradients.
 // ============================================================================
 template <int S>
-__device__ __forceinline__ void tail_slice_forward(const TailBwdArgs& a, int64_t b, int q, float lnA, float lnC,
-                                                   float (&x)[S], float (&act)[32], float& y) {
-#pragma unroll
-    for (int i = 0; i < S; ++i) {
-        const int d = q * S + i;
-        x[i] = fmaf(lnA, a.z[b * a.D + d], fmaf(lnC, a.gamma[d], a.beta[d]));
-    }
-    y = a.b2[q];
-    // (thread <-> slice q: the packed layouts put the Q slices of one (i, j) side by side -- with the keras layout every
-    // load touched 64 cache lines, which is what this kernel's time consisted of)
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        float h = a.b1p[j * a.Q + q];
-#pragma unroll
-        for (int i = 0; i < S; ++i) h = fmaf(x[i], a.w1p[(i * 32 + j) * a.Q + q], h);
-        act[j] = h;                                              // pre-activation
-        y = fmaf(elu1(h), a.w2p[j * a.Q + q], y);
-    }
-}
-
-template <int S>
 __global__ __launch_bounds__(256) void tail_bwd_a_kernel(const TailBwdArgs a) {
     const int q = threadIdx.x, Q = a.Q;
     const int64_t b = blockIdx.x;
@@ -1172,8 +1151,25 @@ __global__ __launch_bounds__(256) void tail_bwd_a_kernel(const TailBwdArgs a) {
     const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
     const float lnA = (float)rstd, lnC = (float)(-mean * rstd);
     if (q == 0) { a.ln[2 * b] = lnA; a.ln[2 * b + 1] = lnC; }     // kernel B reads them instead of redoing the double arithmetic per thread
-    float x[S], act[32], y;
-    tail_slice_forward<S>(a, b, q, lnA, lnC, x, act, y);
+    float x[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        const int d = q * S + i;
+        x[i] = fmaf(lnA, a.z[b * a.D + d], fmaf(lnC, a.gamma[d], a.beta[d]));
+    }
+    // thread <-> slice q: the packed layouts (S,32,Q) / (32,Q) put the Q slices of one (i, j) side by side, so every load is one
+    // 256-B row per wave (the keras layout (Q,S,32) touched 64 cache lines per load).  The hidden pre-activation h_j is formed
+    // twice -- for y, then again for the gradient -- instead of kept: 32 live values per thread plus the weights the compiler then
+    // hoists spilled to scratch.
+    const float* w1q = a.w1p + q; const float* b1q = a.b1p + q; const float* w2q = a.w2p + q;
+    float y = a.b2[q];
+#pragma unroll 4
+    for (int j = 0; j < 32; ++j) {
+        float h = b1q[j * Q];
+#pragma unroll
+        for (int i = 0; i < S; ++i) h = fmaf(x[i], w1q[(i * 32 + j) * Q], h);
+        y = fmaf(elu1(h), w2q[j * Q], y);
+    }
     float dyq = a.d_emb[b * Q + q];
     if (a.l2norm) {
         __shared__ float red[2][8];
@@ -1190,12 +1186,15 @@ __global__ __launch_bounds__(256) void tail_bwd_a_kernel(const TailBwdArgs a) {
     float dx[S];
 #pragma unroll
     for (int i = 0; i < S; ++i) dx[i] = 0.f;
-#pragma unroll
+#pragma unroll 4
     for (int j = 0; j < 32; ++j) {
-        const float h = act[j];
-        const float da = dyq * a.w2p[j * Q + q] * (h > 0.f ? 1.f : __expf(h));
+        float w[S];
+        float h = b1q[j * Q];
 #pragma unroll
-        for (int i = 0; i < S; ++i) dx[i] = fmaf(a.w1p[(i * 32 + j) * Q + q], da, dx[i]);
+        for (int i = 0; i < S; ++i) { w[i] = w1q[(i * 32 + j) * Q]; h = fmaf(x[i], w[i], h); }
+        const float da = dyq * w2q[j * Q] * (h > 0.f ? 1.f : __expf(h));
+#pragma unroll
+        for (int i = 0; i < S; ++i) dx[i] = fmaf(w[i], da, dx[i]);
     }
 #pragma unroll
     for (int i = 0; i < S; ++i) a.dxh[b * a.D + q * S + i] = lnA * dx[i];      // r_b * dL/dxhat: ln_bwd_fused's convention
