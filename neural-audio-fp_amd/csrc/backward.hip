@@ -307,13 +307,23 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
             float4 t4[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a) t4[a] = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int y = 0; y < (int)gridDim.y; ++y) {
-                const int off = (y * n_arr * 1024 + 4 * (int)threadIdx.x) * 4;
+            // (chunks four at a time: the 16 loads of a group are issued before the first add -- the adds keep the chunk order)
+            const int ny = (int)gridDim.y;
+            for (int y0 = 0; y0 < ny; y0 += 4) {
+                float4 v[4][4];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    if (a >= n_arr) break;
-                    const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + a * 4096, 0, 17));
-                    t4[a].x += v.x; t4[a].y += v.y; t4[a].z += v.z; t4[a].w += v.w;
+                for (int u = 0; u < 4; ++u) {
+                    const int off = (std::min(y0 + u, ny - 1) * n_arr * 1024 + 4 * (int)threadIdx.x) * 4;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        v[u][a] = a < n_arr ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + a * 4096, 0, 17))
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (y0 + u >= ny) break;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) { t4[a].x += v[u][a].x; t4[a].y += v[u][a].y; t4[a].z += v[u][a].z; t4[a].w += v[u][a].w; }
                 }
             }
             *(float4*)(dgamma + 4 * i) = t4[0]; *(float4*)(dbeta + 4 * i) = t4[1];

@@ -19,7 +19,10 @@ print(f'step: {(int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"]
 c0 = next(i for i, r in enumerate(step) if 'conv0_kernel' in r['Kernel_Name'])
 tail = next(i for i, r in enumerate(step) if 'tail_kernel' in r['Kernel_Name'])
 fwd, j = [], 0
+main_fwd = step[c0].get('Stream_Id')          # (the re-pack of the weights runs next to conv0 / conv1 on other streams: not the forward's launches)
 for r in step[c0 + 1:tail]:
+    if r.get('Stream_Id') != main_fwd:
+        continue
     n = r['Kernel_Name']
     if 'conv_gemm' in n:
         j += 1; fwd.append([j, us(r)])
