@@ -21,6 +21,10 @@ SOURCES = ['api.hip', 'melspec.hip', 'conv.hip', 'tail.hip', 'ntxent.hip', 'opti
            'search.hip', 'augment.hip', 'triplet.hip']
 HEADERS = ['nafp_common.h', os.path.join('..', '..', 'include', 'nafp.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-result', '-fno-gpu-rdc']
+# the compiler's per-kernel resource remarks (VGPRs, scratch, occupancy) are kept next to every object (build/<src>.resources.txt;
+# tests/test_abi.py holds the kernels that must not spill to it): a kernel that starts spilling still computes the right thing,
+# just 5-10x slower
+RESOURCE_FLAG = '-Rpass-analysis=kernel-resource-usage'
 
 
 def _sha(paths, extra=''):
@@ -51,10 +55,18 @@ def build(force=False, verbose=True):
         tag_path = obj + '.sha'
         if not force and os.path.exists(obj) and os.path.exists(tag_path) and open(tag_path).read().strip() == tag:
             return obj
-        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+        cmd = [hipcc] + FLAGS + [RESOURCE_FLAG, '-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print('[nafp build]', ' '.join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
+        res = subprocess.run(cmd, check=False, stderr=subprocess.PIPE, text=True)
+        remarks = [ln for ln in res.stderr.splitlines() if 'kernel-resource-usage' in ln]
+        rest = [ln for ln in res.stderr.splitlines() if 'kernel-resource-usage' not in ln]
+        if rest:
+            print('\n'.join(rest), file=sys.stderr, flush=True)
+        if res.returncode != 0:
+            raise subprocess.CalledProcessError(res.returncode, cmd)
+        with open(obj[:-2] + '.resources.txt', 'w') as fh:
+            fh.write('\n'.join(ln.split('remark: ', 1)[-1].replace(' [-Rpass-analysis=kernel-resource-usage]', '') for ln in remarks) + '\n')
         with open(tag_path, 'w') as fh:
             fh.write(tag)
         return obj
@@ -68,6 +80,28 @@ def build(force=False, verbose=True):
     with open(STAMP, 'w') as fh:
         fh.write(want)
     return LIB
+
+
+def kernel_resources():
+    """{kernel symbol: {'VGPRs': .., 'ScratchSize [bytes/lane]': .., 'Occupancy [waves/SIMD]': .., ...}} from the last build."""
+    out = {}
+    for src in SOURCES:
+        path = os.path.join(OBJ, src[:-4] + '.resources.txt')
+        if not os.path.exists(path):
+            continue
+        name = None
+        for ln in open(path):
+            ln = ln.strip()
+            if ln.startswith('Function Name:'):
+                name = ln.split(':', 1)[1].strip()
+                out[name] = {'source': src}
+            elif name and ':' in ln:
+                k, v = ln.rsplit(':', 1)
+                try:
+                    out[name][k.strip()] = int(v)
+                except ValueError:
+                    pass
+    return out
 
 
 if __name__ == '__main__':
