@@ -186,7 +186,8 @@ def test_train_step_with_other_embedding_widths(nafp, cfg, emb_sz):
 
 def test_prefetched_weight_repack_equals_the_lazy_one(nafp, cfg, monkeypatch):
     """`train_step` starts the re-pack of the updated weights on a stream of the handle's own right after the optimizer
-    (`FingerPrinter.prefetch_weights`); the next forward only waits for its completion event.  Five steps with the
+    (`FingerPrinter.prefetch_weights`); the next passes wait INSIDE the library for the part of it they read (the training forward:
+    plain copies -> conv0, layer 1's share -> conv1, everything -> conv2; any other pass: everything).  Five steps with the
     prefetch and five with the lazy re-pack at the next forward (same seeded data, no spec-augment) must give the same
     losses and variables to the rounding of the backward pass's atomics -- and a forward issued on ANOTHER stream right
     after a step must see the new weights, not the old blob."""
