@@ -1215,35 +1215,56 @@ __global__ __launch_bounds__(256) void tail_bwd_b_kernel(const TailBwdArgs a, in
     const int q = blockIdx.x;
     const int j = threadIdx.x & 31, i = threadIdx.x >> 5;         // 32 x 8 threads; row i computes dw1[q][i + 8t][j]
     constexpr int NI = (S + 7) / 8;
+    constexpr int SB = 128;                                       // samples staged at a time
     const int64_t per = (B + gridDim.y - 1) / gridDim.y;
     const int64_t bb0 = blockIdx.y * per, bb1 = std::min<int64_t>(B, bb0 + per);
+    // The slice's inputs of SB samples at a time go through LDS: x (the LayerNorm output of the slice's S flatten elements) and
+    // dL/dy.  Every thread of the workgroup needs every sample's S + 1 numbers; loading them per sample inside the loop was one
+    // dependent memory round trip per sample (40 of them at a batch of 640: the whole kernel).
+    __shared__ float s_x[SB][S + 1];
     float aw1[NI], ab1 = 0.f, aw2 = 0.f, ab2 = 0.f;
 #pragma unroll
     for (int t = 0; t < NI; ++t) aw1[t] = 0.f;
-#pragma unroll 4
-    for (int64_t b = bb0; b < bb1; ++b) {
-        const float lnA = a.ln[2 * b], lnC = a.ln[2 * b + 1];     // (a double sqrt + divide per thread and sample were most of this kernel)
-        float x[S];
+    const float b1v = a.b1[q * 32 + j], w2v = a.w2[q * 32 + j];
+    float w1v[S];
 #pragma unroll
-        for (int k = 0; k < S; ++k) {
-            const int d = q * S + k;
-            x[k] = fmaf(lnA, a.z[b * a.D + d], fmaf(lnC, a.gamma[d], a.beta[d]));
+    for (int k = 0; k < S; ++k) w1v[k] = a.w1[(q * S + k) * 32 + j];
+    for (int64_t s0 = bb0; s0 < bb1; s0 += SB) {
+        const int ns = (int)std::min<int64_t>(SB, bb1 - s0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < ns * (S + 1); e += 256) {
+            const int sb = e / (S + 1), k = e - sb * (S + 1);
+            const int64_t b = s0 + sb;
+            float v;
+            if (k < S) {
+                const int d = q * S + k;
+                v = fmaf(a.ln[2 * b], a.z[b * a.D + d], fmaf(a.ln[2 * b + 1], a.gamma[d], a.beta[d]));
+            } else {
+                v = a.dy[b * a.Q + q];
+            }
+            s_x[sb][k] = v;
         }
-        float h = a.b1[q * 32 + j];
+        __syncthreads();
+        for (int sb = 0; sb < ns; ++sb) {
+            float x[S];
 #pragma unroll
-        for (int k = 0; k < S; ++k) h = fmaf(x[k], a.w1[(q * S + k) * 32 + j], h);
-        const float dyq = a.dy[b * a.Q + q];
-        const float da = dyq * a.w2[q * 32 + j] * (h > 0.f ? 1.f : __expf(h));
+            for (int k = 0; k < S; ++k) x[k] = s_x[sb][k];
+            const float dyq = s_x[sb][S];
+            float h = b1v;
 #pragma unroll
-        for (int t = 0; t < NI; ++t) {
-            float xi = 0.f;
+            for (int k = 0; k < S; ++k) h = fmaf(x[k], w1v[k], h);
+            const float da = dyq * w2v * (h > 0.f ? 1.f : __expf(h));
 #pragma unroll
-            for (int k = 0; k < S; ++k) xi = (k == i + 8 * t) ? x[k] : xi;
-            aw1[t] += xi * da;
+            for (int t = 0; t < NI; ++t) {
+                float xi = 0.f;
+#pragma unroll
+                for (int k = 0; k < S; ++k) xi = (k == i + 8 * t) ? x[k] : xi;
+                aw1[t] += xi * da;
+            }
+            ab1 += da;
+            aw2 += dyq * elu1(h);
+            ab2 += dyq;
         }
-        ab1 += da;
-        aw2 += dyq * elu1(h);
-        ab2 += dyq;
     }
     // the batch chunks (blockIdx.y) meet through atomics; the gradients are zeroed by the caller
 #pragma unroll

@@ -91,11 +91,24 @@ class SpecAugChainer:
                                                    _lib.current_stream()), 'specaug_mean')
         return out
 
-    def __call__(self, x):
+    def __call__(self, x, inplace=False):
+        """`inplace=True`: mask `x` itself (the caller owns it and nothing else reads it -- `train_step` passes the front end's
+        fresh output) instead of a copy.  With zero filling and every stage always active (the shipped configs) the stages'
+        rectangles -- drawn in chain order, the same random sequence -- go to the device as ONE launch: with a constant filler the
+        result does not depend on the order."""
         if self.bypass:
             return x
-        x = x.float().contiguous().clone()
+        x = x.float().contiguous()
+        if not inplace:
+            x = x.clone()
         B, H, W = x.shape[0], x.shape[1], x.shape[2]
+        stages = [(k, p) for k, p in zip(self.chain_config, self.probs) if p > 0]
+        if self.hole_fill == 'zeros' and stages and all(p >= 1.0 for _, p in stages) and len(stages) * self.n_holes <= 8:
+            rects = []
+            for kind, _ in stages:
+                rects += draw_holes(kind, H, W, self.n_holes, self.rng, tuple(self.hole_config))
+            self.apply_rects(x, rects, None, 0.0)
+            return x
         for kind, prob in zip(self.chain_config, self.probs):
             if not prob > 0:
                 continue

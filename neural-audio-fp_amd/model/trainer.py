@@ -31,7 +31,7 @@ from .fp.nnfp import get_fingerprinter
 from .fp.NTxent_loss_single_gpu import NTxentLoss, _ntxent_call
 from .fp.online_triplet_loss import OnlineTripletLoss
 from .fp.lamb_optimizer import LAMB, Adam, CosineDecay, CosineDecayRestarts
-from .fp.specaug_chain.specaug_chain import get_specaug_chain_layer
+from .fp.specaug_chain.specaug_chain import SpecAugChainer, get_specaug_chain_layer
 from . import generate as _gen
 
 
@@ -113,7 +113,8 @@ def train_step(X, m_pre, m_specaug, m_fp, loss_obj, opt, bucket=None, timers=Non
     Xa, Xp = X
     n_anchors = len(Xa)
     X = torch.cat([torch.as_tensor(Xa), torch.as_tensor(Xp)], dim=0)
-    feat = m_specaug(m_pre(X))                      # outside the tape (trainer.py:41)
+    feat = m_pre(X)                                 # outside the tape (trainer.py:41)
+    feat = m_specaug(feat, inplace=True) if isinstance(m_specaug, SpecAugChainer) else m_specaug(feat)   # (the front end's own fresh tensor)
     m_fp.trainable = True
     emb = m_fp.forward_train(feat)
     ha, hb = emb[:n_anchors].contiguous(), emb[n_anchors:].contiguous()
