@@ -303,10 +303,13 @@ __global__ void ntxent_bwd_combine_kernel(const float* __restrict__ partC, const
 
 using namespace nafp;
 
-// Splits of the "other" set per block of 32 owners: enough workgroups for the chip (about 320), at most 16.
+// Splits of the "other" set per block of 32 owners: enough workgroups for the chip, at most 16.  (NAFP_NTXENT_WGS sweeps the
+// target: 320 / 640 / 1280 / 2560 workgroups -> 0.883 / 0.843 / 0.800 / 0.893 ms for loss + both gradients at 5120 x 5120,
+// 0.145 / 0.129 / 0.129 / 0.129 at 1280 x 1280; beyond 8 splits the partial sums of the gradients cost more than the occupancy gains.)
 static int ntxent_splits(int64_t owners, int64_t others) {
     const int64_t blocks = (owners + 31) / 32, tiles = (others + 31) / 32;
-    int64_t s = std::max<int64_t>(1, std::min<int64_t>(16, 320 / std::max<int64_t>(blocks, 1)));
+    static const int64_t wg_target = []() { const char* e = getenv("NAFP_NTXENT_WGS"); return e && atoll(e) > 0 ? atoll(e) : (int64_t)1280; }();
+    int64_t s = std::max<int64_t>(1, std::min<int64_t>(16, wg_target / std::max<int64_t>(blocks, 1)));
     s = std::min<int64_t>(s, std::max<int64_t>(1, tiles / 4));            // every wave of every split gets a tile
     return (int)s;
 }
