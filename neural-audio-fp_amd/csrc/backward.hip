@@ -1063,7 +1063,9 @@ int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const Con
     static const bool aux_fold = []() { const char* e = getenv("NAFP_WGRAD_AUXFOLD"); return !e || e[0] != '0'; }();
     // aux rows ride in the fast kernel when every K-step stays on one side of row B * P (a K-step takes 16 rows, 32 for the
     // half-dead taps of the two-frame layers)
-    const bool fold = fast && have_aux && aux_fold && p.P % 32 == 0;
+    // (16-row K-steps everywhere except the convs along T with two output frames, whose half-dead taps take 32: wgrad_fast_kernel's to_sel)
+    const int rows_step = (g.axis == 0 && g.Tout == 2) ? 32 : 16;
+    const bool fold = fast && have_aux && aux_fold && p.P % rows_step == 0;
     auto launch_one = [&](const float* Xq, const float* Dq, int64_t Bq, bool with_aux, const ScalarsJob* job) -> int {
         WgradParams q = p;
         q.X = Xq; q.D = Dq; q.B = (int)Bq; q.M_main = (long long)Bq * q.P;
