@@ -735,27 +735,39 @@ __global__ __launch_bounds__(256, 3) void wgrad_fast_kernel(const WgradParams p,
             }
 }
 
-// dW tile = sum over the row chunks of its partial tiles, in chunk order (deterministic), stored once.
-// grid = (32 slices of 512 elements, n-tiles, live taps x c-tiles) -- the wgrad grid's y / z; 256 threads x 2 floats.
+// dW tile = sum over the row chunks of its partial tiles, in a fixed order (deterministic), stored once.
+// grid = (128 slices of 128 elements, n-tiles, live taps x c-tiles) -- the wgrad grid's y / z.  A lane owns 2 elements of the slice
+// and each of the four waves a quarter of the chunks (contiguous, in order); the four partial sums meet in LDS and are added in
+// wave order.  (32 slices of 512 elements with one thread walking ALL chunks of its 2 elements were 96 workgroups and 32 dependent
+// memory round trips for layer 1's 3 tiles x 256 chunks.)
+constexpr int WGRAD_REDUCE_SLICES = 128;
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dW, int n_chunks,
                                                            int Cin, int Cout, int tap_pack) {
     typedef float f32x2w __attribute__((ext_vector_type(2)));
     const int ctiles = Cin / 128;
     const int tap = (tap_pack >> (2 * (blockIdx.z / ctiles))) & 3, c0 = (blockIdx.z % ctiles) * 128, n0 = blockIdx.y * 128;
-    const int e = blockIdx.x * 512 + threadIdx.x * 2;               // element of the 128 x 128 tile
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 128 + lane * 2;                      // this lane's 2 elements of the 128 x 128 tile (one row per slice)
     const f32x2w* src = (const f32x2w*)(slab + ((long long)(blockIdx.y + gridDim.y * blockIdx.z) * n_chunks) * (128 * 128) + e);
+    const int per = (n_chunks + 3) / 4, k0 = wave * per, k1 = min(n_chunks, k0 + per);
     f32x2w t = {0.f, 0.f};
-    int k = 0;
-    for (; k + 8 <= n_chunks; k += 8) {
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
         f32x2w v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + (long long)(k + u) * (128 * 128 / 2));
 #pragma unroll
         for (int u = 0; u < 8; ++u) t += v[u];
     }
-    for (; k < n_chunks; ++k) t += __builtin_nontemporal_load(src + (long long)k * (128 * 128 / 2));
-    const int c = c0 + (e >> 7), n = n0 + (e & 127);
-    *(f32x2w*)(dW + ((long long)tap * Cin + c) * Cout + n) = t;
+    for (; k < k1; ++k) t += __builtin_nontemporal_load(src + (long long)k * (128 * 128 / 2));
+    __shared__ f32x2w red[3][64];
+    if (wave > 0) red[wave - 1][lane] = t;
+    __syncthreads();
+    if (wave == 0) {
+        t += red[0][lane]; t += red[1][lane]; t += red[2][lane];
+        const int c = c0 + (e >> 7), n = n0 + (e & 127);
+        *(f32x2w*)(dW + ((long long)tap * Cin + c) * Cout + n) = t;
+    }
 }
 
 // wgrad for the SMALL layers: P = Fout * Tout a power of two below 16 (every layer from b5 on at the 1-s input: P = 8, 4, 4, 2,
@@ -1090,7 +1102,7 @@ int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const Con
         else wgrad_kernel<<<dim3(gx, g.Cout / 128, q.n_live * g.Cin / 128), 256, lds, st>>>(q);
         NAFP_LAUNCH_CHECK();
         if (use_slab) {
-            wgrad_reduce_kernel<<<dim3(32, g.Cout / 128, q.n_live * g.Cin / 128), 256, 0, st>>>(slab, dW, (int)gx, g.Cin, g.Cout, q.tap_pack);
+            wgrad_reduce_kernel<<<dim3(WGRAD_REDUCE_SLICES, g.Cout / 128, q.n_live * g.Cin / 128), 256, 0, st>>>(slab, dW, (int)gx, g.Cin, g.Cout, q.tap_pack);
             NAFP_LAUNCH_CHECK();
         }
         return NAFP_OK;
