@@ -272,10 +272,55 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
                 t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
             }
             float* o = (wv == 0 ? dgamma : (wv == 1 ? dbeta : (wv == 2 ? S1 : S2))) + 4 * i;
-            atomicAdd(o, t.x); atomicAdd(o + 1, t.y); atomicAdd(o + 2, t.z); atomicAdd(o + 3, t.w);
+            if (!part_slab) {
+                atomicAdd(o, t.x); atomicAdd(o + 1, t.y); atomicAdd(o + 2, t.z); atomicAdd(o + 3, t.w);
+                if (wv == 3) {
+                    float* ob = dbias + (4 * i) % C;
+                    atomicAdd(ob, t.x); atomicAdd(ob + 1, t.y); atomicAdd(ob + 2, t.z); atomicAdd(ob + 3, t.w);
+                }
+                return;
+            }
+            // The larger layers at a small batch (n > 4096, B <= 2048): the batch chunks of a 256-element block meet through the slab
+            // -- [block][chunk][array][256], written through the caches -- and an arrival ticket per block; in the LAST arriver wave w
+            // adds up array w over the chunks, in chunk order, and stores it once.  A quarter of the chunks per element of the
+            // 1024-element blocks above for the same samples per thread, and the last arriver's pass runs four arrays abreast.
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            const int ny = (int)gridDim.y;
+            float* base = part_slab + (int64_t)blockIdx.x * ny * 1024;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, ny * 4096, 0x00020000);
+            const int mine = (wv * 256 + 4 * lane) * 4;                                 // byte offset inside a chunk's 4 x 256 floats
+            if (ny > 1) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, t), rs, (int)blockIdx.y * 4096 + mine, 0, 17);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __shared__ unsigned s_wtk;
+            __syncthreads();
+            if (threadIdx.x == 0) s_wtk = ny > 1 ? __hip_atomic_fetch_add(tickets + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            __syncthreads();
+            if ((int)s_wtk != ny - 1) return;
+            if (ny > 1) {
+                if (threadIdx.x == 0) __hip_atomic_store(tickets + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                t = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int y0 = 0; y0 < ny; y0 += 4) {
+                    float4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        v[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, std::min(y0 + u, ny - 1) * 4096 + mine, 0, 17));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (y0 + u >= ny) break;
+                        t.x += v[u].x; t.y += v[u].y; t.z += v[u].z; t.w += v[u].w;
+                    }
+                }
+            }
+            *(float4*)o = t;
             if (wv == 3) {
-                float* ob = dbias + (4 * i) % C;
-                atomicAdd(ob, t.x); atomicAdd(ob + 1, t.y); atomicAdd(ob + 2, t.z); atomicAdd(ob + 3, t.w);
+                // dbias: with C = 128 the block spans two positions and lanes l, l + 32 hold the same channels
+                if (C == 128) { t.x += __shfl_xor(t.x, 32, 64); t.y += __shfl_xor(t.y, 32, 64); t.z += __shfl_xor(t.z, 32, 64); t.w += __shfl_xor(t.w, 32, 64); }
+                if (C != 128 || lane < 32) {
+                    float* ob = dbias + (4 * i) % C;
+                    atomicAdd(ob, t.x); atomicAdd(ob + 1, t.y); atomicAdd(ob + 2, t.z); atomicAdd(ob + 3, t.w);
+                }
             }
         }
         return;
@@ -1368,20 +1413,34 @@ int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* 
     static const bool slab_on = []() { const char* e = getenv("NAFP_LNB_SLAB"); return !e || e[0] != '0'; }();
     // (taken for the layers with >= 8 blocks of 1024 elements: there it is faster -- B = 640: layers 0-9 lose 5-25 us each --; on the
     // small layers the 1-4 last arrivers add 32 chunks each on their own, +8-12 us per launch, so those keep the atomics)
+    float* const slab_in = slab_on ? part_slab : nullptr; unsigned* const tickets_in = tickets;     // (the wave-split variant below sizes its own layout)
     if (!(slab_on && bx >= 8 && part_slab && tickets && bx <= NAFP_TICKET_SLOTS && bx * by * 4 * 1024 <= part_slab_floats &&
           bx * by * 4 * 1024 * 4 < ((int64_t)1 << 31))) { part_slab = nullptr; tickets = nullptr; }
     Conv0Regen c0{};
     // the small layers: four waves of a workgroup share its batch chunk (ln_bwd_fused_kernel<.., WAVE>); NAFP_LNB_WAVE_MAXN=0 turns it off
     static const int64_t wave_maxn = []() { const char* e = getenv("NAFP_LNB_WAVE_MAXN"); return e ? atoll(e) : (int64_t)4096; }();
-    static const int64_t wave_spw = []() { const char* e = getenv("NAFP_LNB_WAVE_SPW"); return e && atoll(e) > 0 ? atoll(e) : (int64_t)20; }();
-    if (!feat0 && tpre_is_z && S1 && S2 && n <= wave_maxn && C % 256 == 0) {
+    // samples per wave: 10 for the small layers, 20 for the slab variant (B = 640, us per layer with 10 / 20 / 40: layers 15-10
+    // 14-27 / 19-52 / 30-86; layers 8, 6, 5 with 10 / 20: 36 38 67 / 29 34 59).  NAFP_LNB_WAVE_SPW overrides both.
+    static const int64_t wave_spw_env = []() { const char* e = getenv("NAFP_LNB_WAVE_SPW"); return e && atoll(e) > 0 ? atoll(e) : (int64_t)0; }();
+    static const int64_t wslab_maxn = []() { const char* e = getenv("NAFP_LNB_WSLAB_MAXN"); return e ? atoll(e) : (int64_t)65536; }();
+    const int64_t wave_spw = wave_spw_env > 0 ? wave_spw_env : (n <= wave_maxn ? 10 : 20);
+    // ... and, through a slab instead of atomics, the larger layers at a small batch (NAFP_LNB_WSLAB_MAXB, default 2048; 0 = off)
+    static const int64_t wslab_maxb = []() { const char* e = getenv("NAFP_LNB_WSLAB_MAXB"); return e ? atoll(e) : (int64_t)2048; }();
+    if (!feat0 && tpre_is_z && S1 && S2 && n % 256 == 0) {
         int byw = (int)std::max<int64_t>(1, std::min<int64_t>(64, B / (4 * wave_spw)));
         while (lnsum_below && (B + byw - 1) / byw * 8 > 32768 && byw < B) byw *= 2;
         const size_t ldsw = lnsum_below ? (size_t)((B + byw - 1) / byw) * 2 * sizeof(float) : 0;
-        ln_bwd_fused_kernel<false, true, true><<<dim3((unsigned)(n / 256), byw), 256, ldsw, st>>>(d, tpre, gamma, sc, dgamma, dbeta, dbias, S1, S2, n, B,
-                                                                                            C, Gj, Hbj, lnsum_below, c0, nullptr, nullptr);
-        NAFP_LAUNCH_CHECK();
-        return NAFP_OK;
+        const int64_t nblk = n / 256;
+        const bool small = n <= wave_maxn && C % 256 == 0;
+        const bool wslab = !small && n > wave_maxn && n <= wslab_maxn && B <= wslab_maxb && (C == 128 || C % 256 == 0) && slab_in && tickets_in &&
+                           nblk <= NAFP_TICKET_SLOTS && nblk * byw * 1024 <= part_slab_floats && (int64_t)byw * 4096 < ((int64_t)1 << 31);
+        if (small || wslab) {
+            ln_bwd_fused_kernel<false, true, true><<<dim3((unsigned)nblk, byw), 256, ldsw, st>>>(d, tpre, gamma, sc, dgamma, dbeta, dbias, S1, S2, n, B,
+                                                                                           C, Gj, Hbj, lnsum_below, c0, wslab ? slab_in : nullptr,
+                                                                                           wslab ? tickets_in : nullptr);
+            NAFP_LAUNCH_CHECK();
+            return NAFP_OK;
+        }
     }
     if (feat0) {
         if (!g0 || g0->Cin != 1 || g0->axis != 0 || g0->Cout != C || g0->Fout * g0->Tout != P || reduce_here) return NAFP_ERR_INVALID_ARG;
