@@ -140,6 +140,9 @@ struct nafp_encoder {
     // LayerNorm-backward path (opt_fused_ln_bwd) reads t and therefore implies keeping it.
     bool keep_t_env = []() { const char* v = getenv("NAFP_KEEP_T"); return v && v[0] == '1'; }();
     bool keep_t() const { return keep_t_env || opt_fused_ln_bwd != 0; }
+    // what the last forward_train laid the training workspace out with: the backward pass re-derives the layout from (B, keep_t())
+    // and must find the same one (an option changed in between would make it read activations at other offsets)
+    int64_t train_B = -1; bool train_keep_t = false;
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_main[16] = {}, ev_side[16] = {};
     // set_weights: the 15 G / Hb images are small, latency-bound launches (2 "samples"; the late ones stream 6-12 MB of
@@ -704,6 +707,7 @@ extern "C" int nafp_encoder_forward_train(nafp_encoder* e, const float* feat, in
     if (workspace_bytes < nafp_encoder_train_workspace_bytes(e, n_seg)) return NAFP_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     TrainLayout L = train_layout(e, n_seg, workspace);
+    e->train_B = n_seg; e->train_keep_t = e->keep_t();
     NAFP_HIP_CHECK(hipMemsetAsync(L.stats, 0, (char*)(L.tickets + 2 * NAFP_TICKET_SLOTS) - (char*)L.stats, st));
     static const bool split_wait = []() { const char* v = getenv("NAFP_SW_SPLIT_WAIT"); return !v || v[0] != '0'; }();
     { int wrc = wait_weights(e, st, split_wait ? 0 : 2); if (wrc != NAFP_OK) return wrc; }
@@ -734,6 +738,7 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
     if (!e || !feat || !d_emb || !workspace || !grads || n_seg <= 0) return NAFP_ERR_INVALID_ARG;
     if (!e->has_weights) return NAFP_ERR_NO_WEIGHTS;
     if (workspace_bytes < nafp_encoder_train_workspace_bytes(e, n_seg)) return NAFP_ERR_WORKSPACE;
+    if (e->train_B != n_seg || e->train_keep_t != e->keep_t()) return NAFP_ERR_INVALID_ARG;     // not the layout forward_train wrote
     hipStream_t st = (hipStream_t)stream;
     const int64_t B = n_seg;
     TrainLayout L = train_layout(e, B, workspace);
@@ -790,6 +795,7 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
     static const bool ride = []() { const char* v = getenv("NAFP_SIDE_RIDE"); return !v || v[0] != '0'; }();
     bool ln_done = false;       // `cur` already holds dts_j (the LayerNorm backward of layer j ran inside dgrad_{j+1})
     bool sc_ready = false;      // L.sc already holds the scalar records of layer j (side job of wgrad_{j+1})
+    bool side_pending = false;  // a weight gradient has been enqueued on the weight-gradient stream (never joined before the end of the pass)
     for (int j = 15; j >= 1; --j) {
         const ConvGeom& g = e->geom[j];
         const int P = g.Fout * g.Tout;
@@ -869,8 +875,21 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
         // j-1 ran fused, its dgamma / dbeta / dbias are final too: they belong to the next group or are simply early)
         // (with the weight-gradient stream the event is recorded THERE: behind wgrad(j), and -- through ev_main[j] -- behind
         // everything the main stream had enqueued up to the LayerNorm backward of layer j)
+        // A group whose boundary layer runs on the MAIN stream may still hold layers whose weight gradient is in flight on the
+        // weight-gradient stream (mode 2: group 1 = layers 8..11, boundary 8 on the main stream, wgrad(10) / wgrad(11) over there):
+        // its event is then recorded on the weight-gradient stream too, behind a main-stream event -- that stream is in order, so
+        // every earlier wgrad is done, and nothing is put in front of the main stream's next kernel but one record.
+        if (on_side) side_pending = true;
         for (int k = 0; k < NAFP_GRAD_GROUPS - 1; ++k)
-            if (4 * j == kGroupFirst[k]) NAFP_HIP_CHECK(hipEventRecord(e->grad_events[k], sw));
+            if (4 * j == kGroupFirst[k]) {
+                if (sw == st && side_pending) {
+                    NAFP_HIP_CHECK(hipEventRecord(e->ev_main[j], st));
+                    NAFP_HIP_CHECK(hipStreamWaitEvent(e->side_stream, e->ev_main[j], 0));
+                    NAFP_HIP_CHECK(hipEventRecord(e->grad_events[k], e->side_stream));
+                } else {
+                    NAFP_HIP_CHECK(hipEventRecord(e->grad_events[k], sw));
+                }
+            }
     }
     {
         const ConvGeom& g = e->geom[0];

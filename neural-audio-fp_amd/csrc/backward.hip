@@ -1123,7 +1123,7 @@ int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const Con
     // (16-row K-steps everywhere except the convs along T with two output frames, whose half-dead taps take 32: wgrad_fast_kernel's to_sel)
     const int rows_step = (g.axis == 0 && g.Tout == 2) ? 32 : 16;
     const bool fold = fast && have_aux && aux_fold && p.P % rows_step == 0;
-    auto launch_one = [&](const float* Xq, const float* Dq, int64_t Bq, bool with_aux, const ScalarsJob* job) -> int {
+    auto launch_one = [&](const float* Xq, const float* Dq, int64_t Bq, bool with_aux, const ScalarsJob* job, bool is_main) -> int {
         WgradParams q = p;
         q.X = Xq; q.D = Dq; q.B = (int)Bq; q.M_main = (long long)Bq * q.P;
         q.n_aux = with_aux ? 2 : 0; q.X2 = with_aux ? X2 : Xq; q.D2 = with_aux ? D2 : Dq;
@@ -1139,9 +1139,10 @@ int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const Con
         while (rpw > 64 && (rpw / q.P + 2) * q.sample_in * 4 >= (1ll << 31)) rpw = std::max<long long>(64, rpw / 2 / 32 * 32);
         q.rows_per_wg = (int)rpw;
         const unsigned gx = (unsigned)((M + rpw - 1) / rpw);
-        // the main launch of the fast kernel leaves its partial tiles in the slab; wgrad_reduce_kernel sums them into dW
+        // the main launch of the fast kernel leaves its partial tiles in the slab; wgrad_reduce_kernel STORES their sum into dW
+        // (is_main: the separate rank-one launches of the non-fold fallback accumulate into that sum by atomics -- also at B = 1)
         static const bool slab_on = []() { const char* e = getenv("NAFP_WGRAD_SLAB"); return !e || e[0] != '0'; }();
-        const bool use_slab = slab_on && fast && Bq == B && slab && (int64_t)col_tiles * gx * 128 * 128 <= slab_floats;
+        const bool use_slab = slab_on && fast && is_main && slab && (int64_t)col_tiles * gx * 128 * 128 <= slab_floats;
         q.slab = use_slab ? slab : nullptr; q.n_chunks = (int)gx;
         if (fast) wgrad_fast_kernel<<<dim3(gx, g.Cout / 128, q.n_live * g.Cin / 128), 256, lds, st>>>(q, lt, lfo);
         else wgrad_kernel<<<dim3(gx, g.Cout / 128, q.n_live * g.Cin / 128), 256, lds, st>>>(q);
@@ -1152,11 +1153,11 @@ int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const Con
         }
         return NAFP_OK;
     };
-    int rc = launch_one(X, D, B, fold, sj);
+    int rc = launch_one(X, D, B, fold, sj, true);
     if (rc != NAFP_OK || !have_aux || fold) return rc;
-    rc = launch_one(X2, D2, 1, false, nullptr);                                   // gamma_{j-1} against S1_j
+    rc = launch_one(X2, D2, 1, false, nullptr, false);                                   // gamma_{j-1} against S1_j
     if (rc != NAFP_OK) return rc;
-    return launch_one(X2 + p.sample_in, D2 + (long long)p.P * p.Cout, 1, false, nullptr);   // beta_{j-1} against S2_j
+    return launch_one(X2 + p.sample_in, D2 + (long long)p.P * p.Cout, 1, false, nullptr, false);   // beta_{j-1} against S2_j
 }
 
 // ============================================================================

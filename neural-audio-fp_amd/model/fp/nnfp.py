@@ -265,6 +265,9 @@ class FingerPrinter:
             self._grads = [torch.empty_like(v) for v in self._vars]
         arr = (ctypes.c_void_p * len(self._grads))(*[g.data_ptr() for g in self._grads])
         need = int(self._lib.nafp_encoder_train_workspace_bytes(self._h, B))
+        if getattr(self, '_train_ws', None) is None or need > self._train_ws.numel():
+            raise RuntimeError('backward: the training workspace does not match the last forward_train '
+                               '(an execution option was changed in between?)')
         with torch.cuda.device(feat.device):
             _lib.check(self._lib.nafp_encoder_backward(self._h, _lib.ptr(feat), _lib.ptr(d_emb), B,
                                                        _lib.ptr(self._train_ws), need, arr,

@@ -181,6 +181,42 @@ def test_weight_gradients_on_the_side_stream_equal_the_single_stream_pass(nafp, 
     observe('side-stream vs single-stream gradients, rel. to the tensor max', worst, 2e-5)
 
 
+@pytest.mark.parametrize('side_mode', [2, 1])
+@pytest.mark.parametrize('B', [160, 640])
+def test_each_gradient_group_event_covers_exactly_its_own_tensors(nafp, B, side_mode):
+    """What GradientBucket.all_reduce relies on: a consumer that waits for group k ONLY (one consumer stream per group, none of
+    them waiting for a later group) reads finished values of group k's tensors.  In mode 2 group 1 (layers 8..11) has its
+    boundary layer on the main stream while wgrad(10) / wgrad(11) run on the weight-gradient stream: its event must be ordered
+    behind those too (round-4 ADVICE: it was recorded on the main stream alone).  A copy loop on a further stream keeps the
+    chip busy so that the weight-gradient stream lags the main one."""
+    g = torch.Generator(device='cuda').manual_seed(90 + B)
+    feat = -1.2 * torch.rand((B, 256, 32, 1), generator=g, device='cuda')
+    d_emb = torch.randn((B, 128), generator=g, device='cuda')
+    m_fp = nafp.FingerPrinter(seed=0)
+    m_fp.set_option(4, side_mode)
+    m_fp.set_weights(_inputs.weight_list(_inputs.weights(seed=16)))
+    groups = m_fp.grad_groups()
+    assert sorted(i for a, b in groups for i in range(a, b + 1)) == list(range(68))
+    consumers = [torch.cuda.Stream() for _ in groups]
+    noise, junk = torch.cuda.Stream(), torch.empty((64 << 20,), device='cuda')
+    for rep in range(3):
+        m_fp.forward_train(feat)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(noise):
+            for _ in range(40):
+                junk[:32 << 20].copy_(junk[32 << 20:])
+        grads = m_fp.backward(d_emb)
+        seen = {}
+        for k, (a, b) in enumerate(groups):
+            with torch.cuda.stream(consumers[k]):
+                m_fp.grad_group_wait(k)
+                seen[k] = [grads[i].clone() for i in range(a, b + 1)]
+        torch.cuda.synchronize()
+        for k, (a, b) in enumerate(groups):
+            for i, t in zip(range(a, b + 1), seen[k]):
+                assert torch.equal(t, grads[i]), (rep, k, i)
+
+
 def test_backward_with_aux_rows_and_small_layer_kernel(nafp, observe):
     """B = 32: B * P is a multiple of 16 for every layer, so the weight gradients take the round-4 paths -- the two rank-one
     terms (gamma | beta against S1 | S2) as aux rows of the main launch, the small-layer kernel (P < 16: plain stores or
