@@ -149,12 +149,14 @@ def cpu_baseline(target_s=10.0, max_batches=40):
                       f"for {best['seconds']} s; the host was timed half-filled and filled ({cores} logical cores), the faster is reported"}
 
 
-def train_region(cfg, world, rank, dist, global_bsz, steps, torch, warmup=2, optimizer='LAMB'):
+def train_region(cfg, world, rank, dist, global_bsz, steps, torch, warmup=2, optimizer='LAMB', repeats=3):
     """Second half of BASELINE.json's metric: contrastive-train steps/s at a GLOBAL batch of 5120
     (configs[3]: config/640_lamb.yaml scaled, LAMB, tau 0.05), strong scaling: every rank takes
     5120/N segments (anchors + replicas), all-gathers the embeddings, all-reduces the gradients.
     A step = melspec + spec-augment + forward + NT-Xent + backward + (collectives) + optimizer.
-    Also used for configs[2] (BSZ 1280, Adam: `train_1280`)."""
+    Also used for configs[2] (BSZ 1280, Adam: `train_1280`).  Like the headline: `repeats` timed regions of exactly
+    `steps` steps each (barrier + synchronize on both sides, MAX over ranks), the MEDIAN region is reported, `spread`
+    lists all of them."""
     import copy
     from neural_audio_fp_amd.model import trainer as T
     c = copy.deepcopy(cfg)
@@ -166,20 +168,24 @@ def train_region(cfg, world, rank, dist, global_bsz, steps, torch, warmup=2, opt
     batches = list(T.synthetic_batches(c, 2)(1))
     for i in range(warmup):
         T.train_step(batches[i % 2], m_pre, m_specaug, m_fp, loss_obj, opt, bucket)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        loss, _ = T.train_step(batches[i % 2], m_pre, m_specaug, m_fp, loss_obj, opt, bucket)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([el], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t[0])
+    regions = []
+    for _ in range(max(1, repeats)):
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss, _ = T.train_step(batches[i % 2], m_pre, m_specaug, m_fp, loss_obj, opt, bucket)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([el], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t[0])
+        regions.append(el)
+    el = sorted(regions)[len(regions) // 2]
     coll = 'none'
     if dist:
         # one more step, outside the timed region, with device events around every collective (rank 0's view):
@@ -200,20 +206,38 @@ def train_region(cfg, world, rank, dist, global_bsz, steps, torch, warmup=2, opt
                           'all_reduce': int(bucket.flat.numel() * 4)}}
         for name, a, b in timers:
             coll[name + '_ms'] = round(a.elapsed_time(b), 4)
+    exposed = None
+    if dist and world > 1:
+        # the same per-rank step with NO process group (own models, per-rank batch as its whole batch, an n x n loss instead of
+        # the rank's n x N share), timed the same way in this run: step - that = what the collectives leave exposed
+        T.NO_DIST = True
+        try:
+            plain = train_region(cfg, 1, 0, None, global_bsz // world, steps, torch, warmup=warmup, optimizer=optimizer, repeats=repeats)
+        finally:
+            T.NO_DIST = False
+        dist.barrier()
+        exposed = {'exposed_comm_ms': round(el / steps * 1e3 - plain['ms_per_step'], 3),
+                   'no_process_group_ms_per_step': plain['ms_per_step'], 'no_process_group_spread': plain['spread']['ms_per_step_all'],
+                   'note': "rank 0's compute-only step (per-rank batch, no collectives, n x n loss) in the same run; the difference also "
+                           "holds the larger n x N loss share of the distributed step"}
     enc = 2.0 * (sum(conv_effective_macs()) + 36864)               # forward FLOPs per segment
     flops = 3.0 * enc * global_bsz + 3.0 * 2.0 * global_bsz * global_bsz * 128   # fwd + dgrad + wgrad, NT-Xent x3
     tf = flops / (el / steps) / 1e12
     return {'metric': 'contrastive train steps/s', 'value': round(steps / el, 4), 'unit': 'steps/s',
             'global_batch': global_bsz, 'per_gpu_batch': global_bsz // world, 'n_gpus': world, 'steps': steps,
-            'warmup': warmup, 'ms_per_step': round(el / steps * 1e3, 3), 'scaling': 'strong', 'optimizer': optimizer,
+            'warmup': warmup, 'ms_per_step': round(el / steps * 1e3, 3), 'repeats': len(regions),
+            'spread': {'ms_per_step_all': [round(r / steps * 1e3, 3) for r in regions], 'min': round(min(regions) / steps * 1e3, 3),
+                       'max': round(max(regions) / steps * 1e3, 3),
+                       'note': f'{len(regions)} timed regions of {steps} steps each; value / ms_per_step = the median region'},
+            'scaling': 'strong', 'optimizer': optimizer,
             'segments_per_s': round(global_bsz * steps / el, 1), 'loss': round(float(loss), 4),
             'algorithmic_TFLOP_per_step': round(flops / 1e12, 3), 'achieved_TFLOP/s': round(tf, 2),
             'mfma_frac_of_peak': round(tf / (FP32_MFMA_PEAK_TFLOPS * world), 4),
-            'collectives': coll,
+            'collectives': coll, **(exposed or {}),
             'data': 'synthetic (seeded noise anchors, replicas = anchors + noise at 5 dB SNR), resident in HBM'}
 
 
-def train_rank640(cfg, torch, steps=20, warmup=4):
+def train_rank640(cfg, torch, steps=20, warmup=4, repeats=3):
     """The operating point of the metric's 8-GPU entry, on ONE GPU: a rank's share of the global batch of 5120 is 640
     segments (320 anchors + 320 replicas), LAMB.  The step runs through a process group of ONE rank on RCCL (legal for
     RCCL), so every collective of `train_step` executes -- all-gather of the embeddings, reduce-scatter of their
@@ -253,6 +277,9 @@ def train_rank640(cfg, torch, steps=20, warmup=4):
                 tot[k] += e[k].elapsed_time(e[k + 1])
     stage = {n: round(t / n_split, 4) for n, t in zip(names, tot)}
     del m_pre, m_specaug, m_fp, opt, loss_obj, bucket
+    # ---- the same step WITHOUT a process group, timed like the one below: the difference is what the six collectives and
+    # their stream hand-overs add to the step when none of them moves data off the GPU (`exposed_comm_ms`) ----
+    plain = train_region(cfg, 1, 0, None, bsz, steps, torch, warmup=warmup, optimizer='LAMB', repeats=repeats)
     # ---- the step itself, through a 1-rank RCCL group ----
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
@@ -260,10 +287,17 @@ def train_rank640(cfg, torch, steps=20, warmup=4):
     dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1,
                             device_id=torch.device('cuda', torch.cuda.current_device()))
     try:
-        r = train_region(cfg, 1, 0, dist, bsz, steps, torch, warmup=warmup, optimizer='LAMB')
+        r = train_region(cfg, 1, 0, dist, bsz, steps, torch, warmup=warmup, optimizer='LAMB', repeats=repeats)
     finally:
         dist.destroy_process_group()
     r['stage_ms'] = stage
+    r['no_process_group_ms_per_step'] = plain['ms_per_step']
+    r['no_process_group_spread'] = plain['spread']['ms_per_step_all']
+    r['exposed_comm_ms'] = round(r['ms_per_step'] - plain['ms_per_step'], 3)
+    r['exposed_comm_note'] = ('ms_per_step through the 1-rank RCCL group minus the same step with no process group, both the median of '
+                              f'{repeats} regions of {steps} steps in this run: what the all-gather, the reduce-scatter and the 4 gradient pieces cost '
+                              'when nothing crosses xGMI (stream hand-overs and launch overhead of the collectives; the wire time of a real '
+                              '8-rank step comes on top where the backward pass does not hide it -- DESIGN.md section 6)')
     r['what'] = ('one rank\'s share (640 of 5120 segments) of the 8-GPU train step on ONE GPU through a 1-rank RCCL group: every '
                  'collective of the step executes, none crosses xGMI -- a one-GPU compute bound of the 8-rank step, not a scaling '
                  'measurement')
@@ -412,7 +446,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-e2e', action='store_true', help='skip the disk -> .mm figures (reported as "e2e_generate")')
     ap.add_argument('--no-train', action='store_true', help='skip the contrastive-train region (reported as "train")')
-    ap.add_argument('--train-steps', type=int, default=6)
+    ap.add_argument('--train-steps', type=int, default=10, help='steps per timed region of the BSZ-5120 train object')
+    ap.add_argument('--train-repeats', type=int, default=3, help='timed regions of the train objects; the median is reported')
     ap.add_argument('--train-bsz', type=int, default=5120, help='GLOBAL train batch (BASELINE.json configs[3])')
     ap.add_argument('--fullscale-rows', type=int, default=1_250_000,
                     help='rows of the configs[4] stand-in (reported as "fullscale_generate"); 12500000 = one rank\'s whole share; 0 = skip')
@@ -590,14 +625,14 @@ def main():
                           "reference's arithmetic, not part of `value`"}
     train, train_1280, train_r640 = None, None, None
     if not args.no_train:
-        train = train_region(cfg, world, rank, dist, args.train_bsz, args.train_steps, torch)
+        train = train_region(cfg, world, rank, dist, args.train_bsz, args.train_steps, torch, repeats=args.train_repeats)
         if world == 1:                                  # BSZ 1280, Adam, one GPU
             train_1280 = train_region(cfg, world, rank, dist, min(1280, args.train_bsz), max(args.train_steps, 12), torch,
-                                      warmup=3, optimizer='Adam')
+                                      warmup=3, optimizer='Adam', repeats=args.train_repeats)
             # the 8-GPU operating point (per-rank batch 640) as a one-GPU compute bound.  Secondary object: if the 1-rank RCCL
             # group cannot be created on this box the headline line must still come out -- the failure is reported, not hidden
             try:
-                train_r640 = train_rank640(cfg, torch)
+                train_r640 = train_rank640(cfg, torch, repeats=args.train_repeats)
             except Exception as ex:                      # noqa: BLE001
                 train_r640 = {'error': f'{type(ex).__name__}: {ex}'[:400]}
     e2e, fullscale = None, None

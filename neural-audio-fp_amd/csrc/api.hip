@@ -36,23 +36,35 @@ std::vector<ConvGeom> encoder_geometry(int in_f, int in_t) {
 // tensor (the pre-activation) per layer, which needs gamma != 0.  Against activations of O(1) a scale of 1e-30 IS zero in
 // float32 (its contribution vanishes in the first addition it meets), so the forward result does not change; the variable
 // the caller sees is not touched.
-struct CopyTable { const float* src[64]; float* dst[64]; int64_t n[64]; int nz[64]; int count; };
+struct CopyTable { const float* src[64]; float* dst[64]; int64_t n[64]; int nz[64]; int count; int* nonfinite; };
 __device__ __forceinline__ float nz_scale(float g) { return fabsf(g) < 1e-30f ? copysignf(1e-30f, g) : g; }
+__device__ __forceinline__ bool nonfinite4(float4 v) {
+    return !(fabsf(v.x) <= 3.4028234664e38f) || !(fabsf(v.y) <= 3.4028234664e38f) || !(fabsf(v.z) <= 3.4028234664e38f) || !(fabsf(v.w) <= 3.4028234664e38f);
+}
 __global__ __launch_bounds__(256) void multi_copy_kernel(const CopyTable t) {
     const int e = blockIdx.y;
     const float* __restrict__ s = t.src[e]; float* __restrict__ d = t.dst[e];
     const int64_t n = t.n[e];
     const bool nz = t.nz[e] != 0;
+    bool bad = false;                 // a NaN / Inf among the parameters (nafp_encoder::d_wflag)
     if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) {
         for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n / 4; i += (int64_t)gridDim.x * 256) {
             float4 v = ((const float4*)s)[i];
+            bad = bad || nonfinite4(v);
             if (nz) { v.x = nz_scale(v.x); v.y = nz_scale(v.y); v.z = nz_scale(v.z); v.w = nz_scale(v.w); }
             ((float4*)d)[i] = v;
         }
-        for (int64_t i = n / 4 * 4 + blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = nz ? nz_scale(s[i]) : s[i];
+        for (int64_t i = n / 4 * 4 + blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+            bad = bad || !(fabsf(s[i]) <= 3.4028234664e38f);
+            d[i] = nz ? nz_scale(s[i]) : s[i];
+        }
     } else {
-        for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = nz ? nz_scale(s[i]) : s[i];
+        for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+            bad = bad || !(fabsf(s[i]) <= 3.4028234664e38f);
+            d[i] = nz ? nz_scale(s[i]) : s[i];
+        }
     }
+    if (bad && t.nonfinite) atomicOr(t.nonfinite, 1);
 }
 struct BiasTable { float* hb[16]; const float* bias[16]; int64_t n[16]; int cout[16]; int count; };
 __global__ __launch_bounds__(256) void add_bias_kernel(const BiasTable t) {
@@ -85,6 +97,10 @@ struct nafp_encoder {
     std::vector<float*> d_wd;
     float *d_w1k = nullptr, *d_b1k = nullptr, *d_w2k = nullptr;
     double* d_inv_n = nullptr;
+    // != 0: the parameter set of the last set_weights holds a NaN or an Inf.  The packed ELU of the GEMM epilogues (max(t, exp(min(t, 0)) - 1))
+    // drops a NaN operand, so NaN weights would come out as FINITE garbage; keras gives NaN fingerprints (nnfp.py:73-79).  The kernels
+    // of set_weights that touch every parameter anyway raise this word, and the tail writes NaN rows when it is set.
+    int* d_wflag = nullptr;
     float* d_sw_slab = nullptr; int64_t sw_slab_floats = 0;      // split-K slab of the G/Hb launches in set_weights
     bool has_weights = false;
     // Ordering of set_weights against the passes that read what it writes, when they run on DIFFERENT streams (a trainer
@@ -241,7 +257,7 @@ extern "C" int nafp_encoder_create(nafp_encoder** out, int in_f, int in_t, int e
     for (auto& s : e->shapes) total += (numel(s) + 63) / 64 * 64;      // 256-B aligned slots
     for (int j = 1; j < 16; ++j) total += 2 * ((numel(e->shapes[4 * j + 2]) + 63) / 64 * 64);   // G, Hb
     for (int j = 1; j < 16; ++j) total += (numel(e->shapes[4 * j]) + 63) / 64 * 64;               // dgrad weights
-    total += (numel(e->shapes[64]) + 63) / 64 * 64 + 2 * ((numel(e->shapes[65]) + 63) / 64 * 64) + 64;   // keras div copies, inv_n
+    total += (numel(e->shapes[64]) + 63) / 64 * 64 + 2 * ((numel(e->shapes[65]) + 63) / 64 * 64) + 64 + 64;   // keras div copies, inv_n, d_wflag
     for (int j = 1; j < 16; ++j) e->sw_slab_floats = std::max(e->sw_slab_floats, conv_gemm_slab_floats(2, e->geom[j]));
     total += nafp_encoder::NAFP_SW_STREAMS * (e->sw_slab_floats + 64);
     e->blob_floats = total;
@@ -262,6 +278,7 @@ extern "C" int nafp_encoder_create(nafp_encoder** out, int in_f, int in_t, int e
     for (int j = 1; j < 16; ++j) e->d_wd.push_back(take(4 * j));
     e->d_w1k = take(64); e->d_b1k = take(65); e->d_w2k = take(65);
     e->d_inv_n = (double*)p; p += 64;
+    e->d_wflag = (int*)p; p += 64;
     e->d_sw_slab = p; p += nafp_encoder::NAFP_SW_STREAMS * (e->sw_slab_floats + 64);      // one slab per helper stream, (sw_slab_floats + 64) apart
     // set_weights runs G_j and Hb_j as the two "samples" of one launch: the pairs must be adjacent
     for (int j = 0; j < 16; ++j) {
@@ -358,11 +375,13 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
         NAFP_HIP_CHECK(hipEventCreateWithFlags(&e->sw_l1, hipEventDisableTiming));
     }
     e->sw_recorded = false;                 // (an early return below leaves the passes without events to wait for: the caller got an error)
+    NAFP_HIP_CHECK(hipMemsetAsync(e->d_wflag, 0, sizeof(int), st));
+    ct.nonfinite = e->d_wflag;
     multi_copy_kernel<<<dim3(32, ct.count), 256, 0, st>>>(ct);
     NAFP_LAUNCH_CHECK();
     NAFP_HIP_CHECK(hipEventRecord(e->sw_copied, st));
     {
-        PackTable pt; pt.count = 0;
+        PackTable pt; pt.count = 0; pt.nonfinite = e->d_wflag;
         for (int j = 1; j < 16; ++j) {
             pt.k3[pt.count] = t[4 * j]; pt.wp[pt.count] = e->d_w[j]; pt.wd[pt.count] = e->d_wd[j];
             pt.cin[pt.count] = e->geom[j].Cin; pt.cout[pt.count] = e->geom[j].Cout; ++pt.count;
@@ -552,7 +571,7 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
     t.x = cur; t.stats = stats + 2 * n_seg * 15; t.gamma = e->d_gamma[15]; t.beta = e->d_beta[15];
     t.w1p = e->d_w1p; t.b1p = e->d_b1p; t.w2p = e->d_w2p; t.b2 = e->d_b2;
     t.out_flat = out_flat; t.out_emb = out_emb;
-    t.D = (int)e->flat_dim; t.Q = e->emb_sz; t.S = e->S; t.l2norm = l2norm;
+    t.D = (int)e->flat_dim; t.Q = e->emb_sz; t.S = e->S; t.l2norm = l2norm; t.nonfinite_weights = e->d_wflag;
     if (ev && e->prof_coarse < 2) NAFP_HIP_CHECK(hipEventRecord(ev[32], st));
     rc = launch_tail(t, n_seg, st);
     if (rc != NAFP_OK) return rc;
@@ -622,7 +641,7 @@ extern "C" int nafp_encoder_div_enc(nafp_encoder* e, const float* flat, int64_t 
     t.x = flat; t.stats = nullptr; t.gamma = nullptr; t.beta = nullptr;
     t.w1p = e->d_w1p; t.b1p = e->d_b1p; t.w2p = e->d_w2p; t.b2 = e->d_b2;
     t.out_flat = nullptr; t.out_emb = out_emb;
-    t.D = (int)e->flat_dim; t.Q = e->emb_sz; t.S = e->S; t.l2norm = l2norm;
+    t.D = (int)e->flat_dim; t.Q = e->emb_sz; t.S = e->S; t.l2norm = l2norm; t.nonfinite_weights = e->d_wflag;
     { int wrc = wait_weights(e, (hipStream_t)stream); if (wrc != NAFP_OK) return wrc; }
     return launch_tail(t, n_seg, (hipStream_t)stream);
 }
@@ -728,7 +747,7 @@ extern "C" int nafp_encoder_forward_train(nafp_encoder* e, const float* feat, in
     t.x = L.z[15]; t.stats = L.stats + 2 * n_seg * 15; t.gamma = e->d_gamma[15]; t.beta = e->d_beta[15];
     t.w1p = e->d_w1p; t.b1p = e->d_b1p; t.w2p = e->d_w2p; t.b2 = e->d_b2;
     t.out_flat = nullptr; t.out_emb = out_emb;
-    t.D = (int)e->flat_dim; t.Q = e->emb_sz; t.S = e->S; t.l2norm = l2norm;
+    t.D = (int)e->flat_dim; t.Q = e->emb_sz; t.S = e->S; t.l2norm = l2norm; t.nonfinite_weights = e->d_wflag;
     return launch_tail(t, n_seg, st);
 }
 

@@ -38,7 +38,7 @@ __global__ void stats_to_mr_kernel(const stat_t* __restrict__ stats, float* __re
     const double inv_n = inv_n_per_layer[i / B];
     const double mean = stat_get(stats + 2 * i) * inv_n;
     double var = stat_get(stats + 2 * i + 1) * inv_n - mean * mean;
-    var = var > 0.0 ? var : 0.0;
+    var = var < 0.0 ? 0.0 : var;
     mr[2 * i] = (float)mean;
     mr[2 * i + 1] = (float)(1.0 / sqrt(var + (double)LN_EPS));
 }
@@ -1217,7 +1217,7 @@ __global__ __launch_bounds__(256) void tail_bwd_a_kernel(const TailBwdArgs a) {
     const int64_t b = blockIdx.x;
     const double mean = stat_get(a.stats + 2 * b) / (double)a.D;
     double var = stat_get(a.stats + 2 * b + 1) / (double)a.D - mean * mean;
-    var = var > 0.0 ? var : 0.0;
+    var = var < 0.0 ? 0.0 : var;
     const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
     const float lnA = (float)rstd, lnC = (float)(-mean * rstd);
     if (q == 0) { a.ln[2 * b] = lnA; a.ln[2 * b + 1] = lnC; }     // kernel B reads them instead of redoing the double arithmetic per thread

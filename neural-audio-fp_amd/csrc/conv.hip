@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(
         for (int i = tid; i < rows * Tin; i += 256) {
             float v = xin[i];
             if (gstat) {
-                v = fmaxf(v - gmax, -80.f);
+                v = max_keep_nan(v - gmax, -80.f);
                 if (segment_norm) v = (v - nh) / nd;
             }
             s_x[(i / Tin) * 64 + (i % Tin)] = v;
@@ -535,7 +535,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     double st_sum = 0.0, st_sq = 0.0;             // loaded here, turned into (r, c) after the first DMAs are on their way
     if (stat_thread && p.mode != 1 && b0 + tid - 64 < p.B) {
         st_sum = stat_get(p.stats_in + 2 * (int64_t)(b0 + tid - 64));
-        st_sq = stat_get(p.stats_in + 2 * (int64_t)(b0 + tid - 64) + 1);
+        st_sq = stat_get(p.stats_in + 2 * (int64_t)(b0 + tid - 64) + 1);          // NaN for a poisoned sample (nafp_common.h)
+        if (st_sq != st_sq && p.stats_out) stat_poison(p.stats_out + 2 * (int64_t)(b0 + tid - 64));   // ... which stays poisoned
     }
     if (tid < 32) {
         int pos = p.P, inner = 0; unsigned mask = 0;
@@ -713,7 +714,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         if (p.mode != 1 && b0 + tid - 64 < p.B) {
             const double mean = st_sum * p.inv_n_in;
             double var = st_sq * p.inv_n_in - mean * mean;
-            var = var > 0.0 ? var : 0.0;
+            var = var < 0.0 ? 0.0 : var;                          // (keeps a NaN)
             const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
             r = (float)rstd; c = (float)(-mean * rstd);
         }
@@ -1336,11 +1337,8 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(
     const int b_first = (int)((i0 / c4) / P), b_last = (int)((i_last / c4) / P);
     if (tid <= b_last - b_first) {
         const int b = b_first + tid;
-        const double mean = stat_get(stats_in + 2 * (int64_t)b) * inv_n_in;
-        double var = stat_get(stats_in + 2 * (int64_t)b + 1) * inv_n_in - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
-        sR[tid] = (float)rstd; sC[tid] = (float)(-mean * rstd);
+        stat_ln_scalars(stats_in + 2 * (int64_t)b, inv_n_in, &sR[tid], &sC[tid]);
+        stat_forward_poison(stats_in + 2 * (int64_t)b, stats_out + 2 * (int64_t)b);
     }
     __syncthreads();
     const int64_t slab_stride4 = total;                 // float4 per slab
@@ -2124,7 +2122,11 @@ __global__ __launch_bounds__(256) void multi_pack_kernel(const PackTable t) {
         const int k0 = (tl % tiles_k) * 32, n0 = (tl / tiles_k) * 32;
         __syncthreads();
         for (int r = ty; r < 32; r += 8)
-            if (k0 + r < K && n0 + tx < Cout) tile[r][tx] = k3[(int64_t)(k0 + r) * Cout + n0 + tx];
+            if (k0 + r < K && n0 + tx < Cout) {
+                const float w = k3[(int64_t)(k0 + r) * Cout + n0 + tx];
+                tile[r][tx] = w;
+                if (!(fabsf(w) <= 3.4028234664e38f) && t.nonfinite) atomicOr(t.nonfinite, 1);      // NaN / Inf: rare, see d_wflag
+            }
         __syncthreads();
         for (int r = ty; r < 32; r += 8)
             if (n0 + r < Cout && k0 + tx < K) wp[(int64_t)(n0 + r) * K + k0 + tx] = tile[tx][r];

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void melspec_kernel(
 #pragma unroll
                             for (int j = 0; j < MAX_TAPS; ++j) acc += mw[j] * mm[j];
                             // melspectrogram.py:104,107
-                            const float v = logf(fmaxf(acc + 0.06f, 1e-10f)) / 2.302585092994046f;
+                            const float v = logf(max_keep_nan(acc + 0.06f, 1e-10f)) / 2.302585092994046f;
                             tile[tid * TILE_LD + (f - chunk0)] = v;
                             lmax = fmaxf(lmax, v);
                             lmin = fminf(lmin, v);
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256, 2) void melspec_r16_kernel(
                         float acc = 0.f;
 #pragma unroll
                         for (int j = 0; j < MAX_TAPS; ++j) acc += mw[j] * mm[j];
-                        const float v = logf(fmaxf(acc + 0.06f, 1e-10f)) / 2.302585092994046f;     // melspectrogram.py:104,107
+                        const float v = logf(max_keep_nan(acc + 0.06f, 1e-10f)) / 2.302585092994046f;     // melspectrogram.py:104,107
                         tile[tid * TILE_LD + (f - chunk0)] = v;
                         lmax = fmaxf(lmax, v);
                         lmin = fminf(lmin, v);
@@ -624,10 +624,10 @@ __global__ __launch_bounds__(256) void melspec_finalize_kernel(
         const int64_t g = group_size > 0 ? seg / group_size : 0;
         const float gmax = group_stat[2 * g];
         float4 v = ((float4*)feat)[i];
-        v.x = fmaxf(v.x - gmax, -80.f);
-        v.y = fmaxf(v.y - gmax, -80.f);
-        v.z = fmaxf(v.z - gmax, -80.f);
-        v.w = fmaxf(v.w - gmax, -80.f);
+        v.x = max_keep_nan(v.x - gmax, -80.f);
+        v.y = max_keep_nan(v.y - gmax, -80.f);
+        v.z = max_keep_nan(v.z - gmax, -80.f);
+        v.w = max_keep_nan(v.w - gmax, -80.f);
         if (segment_norm) {
             const float mn = fmaxf(group_stat[2 * g + 1] - gmax, -80.f);
             const float h = mn / 2.f, d = fabsf(h + 1e-10f);

@@ -45,11 +45,15 @@ struct ConvGeom {
 std::vector<ConvGeom> encoder_geometry(int in_f, int in_t);
 
 // keras ELU(alpha=1) (nnfp.py:74,77).  TF computes exp(x) - 1 for x < 0; branch-free here
-// (v_exp_f32 + select) because it sits in every conv epilogue.
+// (v_exp_f32 + select) because it sits in every conv epilogue.  A NaN stays a NaN (fminf would hand back the 0).
 __device__ __forceinline__ float elu1(float v) {
     const float e = __expf(fminf(v, 0.f)) - 1.f;
-    return v > 0.f ? v : e;
+    return v > 0.f ? v : (v != v ? v : e);
 }
+
+// max(v, lo) that keeps a NaN (fmaxf hands back `lo`): the -80 dB clamp of the log-mel layer (melspectrogram.py:109) must not
+// turn a NaN segment into a finite one.  Bit-identical to fmaxf for every other input.
+__device__ __forceinline__ float max_keep_nan(float v, float lo) { return v < lo ? lo : v; }
 
 // Per-sample LayerNorm statistics (sum, sum of squares of a conv's ELU output) are accumulated as 64-bit FIXED-POINT
 // integers with STAT_FRAC_BITS fractional bits.  Integer addition is associative, so the totals do not depend on the
@@ -57,15 +61,52 @@ __device__ __forceinline__ float elu1(float v) {
 // BIT-REPRODUCIBLE run to run (the double atomicAdd used before made two generate runs differ by ~1e-6).  Each partial is
 // a double formed in a fixed order inside its workgroup and rounded once to the grid: <= 2^-21 absolute per partial
 // (at most a few thousand partials per sample), against sums that are divided by n >= 1024 and compared with the
-// LayerNorm epsilon 1e-3 -- far below float32 rounding of the activations themselves.  Range: |sum| < 2^43 ~ 8.8e12,
-// i.e. an RMS activation below 4096 at the largest layer (n = 2^19); LayerNorm keeps activations O(1).
+// LayerNorm epsilon 1e-3 -- far below float32 rounding of the activations themselves.
+//
+// NON-FINITE VALUES AND RANGE [r5].  A partial that is NaN, infinite or >= 2^31 in magnitude (a workgroup's share of one
+// sample: an RMS activation above ~250 at the widest tile; LayerNorm keeps activations O(1)) is not added: it POISONS the
+// sample instead -- atomicOr of STAT_POISON into the sample's sum-of-squares slot.  That slot only ever receives
+// non-negative partials below 2^51 (fixed point), at most 2^11 of them, so its two top bits are clear unless poisoned, an
+// OR is idempotent, and later adds cannot carry into them: the flag is sticky and order-free.  stat_get() of a poisoned slot
+// is NaN, hence r_b = c_b = NaN for that sample in every consumer; and because the packed ELU of the GEMM epilogues
+// (max(t, exp(min(t, 0)) - 1): IEEE maxNum drops a NaN operand) would wash a NaN row back to finite values one layer
+// later, every consumer hands the poison of its input statistics on to its output statistics (stat_forward_poison: one
+// thread per sample and workgroup, in the prologue).  The tail writes NaN rows for poisoned samples: what keras
+// LayerNormalization does with such a sample (nnfp.py:73-79), while the other samples of the launch are untouched.
 typedef long long stat_t;
 constexpr int STAT_FRAC_BITS = 20;
+constexpr double STAT_PARTIAL_LIMIT = 2147483648.0;                 // 2^31
+constexpr unsigned long long STAT_POISON = 1ull << 62;
 #ifdef __HIPCC__
-__device__ __forceinline__ void stat_add(stat_t* slot, double v) {
-    atomicAdd((unsigned long long*)slot, (unsigned long long)__double2ll_rn(v * (double)(1 << STAT_FRAC_BITS)));
+__device__ __forceinline__ void stat_poison(stat_t* sample_slots) {      // sample_slots = the sample's (sum, sumsq) pair
+    atomicOr((unsigned long long*)(sample_slots + 1), STAT_POISON);
 }
-__device__ __forceinline__ double stat_get(const stat_t* slot) { return (double)(*slot) * (1.0 / (double)(1 << STAT_FRAC_BITS)); }
+// `slot` = &stats[2 b + which]; the pair of a sample is 16-byte aligned, so (slot | 8) is its sum-of-squares slot
+__device__ __forceinline__ void stat_add(stat_t* slot, double v) {
+    if (fabs(v) < STAT_PARTIAL_LIMIT)
+        atomicAdd((unsigned long long*)slot, (unsigned long long)__double2ll_rn(v * (double)(1 << STAT_FRAC_BITS)));
+    else
+        atomicOr((unsigned long long*)((uintptr_t)slot | 8), STAT_POISON);
+}
+__device__ __forceinline__ double stat_get(const stat_t* slot) {
+    const long long x = *slot;
+    if (((uintptr_t)slot & 8) && (unsigned long long)x >= STAT_POISON) return __builtin_nan("");
+    return (double)x * (1.0 / (double)(1 << STAT_FRAC_BITS));
+}
+// (r_b, c_b) = (rstd, -mean * rstd) of one sample from its statistics; NaN for a poisoned sample (the variance clamp keeps a NaN)
+__device__ __forceinline__ void stat_ln_scalars(const stat_t* sample_slots, double inv_n, float* r, float* c) {
+    const double mean = stat_get(sample_slots) * inv_n;
+    double var = stat_get(sample_slots + 1) * inv_n - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
+    *r = (float)rstd; *c = (float)(-mean * rstd);
+}
+__device__ __forceinline__ bool stat_is_poisoned(const stat_t* sample_slots) {
+    return (unsigned long long)sample_slots[1] >= STAT_POISON;
+}
+__device__ __forceinline__ void stat_forward_poison(const stat_t* in_slots, stat_t* out_slots) {
+    if (stat_is_poisoned(in_slots)) stat_poison(out_slots);
+}
 #endif
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -172,6 +213,7 @@ struct TailArgs {
     float* out_flat;         // (B,D) or nullptr
     float* out_emb;          // (B,Q) or nullptr
     int D, Q, S, l2norm;
+    const int* nonfinite_weights;   // (or null) != 0: the parameter set holds a NaN / Inf -> every output row is NaN
 };
 int launch_tail(const TailArgs& a, int64_t B, hipStream_t st);
 
@@ -217,7 +259,8 @@ int launch_conv0_bwd(const float* feat, const float* dt, float* dW0, float* dbia
 int launch_pack_dgrad_weight(const float* k3, float* wd, int Cin, int Cout, hipStream_t st);
 
 // weight packing
-struct PackTable { const float* k3[16]; float* wp[16]; float* wd[16]; int cin[16], cout[16]; int unit0[17]; int count; };
+struct PackTable { const float* k3[16]; float* wp[16]; float* wd[16]; int cin[16], cout[16]; int unit0[17]; int count;
+                   int* nonfinite; };      // nonfinite (or null): set to 1 when a conv kernel holds a NaN / Inf (see nafp_encoder::d_wflag)
 int launch_multi_pack(const PackTable& t, hipStream_t st);
 int launch_pack_conv_weight(const float* k3, float* wp, int Cin, int Cout, hipStream_t st);
 // Positional epilogue tensors G_j = conv_j(gamma_{j-1}), Hb_j = conv_j(beta_{j-1}) (bias added later) of the SMALL layers

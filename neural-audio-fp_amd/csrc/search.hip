@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void search_half_norms_kernel(const float* __r
 constexpr int TILE_ROWS = 64;
 
 template <int D, int K>
-__global__ __launch_bounds__(256, 2) void search_topk_kernel(
+__device__ __forceinline__ void search_topk_body(
         const float* __restrict__ Q, const float* __restrict__ X, const float* __restrict__ hn,
         float* __restrict__ out_key, int* __restrict__ out_id, int nq, int64_t N, int tiles_per_split, int n_lists) {
     constexpr int CH = D / 4;                        // 16-B chunks per row
@@ -171,6 +171,21 @@ __global__ __launch_bounds__(256, 2) void search_topk_kernel(
     }
 }
 
+template <int D, int K>
+__global__ __launch_bounds__(256, 2) void search_topk_kernel(
+        const float* __restrict__ Q, const float* __restrict__ X, const float* __restrict__ hn,
+        float* __restrict__ out_key, int* __restrict__ out_id, int nq, int64_t N, int tiles_per_split, int n_lists) {
+    search_topk_body<D, K>(Q, X, hn, out_key, out_id, nq, N, tiles_per_split, n_lists);
+}
+// d = 256 (EMB_SZ 256: the encoder and NT-Xent support it, so the exact index does too): a lane keeps 128 floats of its query
+// column, and the 2-tile ring is 128 KB of LDS -- one workgroup per CU either way, so the kernel may use the whole register file
+template <int K>
+__global__ __launch_bounds__(256, 1) void search_topk_kernel_d256(
+        const float* __restrict__ Q, const float* __restrict__ X, const float* __restrict__ hn,
+        float* __restrict__ out_key, int* __restrict__ out_id, int nq, int64_t N, int tiles_per_split, int n_lists) {
+    search_topk_body<256, K>(Q, X, hn, out_key, out_id, nq, N, tiles_per_split, n_lists);
+}
+
 __device__ __forceinline__ unsigned long long pack_key(float key, int id) {
     unsigned u = __float_as_uint(key);
     u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;                 // order-preserving map
@@ -243,9 +258,14 @@ template <int D, int K>
 static int launch_topk(const float* Q, int nq, const float* X, const float* hn, int64_t N, float* pk, int* pi, int splits,
                        int tps, hipStream_t st) {
     const int lds = 2 * TILE_ROWS * D * (int)sizeof(float);
-    NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)search_topk_kernel<D, K>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    search_topk_kernel<D, K><<<dim3((unsigned)((nq + 127) / 128), (unsigned)splits), 256, lds, st>>>(Q, X, hn, pk, pi, nq, N, tps,
-                                                                                                  2 * splits);
+    const dim3 grid((unsigned)((nq + 127) / 128), (unsigned)splits);
+    if constexpr (D == 256) {
+        NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)search_topk_kernel_d256<K>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        search_topk_kernel_d256<K><<<grid, 256, lds, st>>>(Q, X, hn, pk, pi, nq, N, tps, 2 * splits);
+    } else {
+        NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)search_topk_kernel<D, K>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        search_topk_kernel<D, K><<<grid, 256, lds, st>>>(Q, X, hn, pk, pi, nq, N, tps, 2 * splits);
+    }
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }
@@ -270,7 +290,7 @@ extern "C" int64_t nafp_search_index_aux_floats(int64_t n_index) {
 
 extern "C" int nafp_search_index_prepare(const float* index, int64_t n_index, int dim, float* aux, void* stream) {
     if (!index || !aux || n_index <= 0) return NAFP_ERR_INVALID_ARG;
-    if (dim != 64 && dim != 128) return NAFP_ERR_UNSUPPORTED;
+    if (dim != 64 && dim != 128 && dim != 256) return NAFP_ERR_UNSUPPORTED;
     const int64_t n_pad = nafp_search_index_aux_floats(n_index);
     search_half_norms_kernel<<<(unsigned)((n_pad + 255) / 256), 256, 0, (hipStream_t)stream>>>(index, aux, n_index, n_pad, dim);
     NAFP_LAUNCH_CHECK();
@@ -290,7 +310,7 @@ extern "C" int nafp_search_topk_l2(const float* query, int64_t n_query, const fl
                                    void* workspace, int64_t workspace_bytes, void* stream) {
     if (!query || !index || !aux || !out_dist || !out_ids || !workspace || n_query < 0 || n_index <= 0 || k <= 0)
         return NAFP_ERR_INVALID_ARG;
-    if ((dim != 64 && dim != 128) || k > 32 || n_index >= ((int64_t)1 << 31) || n_query > (1 << 30)) return NAFP_ERR_UNSUPPORTED;
+    if ((dim != 64 && dim != 128 && dim != 256) || k > 32 || n_index >= ((int64_t)1 << 31) || n_query > (1 << 30)) return NAFP_ERR_UNSUPPORTED;
     if (n_query == 0) return NAFP_OK;
     if (workspace_bytes < nafp_search_workspace_bytes(n_query, n_index, k)) return NAFP_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -303,6 +323,8 @@ extern "C" int nafp_search_topk_l2(const float* query, int64_t n_query, const fl
     int rc;
     if (dim == 128) rc = K == 20 ? launch_topk<128, 20>(query, (int)n_query, index, aux, n_index, pk, pi, splits, tps, st)
                                  : launch_topk<128, 32>(query, (int)n_query, index, aux, n_index, pk, pi, splits, tps, st);
+    else if (dim == 256) rc = K == 20 ? launch_topk<256, 20>(query, (int)n_query, index, aux, n_index, pk, pi, splits, tps, st)
+                                      : launch_topk<256, 32>(query, (int)n_query, index, aux, n_index, pk, pi, splits, tps, st);
     else            rc = K == 20 ? launch_topk<64, 20>(query, (int)n_query, index, aux, n_index, pk, pi, splits, tps, st)
                                  : launch_topk<64, 32>(query, (int)n_query, index, aux, n_index, pk, pi, splits, tps, st);
     if (rc != NAFP_OK) return rc;
@@ -318,11 +340,12 @@ extern "C" int nafp_search_seq_scores(const float* query, const float* index, in
                                       const int32_t* cand, int n_slots, float* out_scores, void* stream) {
     if (!query || !index || !task_q0 || !task_len || !cand || !out_scores || n_tasks < 0 || n_slots <= 0 || n_index <= 0)
         return NAFP_ERR_INVALID_ARG;
-    if (dim != 64 && dim != 128) return NAFP_ERR_UNSUPPORTED;
+    if (dim != 64 && dim != 128 && dim != 256) return NAFP_ERR_UNSUPPORTED;
     const int64_t total = n_tasks * n_slots;
     if (total == 0) return NAFP_OK;
     const unsigned blocks = (unsigned)((total + 3) / 4);
     if (dim == 128) search_seq_score_kernel<128><<<blocks, 256, 0, (hipStream_t)stream>>>(query, index, task_q0, task_len, cand, out_scores, n_index, n_slots, total);
+    else if (dim == 256) search_seq_score_kernel<256><<<blocks, 256, 0, (hipStream_t)stream>>>(query, index, task_q0, task_len, cand, out_scores, n_index, n_slots, total);
     else            search_seq_score_kernel<64><<<blocks, 256, 0, (hipStream_t)stream>>>(query, index, task_q0, task_len, cand, out_scores, n_index, n_slots, total);
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;

@@ -47,21 +47,19 @@ __global__ __launch_bounds__(512) void tail_kernel(const TailArgs a, int64_t B) 
         bet[i] = a.stats ? a.beta[q * S + i] : 0.f;
     }
 
+    // a parameter set with a NaN / Inf in it (set_weights found one): every row is NaN, as with keras
+    const bool bad_weights = a.nonfinite_weights && *a.nonfinite_weights != 0;
     for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
         float lnA = 1.f, lnC = 0.f;
-        if (a.stats) {
-            const double mean = stat_get(a.stats + 2 * b) / (double)a.D;
-            double var = stat_get(a.stats + 2 * b + 1) / (double)a.D - mean * mean;
-            var = var > 0.0 ? var : 0.0;
-            const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
-            lnA = (float)rstd; lnC = (float)(-mean * rstd);
-        }
+        if (a.stats) stat_ln_scalars(a.stats + 2 * b, 1.0 / (double)a.D, &lnA, &lnC);     // NaN for a poisoned sample: its row comes out NaN
+        if (bad_weights) lnA = __builtin_nanf("");
         float x[S];
 #pragma unroll
         for (int i = 0; i < S; ++i) {
             const int d = q * S + i;                    // tf.reshape (B,D)->(B,Q,S): nnfp.py:155
             float v = a.x[b * a.D + d];
             if (a.stats) v = fmaf(lnA, v, fmaf(lnC, gam[i], bet[i]));   // v held gamma . ELU(.)
+            else if (bad_weights) v = lnA;
             x[i] = v;
             if (a.out_flat && half == 0) a.out_flat[b * a.D + d] = v;
         }

@@ -3,9 +3,11 @@
 Host mirror of the reference's eval/eval_faiss.py (`load_memmap_data` :18-62, `eval_faiss` :93-275)
 and of `get_index` (eval/utils/get_index_faiss.py:10-121) for index_type 'L2' -- the exact
 faiss.IndexFlatL2 -- backed by libnafp's search kernels (include/nafp.h "Search / evaluation").
-The approximate index types (IVF, IVFPQ, IVFPQ-RR, IVFPQ-ONDISK, HNSW) raise NotImplementedError:
-on an MI355X the whole [dummy_db ; db] table stays resident in HBM (51 GB for 100 M fingerprints
-out of 288 GB) and is searched exactly.
+The approximate index types (IVF, IVFPQ, IVFPQ-RR, IVFPQ-ONDISK, HNSW) are not built: a request for one of them
+(the reference's default is `-i ivfpq`) is SERVED BY THE EXACT SEARCH, with a notice on stderr and the substitution
+recorded in `index_used.json` next to `raw_score.npy` -- on an MI355X the whole [dummy_db ; db] table stays resident
+in HBM (51 GB for 100 M fingerprints out of 288 GB), and the exact index is the accuracy ceiling of the approximate ones.
+Fingerprint dimensions 64 / 128 / 256 (EMB_SZ).
 
 Same inputs ({query, db, dummy_db}.mm + *_shape.npy written by `generate`), same outputs
 (`raw_score.npy` = [top1_exact | top1_near | top3_exact | top10_exact] per test id and sequence
@@ -51,7 +53,7 @@ class FlatL2Index:
     `.sequence_scores` the evaluation needs.  The vectors live in ONE device array."""
 
     def __init__(self, d, capacity=0, device=None):
-        if d not in (64, 128):
+        if d not in (64, 128, 256):
             raise NotImplementedError(f'fingerprint dimension {d}')
         self.d = int(d)
         self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())

@@ -47,10 +47,15 @@ def build_fp(cfg):
     return m_pre, m_specaug, m_fp
 
 
+NO_DIST = False       # bench.py sets this around its compute-only reference step (`exposed_comm_ms`): the step of ONE rank, no collectives
+
+
 def _dist():
     """torch.distributed when a process group exists -- also a group of ONE rank (legal for RCCL): the step then runs
     the same collectives as on a node (tests/test_gpu_train_dp.py drives that on the 1-GPU box)."""
     import torch.distributed as dist
+    if NO_DIST:
+        return None
     if dist.is_available() and dist.is_initialized():
         return dist
     return None
@@ -246,8 +251,8 @@ def make_optimizer(cfg, total_nsteps):
 def synthetic_batches(cfg, steps_per_epoch, device=None, snr_db=5.0):
     """SURVEY.md section 8(d) config 3/4 input: Xa = seeded noise segments, Xp = Xa + noise at
     5 dB SNR, float32 (n_local, 1, T) on the device; seeds differ per rank and per step."""
-    import torch.distributed as td
-    world = td.get_world_size() if (td.is_available() and td.is_initialized()) else 1
+    td = _dist()
+    world = td.get_world_size() if td is not None else 1
     rank = td.get_rank() if world > 1 else 0
     n_a = cfg['BSZ']['TR_N_ANCHOR']
     if n_a % world or cfg['BSZ']['TR_BATCH_SZ'] != 2 * n_a:

@@ -110,7 +110,7 @@ def test_kernels_do_not_spill_beyond_what_is_known(nafp):
         res = build.kernel_resources()
     assert len(res) >= 90, 'kernel resource remarks missing'
     known = {'conv_gemm_k16s3_any': 232, 'conv_gemm_n64k16s2_splitfin': 148, 'conv_gemm_m256k16s3_infer': 12,
-             'conv_gemm_m256k16s3_train': 20, 'gh_gemv_kernel': 272, 'tail_kernelILi16E': 408}
+             'conv_gemm_m256k16s3_train': 20, 'gh_gemv_kernel': 272, 'tail_kernelILi16E': 416}
     spilling = {n: r['ScratchSize [bytes/lane]'] for n, r in res.items() if r.get('ScratchSize [bytes/lane]', 0) > 0}
     for name, scratch in spilling.items():
         bound = max([v for k, v in known.items() if k in name] or [0])

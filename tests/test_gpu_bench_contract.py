@@ -46,6 +46,15 @@ def test_bench_line_contract():
     assert tr['global_batch'] == 256 and tr['unit'] == 'steps/s' and tr['value'] > 0 and tr['scaling'] == 'strong'
     t2 = d['train_1280']
     assert t2['optimizer'] == 'Adam' and t2['global_batch'] == 256 and t2['value'] > 0
+    # the second half of the metric is timed like the first: >= 3 regions, the median reported, all of them listed
+    for obj in (tr, t2, d['train_rank640']):
+        assert 'error' not in obj, obj
+        sp = obj['spread']
+        assert obj['repeats'] >= 3 and len(sp['ms_per_step_all']) == obj['repeats'] and sp['min'] <= obj['ms_per_step'] <= sp['max']
+        assert obj['ms_per_step'] == sorted(sp['ms_per_step_all'])[len(sp['ms_per_step_all']) // 2]
+    r6 = d['train_rank640']
+    assert r6['global_batch'] == 640 and r6['collectives']['backend'] == 'nccl' and r6['collectives']['world_size'] == 1
+    assert abs(r6['exposed_comm_ms'] - (r6['ms_per_step'] - r6['no_process_group_ms_per_step'])) < 2e-3
     e = d['e2e_generate']
     assert e['clips_100']['segments'] == 5900 and e['clips_600']['segments'] == 35400
     assert e['clips_100']['value'] > 0 and e['clips_600']['value'] > 0 and e['clips_600']['ingest_only_segments_per_s'] > 0
@@ -80,3 +89,5 @@ def test_bench_two_ranks_on_one_gpu_prints_train_with_collective_timings(form):
     assert c['all_gather(emb)_ms'] > 0 and c['reduce_scatter(d emb)_ms'] > 0
     assert len(c['all_reduce(grad pieces)_ms']) == 4 and all(x > 0 for x in c['all_reduce(grad pieces)_ms'])
     assert abs(sum(c['grad_piece_MB']) - 67.76) < 0.1
+    # what the collectives leave exposed: the step minus rank 0's compute-only step of the same run
+    assert abs(tr['exposed_comm_ms'] - (tr['ms_per_step'] - tr['no_process_group_ms_per_step'])) < 2e-3

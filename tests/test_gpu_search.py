@@ -35,7 +35,8 @@ def _check_topk(D, I, q, x, k):
 
 
 @pytest.mark.parametrize('n,nq,d,k', [(1000, 37, 128, 20), (64, 5, 128, 20), (50, 3, 128, 20), (5000, 300, 64, 20),
-                                      (20001, 130, 128, 32), (777, 129, 128, 1), (100000, 40, 128, 20)])
+                                      (20001, 130, 128, 32), (777, 129, 128, 1), (100000, 40, 128, 20),
+                                      (3000, 131, 256, 20), (12345, 70, 256, 32), (40, 2, 256, 5)])     # EMB_SZ 256
 def test_topk_matches_oracle(nafp, n, nq, d, k):
     from neural_audio_fp_amd.eval.eval_faiss import FlatL2Index
     x = _unit(n, d, n)
