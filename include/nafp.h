@@ -224,10 +224,17 @@ int nafp_encoder_grad_group_wait(nafp_encoder* enc, int group, void* stream);
  *                        made to wait for them before the last event of the call, so callers see the same ordering as with 0.
  *                        2 (default): those of the SMALL layers (fewer than 16 output positions), next to the LayerNorm backward
  *                        and transposed conv of the layer below; 1: every layer's (measured slower); 0: everything on
- *                        `stream`. */
+ *                        `stream`.
+ *   NAFP_OPT_SMALLNET    forward passes: the layers with <= 8 output positions (b5 ... b7 of the 1-s model) as ONE persistent launch
+ *                        whose workgroups claim (layer, sample group, tile, split-K part) items in order from a counter and wait only
+ *                        for finished tiles of the layer below for the SAME 128 samples (deadlock-free under any residency; bounded
+ *                        spins; a give-up shows as NaN rows).  0 (default): per-layer launches -- measured faster;
+ *                        1: the persistent launch at batches up to NAFP_SMALLNET_MAXB (env, default 1536).  Results agree to float32
+ *                        rounding (another split-K summation order), run-to-run bit-identical either way. */
 #define NAFP_OPT_FUSE_CONV0 1
 #define NAFP_OPT_FUSED_LN_BWD 2
 #define NAFP_OPT_BWD_OVERLAP 4
+#define NAFP_OPT_SMALLNET 5
 /* EXPERIMENTAL, changes the arithmetic (the only option that does): the unsplit GEMM convs of nafp_encoder_forward form their
  * products on the bf16 matrix pipe from f32 operands split into hi + lo bf16 halves (hi*hi + hi*lo + lo*hi, f32
  * accumulation).  Fingerprints move at the 1e-6 level against the f32 path.  Off by default; bench.py reports it as a

@@ -429,8 +429,12 @@ __device__ __forceinline__ float half_wave_sum_dpp(float x) {
 // split in registers into hi + lo bf16 halves, hi*hi + hi*lo + lo*hi with f32 accumulation (lo*lo, ~2^-16 of a product,
 // is dropped).  Not the arithmetic of the reference: results differ from the f32 path at the 1e-6 level of a fingerprint
 // component; bench.py reports it as a separate object with its measured error and never as `value`.
-template <int BM, int BNT, int BK, int NSTAGE, bool FUSE0, int EPI, int PREC = 0>
-__device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
+// PERSIST = 1: one work item of the persistent small-layer kernel (smallnet_kernel below): the tile ids come from the caller
+// instead of blockIdx, the z stores are write-through (the consumer is another workgroup of the SAME launch), and the function
+// tells its caller whether this workgroup ran the full epilogue (true) or left after handing in a split-K part (false).
+template <int BM, int BNT, int BK, int NSTAGE, bool FUSE0, int EPI, int PREC = 0, int PERSIST = 0>
+__device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p, const int it_sg = 0, const int it_pb = 0, const int it_col = 0,
+                                               const int it_z = 0) {
     static_assert(!FUSE0 || (BK == 16 && BM == 128), "the in-kernel conv0 generator is written for BK = 16, BM = 128");
     static_assert(BM == 128 || BM == 256, "tile rows");
     static_assert(BNT == 128 || (BNT == 64 && BM == 128 && !FUSE0), "tile columns");
@@ -460,6 +464,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     // grid = (sample groups, position blocks, column tiles): no division to take a block id apart
     // (split-K launches keep (sample groups x position blocks, column tiles, parts): their dispatch order matters more)
     int sg = blockIdx.x, pb = blockIdx.y, colz = blockIdx.z, zsp = 0;      // ..., column tile, split-K part
+    if (PERSIST) { sg = it_sg; pb = it_pb; colz = it_col; zsp = it_z; } else
     if (p.opt & 8) {
         // XCD-aware order on a 1-D grid: workgroup b runs on XCD b % 8 and every XCD has its own L2.  The
         // work items v are laid out so that the G items which share an operand are consecutive (G = p.xcd_group), and
@@ -512,10 +517,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     const int K = 3 * p.Cin;
     // diagnostic timeline: lane 0 of every wave stamps the shader clock at the phase boundaries of its tile
 #define NAFP_TL(k_)                                                                            \
-    if (p.tl && lane == 0)                                                                     \
+    if (!PERSIST && p.tl && lane == 0)                                                                     \
         p.tl[(((size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z)) * 8 + wave) * 8 + (k_)] = \
             __builtin_readcyclecounter();
-    if (p.tl && lane == 0)
+    if (!PERSIST && p.tl && lane == 0)
         p.tl[(((size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z)) * 8 + wave) * 8] =
             (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) |                    // HW_REG_HW_ID: wave/simd/cu/sh/se
             ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32);             // HW_REG_XCC_ID
@@ -752,7 +757,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     if NAFP_ABL(p, 8) {          // ablation: prologue + pipeline fill only (wait for the prefilled stages, then leave)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (acc[0][0][0] == 12345.678f) p.y[tid] = smem[tid];
-        return;
+        return false;
     }
     // Operand fragments of half a K-step (8 k-values): lane (row rl, half hh) reads logical chunk 2*kk + hh of its
     // A rows (2 x 32-row blocks) and B rows (NIW x 32-column blocks); one fragment set feeds 4 * 2 * NIW MFMAs.
@@ -997,7 +1002,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) t += acc[mi][ni][r];
         if (t == 12345.678f) p.y[tid] = t;
-        return;
+        return false;
     }
     // ---- epilogue ----
     // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).
@@ -1030,7 +1035,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
             }
         NAFP_TL(6)
         NAFP_TL(7)
-        return;
+        return false;
     }
 
     if (EPI == 4 || EPI == 5) {
@@ -1065,7 +1070,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
         if (tid == 0) sTicket[0] = __hip_atomic_fetch_add(p.tickets + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const unsigned ticket = sTicket[0];
-        if (ticket != (unsigned)(p.n_split - 1)) return;
+        if (ticket != (unsigned)(p.n_split - 1)) return false;
         __syncthreads();                                              // sTicket is read: LDS is reused by the statistics below
         if (tid == 0)                                                 // ready for the next launch; agent scope like every other access
             __hip_atomic_store(p.tickets + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1106,7 +1111,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
 #pragma unroll
                         for (int ni = 0; ni < NIW; ++ni)
                             __builtin_amdgcn_raw_buffer_store_b32(f2i(acc[mi][ni][rg * 4 + q] + bv[ni]), rsF, voffs[mi][rg], q * ystep_b + ni * 128, 0);
-            return;
+            return false;
         }
     }
 
@@ -1158,8 +1163,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
                     const f32x2 v2 = NAFP_ABL(p, 128) ? t2 : elu2(t2);    /* ablation 128: no exp */ \
                     const f32x2 z2 = v2 * gv[ms][rg][ni];                                      \
                     if (!NAFP_ABL(p, 64)) {                                /* ablation 64: no stores */ \
-                        __builtin_amdgcn_raw_buffer_store_b32(f2i(z2.x), rsY, voff, (2 * qp) * ystep_b + ni * 128, NAFP_Z_AUX); \
-                        __builtin_amdgcn_raw_buffer_store_b32(f2i(z2.y), rsY, voff, (2 * qp + 1) * ystep_b + ni * 128, NAFP_Z_AUX); \
+                        __builtin_amdgcn_raw_buffer_store_b32(f2i(z2.x), rsY, voff, (2 * qp) * ystep_b + ni * 128, PERSIST ? 16 : NAFP_Z_AUX); \
+                        __builtin_amdgcn_raw_buffer_store_b32(f2i(z2.y), rsY, voff, (2 * qp + 1) * ystep_b + ni * 128, PERSIST ? 16 : NAFP_Z_AUX); \
                     }                                                                          \
                     if (KEEP_) {                                           /* training keeps the pre-activation */ \
                         __builtin_amdgcn_raw_buffer_store_b32(f2i(t2.x), rsV, voff, (2 * qp) * ystep_b + ni * 128, NAFP_T_AUX); \
@@ -1189,7 +1194,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     NAFP_TL(6)
     if NAFP_ABL(p, 16) {         // ablation: no statistics reduction (keep the sums alive)
         if (s2[0].x + s2[0].y + s2[1].x + s2[1].y + q2[0].x + q2[0].y + q2[1].x + q2[1].y == 12345.678f) p.y[tid] = 1.f;
-        return;
+        return false;
     }
     if (fast_stats) {
         // ST == 4: the tile's 4 samples are the 4 register slots (r & 3) of every lane.
@@ -1238,6 +1243,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvKernelParams& p) {
     }
     NAFP_TL(7)
 #undef NAFP_TL
+    return true;
 }
 
 // One __global__ per tile shape and epilogue (launch bounds are not template-dependent).
@@ -1785,6 +1791,194 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     else if (f4 >= 1024 * 512) { NAFP_FIN(512); }
     else { NAFP_FIN(256); }
 #undef NAFP_FIN
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}
+
+// ============================================================================
+// [r5] The SMALL layers (b5 ... b7: convs 10-15 of the 1-s model; P <= 8 output positions) in ONE persistent launch.
+//
+// At the batch sizes the metric runs (640 per step / per rank) these six GEMMs have 40-160 output tiles each: every one of them
+// was a launch of <= 480 short workgroups (one round, split-K 3-6) plus a finish launch -- twelve launches that spend more time
+// filling, draining and waiting for their longest tile than multiplying (62-83 TFLOP/s; 316 us of a 3,345 us step for 7 % of its
+// FLOPs).  Here the work of all six layers is ONE ordered list of items (layer, 128-sample group, tile, split-K part), and a fixed
+// grid of workgroups claims items IN ORDER from a counter:
+//   * an item is the body of conv_gemm_body<128, 128, 16, 3, ., EPI 4>: its K-range of one output tile into the layer's slab,
+//     arrival ticket, and -- for the last arriver of the tile -- the parts summed in part order and the FULL epilogue;
+//   * the only dependency is per SAMPLE GROUP: a tile of layer j reads z_{j-1} and the statistics of ITS 128 samples only, so an
+//     item of (layer j, group g) waits until all tiles of (layer j-1, group g) are finished (one counter per (layer, group)),
+//     while other groups are layers ahead or behind: no per-layer barrier, the fill and drain of one layer overlaps the K-loops of
+//     its neighbours, and the live-tap classes / tile counts of different layers average out over the 256 CUs;
+//   * DEADLOCK-FREE under any residency (four generate streams share the chip): a waiter only ever waits for items with a
+//     SMALLER index, all of which were claimed before its own by workgroups that are running (a claim is made by a resident
+//     workgroup) and that in turn wait only for smaller indices; the smallest unfinished item never waits.  Every spin is bounded:
+//     on a time-out the workgroup raises the launch's error word and goes on (the tail then writes NaN rows: loud, never a hang);
+//   * visibility between workgroups of one launch (MI355X_MICROARCH.md): z and slab stores are write-through (sc1), every storing
+//     wave drains vmcnt before the finisher's counter increment; a consumer polls the counter relaxed, then ONE agent-scope
+//     acquire, then plain loads / LDS-DMA.  The statistics travel by agent-scope atomics as before.
+// ============================================================================
+constexpr int SMALLNET_MAX_LAYERS = 6;
+struct SmallNetLayer {
+    ConvKernelParams p;
+    int item0, n_items;            // this layer's items are [item0, item0 + n_items) of the launch
+    int sg_per_group;              // sample groups (tile rows of ST samples) per 128-sample dependency group
+    int items_per_group;           // of a FULL group: sg_per_group * n_pb * n_col * n_split
+    int n_groups, n_col;
+};
+struct SmallNetParams {
+    SmallNetLayer L[SMALLNET_MAX_LAYERS];
+    int n_layers, n_items, n_groups, prio_mode;
+    unsigned* ctrl;                // [0] next item, [1] error word, [16 + l * n_groups + g] finished tiles of (layer l, group g); zero at launch
+};
+constexpr int SMALLNET_CTRL_WORDS = 1024;
+constexpr unsigned SMALLNET_SPIN_LIMIT = 1u << 22;      // polls of ~0.25 us each: ~1 s
+
+__global__ __launch_bounds__(256, 2) void smallnet_kernel(const SmallNetParams P) {
+    __shared__ int s_item[4];
+    const int tid = threadIdx.x;
+    for (;;) {
+        if (tid == 0) s_item[0] = (int)__hip_atomic_fetch_add(P.ctrl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int item = __builtin_amdgcn_readfirstlane(s_item[0]);
+        if (item >= P.n_items) return;
+        int l = 0;
+#pragma unroll
+        for (int k = 1; k < SMALLNET_MAX_LAYERS; ++k)
+            if (k < P.n_layers && item >= P.L[k].item0) l = k;
+        const SmallNetLayer& Ly = P.L[l];
+        const ConvKernelParams& p = Ly.p;
+        const int il = item - Ly.item0;
+        const int g = min(il / Ly.items_per_group, Ly.n_groups - 1);      // (only the last group can be short)
+        int rem = il - g * Ly.items_per_group;
+        const int zsp = rem % p.n_split; rem /= p.n_split;
+        const int colz = rem % Ly.n_col; rem /= Ly.n_col;
+        const int pb = rem % p.n_pb;
+        const int sg = g * Ly.sg_per_group + rem / p.n_pb;
+        // ---- dependency: every tile of (layer l - 1, group g) is finished ----
+        if (l > 0) {
+            if (tid == 0) {
+                const SmallNetLayer& Lp = P.L[l - 1];
+                const int sgs = min(Lp.sg_per_group, Lp.p.n_sg - g * Lp.sg_per_group);
+                const unsigned target = (unsigned)(sgs * Lp.p.n_pb * Lp.n_col);
+                const unsigned* cnt = P.ctrl + 16 + (l - 1) * P.n_groups + g;
+                unsigned spins = 0;
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > SMALLNET_SPIN_LIMIT) { __hip_atomic_store(P.ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+        }
+        // two workgroups of a CU share its matrix pipes: the one with the EARLIER layer goes first (its tiles are what later items wait for)
+        if (P.prio_mode == 1) {
+            if (l == 0) __builtin_amdgcn_s_setprio(3); else if (l == 1) __builtin_amdgcn_s_setprio(2);
+            else if (l == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        } else if (P.prio_mode == 2) {
+            if (l & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
+        }
+        const bool finished = conv_gemm_body<128, 128, 16, 3, false, 4, 0, 1>(p, sg, pb, colz, zsp);
+        // every wave's stores (z, statistics) have left before the tile is counted as finished
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                    // ... and the LDS of this item is free for the next one
+        if (finished && tid == 0)
+            __hip_atomic_fetch_add(P.ctrl + 16 + l * P.n_groups + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Split-K parts per tile of a small layer: parts of ~NAFP_SMALLNET_STEPS K-steps (the longest live-tap class decides)
+static int smallnet_split(const ConvGeom& g) {
+    static const int target = []() { const char* e = getenv("NAFP_SMALLNET_STEPS"); return e && atoi(e) > 0 ? atoi(e) : 24; }();
+    const int k = live_k_steps(g);
+    int S = (k + target / 2) / target;
+    S = std::max(1, std::min(8, S));
+    while (S > 1 && k / S < 8) --S;
+    return S;
+}
+bool smallnet_layer_ok(const ConvGeom& g) {
+    const int P = g.Fout * g.Tout;
+    return P <= 8 && g.Cin % 32 == 0 && g.Cout % BN == 0 && (g.stride == 1 || g.stride == 2);
+}
+// floats of split-K slab the persistent launch needs for layers [j0, j1]: every layer has a region of its own (groups of
+// different layers are in flight at the same time)
+int64_t smallnet_slab_floats(int64_t B, const ConvGeom* geoms, int j0, int j1) {
+    int64_t tot = 0;
+    for (int j = j0; j <= j1; ++j) tot += (int64_t)smallnet_split(geoms[j]) * B * geoms[j].Fout * geoms[j].Tout * geoms[j].Cout;
+    return tot;
+}
+
+int launch_smallnet(const SmallNetArgs& a, int64_t B, const ConvGeom* geoms, hipStream_t st) {
+    const int nl = a.j1 - a.j0 + 1;
+    if (nl < 1 || nl > SMALLNET_MAX_LAYERS || B <= 0 || B > (1 << 24)) return NAFP_ERR_UNSUPPORTED;
+    SmallNetParams P;
+    P.n_layers = nl; P.ctrl = a.ctrl;
+    static const int prio_mode = []() { const char* e = getenv("NAFP_SMALLNET_PRIO"); return e ? atoi(e) : 0; }();
+    P.prio_mode = prio_mode;
+    P.n_groups = (int)((B + 127) / 128);
+    if (16 + nl * P.n_groups > SMALLNET_CTRL_WORDS) return NAFP_ERR_UNSUPPORTED;
+    int item0 = 0; int64_t slab_off = 0; int ticket_off = 0;
+    static const int gemm_prio = []() { const char* e = getenv("NAFP_GEMM_PRIO"); return e ? atoi(e) : 0; }();
+    for (int k = 0; k < nl; ++k) {
+        const int j = a.j0 + k;
+        const ConvGeom& g = geoms[j];
+        if (!smallnet_layer_ok(g)) return NAFP_ERR_UNSUPPORTED;
+        SmallNetLayer& Ly = P.L[k];
+        ConvKernelParams& p = Ly.p;
+        p = ConvKernelParams{};
+        const FwdPlan fp = fwd_plan(B, g, true, false);
+        const int pt = fp.BM == 128 ? fp.pt : fwd_tile(g, 128).pt;
+        p.x = a.x[k]; p.wp = a.wp[k]; p.G = a.G[k]; p.Hb = a.Hb[k]; p.gamma_out = a.gamma_out[k]; p.bias = nullptr;
+        p.stats_in = a.stats_in[k]; p.stats_out = a.stats_out[k]; p.v_out = nullptr;
+        p.Fin = g.Fin; p.Tin = g.Tin; p.Cin = g.Cin; p.Tout = g.Tout; p.Cout = g.Cout;
+        p.axis = g.axis; p.stride = g.stride; p.pad = g.pad;
+        p.B = (int)B; p.P = g.Fout * g.Tout;
+        p.PT = pt; p.ST = 128 / pt;
+        p.log2ST = 0;
+        while ((1 << p.log2ST) < p.ST) ++p.log2ST;
+        if ((1 << p.log2ST) != p.ST || p.ST < 4) return NAFP_ERR_UNSUPPORTED;
+        p.n_sg = (int)((B + p.ST - 1) / p.ST);
+        p.n_pb = (p.P + p.PT - 1) / p.PT; p.log2_ncol = 0; p.xcd_group = 1; p.xcd_full = 0;
+        p.sample_in = (int64_t)g.Fin * g.Tin * g.Cin;
+        p.tap_stride = g.axis == 0 ? g.Cin : g.Tin * g.Cin;
+        p.inv_n_in = 1.0 / (double)p.sample_in;
+        p.mode = 2; p.dgrad = 0;
+        p.perm_on = (fp.BM == 128 ? fp.perm : (g.axis == 0 ? (fwd_tile(g, 128).perm) : 0)); p.perm_n0 = 0; p.perm_c0 = 0;
+        if ((int64_t)p.ST * p.sample_in * 4 >= ((int64_t)1 << 31)) return NAFP_ERR_UNSUPPORTED;
+        const int64_t wbytes = (int64_t)g.Cout * 3 * g.Cin * 4;
+        if (wbytes >= ((int64_t)1 << 31)) return NAFP_ERR_UNSUPPORTED;
+        p.wp_bytes = (unsigned)wbytes;
+        p.n_split = smallnet_split(g);
+        p.abl = 0; p.tl = nullptr; p.opt = gemm_prio & 3;
+        const int64_t out_floats = B * p.P * p.Cout;
+        if (slab_off + (int64_t)p.n_split * out_floats > a.slab_floats) return NAFP_ERR_WORKSPACE;
+        p.y = a.slab + slab_off; slab_off += (int64_t)p.n_split * out_floats;
+        p.y_final = a.y[k];
+        Ly.n_col = p.Cout / BN;
+        const int n_tiles = p.n_sg * p.n_pb * Ly.n_col;
+        if (ticket_off + n_tiles > NAFP_TICKET_SLOTS) return NAFP_ERR_UNSUPPORTED;
+        p.tickets = a.tickets + ticket_off; ticket_off += n_tiles;
+        p.f0_feat = nullptr; p.f0_w = nullptr; p.f0_bias = nullptr; p.f0_gamma = nullptr; p.f0_T = 0; p.f0_stride = 1; p.f0_pad = 0;
+        p.sj = ScalarsJob{nullptr, nullptr, nullptr, nullptr, 0, 0.0};
+        if (128 % p.ST != 0) return NAFP_ERR_UNSUPPORTED;
+        Ly.sg_per_group = 128 / p.ST;
+        Ly.n_groups = P.n_groups;
+        Ly.items_per_group = Ly.sg_per_group * p.n_pb * Ly.n_col * p.n_split;
+        Ly.item0 = item0; Ly.n_items = n_tiles * p.n_split;
+        item0 += Ly.n_items;
+    }
+    P.n_items = item0;
+    static bool attr = false;
+    const int lds = (3 * (128 + 128) * 16 + 2 * 128 + 96) * (int)sizeof(float);
+    if (!attr) { NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)smallnet_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr = true; }
+    static const int wgs = []() { const char* e = getenv("NAFP_SMALLNET_WGS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
+    const unsigned grid = (unsigned)std::min(P.n_items, wgs);
+    if (a.ev_start || a.ev_stop) {
+        SmallNetParams pc = P;
+        void* args[] = {(void*)&pc};
+        NAFP_HIP_CHECK(hipExtLaunchKernel((const void*)smallnet_kernel, dim3(grid), dim3(256), args, (size_t)lds, st, a.ev_start, a.ev_stop, 0));
+    } else {
+        smallnet_kernel<<<grid, 256, lds, st>>>(P);
+    }
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }

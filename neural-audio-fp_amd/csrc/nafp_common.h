@@ -184,6 +184,20 @@ int launch_conv0_stats(const float* feat, const float* w3, const float* bias, st
                        const ConvGeom& g, hipStream_t st);
 int64_t conv_gemm_slab_floats(int64_t B, const ConvGeom& g, bool with_dgrad = false);   // workspace the split-K policy wants
 int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStream_t st);
+// The small layers (P <= 8: convs 10-15 of the 1-s model) in one persistent launch (conv.hip, smallnet_kernel): layers j0 .. j1.
+constexpr int NAFP_SMALLNET_CTRL_WORDS = 1024;          // control block (next item, error word, per (layer, group) counters): zero at launch
+struct SmallNetArgs {
+    int j0, j1;
+    const float* x[6]; const float* wp[6]; const float* G[6]; const float* Hb[6]; const float* gamma_out[6];
+    const stat_t* stats_in[6]; stat_t* stats_out[6]; float* y[6];
+    float* slab; int64_t slab_floats;                    // >= smallnet_slab_floats()
+    unsigned* tickets;                                   // NAFP_TICKET_SLOTS arrival counters, zero on entry and exit
+    unsigned* ctrl;                                      // NAFP_SMALLNET_CTRL_WORDS words, zero on entry
+    hipEvent_t ev_start, ev_stop;
+};
+bool smallnet_layer_ok(const ConvGeom& g);
+int64_t smallnet_slab_floats(int64_t B, const ConvGeom* geoms, int j0, int j1);
+int launch_smallnet(const SmallNetArgs& a, int64_t B, const ConvGeom* geoms, hipStream_t st);
 int conv_timeline_set(unsigned long long* buf, int64_t capacity_u64, int cin, int cout, int positions);
 int conv_timeline_grid(int* out5);
 
@@ -214,6 +228,7 @@ struct TailArgs {
     float* out_emb;          // (B,Q) or nullptr
     int D, Q, S, l2norm;
     const int* nonfinite_weights;   // (or null) != 0: the parameter set holds a NaN / Inf -> every output row is NaN
+    const unsigned* launch_error;   // (or null) != 0: the persistent small-layer launch of this pass gave up a wait (smallnet_kernel) -> NaN rows
 };
 int launch_tail(const TailArgs& a, int64_t B, hipStream_t st);
 

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(512) void tail_kernel(const TailArgs a, int64_t B) 
     }
 
     // a parameter set with a NaN / Inf in it (set_weights found one): every row is NaN, as with keras
-    const bool bad_weights = a.nonfinite_weights && *a.nonfinite_weights != 0;
+    const bool bad_weights = (a.nonfinite_weights && *a.nonfinite_weights != 0) || (a.launch_error && *a.launch_error != 0);
     for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
         float lnA = 1.f, lnC = 0.f;
         if (a.stats) stat_ln_scalars(a.stats + 2 * b, 1.0 / (double)a.D, &lnA, &lnC);     // NaN for a poisoned sample: its row comes out NaN
