@@ -118,6 +118,24 @@ struct Conv0Regen { const float* feat; const float* w3; const float* bias; float
 // waves take a quarter each of the workgroup's batch chunk.  Same number of threads, same samples per thread, but the four waves'
 // sums meet in LDS first, so a launch ends in a quarter of the atomics (they are what such a launch mostly consists of: 32
 // chunks x 5 atomics per element onto the same addresses at ~33 G/s).
+// Cache policy of the pass's three streams (gradient in, stored activation in, dts out, each touched once per launch):
+// -DNAFP_LNB_NT=1 loads / 2 stores / 3 both non-temporal (tools/build_variant.sh; A/B in DESIGN.md 4.6 [r5])
+#ifndef NAFP_LNB_NT
+#define NAFP_LNB_NT 0
+#endif
+typedef float f4nt_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 lnb_ld_nt(const float4* p) { const f4nt_t v = __builtin_nontemporal_load((const f4nt_t*)p); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void lnb_st_nt(float4* p, float4 v) { const f4nt_t t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, (f4nt_t*)p); }
+#if NAFP_LNB_NT & 1
+#define NAFP_LNB_LD(p_) lnb_ld_nt(p_)
+#else
+#define NAFP_LNB_LD(p_) (*(p_))
+#endif
+#if NAFP_LNB_NT & 2
+#define NAFP_LNB_ST(p_, v_) lnb_st_nt(p_, v_)
+#else
+#define NAFP_LNB_ST(p_, v_) (*(p_) = (v_))
+#endif
 template <bool CONV0, bool FROMZ = false, bool WAVE = false>
 __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
         float* __restrict__ d, const float* __restrict__ tpre, const float* __restrict__ gamma,
@@ -171,14 +189,14 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
     _Pragma("unroll") for (int u = 0; u < UNR; ++u) {                                                          \
         const int64_t b_l = std::min<int64_t>((bq_) + u, b1 - 1);        /* (a clamped duplicate is loaded, not used) */ \
         G_.s0[u] = *(const float4*)(sc + 8 * b_l); G_.s1[u] = *(const float4*)(sc + 8 * b_l + 4);             \
-        G_.dd[u] = *((const float4*)(d + b_l * n) + ii);                                                       \
+        G_.dd[u] = NAFP_LNB_LD((const float4*)(d + b_l * n) + ii);                                             \
         G_.x[u][0] = 0.f; G_.x[u][1] = 0.f; G_.x[u][2] = 0.f;                                                  \
         if (CONV0) {                                                                                           \
             const float* xr = c0.feat + b_l * (int64_t)c0.F * c0.Tin + x_off;                                  \
             G_.x[u][0] = x_ok[0] ? xr[0] : 0.f; G_.x[u][1] = x_ok[1] ? xr[1] : 0.f; G_.x[u][2] = x_ok[2] ? xr[2] : 0.f; \
             G_.tt[u] = make_float4(0.f, 0.f, 0.f, 0.f);                                                        \
         } else {                                                                                               \
-            G_.tt[u] = ((const float4*)(tpre + b_l * n))[ii];                                                  \
+            G_.tt[u] = NAFP_LNB_LD((const float4*)(tpre + b_l * n) + ii);                                      \
         }                                                                                                      \
     }
 #define NAFP_LN_ONE(c_)                                                                     \
@@ -222,7 +240,7 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(
             gw1.x = fmaf(x1, o.x, gw1.x); gw1.y = fmaf(x1, o.y, gw1.y); gw1.z = fmaf(x1, o.z, gw1.z); gw1.w = fmaf(x1, o.w, gw1.w); \
             gw2.x = fmaf(x2, o.x, gw2.x); gw2.y = fmaf(x2, o.y, gw2.y); gw2.z = fmaf(x2, o.z, gw2.z); gw2.w = fmaf(x2, o.w, gw2.w); \
         }                                                                                                      \
-        if (live && !(CONV0 && c0.dW0)) *dp = o;               /* (nothing reads dts_0 once dW0 is formed here) */ \
+        if (live && !(CONV0 && c0.dW0)) NAFP_LNB_ST(dp, o);    /* (nothing reads dts_0 once dW0 is formed here) */ \
         if (!CONV0 && lnsum_below) {                                                                           \
             /* wave sums of (q1, q2) in 7 shuffles: fold the halves, then q1 lives in lanes 0..31 and q2 in 32..63 */ \
             if (!live) { q1 = 0.f; q2 = 0.f; }                                                                 \

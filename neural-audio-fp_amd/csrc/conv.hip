@@ -1472,7 +1472,10 @@ __global__ __launch_bounds__(256) void plain_finish_kernel(const float* __restri
 }
 
 // K-steps (BK = 16) of a tile of the transposed conv: with stride 2 the parity classes of tile_pos()
-// carry 2 resp. 1 live taps (1.5 on average), with stride 1 all three.
+// carry 2 resp. 1 live taps (1.5 on average), with stride 1 all three.  (An estimate for the split-K policy only: the kernel skips
+// dead taps per tile.  [r5] The exact per-class count -- a third of this for the layers whose forward conv has ONE live tap at the
+// 1-s input -- was tried in its place: same-box A/B 11.69 vs 11.75 ms at B = 640, 22.29 vs 22.21 at 1280, 85.6 vs 85.2 at 5120:
+// the split factor is not what limits those launches -- they share the chip with the side stream's weight gradients.)
 static int dgrad_k_steps(const ConvGeom& g) { return (g.stride == 2 ? 3 : 6) * g.Cout / 32; }
 
 static int tile_pt(int P) {
@@ -1563,6 +1566,17 @@ static const PlanOverride& plan_override() {
     return po;
 }
 
+// the same for the transposed convs (DGRAD launches on 128-row tiles): NAFP_DGRAD_PLAN="bn:S"
+static const PlanOverride& dgrad_plan_override() {
+    static const PlanOverride po = []() {
+        PlanOverride r{0, 0};
+        const char* e = getenv("NAFP_DGRAD_PLAN");
+        if (e) sscanf(e, "%d:%d", &r.bn, &r.S);
+        return r;
+    }();
+    return po;
+}
+
 static int pick_bn(int64_t n_tiles128, int Cout, int k_steps = 0) {
     static const int mode = []() { const char* e = getenv("NAFP_BN64"); return e ? atoi(e) : 1; }();
     static const int64_t thr = []() { const char* e = getenv("NAFP_BN64_TILES"); return e ? atoll(e) : (int64_t)1000; }();
@@ -1608,7 +1622,8 @@ int64_t conv_gemm_slab_floats(int64_t B, const ConvGeom& g, bool with_dgrad) {
         const int ptd = dgrad_tile_pt(g), STd = 128 / ptd;
         const int64_t tiles_d = ((B + STd - 1) / STd) * ((Pd + ptd - 1) / ptd) * (g.Cin / BN);
         const int bnd = pick_bn(tiles_d, g.Cin);
-        const int Sd = choose_split(tiles_d * (BN / bnd), dgrad_k_steps(g), B * Pd * g.Cin, bnd == 64 ? 1024.0 : 768.0);
+        int Sd = choose_split(tiles_d * (BN / bnd), dgrad_k_steps(g), B * Pd * g.Cin, bnd == 64 ? 1024.0 : 768.0);
+        if (dgrad_plan_override().S > 0) Sd = std::max(Sd, dgrad_plan_override().S);
         if (Sd > 1) need = std::max(need, (int64_t)Sd * B * Pd * g.Cin);
     }
     return need;
@@ -1688,12 +1703,15 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     int bn = (BM == 256 || a.f0_feat) ? 128 : pick_bn(n_tiles128, p.Cout, (a.plain || a.dgrad) ? 0 : k_steps);
     const bool plan_forced = BM == 128 && !a.plain && !a.dgrad && !a.f0_feat && plan_override().bn > 0;
     if (plan_forced && (plan_override().bn == 128 || p.Cout % 64 == 0)) bn = plan_override().bn;
+    const bool dplan_forced = BM == 128 && a.dgrad && dgrad_plan_override().bn > 0;
+    if (dplan_forced && (dgrad_plan_override().bn == 128 || p.Cout % 64 == 0)) bn = dgrad_plan_override().bn;
     const int64_t n_tiles = n_tiles128 * (BN / bn);
     int S = 1;
     const int64_t out_floats = B * p.P * p.Cout;
     if (a.slab && !a.f0_feat && BM == 128) {
         S = choose_split(n_tiles, k_steps, out_floats, bn == 64 ? ((n64_two_stage() && !a.plain) ? 1280.0 : 1024.0) : 768.0);
         if (plan_forced && plan_override().S > 0) { S = plan_override().S; while (S > 1 && k_steps / S < 4) --S; }
+        if (dplan_forced && dgrad_plan_override().S > 0) { S = dgrad_plan_override().S; while (S > 1 && k_steps / S < 4) --S; }
         if ((int64_t)S * out_floats > a.slab_floats) S = 1;
     }
     if (S > 1) { p.mode = a.plain ? 1 : 2; p.n_split = S; p.y = a.slab; p.bias = nullptr; }
