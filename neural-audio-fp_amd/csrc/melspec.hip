@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void melspec_kernel(
 //   A  lane l:            Y[k1, l] = W1024^(l k1) . DFT16_{n1}( w[n] z[n] )                 -> buf[68 k1 + l]
 //   B  lane (k1, r):      T[k1, r, q] = W64^(r q) . DFT16_{m}( Y[k1, 4 m + r] )             -> buf[68 k1 + 17 r + q]
 //   C  lane (k1, g):      X[k1 + 16 q + 256 p] = DFT4_{r}( T[k1, r, q] ),  q = 4 j + g      -> buf[nat(k)]
-// nat(k) = k with bit 3 flipped when bit 5 is set (keeps the C stores and the un-pack reads on 64 distinct banks).
+// nat(k): see nat_addr() (keeps the C stores and the un-pack reads free of bank conflicts).
 // The level-1 twiddles W1024^(l k1) depend on the lane only: 15 registers, loaded once per workgroup.
 constexpr int R16_BUF = 16 * 68;             // float2 per wave
 
@@ -408,7 +408,11 @@ __device__ __forceinline__ void dft16(float2 (&x)[16]) {
     for (int c = 0; c < 4; ++c) dft4(y[c][0], y[c][1], y[c][2], y[c][3], x[c], x[c + 4], x[c + 8], x[c + 12]);
 }
 
-__device__ __forceinline__ int nat_addr(int k) { return k ^ ((k >> 2) & 8); }
+// [r5] k with bits 2-3 flipped by bits 4-5: the 16 lanes a ds_write_b64 serves per cycle (k1 = 4 a .. 4 a + 3 in bits 0-1, r in
+// bits 4-5 of k) then cover 32 distinct banks -- the round-3 form (bit 3 flipped by bit 5) left r = 0 / 1 and 2 / 3 on the same
+// banks (a 2-way conflict on every store of stage C); the un-pack reads (64 consecutive k per half wave) stay a permutation of
+// 64 consecutive float2.
+__device__ __forceinline__ int nat_addr(int k) { return k ^ (((k >> 4) & 3) << 2); }
 
 // LDS carve (75,328 B: two workgroups per CU):
 //   sig  [SIG_CHUNK]            zero-padded samples of the 16-frame chunk (19 KB)
@@ -443,6 +447,17 @@ __global__ __launch_bounds__(256, 2) void melspec_r16_kernel(
 #pragma unroll
         for (int j = 0; j < MAX_TAPS; ++j) mw[j] = mel_w[tid * MAX_TAPS + j];
     }
+    // [r5] taps this WAVE needs: the Slaney bank has 2-3 taps per filter at the bottom and 8 at the top (mean 3.7), and a wave holds 64
+    // neighbouring filters -- the gather below runs as many tap rounds as the widest filter of the wave has, not always 8
+    int ntap = 0;
+#pragma unroll
+    for (int j = 0; j < MAX_TAPS; ++j) ntap = mw[j] != 0.f ? j + 1 : ntap;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ntap = max(ntap, __shfl_xor(ntap, o, 64));
+    ntap = __builtin_amdgcn_readfirstlane(ntap);
+    // tile[mel][frame] with TILE_LD = 20: lanes t, t + 8, t + 16, t + 24 of a half wave write the same bank; the low two bits of the
+    // frame are XOR-ed with (mel >> 3) & 3 on the way in and undone on the way out (a float4 of the row holds the same four frames)
+    const int tsw = (tid >> 3) & 3;
     // per lane, once: the window of its 16 points n = 64 n1 + lane and the level-1 twiddles W1024^(lane k1)
     float wreg[16];
     float2 tw1[16];
@@ -565,23 +580,28 @@ __global__ __launch_bounds__(256, 2) void melspec_r16_kernel(
         }
         __syncthreads();
         if (has_mel) {
+            // tap-major: one wave-uniform test per tap round (the taps beyond a filter's own are zero weights: the shorter rounds
+            // drop only x * 0 terms, added in the same order -- bit-identical to the 8-tap loop), 8 gathers + FMAs per round, all
+            // addresses one per-lane base (mstart) plus immediates
+            const float* mg0 = (const float*)((float2*)(smem + SIG_CHUNK)) + mstart;
+            float acc[8];
 #pragma unroll
-            for (int wv = 0; wv < 4; ++wv) {
-                const int pp = chunk0 / 2 + round * 4 + wv;
-                const float* mg = (const float*)((float2*)(smem + SIG_CHUNK) + wv * R16_BUF);
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int f = 2 * pp + h;
-                    if (f < chunk0 + chunk_frames && f < n_frames) {
-                        const float* mm = mg + h * 520 + mstart;
-                        float acc = 0.f;
+            for (int j = 0; j < MAX_TAPS; ++j) {
+                if (j < ntap) {
 #pragma unroll
-                        for (int j = 0; j < MAX_TAPS; ++j) acc += mw[j] * mm[j];
-                        const float v = logf(max_keep_nan(acc + 0.06f, 1e-10f)) / 2.302585092994046f;     // melspectrogram.py:104,107
-                        tile[tid * TILE_LD + (f - chunk0)] = v;
-                        lmax = fmaxf(lmax, v);
-                        lmin = fminf(lmin, v);
-                    }
+                    for (int e = 0; e < 8; ++e) acc[e] += mw[j] * mg0[(e >> 1) * (2 * R16_BUF) + (e & 1) * 520 + j];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int f = 2 * (chunk0 / 2 + round * 4 + (e >> 1)) + (e & 1);
+                if (f < chunk0 + chunk_frames && f < n_frames) {
+                    const float v = logf(max_keep_nan(acc[e] + 0.06f, 1e-10f)) / 2.302585092994046f;     // melspectrogram.py:104,107
+                    tile[tid * TILE_LD + ((f - chunk0) ^ tsw)] = v;
+                    lmax = fmaxf(lmax, v);
+                    lmin = fminf(lmin, v);
                 }
             }
         }
@@ -590,13 +610,16 @@ __global__ __launch_bounds__(256, 2) void melspec_r16_kernel(
     if (chunk_frames == CHUNK_FRAMES && (n_frames & 3) == 0) {
         for (int idx = tid; idx < n_mels * (CHUNK_FRAMES / 4); idx += 256) {
             const int m = idx / (CHUNK_FRAMES / 4), q = idx % (CHUNK_FRAMES / 4);
-            const float4 v = *(const float4*)(tile + m * TILE_LD + 4 * q);
+            float4 v = *(const float4*)(tile + m * TILE_LD + 4 * q);
+            const int sw = (m >> 3) & 3;                  // undo the frame swizzle of the row: element e holds frame e ^ sw
+            if (sw & 1) { float t = v.x; v.x = v.y; v.y = t; t = v.z; v.z = v.w; v.w = t; }
+            if (sw & 2) { float t = v.x; v.x = v.z; v.z = t; t = v.y; v.y = v.w; v.w = t; }
             *(float4*)(out_seg + (int64_t)m * n_frames + chunk0 + 4 * q) = v;
         }
     } else {
         for (int idx = tid; idx < n_mels * chunk_frames; idx += 256) {
             const int m = idx / chunk_frames, t = idx % chunk_frames;
-            out_seg[(int64_t)m * n_frames + chunk0 + t] = tile[m * TILE_LD + t];
+            out_seg[(int64_t)m * n_frames + chunk0 + t] = tile[m * TILE_LD + (t ^ ((m >> 3) & 3))];
         }
     }
     __syncthreads();
