@@ -15,6 +15,7 @@
 #include "nafp_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace nafp {
 
@@ -99,7 +100,9 @@ int launch_tail(const TailArgs& a, int64_t B, hipStream_t st) {
     if (B == 0) return NAFP_OK;
     // enough workgroups to cover the CUs, few enough that the register fill (S*16+32 floats
     // per thread, from L2) is amortised over several segments
-    const int grid = (int)std::min<int64_t>(B, 128);
+    // (NAFP_TAIL_WGS sweep at B = 640, kernel us under rocprofv3: 128 -> 17.8, 256 -> 13.1, 320 -> 14.6, 640 -> 18.0)
+    static const int64_t wg_env = []() { const char* e = getenv("NAFP_TAIL_WGS"); return e && atoll(e) > 0 ? atoll(e) : (int64_t)256; }();
+    const int grid = (int)std::min<int64_t>(B, wg_env);
     const size_t lds = (size_t)(a.Q + 16) * sizeof(float);
     switch (a.S) {
         case 8: tail_kernel<8><<<grid, 2 * a.Q, lds, st>>>(a, B); break;
