@@ -497,7 +497,7 @@ static int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 // their regions (groups of different layers are in flight at the same time)
 static int64_t forward_slab_floats(const nafp_encoder* e, int64_t n_seg) {
     int64_t slab = 0;
-    for (int j = 1; j < 16; ++j) slab = std::max(slab, conv_gemm_slab_floats(n_seg, e->geom[j]));
+    for (int j = 1; j < 16; ++j) slab = std::max(slab, conv_gemm_slab_floats(n_seg, e->geom[j], false, fwd_plan_b()));
     if (e->use_smallnet(n_seg)) slab = std::max(slab, smallnet_slab_floats(n_seg, e->geom.data(), e->smallnet_j0, 15));
     return slab;
 }
@@ -600,6 +600,7 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
         a.wp = e->d_w[j]; a.G = e->d_G[j]; a.Hb = e->d_Hb[j]; a.gamma_out = e->d_gamma[j];
         a.y = nxt; a.stats_out = stats + 2 * n_seg * j; a.plain = false;
         a.slab = slab_floats ? slab : nullptr; a.slab_floats = slab_floats; a.tickets = tickets; a.bf16x3 = e->opt_bf16x3;
+        a.plan_b = fwd_plan_b();              // tile shape and split-K factor as at the reference launch size: results do not depend on n_seg
         if (j == 1 && fuse0) {
             a.x = nullptr; a.f0_feat = feat; a.f0_w = e->d_w[0]; a.f0_bias = e->d_bias[0];
             a.f0_gamma = e->d_gamma[0]; a.f0_geom = &e->geom[0];

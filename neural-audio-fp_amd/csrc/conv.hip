@@ -1608,13 +1608,24 @@ static FwdPlan fwd_plan(int64_t B, const ConvGeom& g, bool full_epilogue, bool f
     return r;
 }
 
-int64_t conv_gemm_slab_floats(int64_t B, const ConvGeom& g, bool with_dgrad) {
+// [r5] The batch size the INFERENCE forward plans for.  Tile shape and split-K factor of a layer used to follow the launch's own
+// batch, so the fp32 summation order of a segment -- the last bits of its fingerprint -- depended on how many segments shared its
+// launch.  nafp_encoder_forward* now plan every launch as if it held fwd_plan_b() segments (640: the bench
+// and generate launch size, so nothing changes there) and only the grid follows B: the bytes of a fingerprint no longer depend on
+// TS_BATCH_SZ or on the launch size.  Training plans per launch as before.
+int64_t fwd_plan_b() {
+    static const int64_t b = []() { const char* e = getenv("NAFP_PLAN_B"); return e ? atoll(e) : (int64_t)640; }();
+    return b;
+}
+
+int64_t conv_gemm_slab_floats(int64_t B, const ConvGeom& g, bool with_dgrad, int64_t plan_b) {
     const int P = g.Fout * g.Tout;
-    const FwdPlan fp = fwd_plan(B, g, true, false);
+    const int64_t Bp = plan_b > 0 ? plan_b : B;
+    const FwdPlan fp = fwd_plan(Bp, g, true, false);
     const int BM = fp.BM, pt = fp.pt, ST = BM / pt;
-    const int64_t n_tiles = ((B + ST - 1) / ST) * ((P + pt - 1) / pt) * (g.Cout / BN);
+    const int64_t n_tiles = ((Bp + ST - 1) / ST) * ((P + pt - 1) / pt) * (g.Cout / BN);
     const int bn = BM == 256 ? 128 : pick_bn(n_tiles, g.Cout, live_k_steps(g));
-    int S = BM == 256 ? 1 : choose_split(n_tiles * (BN / bn), live_k_steps(g), B * P * g.Cout, bn == 64 ? (n64_two_stage() ? 1280.0 : 1024.0) : 768.0);
+    int S = BM == 256 ? 1 : choose_split(n_tiles * (BN / bn), live_k_steps(g), Bp * P * g.Cout, bn == 64 ? (n64_two_stage() ? 1280.0 : 1024.0) : 768.0);
     if (BM == 128 && plan_override().S > 0) S = std::max(S, plan_override().S);
     int64_t need = S > 1 ? (int64_t)S * B * P * g.Cout : 0;
     if (with_dgrad && g.Cin % BN == 0 && pick_bm(B, g.Fin * g.Tin, g.Cin) == 128) {
@@ -1646,7 +1657,9 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     p.axis = g.axis; p.stride = g.stride; p.pad = g.pad;
     p.B = (int)B; p.P = g.Fout * g.Tout;
     // forward launches: fwd_plan() (shared with conv_gemm_slab_floats); the transposed conv picks its rows from ITS output
-    const FwdPlan fp = fwd_plan(B, g, !a.plain && !a.dgrad, a.f0_feat != nullptr);
+    // (plan_b: the inference forward plans as if the launch held plan_b segments -- see fwd_plan_b())
+    const int64_t Bp = (a.plan_b > 0 && !a.plain && !a.dgrad && !a.f0_feat) ? a.plan_b : B;
+    const FwdPlan fp = fwd_plan(Bp, g, !a.plain && !a.dgrad, a.f0_feat != nullptr);
     int BM = a.dgrad ? pick_bm(B, g.Fin * g.Tin, g.Cin) : fp.BM;
     int pt = fp.pt;
     const int fwd_perm = a.dgrad ? 0 : fp.perm;
@@ -1700,7 +1713,8 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     p.opt = gemm_prio;
     const int n_pb = (p.P + p.PT - 1) / p.PT;
     const int64_t n_tiles128 = (int64_t)p.n_sg * n_pb * (p.Cout / BN);
-    int bn = (BM == 256 || a.f0_feat) ? 128 : pick_bn(n_tiles128, p.Cout, (a.plain || a.dgrad) ? 0 : k_steps);
+    const int64_t n_tiles128_plan = ((Bp + p.ST - 1) / p.ST) * n_pb * (p.Cout / BN);      // ... at the planning batch
+    int bn = (BM == 256 || a.f0_feat) ? 128 : pick_bn(n_tiles128_plan, p.Cout, (a.plain || a.dgrad) ? 0 : k_steps);
     const bool plan_forced = BM == 128 && !a.plain && !a.dgrad && !a.f0_feat && plan_override().bn > 0;
     if (plan_forced && (plan_override().bn == 128 || p.Cout % 64 == 0)) bn = plan_override().bn;
     const bool dplan_forced = BM == 128 && a.dgrad && dgrad_plan_override().bn > 0;
@@ -1709,7 +1723,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     int S = 1;
     const int64_t out_floats = B * p.P * p.Cout;
     if (a.slab && !a.f0_feat && BM == 128) {
-        S = choose_split(n_tiles, k_steps, out_floats, bn == 64 ? ((n64_two_stage() && !a.plain) ? 1280.0 : 1024.0) : 768.0);
+        S = choose_split(n_tiles128_plan * (BN / bn), k_steps, Bp * p.P * p.Cout, bn == 64 ? ((n64_two_stage() && !a.plain) ? 1280.0 : 1024.0) : 768.0);
         if (plan_forced && plan_override().S > 0) { S = plan_override().S; while (S > 1 && k_steps / S < 4) --S; }
         if (dplan_forced && dgrad_plan_override().S > 0) { S = dgrad_plan_override().S; while (S > 1 && k_steps / S < 4) --S; }
         if ((int64_t)S * out_floats > a.slab_floats) S = 1;
@@ -1719,7 +1733,8 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     // (measured per conv at B = 640: with >= 320 output tiles the last arrivers finish faster than a second launch --
     // conv7 0.119 -> 0.104 ms, conv9 0.193 -> 0.178 --, with 160 or fewer the finish kernel's finer split wins by 2-8 %)
     static const int fin_min = []() { const char* e = getenv("NAFP_SPLIT_INKERNEL"); return e ? atoi(e) : 320; }();
-    const bool in_kernel_finish = fin_min > 0 && S > 1 && !a.plain && bn == 64 && a.tickets && n_tiles >= fin_min && n_tiles <= NAFP_TICKET_SLOTS;
+    // (decided at the planning batch like S itself: the two finishes group a sample's statistics into different partial sums)
+    const bool in_kernel_finish = fin_min > 0 && S > 1 && !a.plain && bn == 64 && a.tickets && n_tiles128_plan * (BN / bn) >= fin_min && n_tiles <= NAFP_TICKET_SLOTS;
     // PLAIN split launches (the transposed convs) with arrival counters: the last arriver adds the parts and stores the result
     // (its epilogue is a sum: nothing like the FULL epilogue's serial tail) -- NAFP_PLAIN_INKERNEL=0 restores slab + plain_finish_kernel
     static const int plain_fin = []() { const char* e = getenv("NAFP_PLAIN_INKERNEL"); return e ? atoi(e) : 1; }();
@@ -1799,14 +1814,15 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     }
     if (4096 / g.Cout + 1 > FIN_MAXS || g.Cout < 128) return NAFP_ERR_UNSUPPORTED;      // a wave (256 floats) spans <= 2 rows
     const int64_t f4 = out_floats / 4;
+    const int64_t f4_plan = Bp * p.P * p.Cout / 4;          // the finish kernel's block size follows the planning batch (it sets the partial sums of the statistics)
 #define NAFP_FIN(E_)                                                                                             \
     if (a.ev_stop) hipExtLaunchKernelGGL(splitk_finish_kernel<E_>, dim3((unsigned)((f4 + (E_) - 1) / (E_))), dim3(256), 0, st, nullptr,   \
                                          a.ev_stop, 0, (const float*)a.slab, S, a.G, a.Hb, a.gamma_out, a.stats_in, a.stats_out, a.y,   \
                                          a.v_out, p.B, p.P, g.Cout, p.inv_n_in);                                   \
     else splitk_finish_kernel<E_><<<dim3((unsigned)((f4 + (E_) - 1) / (E_))), 256, 0, st>>>(                       \
         a.slab, S, a.G, a.Hb, a.gamma_out, a.stats_in, a.stats_out, a.y, a.v_out, p.B, p.P, g.Cout, p.inv_n_in)
-    if (f4 >= 1024 * 1024) { NAFP_FIN(1024); }
-    else if (f4 >= 1024 * 512) { NAFP_FIN(512); }
+    if (f4_plan >= 1024 * 1024) { NAFP_FIN(1024); }
+    else if (f4_plan >= 1024 * 512) { NAFP_FIN(512); }
     else { NAFP_FIN(256); }
 #undef NAFP_FIN
     NAFP_LAUNCH_CHECK();

@@ -105,8 +105,7 @@ def test_config0_generate_100_clips_ts_batch_125(nafp, cfg, tmp_path):
     again = open(out_dir + 'custom_source.mm', 'rb').read()
     assert first == again, 'two runs of run.py generate differ'
     # (b) other launch sizes through the product's writer, each twice: 125 (one group per launch), 750, 1000 (8 groups; the
-    #     last launch ragged): run-to-run identical bytes at every size.  ACROSS sizes the tile plan and the split-K factors
-    #     -- the fp32 summation order -- differ, so those agree to rounding: 1 - cos < 1e-6.
+    #     last launch ragged): run-to-run identical bytes at every size.
     from neural_audio_fp_amd.model.utils.audio_utils import SegmentSource
     m_pre = nafp.get_melspec_layer(c)
     source = SegmentSource(paths, bsz=125)
@@ -120,8 +119,11 @@ def test_config0_generate_100_clips_ts_batch_125(nafp, cfg, tmp_path):
         assert runs[0].tobytes() == runs[1].tobytes(), launch_rows
         by_size[launch_rows] = runs[0]
     assert by_size[750].tobytes() == first                                        # run.py's own launch size (6 groups: LAUNCH_SEGMENTS 640 rounded up)
+    # [r5] ... and ACROSS launch sizes too: the inference forward plans every launch (tile shape, split-K factor) as at the
+    # reference size of 640 segments whatever it holds (csrc/conv.hip fwd_plan_b()), the LayerNorm statistics are order-free
+    # integers, so a segment's fingerprint no longer depends on what shares its launch
     for launch_rows in (125, 1000):
-        assert (1 - (by_size[launch_rows] * got).sum(1)).max() < 1e-6, launch_rows
+        assert by_size[launch_rows].tobytes() == first, launch_rows
     # (c) the committed hash of this output (seeded weights, seeded clips, this kernel generation): tests/golden/
     #     hip_generate_sha256.json.  A change of any forward kernel's summation order legitimately changes it -- then
     #     re-record it from gpurun_out/hip_generate_sha256.json of a run and say so in the commit.

@@ -40,13 +40,15 @@ def test_batch_independence_and_ragged_sizes(nafp, cfg):
     full = m_fp(feat)
     assert bool(torch.isfinite(full).all())
     assert float((full.norm(dim=1) - 1).abs().max()) < 1e-5
-    for n in (1, 3, 127, 129):
-        part = m_fp(feat[:n])
-        # the split-K factor of the late convs depends on the batch size (K is summed in 1, 3 or 6 parts), so a
-        # segment's sums are formed in a different order: a few f32 ulps on unit-norm fingerprints (measured <= 1.1e-6)
-        assert float((part - full[:n]).abs().max()) < 3e-6
+    for n in (1, 3, 127, 129, 1000):
+        # [r5] bit for bit: every launch is planned (tile shape, split-K factor) as at the reference size of 640 segments
+        # (csrc/conv.hip fwd_plan_b()) and the LayerNorm statistics are order-free integers -- until round 4 the split-K factor
+        # of the late convs followed the batch size and these agreed to a few f32 ulps only
+        src = feat[:n] if n <= 640 else torch.cat([feat, feat[:n - 640]])
+        part = m_fp(src)
+        assert torch.equal(part[:min(n, 640)], full[:min(n, 640)]), n
     perm = torch.randperm(640, device='cuda')
-    assert float((m_fp(feat[perm]) - full[perm]).abs().max()) < 1e-6
+    assert torch.equal(m_fp(feat[perm]), full[perm])
     # oracle spot check on 3 rows of the full-size launch
     w = {k: v for k, v in zip(
         [n for j in range(16) for n in (f'conv{j}.kernel', f'conv{j}.bias', f'ln{j}.gamma', f'ln{j}.beta')] +
