@@ -60,6 +60,7 @@ __device__ __forceinline__ void search_topk_body(
         const float* __restrict__ Q, const float* __restrict__ X, const float* __restrict__ hn,
         float* __restrict__ out_key, int* __restrict__ out_id, int nq, int64_t N, int tiles_per_split, int n_lists) {
     constexpr int CH = D / 4;                        // 16-B chunks per row
+    constexpr int SWZ = (CH < 32 ? CH : 32) - 1;      // chunk swizzle mask: the row's low bits -- the same for row rl and row 32 + rl, which share `aoff` (d = 256 has 64 chunks)
     constexpr int RPI = 64 / CH;                     // rows per DMA wave-instruction
     constexpr int NI = 16 / RPI;                     // DMA instructions per wave per tile (16 rows per wave)
     constexpr int TILE = TILE_ROWS * D;              // floats
@@ -90,7 +91,7 @@ __device__ __forceinline__ void search_topk_body(
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int row = wave * 16 + i * RPI + lane / CH;
-        const int lc = (lane % CH) ^ (row & (CH - 1));
+        const int lc = (lane % CH) ^ (row & SWZ);
         voff[i] = (unsigned)(row * D + lc * 4) * 4u;
     }
 #define NAFP_S_DMA(t_, slot_)                                                                       \
@@ -109,7 +110,7 @@ __device__ __forceinline__ void search_topk_body(
     // against the K-th best with one max tree before any per-score work.
     unsigned aoff[D / 8];                          // byte offset of (row rl, logical chunk 2kk + hh) inside a tile
 #pragma unroll
-    for (int kk = 0; kk < D / 8; ++kk) aoff[kk] = (unsigned)((rl * D + (((2 * kk + hh) ^ (rl & (CH - 1))) * 4)) * 4);
+    for (int kk = 0; kk < D / 8; ++kk) aoff[kk] = (unsigned)((rl * D + (((2 * kk + hh) ^ (rl & SWZ)) * 4)) * 4);
     const char* sbase = (const char*)smem;
 #define NAFP_S_TILE(SLOT_)                                                                          \
     {                                                                                               \
