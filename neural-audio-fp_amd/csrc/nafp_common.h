@@ -63,11 +63,12 @@ __device__ __forceinline__ float max_keep_nan(float v, float lo) { return v < lo
 // (at most a few thousand partials per sample), against sums that are divided by n >= 1024 and compared with the
 // LayerNorm epsilon 1e-3 -- far below float32 rounding of the activations themselves.
 //
-// NON-FINITE VALUES AND RANGE [r5].  A partial that is NaN, infinite or >= 2^31 in magnitude (a workgroup's share of one
-// sample: an RMS activation above ~250 at the widest tile; LayerNorm keeps activations O(1)) is not added: it POISONS the
-// sample instead -- atomicOr of STAT_POISON into the sample's sum-of-squares slot.  That slot only ever receives
-// non-negative partials below 2^51 (fixed point), at most 2^11 of them, so its two top bits are clear unless poisoned, an
-// OR is idempotent, and later adds cannot carry into them: the flag is sticky and order-free.  stat_get() of a poisoned slot
+// NON-FINITE VALUES AND RANGE [r5].  A partial that is NaN, infinite or >= 2^34 in magnitude (a workgroup's share of one
+// sample -- at most 32 K elements, conv0's: an RMS activation above ~700; LayerNorm keeps activations O(1)) is not added: it
+// POISONS the sample instead -- atomicOr of STAT_POISON into the sample's sum-of-squares slot.  That slot only ever receives
+// non-negative partials below 2^54 (fixed point), at most 2^7 of them per sample and layer (conv1 of a 2-s input: 128 position
+// blocks), so its two top bits are clear unless poisoned, an OR is idempotent, and later adds cannot carry into them: the
+// flag is sticky and order-free.  stat_get() of a poisoned slot
 // is NaN, hence r_b = c_b = NaN for that sample in every consumer; and because the packed ELU of the GEMM epilogues
 // (max(t, exp(min(t, 0)) - 1): IEEE maxNum drops a NaN operand) would wash a NaN row back to finite values one layer
 // later, every consumer hands the poison of its input statistics on to its output statistics (stat_forward_poison: one
@@ -75,7 +76,7 @@ __device__ __forceinline__ float max_keep_nan(float v, float lo) { return v < lo
 // LayerNormalization does with such a sample (nnfp.py:73-79), while the other samples of the launch are untouched.
 typedef long long stat_t;
 constexpr int STAT_FRAC_BITS = 20;
-constexpr double STAT_PARTIAL_LIMIT = 2147483648.0;                 // 2^31
+constexpr double STAT_PARTIAL_LIMIT = 17179869184.0;                // 2^34
 constexpr unsigned long long STAT_POISON = 1ull << 62;
 #ifdef __HIPCC__
 __device__ __forceinline__ void stat_poison(stat_t* sample_slots) {      // sample_slots = the sample's (sum, sumsq) pair
