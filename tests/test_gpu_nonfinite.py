@@ -52,6 +52,14 @@ def test_one_non_finite_sample_poisons_its_own_row_only(nafp, B, what):
     ok[bad_rows] = False
     assert bool(torch.isnan(emb[~ok]).all()), emb[~ok]
     assert torch.equal(emb[ok], clean[ok])                     # same launch plan, independent rows: bit for bit
+    if B <= 16:
+        # ... and that is what the float64 restatement of the reference graph gives: LayerNormalization over (F, T, C) hands a NaN /
+        # Inf to the whole sample and to nothing else (nnfp.py:73-79)
+        from oracle import nnfp as o_nnfp
+        with np.errstate(all='ignore'):
+            want = o_nnfp.fingerprinter(dirty.cpu().numpy(), _inputs.weights(seed=7))
+        assert np.isnan(want[bad_rows]).all() and np.isfinite(np.delete(want, bad_rows, axis=0)).all()
+        assert float(np.abs(np.delete(emb.cpu().numpy(), bad_rows, axis=0) - np.delete(want, bad_rows, axis=0)).max()) < 5e-6
     # the flatten output and the training forward see the same poison
     flat = m.front_conv(dirty)
     assert bool(torch.isnan(flat[~ok]).all()) and bool(torch.isfinite(flat[ok]).all())

@@ -104,3 +104,20 @@ def test_golden_encoder(golden):
     assert np.abs(o_nnfp.l2_normalize(o_nnfp.div_enc(flat, w)) - golden['emb_seed11_w3']).max() < 1e-6
     assert np.allclose([t.mean() for t in taps], golden['ln_out_mean'], atol=1e-9)
     assert np.allclose([np.abs(t).mean() for t in taps], golden['ln_out_absmean'], atol=1e-9)
+
+
+def test_non_finite_element_poisons_exactly_its_own_sample():
+    """What the HIP path is held to in tests/test_gpu_nonfinite.py: LayerNormalization over (F, T, C) (nnfp.py:73-79) hands a
+    NaN or an Inf of one sample to that sample's whole fingerprint, and to no other sample of the batch."""
+    import _inputs
+    rng = np.random.default_rng(5)
+    feat = (-rng.uniform(0, 1.2, size=(3, 256, 32, 1))).astype(np.float32)
+    w = _inputs.weights(seed=7)
+    clean = o_nnfp.fingerprinter(feat, w)
+    for bad in (np.nan, np.inf, -np.inf):
+        dirty = feat.copy()
+        dirty[1, 17, 5, 0] = bad
+        with np.errstate(all='ignore'):
+            got = o_nnfp.fingerprinter(dirty, w)
+        assert np.isnan(got[1]).all()
+        assert np.array_equal(got[[0, 2]], clean[[0, 2]])
