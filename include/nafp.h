@@ -235,6 +235,7 @@ int nafp_encoder_grad_group_wait(nafp_encoder* enc, int group, void* stream);
 #define NAFP_OPT_FUSED_LN_BWD 2
 #define NAFP_OPT_BWD_OVERLAP 4
 #define NAFP_OPT_SMALLNET 5
+#define NAFP_OPT_DEBUG_SIDE_DELAY 6   /* TEST HOOK: value = microseconds the handle's weight-gradient stream idles in front of its first launch of a backward pass */
 /* EXPERIMENTAL, changes the arithmetic (the only option that does): the unsplit GEMM convs of nafp_encoder_forward form their
  * products on the bf16 matrix pipe from f32 operands split into hi + lo bf16 halves (hi*hi + hi*lo + lo*hi, f32
  * accumulation).  Fingerprints move at the 1e-6 level against the f32 path.  Off by default; bench.py reports it as a

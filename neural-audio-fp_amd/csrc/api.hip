@@ -66,6 +66,12 @@ __global__ __launch_bounds__(256) void multi_copy_kernel(const CopyTable t) {
     }
     if (bad && t.nonfinite) atomicOr(t.nonfinite, 1);
 }
+// TEST HOOK (NAFP_OPT_DEBUG_SIDE_DELAY): holds a stream for `us` microseconds (100 MHz real-time counter), so that a test can make the
+// weight-gradient stream lag the main stream deterministically and see whether every event is ordered behind what it stands for
+__global__ void debug_delay_kernel(long long us) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < us * 100) __builtin_amdgcn_s_sleep(32);
+}
 struct BiasTable { float* hb[16]; const float* bias[16]; int64_t n[16]; int cout[16]; int count; };
 __global__ __launch_bounds__(256) void add_bias_kernel(const BiasTable t) {
     const int e = blockIdx.y;
@@ -171,6 +177,7 @@ struct nafp_encoder {
     int prof_smallnet_j0 = 16;            // per-conv stamps: the layers from here on were stamped as ONE span (slot of this layer)
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_main[16] = {}, ev_side[16] = {};
+    int debug_side_delay_us = 0;          // NAFP_OPT_DEBUG_SIDE_DELAY (tests only): the weight-gradient stream idles this long in front of its first launch of a pass
     // set_weights: the 15 G / Hb images are small, latency-bound launches (2 "samples"; the late ones stream 6-12 MB of
     // weights through a handful of workgroups): they run NAFP_SW_STREAMS abreast on helper streams of the handle, each
     // with its own split-K slab, between a fork and a join on the caller's stream.
@@ -343,6 +350,7 @@ extern "C" int nafp_encoder_set_option(nafp_encoder* e, int option, int value) {
             e->opt_fused_ln_bwd = value; return NAFP_OK;
         case NAFP_OPT_BWD_OVERLAP: e->opt_bwd_overlap = value < 0 ? 0 : (value > 2 ? 1 : value); return NAFP_OK;
         case NAFP_OPT_SMALLNET: e->smallnet_on = value != 0; return NAFP_OK;
+        case NAFP_OPT_DEBUG_SIDE_DELAY: e->debug_side_delay_us = value < 0 ? 0 : value; return NAFP_OK;
         default: return NAFP_ERR_INVALID_ARG;
     }
 }
@@ -935,6 +943,10 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
         if (on_side) {
             if (ln_done || !ride) NAFP_HIP_CHECK(hipEventRecord(e->ev_main[j], st));
             NAFP_HIP_CHECK(hipStreamWaitEvent(sw, e->ev_main[j], 0));
+            if (e->debug_side_delay_us > 0 && !side_pending) {                  // test hook: the weight-gradient stream starts late
+                debug_delay_kernel<<<1, 64, 0, sw>>>((long long)e->debug_side_delay_us);
+                NAFP_LAUNCH_CHECK();
+            }
         }
         float* w_slab = !on_side ? L.slab : (ov_mode == 2 ? L.slab2 : nullptr);
         const int64_t w_slab_floats = !on_side ? L.slab_floats : (ov_mode == 2 ? L.slab2_floats : 0);

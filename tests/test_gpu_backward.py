@@ -194,6 +194,10 @@ def test_each_gradient_group_event_covers_exactly_its_own_tensors(nafp, B, side_
     d_emb = torch.randn((B, 128), generator=g, device='cuda')
     m_fp = nafp.FingerPrinter(seed=0)
     m_fp.set_option(4, side_mode)
+    # the library's test hook makes the weight-gradient stream start 3 ms late: the main stream reaches the boundary of group 1 (and
+    # records its event) while wgrad(10) / wgrad(11) have not even started -- with the round-4 event logic this test then reads
+    # unfinished gradients for group 1 (checked once against a build with that logic: it fails there)
+    m_fp.set_option(6, 3000)
     m_fp.set_weights(_inputs.weight_list(_inputs.weights(seed=16)))
     groups = m_fp.grad_groups()
     assert sorted(i for a, b in groups for i in range(a, b + 1)) == list(range(68))
