@@ -119,10 +119,31 @@ int nafp_melspec_forward_windows_i16(nafp_melspec* plan, const int16_t* pcm, con
 int nafp_encoder_create(nafp_encoder** enc, int in_f, int in_t, int emb_sz);
 int nafp_encoder_destroy(nafp_encoder* enc);
 
+/* The same with the normalisation of the ConvLayers chosen (config MODEL.BN -> ConvLayer(norm=...), nnfp.py:63-71, 250):
+ *   NAFP_NORM_LAYER2D  'layer_norm2d' (the default and what nafp_encoder_create builds): LayerNormalization(axis=(1,2,3)),
+ *                      folded into the GEMM epilogues;
+ *   NAFP_NORM_LAYER1D  'layer_norm1d': LayerNormalization(axis=-1), statistics over the channels of one position; one extra
+ *                      elementwise pass per layer and direction;
+ *   NAFP_NORM_BATCH    'batch_norm' (or any other string): BatchNormalization(axis=-1) AS THE REFERENCE CALLS IT -- `m_fp(feat)`
+ *                      without a `training` argument in train_step, val_step and generate (trainer.py:44, 60; generate.py:88),
+ *                      i.e. always in inference mode: the per-channel affine map of the moving statistics (never updated:
+ *                      keras initialises them to 0 / 1; a checkpoint may hold others), trainable gamma / beta.  Folded exactly
+ *                      into the same epilogues.
+ * With the alternates the tensors 4j+2 / 4j+3 are gamma / beta of shape (C); NAFP_NORM_BATCH appends, behind tensor 67, the
+ * NON-trainable moving statistics: 68+2j moving_mean (C), 69+2j moving_variance (C), j = 0..15.  The gradient list of
+ * nafp_encoder_backward covers the trainable tensors 0..67 only (nafp_encoder_n_trainable).  NAFP_OPT_FUSE_CONV0,
+ * NAFP_OPT_FUSED_LN_BWD and NAFP_OPT_SMALLNET are ignored by the alternates. */
+#define NAFP_NORM_LAYER2D 0
+#define NAFP_NORM_LAYER1D 1
+#define NAFP_NORM_BATCH 2
+int nafp_encoder_create_ex(nafp_encoder** enc, int in_f, int in_t, int emb_sz, int norm);
+int nafp_encoder_norm(const nafp_encoder* enc);            /* NAFP_NORM_* of the handle */
+int nafp_encoder_n_trainable(const nafp_encoder* enc);     /* 68: the tensors nafp_encoder_backward writes gradients for */
+
 /* Parameter tensors, in this fixed order (n = nafp_encoder_n_tensors):
  *   for j in 0..15 (even = conv 1x3, odd = conv 3x1; nnfp.py:48-79):
  *     4j+0 kernel (kh,kw,Cin,Cout)   4j+1 bias (Cout)
- *     4j+2 LN gamma (F,T,C)          4j+3 LN beta (F,T,C)
+ *     4j+2 LN gamma (F,T,C)          4j+3 LN beta (F,T,C)      [(C) each with NAFP_NORM_LAYER1D / NAFP_NORM_BATCH]
  *   64 div.w1 (Q,S,32)   65 div.b1 (Q,32)   66 div.w2 (Q,32,1)   67 div.b2 (Q,1)
  * i.e. the keras variable shapes, C-order float32. */
 int nafp_encoder_n_tensors(const nafp_encoder* enc);
@@ -309,6 +330,22 @@ int nafp_specaug_apply_fill_dev(float* feat, int64_t n_seg, int F, int T, const 
 int64_t nafp_specaug_mean_workspace_bytes(void);
 int nafp_specaug_mean(const float* feat, int64_t n, float* mean_out, void* workspace, int64_t workspace_bytes,
                       void* stream);
+
+/* The general form of the masking: SpecNCutout with uniform_mask=False (a rectangle set and an activation draw per sample and
+ * hole, ncutout_tarray.py:131-186, 270-276) and / or a filler TENSOR (hole_fill = 'random' | [min_mag, max_mag], :106-115,
+ * 200-211: the layer's noise tensor, drawn once, scaled to the batch's value range on every call).
+ *   rects_dev   (n_sets, n_rects, 4) int32 in device memory: f0, f1, t0, t1, inclusive; n_sets == 1 (one set for the batch) or
+ *               n_seg (one per sample); n_rects <= 32
+ *   active_dev  (n_seg, n_rects) bytes or NULL (every hole of every sample)
+ *   filler      (n_fill_seg, F, T) floats, 16-byte aligned, or NULL (reads as 1); sample b uses row b % n_fill_seg
+ *   scale_offset_dev  2 floats in device memory: a hole element becomes filler * scale + offset
+ * nafp_specaug_range leaves {max - min, min} of feat on the device (the 'random' filler's scale and offset, :207-208); it takes
+ * the workspace of nafp_specaug_mean. */
+int nafp_specaug_apply_ex(float* feat, int64_t n_seg, int F, int T, const int32_t* rects_dev, int n_rects, int64_t n_sets,
+                          const unsigned char* active_dev, const float* filler, int64_t n_fill_seg,
+                          const float* scale_offset_dev, void* stream);
+int nafp_specaug_range(const float* feat, int64_t n, float* scale_offset_out, void* workspace, int64_t workspace_bytes,
+                       void* stream);
 
 /* ------------------------------------------------------------------------
  * Optimizer steps of the train step (model/trainer.py:47-48, 119-140)

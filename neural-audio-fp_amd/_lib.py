@@ -36,6 +36,9 @@ PROTOTYPES = {
     'nafp_melspec_forward_windows_i16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p,
                                                  c_void_p, c_void_p]),
     'nafp_encoder_create': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int]),
+    'nafp_encoder_create_ex': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_int]),
+    'nafp_encoder_norm': (c_int, [c_void_p]),
+    'nafp_encoder_n_trainable': (c_int, [c_void_p]),
     'nafp_encoder_destroy': (c_int, [c_void_p]),
     'nafp_encoder_n_tensors': (c_int, [c_void_p]),
     'nafp_encoder_tensor_numel': (c_i64, [c_void_p, c_int]),
@@ -67,6 +70,8 @@ PROTOTYPES = {
     'nafp_specaug_apply_fill_dev': (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     'nafp_specaug_mean_workspace_bytes': (c_i64, []),
     'nafp_specaug_mean': (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p]),
+    'nafp_specaug_apply_ex': (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_int, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
+    'nafp_specaug_range': (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p]),
     'nafp_l2_normalize_rows': (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     'nafp_pack_embedding_grads': (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     'nafp_cosine_decay_lr_host': (c_float, [c_float, c_i64, c_i64, c_float]),

@@ -18,7 +18,7 @@ OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libnafp.so')
 STAMP = os.path.join(HERE, '.libnafp.stamp')
 SOURCES = ['api.hip', 'melspec.hip', 'conv.hip', 'tail.hip', 'ntxent.hip', 'optim.hip', 'specaug.hip', 'backward.hip',
-           'search.hip', 'augment.hip', 'triplet.hip']
+           'search.hip', 'augment.hip', 'triplet.hip', 'norm.hip']
 HEADERS = ['nafp_common.h', os.path.join('..', '..', 'include', 'nafp.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-result', '-fno-gpu-rdc']
 # the compiler's per-kernel resource remarks (VGPRs, scratch, occupancy) are kept next to every object (build/<src>.resources.txt;

@@ -36,7 +36,7 @@ std::vector<ConvGeom> encoder_geometry(int in_f, int in_t) {
 // tensor (the pre-activation) per layer, which needs gamma != 0.  Against activations of O(1) a scale of 1e-30 IS zero in
 // float32 (its contribution vanishes in the first addition it meets), so the forward result does not change; the variable
 // the caller sees is not touched.
-struct CopyTable { const float* src[64]; float* dst[64]; int64_t n[64]; int nz[64]; int count; int* nonfinite; };
+struct CopyTable { const float* src[96]; float* dst[96]; int64_t n[96]; int nz[96]; int count; int* nonfinite; };
 __device__ __forceinline__ float nz_scale(float g) { return fabsf(g) < 1e-30f ? copysignf(1e-30f, g) : g; }
 __device__ __forceinline__ bool nonfinite4(float4 v) {
     return !(fabsf(v.x) <= 3.4028234664e38f) || !(fabsf(v.y) <= 3.4028234664e38f) || !(fabsf(v.z) <= 3.4028234664e38f) || !(fabsf(v.w) <= 3.4028234664e38f);
@@ -87,6 +87,11 @@ using namespace nafp;
 constexpr int NAFP_PROF_EV = 34;
 struct nafp_encoder {
     int in_f, in_t, emb_sz;
+    // NAFP_NORM_*: with the alternates (norm.hip) d_gamma / d_beta below are INTERNAL positional images (1 / 0 for layer_norm1d, the
+    // broadcast affine map for batch_norm) and the caller's per-channel tensors live in d_gc / d_bc (/ d_mm / d_mv)
+    int norm = NAFP_NORM_LAYER2D;
+    int n_trainable = 68;
+    std::vector<float*> d_gc, d_bc, d_mm, d_mv;
     std::vector<ConvGeom> geom;           // 16
     int64_t flat_dim; int S;
     // tensor table (keras shapes)
@@ -161,7 +166,7 @@ struct nafp_encoder {
     // forward convs lose their second store stream and the workspace 4.6 MB per segment.  The fused transposed-conv +
     // LayerNorm-backward path (opt_fused_ln_bwd) reads t and therefore implies keeping it.
     bool keep_t_env = []() { const char* v = getenv("NAFP_KEEP_T"); return v && v[0] == '1'; }();
-    bool keep_t() const { return keep_t_env || opt_fused_ln_bwd != 0; }
+    bool keep_t() const { return keep_t_env || (opt_fused_ln_bwd != 0 && norm == NAFP_NORM_LAYER2D) || norm == NAFP_NORM_LAYER1D; }   // (layer_norm1d overwrites z with the normalised rows: v = z / gamma is gone)
     // what the last forward_train laid the training workspace out with: the backward pass re-derives the layout from (B, keep_t())
     // and must find the same one (an option changed in between would make it read activations at other offsets)
     int64_t train_B = -1; bool train_keep_t = false, train_smallnet = false;
@@ -248,9 +253,16 @@ extern "C" uint32_t nafp_crc32c_host(const void* data, int64_t n, uint32_t crc) 
 }
 
 extern "C" int nafp_encoder_create(nafp_encoder** out, int in_f, int in_t, int emb_sz) {
+    return nafp_encoder_create_ex(out, in_f, in_t, emb_sz, NAFP_NORM_LAYER2D);
+}
+extern "C" int nafp_encoder_norm(const nafp_encoder* e) { return e ? e->norm : -1; }
+extern "C" int nafp_encoder_n_trainable(const nafp_encoder* e) { return e ? e->n_trainable : -1; }
+
+extern "C" int nafp_encoder_create_ex(nafp_encoder** out, int in_f, int in_t, int emb_sz, int norm) {
     if (!out || in_f <= 0 || in_t <= 0 || emb_sz <= 0) return NAFP_ERR_INVALID_ARG;
+    if (norm != NAFP_NORM_LAYER2D && norm != NAFP_NORM_LAYER1D && norm != NAFP_NORM_BATCH) return NAFP_ERR_INVALID_ARG;
     nafp_encoder* e = new nafp_encoder();
-    e->in_f = in_f; e->in_t = in_t; e->emb_sz = emb_sz;
+    e->in_f = in_f; e->in_t = in_t; e->emb_sz = emb_sz; e->norm = norm;
     e->geom = encoder_geometry(in_f, in_t);
     const ConvGeom& last = e->geom.back();
     e->flat_dim = (int64_t)last.Fout * last.Tout * last.Cout;
@@ -270,8 +282,11 @@ extern "C" int nafp_encoder_create(nafp_encoder** out, int in_f, int in_t, int e
     e->shapes.push_back({emb_sz, 32});
     e->shapes.push_back({emb_sz, 32, 1});
     e->shapes.push_back({emb_sz, 1});
+    // (the device blob is laid out from the layer_norm2d shapes -- the alternates keep positional images of that size --; the shapes
+    // the CALLER sees are put in place at the end)
     int64_t total = 0;
     for (auto& s : e->shapes) total += (numel(s) + 63) / 64 * 64;      // 256-B aligned slots
+    if (norm != NAFP_NORM_LAYER2D) for (int j = 0; j < 16; ++j) total += 4 * ((e->geom[j].Cout + 63) / 64 * 64);   // gamma_c, beta_c, moving mean / variance
     for (int j = 1; j < 16; ++j) total += 2 * ((numel(e->shapes[4 * j + 2]) + 63) / 64 * 64);   // G, Hb
     for (int j = 1; j < 16; ++j) total += (numel(e->shapes[4 * j]) + 63) / 64 * 64;               // dgrad weights
     total += (numel(e->shapes[64]) + 63) / 64 * 64 + 2 * ((numel(e->shapes[65]) + 63) / 64 * 64) + 64 + 64;   // keras div copies, inv_n, d_wflag
@@ -297,6 +312,11 @@ extern "C" int nafp_encoder_create(nafp_encoder** out, int in_f, int in_t, int e
     e->d_inv_n = (double*)p; p += 64;
     e->d_wflag = (int*)p; p += 64;
     e->d_sw_slab = p; p += nafp_encoder::NAFP_SW_STREAMS * (e->sw_slab_floats + 64);      // one slab per helper stream, (sw_slab_floats + 64) apart
+    if (norm != NAFP_NORM_LAYER2D)
+        for (int j = 0; j < 16; ++j) {
+            const int64_t c = (e->geom[j].Cout + 63) / 64 * 64;
+            e->d_gc.push_back(p); e->d_bc.push_back(p + c); e->d_mm.push_back(p + 2 * c); e->d_mv.push_back(p + 3 * c); p += 4 * c;
+        }
     // set_weights runs G_j and Hb_j as the two "samples" of one launch: the pairs must be adjacent
     for (int j = 0; j < 16; ++j) {
         const int64_t n = numel(e->shapes[4 * j + 2]);
@@ -317,6 +337,12 @@ extern "C" int nafp_encoder_create(nafp_encoder** out, int in_f, int in_t, int e
         const int64_t n = (int64_t)g.Fout * g.Tout * g.Cout;
         if (j % 2 == 0) e->bufA_per_seg = std::max(e->bufA_per_seg, n);
         else            e->bufB_per_seg = std::max(e->bufB_per_seg, n);
+    }
+    if (norm != NAFP_NORM_LAYER2D) {
+        for (int j = 0; j < 16; ++j) { e->shapes[4 * j + 2] = {e->geom[j].Cout}; e->shapes[4 * j + 3] = {e->geom[j].Cout}; }
+        if (norm == NAFP_NORM_BATCH)
+            for (int j = 0; j < 16; ++j) { e->shapes.push_back({e->geom[j].Cout}); e->shapes.push_back({e->geom[j].Cout}); }
+        e->smallnet_j0 = 16;                 // (the persistent small-layer launch has no place for the row pass between its layers)
     }
     *out = e;
     return NAFP_OK;
@@ -383,8 +409,14 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
         const ConvGeom& g = e->geom[j];
         const int64_t nln = (int64_t)g.Fout * g.Tout * g.Cout;
         add_copy(t[4 * j + 1], e->d_bias[j], g.Cout);
-        add_copy(t[4 * j + 2], e->d_gamma[j], nln, 1);          // LayerNorm scale: kept away from exact zero (multi_copy_kernel)
-        add_copy(t[4 * j + 3], e->d_beta[j], nln);
+        if (e->norm == NAFP_NORM_LAYER2D) {
+            add_copy(t[4 * j + 2], e->d_gamma[j], nln, 1);          // LayerNorm scale: kept away from exact zero (multi_copy_kernel)
+            add_copy(t[4 * j + 3], e->d_beta[j], nln);
+        } else {
+            add_copy(t[4 * j + 2], e->d_gc[j], g.Cout);
+            add_copy(t[4 * j + 3], e->d_bc[j], g.Cout);
+            if (e->norm == NAFP_NORM_BATCH) { add_copy(t[68 + 2 * j], e->d_mm[j], g.Cout); add_copy(t[69 + 2 * j], e->d_mv[j], g.Cout); }
+        }
     }
     add_copy(t[64], e->d_w1k, numel(e->shapes[64]));
     add_copy(t[65], e->d_b1k, numel(e->shapes[65]));
@@ -400,6 +432,23 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
     ct.nonfinite = e->d_wflag;
     multi_copy_kernel<<<dim3(32, ct.count), 256, 0, st>>>(ct);
     NAFP_LAUNCH_CHECK();
+    // the alternates' positional images (norm.hip): 1 / 0 for layer_norm1d (the row pass applies gamma_c / beta_c), the broadcast
+    // affine map of the moving statistics for batch_norm -- in front of `sw_copied`: conv0 reads gamma_pos of layer 0
+    if (e->norm == NAFP_NORM_LAYER1D) {
+        for (int j = 0; j < 16; ++j) {
+            const int64_t nln = (int64_t)e->geom[j].Fout * e->geom[j].Tout * e->geom[j].Cout;
+            NAFP_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)e->d_gamma[j], 0x3f800000, nln, st));
+            NAFP_HIP_CHECK(hipMemsetAsync(e->d_beta[j], 0, sizeof(float) * nln, st));
+        }
+    } else if (e->norm == NAFP_NORM_BATCH) {
+        BnExpandTable bx; bx.count = 16;
+        for (int j = 0; j < 16; ++j) {
+            bx.gamma_c[j] = e->d_gc[j]; bx.beta_c[j] = e->d_bc[j]; bx.mmean[j] = e->d_mm[j]; bx.mvar[j] = e->d_mv[j];
+            bx.gamma_pos[j] = e->d_gamma[j]; bx.n[j] = (int64_t)e->geom[j].Fout * e->geom[j].Tout * e->geom[j].Cout; bx.C[j] = e->geom[j].Cout;
+        }
+        int rcx = launch_bn_expand(bx, st);
+        if (rcx != NAFP_OK) return rcx;
+    }
     NAFP_HIP_CHECK(hipEventRecord(e->sw_copied, st));
     {
         PackTable pt; pt.count = 0; pt.nonfinite = e->d_wflag;
@@ -434,7 +483,7 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
         int rc1 = launch_conv_gemm(a, 2, e->geom[1], st);
         if (rc1 != NAFP_OK) return rc1;
         BiasTable b1; b1.count = 1;
-        b1.hb[0] = e->d_Hb[1]; b1.bias[0] = e->d_bias[1]; b1.n[0] = numel(e->shapes[4 * 1 + 2]); b1.cout[0] = e->geom[1].Cout;
+        b1.hb[0] = e->d_Hb[1]; b1.bias[0] = e->d_bias[1]; b1.n[0] = (int64_t)e->geom[1].Fout * e->geom[1].Tout * e->geom[1].Cout; b1.cout[0] = e->geom[1].Cout;
         add_bias_kernel<<<dim3(32, 1), 256, 0, st>>>(b1);
         NAFP_LAUNCH_CHECK();
         l1_done = true;
@@ -457,7 +506,7 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
             gh_table_add(gh, e->geom[j], e->d_w[j], e->d_gamma[j - 1], e->d_G[j]);
             by_gemv[j] = true;
             bt.hb[bt.count] = e->d_Hb[j]; bt.bias[bt.count] = e->d_bias[j];
-            bt.n[bt.count] = numel(e->shapes[4 * j + 2]); bt.cout[bt.count] = e->geom[j].Cout; ++bt.count;
+            bt.n[bt.count] = (int64_t)e->geom[j].Fout * e->geom[j].Tout * e->geom[j].Cout; bt.cout[bt.count] = e->geom[j].Cout; ++bt.count;
         }
     if (fork_rc == NAFP_OK && forked == NS) fork_rc = launch_gh_gemv(gh, gemv_own ? st : e->sw_streams[NS - 1]);
     else for (int j = 1; j < 16; ++j) by_gemv[j] = false;              // (could not fork: everything through the tiled launches, bt rebuilt below)
@@ -472,7 +521,7 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
         a.slab = e->sw_slab_floats ? e->d_sw_slab + (int64_t)k * (e->sw_slab_floats + 64) : nullptr; a.slab_floats = e->sw_slab_floats;
         fork_rc = launch_conv_gemm(a, 2, e->geom[j], e->sw_streams[k]);
         bt.hb[bt.count] = e->d_Hb[j]; bt.bias[bt.count] = e->d_bias[j];
-        bt.n[bt.count] = numel(e->shapes[4 * j + 2]); bt.cout[bt.count] = e->geom[j].Cout; ++bt.count;
+        bt.n[bt.count] = (int64_t)e->geom[j].Fout * e->geom[j].Tout * e->geom[j].Cout; bt.cout[bt.count] = e->geom[j].Cout; ++bt.count;
     }
     for (int k = 0; k < forked; ++k) {
         if (hipEventRecord(e->sw_join[k], e->sw_streams[k]) != hipSuccess || hipStreamWaitEvent(st, e->sw_join[k], 0) != hipSuccess) {
@@ -520,7 +569,8 @@ extern "C" int64_t nafp_encoder_workspace_bytes(const nafp_encoder* e, int64_t n
     int64_t smallz = 0;
     if (e->use_smallnet(n_seg))
         for (int j = e->smallnet_j0; j < 16; ++j) smallz += align_up((int64_t)sizeof(float) * e->geom[j].Fout * e->geom[j].Tout * e->geom[j].Cout * n_seg, 256);
-    return stats + a + b + align_up(forward_slab_floats(e, n_seg) * (int64_t)sizeof(float), 256) + smallz + 256;
+    const int64_t ident = e->norm != NAFP_NORM_LAYER2D ? align_up((int64_t)sizeof(stat_t) * 2 * 16 * n_seg, 256) : 0;      // identity statistics of the alternates (norm.hip)
+    return stats + a + b + align_up(forward_slab_floats(e, n_seg) * (int64_t)sizeof(float), 256) + smallz + ident + 256;
 }
 
 static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float* gstat, int group_size, int segment_norm,
@@ -572,12 +622,25 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
     // conv0 is either materialised (z0 written to bufA) or -- default -- only its statistics are
     // computed here and conv1 re-generates z0 tiles in-kernel from the log-mel features
     // (NAFP_FUSE0=0 selects the materialised path).
-    const bool fuse0 = e->opt_fuse_conv0 && e->geom[1].axis == 1 && e->geom[1].Cin % 16 == 0;
+    const bool alt = e->norm != NAFP_NORM_LAYER2D;             // layer_norm1d / batch_norm: identity statistics for every consumer (norm.hip)
+    stat_t* ident = nullptr;
+    if (alt) {
+        ident = (stat_t*)((char*)slab + align_up(slab_floats * (int64_t)sizeof(float), 256));
+        int rci = launch_identity_stats(ident, e->d_inv_n, n_seg, 16, st);
+        if (rci != NAFP_OK) return rci;
+    }
+    auto stats_of = [&](int j) { return (alt ? ident : stats) + 2 * n_seg * j; };      // what the consumers of layer j's output read
+    auto row_pass = [&](float* z, int j) -> int {               // layer_norm1d: normalise the rows of layer j's output in place
+        if (e->norm != NAFP_NORM_LAYER1D) return NAFP_OK;
+        return launch_ln1d_fwd(z, n_seg * e->geom[j].Fout * e->geom[j].Tout, e->geom[j].Cout, e->d_gc[j], e->d_bc[j], st);
+    };
+    const bool fuse0 = !alt && e->opt_fuse_conv0 && e->geom[1].axis == 1 && e->geom[1].Cin % 16 == 0;
     if (fuse0 && gstat) return NAFP_ERR_UNSUPPORTED;          // the in-kernel conv0 generator reads finished features
     int rc = fuse0 ? launch_conv0_stats(feat, e->d_w[0], e->d_bias[0], stats, n_seg, e->geom[0], st)
                    : launch_conv0(feat, e->d_w[0], e->d_bias[0], e->d_gamma[0], bufA, nullptr, stats, n_seg, e->geom[0], st,
                                   gstat, group_size, segment_norm);
     if (rc != NAFP_OK) return rc;
+    if (!fuse0) { rc = row_pass(bufA, 0); if (rc != NAFP_OK) return rc; }
     if (ev && e->prof_coarse < 2) NAFP_HIP_CHECK(hipEventRecord(ev[1], st));
     float* cur = bufA;
     for (int j = 1; j < 16; ++j) {
@@ -604,7 +667,7 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
             break;
         }
         ConvGemmArgs a{};
-        a.x = cur; a.stats_in = stats + 2 * n_seg * (j - 1);
+        a.x = cur; a.stats_in = stats_of(j - 1);
         a.wp = e->d_w[j]; a.G = e->d_G[j]; a.Hb = e->d_Hb[j]; a.gamma_out = e->d_gamma[j];
         a.y = nxt; a.stats_out = stats + 2 * n_seg * j; a.plain = false;
         a.slab = slab_floats ? slab : nullptr; a.slab_floats = slab_floats; a.tickets = tickets; a.bf16x3 = e->opt_bf16x3;
@@ -622,10 +685,12 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
         }
         rc = launch_conv_gemm(a, n_seg, e->geom[j], st);
         if (rc != NAFP_OK) return rc;
+        rc = row_pass(nxt, j);
+        if (rc != NAFP_OK) return rc;
         cur = nxt;
     }
     TailArgs t;
-    t.x = cur; t.stats = stats + 2 * n_seg * 15; t.gamma = e->d_gamma[15]; t.beta = e->d_beta[15];
+    t.x = cur; t.stats = stats_of(15); t.gamma = e->d_gamma[15]; t.beta = e->d_beta[15];
     t.w1p = e->d_w1p; t.b1p = e->d_b1p; t.w2p = e->d_w2p; t.b2 = e->d_b2;
     t.out_flat = out_flat; t.out_emb = out_emb;
     t.D = (int)e->flat_dim; t.Q = e->emb_sz; t.S = e->S; t.l2norm = l2norm; t.nonfinite_weights = e->d_wflag; t.launch_error = nullptr;
@@ -721,6 +786,8 @@ struct TrainLayout {
     float* slab2; int64_t slab2_floats; unsigned* tickets2;     // the weight-gradient stream's own slab and arrival counters (opt_bwd_overlap 2)
     float* dA; float* dB; float* dy;
     float* dts[16];                      // the small layers' gradients in buffers of their own (opt_bwd_overlap 2), else nullptr
+    stat_t* ident;                       // the alternates (norm.hip): identity statistics (16, B, 2) ...
+    float* dgp; float* dbp;              // ... and the positional (dgamma | dbeta) sums of the shared LayerNorm backward (max_n floats each)
     int64_t bytes;
 };
 
@@ -748,7 +815,9 @@ TrainLayout train_layout(const nafp_encoder* e, int64_t B, void* ws) {
         const int64_t n = (int64_t)e->geom[j].Fout * e->geom[j].Tout * e->geom[j].Cout;
         max_n = std::max(max_n, n);
         L.z[j] = (float*)take((int64_t)sizeof(float) * n * B);
-        L.v[j] = (j == 0 || !e->keep_t()) ? nullptr : (float*)take((int64_t)sizeof(float) * n * B);   // layer 0: regenerated; else only with keep_t()
+        // the pre-activation: only with keep_t(); layer 0's is regenerated by the backward pass -- except for layer_norm1d, whose row
+        // kernel reads it
+        L.v[j] = ((j == 0 && e->norm != NAFP_NORM_LAYER1D) || !e->keep_t()) ? nullptr : (float*)take((int64_t)sizeof(float) * n * B);
     }
     L.slab_floats = 0;
     for (int j = 1; j < 16; ++j)
@@ -769,6 +838,12 @@ TrainLayout train_layout(const nafp_encoder* e, int64_t B, void* ws) {
     for (int j = 0; j < 16; ++j) {
         const int64_t n = (int64_t)e->geom[j].Fout * e->geom[j].Tout * e->geom[j].Cout;
         L.dts[j] = (j >= 1 && e->geom[j].Fout * e->geom[j].Tout < 16) ? (float*)take((int64_t)sizeof(float) * n * B) : nullptr;
+    }
+    L.ident = nullptr; L.dgp = nullptr; L.dbp = nullptr;
+    if (e->norm != NAFP_NORM_LAYER2D) {
+        L.ident = (stat_t*)take((int64_t)sizeof(stat_t) * 2 * 16 * B);
+        L.dgp = (float*)take((int64_t)sizeof(float) * 2 * max_n);
+        L.dbp = L.dgp + max_n;
     }
     L.bytes = (p - p0) + 256;
     return L;
@@ -792,7 +867,16 @@ extern "C" int nafp_encoder_forward_train(nafp_encoder* e, const float* feat, in
     static const bool split_wait = []() { const char* v = getenv("NAFP_SW_SPLIT_WAIT"); return !v || v[0] != '0'; }();
     { int wrc = wait_weights(e, st, split_wait ? 0 : 2); if (wrc != NAFP_OK) return wrc; }
     // (layer 0 keeps no pre-activation: the backward pass regenerates it from `feat`, 3 FMAs per element)
-    int rc = launch_conv0(feat, e->d_w[0], e->d_bias[0], e->d_gamma[0], L.z[0], nullptr, L.stats, n_seg, e->geom[0], st);
+    const bool alt = e->norm != NAFP_NORM_LAYER2D;             // layer_norm1d / batch_norm (norm.hip), as in encoder_forward_impl
+    if (alt) { int rci = launch_identity_stats(L.ident, e->d_inv_n, n_seg, 16, st); if (rci != NAFP_OK) return rci; }
+    auto stats_of = [&](int j) { return (alt ? L.ident : L.stats) + 2 * n_seg * j; };
+    auto row_pass = [&](float* z, int j) -> int {
+        if (e->norm != NAFP_NORM_LAYER1D) return NAFP_OK;
+        return launch_ln1d_fwd(z, n_seg * e->geom[j].Fout * e->geom[j].Tout, e->geom[j].Cout, e->d_gc[j], e->d_bc[j], st);
+    };
+    int rc = launch_conv0(feat, e->d_w[0], e->d_bias[0], e->d_gamma[0], L.z[0], L.v[0], L.stats, n_seg, e->geom[0], st);
+    if (rc != NAFP_OK) return rc;
+    rc = row_pass(L.z[0], 0);
     if (rc != NAFP_OK) return rc;
     const int sn_j0 = (e->use_smallnet(n_seg) && !e->keep_t()) ? e->smallnet_j0 : 16;      // (the persistent launch keeps z only)
     for (int j = 1; j < 16; ++j) {
@@ -810,15 +894,17 @@ extern "C" int nafp_encoder_forward_train(nafp_encoder* e, const float* feat, in
             break;
         }
         ConvGemmArgs a{};
-        a.x = L.z[j - 1]; a.stats_in = L.stats + 2 * n_seg * (j - 1);
+        a.x = L.z[j - 1]; a.stats_in = stats_of(j - 1);
         a.wp = e->d_w[j]; a.G = e->d_G[j]; a.Hb = e->d_Hb[j]; a.gamma_out = e->d_gamma[j];
         a.y = L.z[j]; a.v_out = L.v[j]; a.stats_out = L.stats + 2 * n_seg * j; a.plain = false;
         a.slab = L.slab_floats ? L.slab : nullptr; a.slab_floats = L.slab_floats; a.tickets = L.tickets;
         rc = launch_conv_gemm(a, n_seg, e->geom[j], st);
         if (rc != NAFP_OK) return rc;
+        rc = row_pass(L.z[j], j);
+        if (rc != NAFP_OK) return rc;
     }
     TailArgs t;
-    t.x = L.z[15]; t.stats = L.stats + 2 * n_seg * 15; t.gamma = e->d_gamma[15]; t.beta = e->d_beta[15];
+    t.x = L.z[15]; t.stats = stats_of(15); t.gamma = e->d_gamma[15]; t.beta = e->d_beta[15];
     t.w1p = e->d_w1p; t.b1p = e->d_b1p; t.w2p = e->d_w2p; t.b2 = e->d_b2;
     t.out_flat = nullptr; t.out_emb = out_emb;
     t.D = (int)e->flat_dim; t.Q = e->emb_sz; t.S = e->S; t.l2norm = l2norm; t.nonfinite_weights = e->d_wflag; t.launch_error = sn_j0 <= 15 ? L.ctrl + 1 : nullptr;
@@ -835,14 +921,17 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
     hipStream_t st = (hipStream_t)stream;
     const int64_t B = n_seg;
     TrainLayout L = train_layout(e, B, workspace);
-    for (size_t i = 0; i < e->shapes.size(); ++i)
+    const size_t n_tr = (size_t)e->n_trainable;                // (batch_norm: the moving statistics behind tensor 67 have no gradient)
+    for (size_t i = 0; i < n_tr; ++i)
         if (!grads[i]) return NAFP_ERR_INVALID_ARG;
     { int wrc = wait_weights(e, st); if (wrc != NAFP_OK) return wrc; }
+    const bool alt = e->norm != NAFP_NORM_LAYER2D;             // layer_norm1d / batch_norm (norm.hip)
+    const stat_t* const stats_r = alt ? L.ident : L.stats;     // the statistics the forward pass's consumers read
     // every gradient accumulates through atomics: zero them (adjacent tensors -- e.g. views into one flat
     // all-reduce bucket -- in one memset) together with the LN sums and S1/S2
-    for (size_t i = 0; i < e->shapes.size();) {
+    for (size_t i = 0; i < n_tr;) {
         size_t k = i; int64_t run = numel(e->shapes[i]);
-        while (k + 1 < e->shapes.size() && grads[k + 1] == grads[i] + run) { ++k; run += numel(e->shapes[k]); }
+        while (k + 1 < n_tr && grads[k + 1] == grads[i] + run) { ++k; run += numel(e->shapes[k]); }
         NAFP_HIP_CHECK(hipMemsetAsync(grads[i], 0, sizeof(float) * run, st));
         i = k + 1;
     }
@@ -866,11 +955,11 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
         for (auto& ev : e->ev_main) NAFP_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         for (auto& ev : e->ev_side) NAFP_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
-    int rc = launch_stats_to_mr(L.stats, L.mr, e->d_inv_n, B, 16, st);
+    int rc = launch_stats_to_mr(stats_r, L.mr, e->d_inv_n, B, 16, st);
     if (rc != NAFP_OK) return rc;
     // tail: d_emb -> r * dxhat of the last conv + divide-and-encode gradients
     TailBwdArgs tb;
-    tb.z = L.z[15]; tb.stats = L.stats + 2 * B * 15; tb.gamma = e->d_gamma[15]; tb.beta = e->d_beta[15];
+    tb.z = L.z[15]; tb.stats = stats_r + 2 * B * 15; tb.gamma = e->d_gamma[15]; tb.beta = e->d_beta[15];
     tb.w1 = e->d_w1k; tb.b1 = e->d_b1k; tb.w2 = e->d_w2k; tb.b2 = e->d_b2;
     tb.w1p = e->d_w1p; tb.b1p = e->d_b1p; tb.w2p = e->d_w2p;
     // gradient buffers: layer j's incoming gradient (then dts_j, in place) lives in its own buffer when its weight gradient runs on
@@ -894,12 +983,31 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
         const int P = g.Fout * g.Tout;
         const float* mr_j = L.mr + 2 * B * j; const float* mr_p = L.mr + 2 * B * (j - 1);
         other = gbuf(j - 1);
-        if (!ln_done) {
+        if (!ln_done && !alt) {
             rc = launch_ln_bwd(cur, L.v[j] ? L.v[j] : L.z[j], e->d_gamma[j], mr_j, mr_p, L.lnsum[j], L.sc, grads[4 * j + 2], grads[4 * j + 3],
                                grads[4 * j + 1], L.S1[j], L.S2[j], B, P, g.Cout, st, j == 15, e->d_G[j], e->d_Hb[j], L.lnsum[j - 1],
                                nullptr, nullptr, nullptr, nullptr, nullptr, sc_ready, L.slab_floats ? L.slab : nullptr, L.slab_floats,
                                L.tickets, L.v[j] == nullptr);
             if (rc != NAFP_OK) return rc;
+        } else if (alt) {
+            // The alternates: `cur` holds dL/d(the stored, normalised activation of layer j).  layer_norm1d first takes it through the
+            // row map's backward (-> dL/dv, dgamma_c, dbeta_c).  Then the shared kernel with identity statistics and NO LayerNorm sums
+            // (lnsum stays at the zeros of the start of the pass: no reduction here, none handed down) is the plain
+            // dts = cur . gamma_pos . ELU'(t) with dbias and S2 = sum_b dt (S1 = 0); its positional (dgamma | dbeta) sums go to
+            // scratch, from which batch_norm forms its per-channel gradients.
+            if (e->norm == NAFP_NORM_LAYER1D) {
+                rc = launch_ln1d_bwd(cur, L.v[j], B * P, g.Cout, e->d_gc[j], grads[4 * j + 2], grads[4 * j + 3], st);
+                if (rc != NAFP_OK) return rc;
+            }
+            NAFP_HIP_CHECK(hipMemsetAsync(L.dgp, 0, sizeof(float) * 2 * (int64_t)P * g.Cout, st));
+            rc = launch_ln_bwd(cur, L.v[j] ? L.v[j] : L.z[j], e->d_gamma[j], mr_j, mr_p, L.lnsum[j], L.sc, L.dgp, L.dgp + (int64_t)P * g.Cout,
+                               grads[4 * j + 1], L.S1[j], L.S2[j], B, P, g.Cout, st, false, nullptr, nullptr, nullptr,
+                               nullptr, nullptr, nullptr, nullptr, nullptr, sc_ready, nullptr, 0, nullptr, L.v[j] == nullptr);
+            if (rc != NAFP_OK) return rc;
+            if (e->norm == NAFP_NORM_BATCH) {
+                rc = launch_bn_param_grad(L.dgp, L.dgp + (int64_t)P * g.Cout, P, g.Cout, e->d_mm[j], e->d_mv[j], grads[4 * j + 2], grads[4 * j + 3], st);
+                if (rc != NAFP_OK) return rc;
+            }
         }
         // the transposed conv below writes `other`; where that is the dA / dB buffer that still holds dts_{j+1}, wgrad(j+1), on the
         // weight-gradient stream, must be done with it (not with buffers of their own: see TrainLayout::dts)
@@ -910,7 +1018,7 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
         ScalarsJob sj{L.mr + 2 * B * (j - 1), L.lnsum[j - 1], j >= 2 ? L.mr + 2 * B * (j - 2) : nullptr, L.sc, (long long)B,
                       1.0 / ((double)gp1.Fout * gp1.Tout * gp1.Cout)};
         sc_ready = false;
-        ln_done = j >= 2 && dgrad_ln_eligible(B, g, e->opt_fused_ln_bwd);   // (layer 0 keeps no pre-activation: see conv0 below)
+        ln_done = !alt && j >= 2 && dgrad_ln_eligible(B, g, e->opt_fused_ln_bwd);   // (layer 0 keeps no pre-activation: see conv0 below)
         if (ln_done) {
             // transposed conv of dts_j with the LayerNorm + ELU backward of layer j-1 in its epilogue: `other` <- dts_{j-1}
             const ConvGeom& gp = e->geom[j - 1];
@@ -990,7 +1098,21 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
     }
     {
         const ConvGeom& g = e->geom[0];
-        if (!ln_done) {
+        if (alt) {
+            if (e->norm == NAFP_NORM_LAYER1D) {
+                rc = launch_ln1d_bwd(cur, L.v[0], B * g.Fout * g.Tout, g.Cout, e->d_gc[0], grads[2], grads[3], st);
+                if (rc != NAFP_OK) return rc;
+            }
+            NAFP_HIP_CHECK(hipMemsetAsync(L.dgp, 0, sizeof(float) * 2 * (int64_t)g.Fout * g.Tout * g.Cout, st));
+            rc = launch_ln_bwd(cur, nullptr, e->d_gamma[0], L.mr, nullptr, L.lnsum[0], L.sc, L.dgp, L.dgp + (int64_t)g.Fout * g.Tout * g.Cout, grads[1],
+                               nullptr, nullptr, B, g.Fout * g.Tout, g.Cout, st, false, nullptr, nullptr, nullptr,
+                               feat, e->d_w[0], e->d_bias[0], &g, grads[0], sc_ready, nullptr, 0, nullptr);
+            if (rc != NAFP_OK) return rc;
+            if (e->norm == NAFP_NORM_BATCH) {
+                rc = launch_bn_param_grad(L.dgp, L.dgp + (int64_t)g.Fout * g.Tout * g.Cout, g.Fout * g.Tout, g.Cout, e->d_mm[0], e->d_mv[0], grads[2], grads[3], st);
+                if (rc != NAFP_OK) return rc;
+            }
+        } else if (!ln_done) {
             rc = launch_ln_bwd(cur, nullptr, e->d_gamma[0], L.mr, nullptr, L.lnsum[0], L.sc, grads[2], grads[3], grads[1],
                                nullptr, nullptr, B, g.Fout * g.Tout, g.Cout, st, false, nullptr, nullptr, nullptr,
                                feat, e->d_w[0], e->d_bias[0], &g, grads[0], sc_ready,     // ... and dW0 in the same pass

@@ -277,6 +277,20 @@ int launch_conv0_bwd(const float* feat, const float* dt, float* dW0, float* dbia
                      hipStream_t st);
 int launch_pack_dgrad_weight(const float* k3, float* wd, int Cin, int Cout, hipStream_t st);
 
+// ---- normalisation alternates (norm.hip): MODEL.BN = 'layer_norm1d' | 'batch_norm' (nnfp.py:63-71) -----------------------------
+// (layers, B, 2) statistics from which every consumer derives r_b = 1, c_b = 0 (inv_n_dev: 1 / n per layer)
+int launch_identity_stats(stat_t* ident, const double* inv_n_dev, int64_t B, int layers, hipStream_t st);
+// batch_norm: the positional scale / offset images (gamma_pos | beta_pos adjacent, n = P * C floats each) from the per-channel
+// parameters and moving statistics
+struct BnExpandTable { const float* gamma_c[16]; const float* beta_c[16]; const float* mmean[16]; const float* mvar[16];
+                       float* gamma_pos[16]; int64_t n[16]; int C[16]; int count; };
+int launch_bn_expand(const BnExpandTable& t, hipStream_t st);
+int launch_bn_param_grad(const float* dgp, const float* dbp, int P, int C, const float* mmean, const float* mvar, float* dgamma_c,
+                         float* dbeta_c, hipStream_t st);
+// layer_norm1d: rows of C channels normalised in place; the backward of that row map in front of the shared LayerNorm / ELU backward
+int launch_ln1d_fwd(float* x, int64_t rows, int C, const float* gamma_c, const float* beta_c, hipStream_t st);
+int launch_ln1d_bwd(float* d, const float* tpre, int64_t rows, int C, const float* gamma_c, float* dgamma_c, float* dbeta_c, hipStream_t st);
+
 // weight packing
 struct PackTable { const float* k3[16]; float* wp[16]; float* wd[16]; int cin[16], cout[16]; int unit0[17]; int count;
                    int* nonfinite; };      // nonfinite (or null): set to 1 when a conv kernel holds a NaN / Inf (see nafp_encoder::d_wflag)

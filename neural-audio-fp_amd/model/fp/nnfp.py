@@ -25,8 +25,18 @@ FRONT_STRIDES = [[(1, 2), (2, 1)], [(1, 2), (2, 1)], [(1, 2), (2, 1)], [(1, 2), 
                  [(1, 1), (2, 1)], [(1, 2), (2, 1)], [(1, 1), (2, 1)], [(1, 2), (2, 1)]]  # nnfp.py:194-197
 
 
-def tensor_names():
-    """Checkpoint key of each parameter tensor, in library order."""
+NORM_KINDS = {'layer_norm2d': 0, 'layer_norm1d': 1}          # anything else is batch normalisation (nnfp.py:63-71): 2
+
+
+def norm_kind(norm):
+    """NAFP_NORM_* of a config MODEL.BN string: 'layer_norm1d', 'layer_norm2d', else ('batch_norm' or any other string, as the
+    `else` of nnfp.py:69-71) batch normalisation."""
+    return NORM_KINDS.get(norm, 2)
+
+
+def tensor_names(norm='layer_norm2d'):
+    """Checkpoint key of each parameter tensor, in library order (batch_norm: the 32 non-trainable moving statistics follow the
+    68 trainable tensors)."""
     names = []
     for j in range(16):
         blk, kind = j // 2, ('conv2d_1x3' if j % 2 == 0 else 'conv2d_3x1')
@@ -34,6 +44,10 @@ def tensor_names():
         names += [f'front_conv.{blk}.{kind}.kernel', f'front_conv.{blk}.{kind}.bias',
                   f'front_conv.{blk}.{bn}.gamma', f'front_conv.{blk}.{bn}.beta']
     names += ['div_enc.fc1.kernel', 'div_enc.fc1.bias', 'div_enc.fc2.kernel', 'div_enc.fc2.bias']
+    if norm_kind(norm) == 2:
+        for j in range(16):
+            blk, bn = j // 2, ('BN_1x3' if j % 2 == 0 else 'BN_3x1')
+            names += [f'front_conv.{blk}.{bn}.moving_mean', f'front_conv.{blk}.{bn}.moving_variance']
     return names
 
 
@@ -46,8 +60,9 @@ class FingerPrinter:
         if front_hidden_ch != FRONT_HIDDEN_CH or front_strides != FRONT_STRIDES or \
                 list(fc_unit_dim) != [32, 1] or input_shape[2] != 1:
             raise NotImplementedError('only the channel/stride tables of nnfp.py:193-197 are built')
-        if norm != 'layer_norm2d':
-            raise NotImplementedError(f"norm='{norm}' (config MODEL.BN); only 'layer_norm2d' is built")
+        # norm (config MODEL.BN, nnfp.py:63-71, 250): 'layer_norm2d' (default), 'layer_norm1d', anything else = BatchNormalization --
+        # which the reference only ever CALLS in inference mode (`m_fp(feat)` without `training=`: trainer.py:44, generate.py:88), so
+        # it is the per-channel affine map of its moving statistics (initially 0 / 1, never updated) with trainable gamma / beta
         self.front_hidden_ch, self.front_strides = front_hidden_ch, front_strides
         self.emb_sz, self.norm, self.use_L2layer = emb_sz, norm, use_L2layer
         self.n_clayers = len(front_strides)
@@ -57,8 +72,8 @@ class FingerPrinter:
         lib = _lib.load()
         h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            _lib.check(lib.nafp_encoder_create(ctypes.byref(h), int(input_shape[0]), int(input_shape[1]),
-                                               int(emb_sz)), 'encoder_create')
+            _lib.check(lib.nafp_encoder_create_ex(ctypes.byref(h), int(input_shape[0]), int(input_shape[1]),
+                                                  int(emb_sz), norm_kind(norm)), 'encoder_create_ex')
         self._h, self._lib = h, lib
         self.flat_dim = int(lib.nafp_encoder_flat_dim(h))
         self._shapes = []
@@ -66,7 +81,8 @@ class FingerPrinter:
         for i in range(lib.nafp_encoder_n_tensors(h)):
             r = lib.nafp_encoder_tensor_shape(h, i, dims)
             self._shapes.append(tuple(int(dims[k]) for k in range(r)))
-        self._names = tensor_names()
+        self._names = tensor_names(norm)
+        self._n_trainable = int(lib.nafp_encoder_n_trainable(h))
         self._vars = self._init_variables(seed)
         self._dirty = True
         self._weights_event, self._weights_stream, self._use_events = None, None, {}
@@ -94,6 +110,8 @@ class FingerPrinter:
                 fan_in, fan_out = shp[1], shp[2]
                 lim = math.sqrt(6.0 / (fan_in + fan_out))
                 t = (torch.rand(shp, generator=g) * 2 - 1) * lim
+            elif i >= 68:                                   # batch_norm: moving_mean = 0, moving_variance = 1 (keras initialisers)
+                t = torch.zeros(shp) if i % 2 == 0 else torch.ones(shp)
             else:
                 t = torch.zeros(shp)
             out.append(t.to(self.device, torch.float32).contiguous())
@@ -101,12 +119,17 @@ class FingerPrinter:
 
     @property
     def trainable_variables(self):
-        return list(self._vars)
+        return list(self._vars[:self._n_trainable])
+
+    @property
+    def non_trainable_variables(self):
+        """batch_norm: the moving statistics (keras keeps them in `model.non_trainable_variables`); else empty."""
+        return list(self._vars[self._n_trainable:])
 
     def variable_lengths(self):
         """Length of one keras variable inside each tensor (LAMB's trust ratio is per keras
         variable): the 4 divide-and-encode tensors stack emb_sz variables each."""
-        return [v.numel() if i < 64 else v.numel() // self.emb_sz for i, v in enumerate(self._vars)]
+        return [v.numel() if i < 64 else v.numel() // self.emb_sz for i, v in enumerate(self._vars[:self._n_trainable])]
 
     def mark_dirty(self):
         """Call after modifying a variable in place (e.g. an optimizer step)."""
@@ -127,7 +150,7 @@ class FingerPrinter:
         self._dirty = True
 
     def set_weights(self, arrays):
-        """arrays: sequence of 68 array-likes in library order (keras shapes)."""
+        """arrays: sequence of array-likes in library order (keras shapes): 68, or 100 with batch normalisation."""
         self.load_state_dict({n: a for n, a in zip(self._names, arrays)})
 
     def _sync(self):
@@ -262,7 +285,7 @@ class FingerPrinter:
         B = feat.shape[0]
         d_emb = _lib.require_cuda(torch.as_tensor(d_emb), 'd_emb').float().contiguous()
         if getattr(self, '_grads', None) is None:
-            self._grads = [torch.empty_like(v) for v in self._vars]
+            self._grads = [torch.empty_like(v) for v in self._vars[:self._n_trainable]]
         arr = (ctypes.c_void_p * len(self._grads))(*[g.data_ptr() for g in self._grads])
         need = int(self._lib.nafp_encoder_train_workspace_bytes(self._h, B))
         if getattr(self, '_train_ws', None) is None or need > self._train_ws.numel():

@@ -67,8 +67,9 @@ def load_checkpoint(checkpoint_root_dir, checkpoint_name, checkpoint_index, m_fp
         from .utils import tf_checkpoint as tfc
         from .fp.nnfp import tensor_names
         fpath = fpath[:-3]
-        m_fp.load_state_dict(tfc.state_dict_from_tf_checkpoint(fpath, tensor_names(), [tuple(v.shape) for v in m_fp.trainable_variables],
-                                                               m_fp.emb_sz))
+        variables = list(m_fp.trainable_variables) + list(getattr(m_fp, 'non_trainable_variables', []))      # (batch_norm: + the moving statistics)
+        m_fp.load_state_dict(tfc.state_dict_from_tf_checkpoint(fpath, tensor_names(getattr(m_fp, 'norm', 'layer_norm2d')),
+                                                               [tuple(v.shape) for v in variables], m_fp.emb_sz))
         fpath += '.index'
     else:
         raise FileNotFoundError(f'Cannot find checkpoint {fpath}')

@@ -205,7 +205,7 @@ def read_bundle(prefix, want=None):
 
 
 _CONV = re.compile(r'^model/front_conv/layer_with_weights-(\d+)/(?:(conv2d_1x3|conv2d_3x1|BN_1x3|BN_3x1)|forward/layer_with_weights-([0-3]))/'
-                   r'(kernel|bias|gamma|beta)' + re.escape(SUFFIX) + '$')
+                   r'(kernel|bias|gamma|beta|moving_mean|moving_variance)' + re.escape(SUFFIX) + '$')      # (moving_*: MODEL.BN = 'batch_norm')
 _DIV = re.compile(r'^model/div_enc/split_fc_layers/(\d+)/layer_with_weights-([01])/(kernel|bias)' + re.escape(SUFFIX) + '$')
 _FWD = {0: 'conv2d_1x3', 1: 'BN_1x3', 2: 'conv2d_3x1', 3: 'BN_3x1'}      # ConvLayer.forward's layers with weights (nnfp.py:69-75)
 

@@ -11,6 +11,13 @@ their published semantics restated here:
   * keras `LayerNormalization(axis=(1,2,3))`: mean / biased variance over all of
     (F,T,C) per sample, epsilon=1e-3, gamma/beta of shape (F,T,C).
   * keras `Dense`: x@W+b.  `tf.math.l2_normalize`: x*rsqrt(max(sum(x^2),1e-12)).
+  * the alternates of MODEL.BN (nnfp.py:63-71): keras `LayerNormalization(axis=-1)` ('layer_norm1d'): mean / biased variance
+    over the channels of one position, epsilon=1e-3, gamma/beta of shape (C,); keras `BatchNormalization(axis=-1)` (any other
+    string): the reference calls the model as `m_fp(feat)` with no `training` argument everywhere (trainer.py:44, 60, 73, 86;
+    generate.py:88) and never sets the learning phase, so keras resolves `training` to False (Layer.__call__: an unset
+    `training` falls back to the learning phase, 0 outside `fit`) and the layer applies
+    (x - moving_mean) / sqrt(moving_variance + 1e-3) * gamma + beta with the moving statistics it was initialised with
+    (0 / 1) or restored from a checkpoint; they are never updated.
 """
 import numpy as np
 
@@ -116,6 +123,44 @@ def layer_norm(x, gamma, beta, eps=LN_EPS):
     return (x - mu) / np.sqrt(var + eps) * gamma[None] + beta[None]
 
 
+def layer_norm1d(x, gamma_c, beta_c, eps=LN_EPS):
+    """keras LayerNormalization(axis=-1) on (B,F,T,C) (nnfp.py:64-65)."""
+    mu = x.mean(axis=-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(axis=-1, keepdims=True)
+    return (x - mu) / np.sqrt(var + eps) * gamma_c + beta_c
+
+
+def batch_norm_inference(x, gamma_c, beta_c, moving_mean, moving_var, eps=1e-3):
+    """keras BatchNormalization(axis=-1) with training=False (nnfp.py:70-71; see the module docstring)."""
+    return (x - moving_mean) / np.sqrt(moving_var + eps) * gamma_c + beta_c
+
+
+def apply_norm(x, w, j, norm, dtype):
+    g, b = w[f'ln{j}.gamma'].astype(dtype), w[f'ln{j}.beta'].astype(dtype)
+    if norm == 'layer_norm2d':
+        return layer_norm(x, g, b)
+    if norm == 'layer_norm1d':
+        return layer_norm1d(x, g, b)
+    return batch_norm_inference(x, g, b, w[f'bn{j}.moving_mean'].astype(dtype), w[f'bn{j}.moving_variance'].astype(dtype))
+
+
+def convert_norm(w, norm, seed=0, randomize=True):
+    """A weight dict of `init_weights` with the normalisation tensors of another MODEL.BN: gamma / beta of shape (C,), and for
+    batch normalisation the moving statistics `bn{j}.moving_mean` / `.moving_variance` (keras: 0 / 1; randomize: as a restored
+    checkpoint could hold them)."""
+    rng = np.random.default_rng(seed)
+    w = dict(w)
+    for j in range(16):
+        C = w[f'conv{j}.bias'].shape[0]
+        dt = w[f'conv{j}.bias'].dtype
+        w[f'ln{j}.gamma'] = (1 + 0.2 * rng.normal(size=C)).astype(dt) if randomize else np.ones(C, dt)
+        w[f'ln{j}.beta'] = (0.1 * rng.normal(size=C)).astype(dt) if randomize else np.zeros(C, dt)
+        if norm not in ('layer_norm1d', 'layer_norm2d'):
+            w[f'bn{j}.moving_mean'] = (0.2 * rng.normal(size=C)).astype(dt) if randomize else np.zeros(C, dt)
+            w[f'bn{j}.moving_variance'] = rng.uniform(0.5, 2.0, C).astype(dt) if randomize else np.ones(C, dt)
+    return w
+
+
 def conv_same(x, kernel, bias, axis, stride, pad):
     """Dense 3-tap conv along one axis with TF SAME padding.
 
@@ -139,10 +184,10 @@ def conv_same(x, kernel, bias, axis, stride, pad):
     return out + bias
 
 
-def front_conv(feat, w, dtype=np.float64, taps=None):
+def front_conv(feat, w, dtype=np.float64, taps=None, norm='layer_norm2d'):
     """FingerPrinter.front_conv (nnfp.py:210-218): (B,F,T,1) -> (B, F'*T'*C) flattened.
 
-    `taps` (optional list) collects the per-conv LN outputs for stage-by-stage parity.
+    `taps` (optional list) collects the per-conv LN outputs for stage-by-stage parity.  `norm`: MODEL.BN (nnfp.py:63-71).
     """
     x = np.asarray(feat, dtype=dtype)
     geo = conv_geometry(x.shape[1:])
@@ -150,7 +195,7 @@ def front_conv(feat, w, dtype=np.float64, taps=None):
         x = conv_same(x, w[f'conv{j}.kernel'].astype(dtype), w[f'conv{j}.bias'].astype(dtype),
                       g['axis'], g['stride'], g['pad'])
         x = elu(x)
-        x = layer_norm(x, w[f'ln{j}.gamma'].astype(dtype), w[f'ln{j}.beta'].astype(dtype))
+        x = apply_norm(x, w, j, norm, dtype)
         if taps is not None:
             taps.append(x)
     return x.reshape(x.shape[0], -1)
@@ -172,6 +217,6 @@ def l2_normalize(x, eps=1e-12):
     return x / np.sqrt(np.maximum(ss, eps))
 
 
-def fingerprinter(feat, w, dtype=np.float64):
+def fingerprinter(feat, w, dtype=np.float64, norm='layer_norm2d'):
     """FingerPrinter.call (nnfp.py:223-231): (B,256,32,1) -> (B,128) unit-norm."""
-    return l2_normalize(div_enc(front_conv(feat, w, dtype), w, dtype))
+    return l2_normalize(div_enc(front_conv(feat, w, dtype, norm=norm), w, dtype))

@@ -46,13 +46,15 @@ def melspec_layer(x, group_size=None, segment_norm=False):
 class TorchFingerprinter:
     """Weights given in the keras shapes of oracle.nnfp.init_weights."""
 
-    def __init__(self, w, input_shape=(256, 32, 1), dtype=torch.float32, requires_grad=False):
+    def __init__(self, w, input_shape=(256, 32, 1), dtype=torch.float32, requires_grad=False, norm='layer_norm2d'):
         """`requires_grad=True` (use dtype=torch.float64): every parameter becomes a leaf in the
         KERAS layout (self.params, ordered as include/nafp.h), so autograd yields the reference
         gradients of the train step (trainer.py:43-47) for the backward-kernel parity tests."""
         self.geo = _nnfp.conv_geometry(input_shape)
         self.dtype = dtype
         self.params = []
+        self.norm = norm          # MODEL.BN (nnfp.py:63-71): 'layer_norm2d' | 'layer_norm1d' | anything else = BatchNormalization in inference mode
+        self.mm, self.mv = [], []
 
         def leaf(a):
             t = torch.tensor(np.ascontiguousarray(a), dtype=dtype, requires_grad=requires_grad)
@@ -63,9 +65,16 @@ class TorchFingerprinter:
             k = leaf(w[f'conv{j}.kernel'])                                         # (kh,kw,Cin,Cout)
             self.k.append(k.permute(3, 2, 0, 1))                                   # (Cout,Cin,kh,kw)
             self.b.append(leaf(w[f'conv{j}.bias']))
-            # LN params (F,T,C) -> (C,F,T) for NCHW
-            self.g.append(leaf(w[f'ln{j}.gamma']).permute(2, 0, 1))
-            self.bt.append(leaf(w[f'ln{j}.beta']).permute(2, 0, 1))
+            if norm == 'layer_norm2d':
+                # LN params (F,T,C) -> (C,F,T) for NCHW
+                self.g.append(leaf(w[f'ln{j}.gamma']).permute(2, 0, 1))
+                self.bt.append(leaf(w[f'ln{j}.beta']).permute(2, 0, 1))
+            else:
+                self.g.append(leaf(w[f'ln{j}.gamma']))                             # (C,)
+                self.bt.append(leaf(w[f'ln{j}.beta']))
+                if norm != 'layer_norm1d':                                         # non-trainable moving statistics: constants
+                    self.mm.append(torch.tensor(np.ascontiguousarray(w[f'bn{j}.moving_mean']), dtype=dtype))
+                    self.mv.append(torch.tensor(np.ascontiguousarray(w[f'bn{j}.moving_variance']), dtype=dtype))
         self.w1 = leaf(w['div.w1']); self.b1 = leaf(w['div.b1'])
         self.w2 = leaf(w['div.w2']); self.b2 = leaf(w['div.b2'])
 
@@ -79,7 +88,13 @@ class TorchFingerprinter:
                 x = F.pad(x, (0, 0, pb, pa))
             x = F.conv2d(x, self.k[j], self.b[j], stride=g['stride'])
             x = F.elu(x)
-            x = F.layer_norm(x, x.shape[1:], self.g[j], self.bt[j], eps=_nnfp.LN_EPS)
+            if self.norm == 'layer_norm2d':
+                x = F.layer_norm(x, x.shape[1:], self.g[j], self.bt[j], eps=_nnfp.LN_EPS)
+            elif self.norm == 'layer_norm1d':
+                x = F.layer_norm(x.permute(0, 2, 3, 1), (x.shape[1],), self.g[j], self.bt[j], eps=_nnfp.LN_EPS).permute(0, 3, 1, 2)
+            else:
+                c = (1, -1, 1, 1)
+                x = (x - self.mm[j].view(c)) / torch.sqrt(self.mv[j].view(c) + 1e-3) * self.g[j].view(c) + self.bt[j].view(c)
         return x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)                      # flatten as (F,T,C)
 
     def div_enc(self, x):

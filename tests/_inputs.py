@@ -21,6 +21,9 @@ def weight_list(w):
     for j in range(16):
         arrays += [w[f'conv{j}.kernel'], w[f'conv{j}.bias'], w[f'ln{j}.gamma'], w[f'ln{j}.beta']]
     arrays += [w['div.w1'], w['div.b1'], w['div.w2'], w['div.b2']]
+    if 'bn0.moving_mean' in w:                       # MODEL.BN = 'batch_norm': the non-trainable moving statistics follow
+        for j in range(16):
+            arrays += [w[f'bn{j}.moving_mean'], w[f'bn{j}.moving_variance']]
     return arrays
 
 

@@ -142,14 +142,17 @@ def test_config_surface_matches_reference_keys():
     assert lamb['BSZ']['TR_BATCH_SZ'] == 640 and lamb['TRAIN']['OPTIMIZER'] == 'LAMB'
 
 
-def test_unknown_feat_and_norm_raise(nafp, cfg):
+def test_unknown_feat_raises_and_every_norm_string_is_a_model(nafp, cfg):
+    """melspectrogram.py:114-131 raises on an unknown FEAT; MODEL.BN never raises in the reference: 'layer_norm1d', 'layer_norm2d',
+    and any other string is BatchNormalization (nnfp.py:63-71).  (The models themselves: tests/test_gpu_norm_alternates.py.)"""
     import copy
+    from neural_audio_fp_amd.model.fp import nnfp
     c = copy.deepcopy(cfg); c['MODEL']['FEAT'] = 'nope'
     with pytest.raises(NotImplementedError):
         nafp.get_melspec_layer(c)
-    c = copy.deepcopy(cfg); c['MODEL']['BN'] = 'batch_norm'
-    with pytest.raises(NotImplementedError):
-        nafp.get_fingerprinter(c)
+    assert [nnfp.norm_kind(s) for s in ('layer_norm2d', 'layer_norm1d', 'batch_norm', 'bn', '')] == [0, 1, 2, 2, 2]
+    assert len(nnfp.tensor_names('layer_norm1d')) == 68 and len(nnfp.tensor_names('batch_norm')) == 100
+    assert nnfp.tensor_names('batch_norm')[:68] == nnfp.tensor_names() and nnfp.tensor_names('batch_norm')[69] == 'front_conv.0.BN_1x3.moving_variance'
 
 
 def test_bench_flop_model_matches_survey():

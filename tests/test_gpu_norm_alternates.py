@@ -1,0 +1,152 @@
+"""MODEL.BN = 'layer_norm1d' / 'batch_norm' (nnfp.py:63-71, 250): the two normalisation alternates of the ConvLayers.
+
+The default 'layer_norm2d' is folded into the GEMM epilogues; the alternates run on the same kernels with identity statistics and
+their own positional images (csrc/norm.hip).  Checked here through the C ABI against the float64 restatement of the reference graph
+(oracle/nnfp.py `norm=`; keras LayerNormalization(axis=-1), and BatchNormalization as the reference calls it: no `training`
+argument anywhere, hence the moving statistics' affine map in the train step too) and, for the gradients, float64 autograd over
+oracle/torch_ref.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nnfp as o_nnfp, torch_ref
+import _inputs
+
+pytestmark = pytest.mark.gpu
+
+NORMS = ['layer_norm1d', 'batch_norm']
+
+
+def _weights(norm, seed=7):
+    return o_nnfp.convert_norm(_inputs.weights(seed=seed), norm, seed=seed + 1)
+
+
+def _model(nafp, norm, w):
+    m = nafp.FingerPrinter(seed=0, norm=norm)
+    m.set_weights(_inputs.weight_list(w))
+    return m
+
+
+@pytest.mark.parametrize('norm', NORMS)
+def test_tensor_table(nafp, norm):
+    """gamma / beta of shape (C,); batch_norm: 32 non-trainable moving statistics behind the 68 trainable tensors; keras initial values."""
+    m = nafp.FingerPrinter(seed=0, norm=norm)
+    names = nafp.model.fp.nnfp.tensor_names(norm)
+    assert len(m.trainable_variables) == 68 and len(names) == (100 if norm == 'batch_norm' else 68)
+    assert tuple(m.trainable_variables[2].shape) == (128,) and tuple(m.trainable_variables[4 * 15 + 3].shape) == (1024,)
+    assert bool((m.trainable_variables[2] == 1).all()) and bool((m.trainable_variables[3] == 0).all())
+    nt = m.non_trainable_variables
+    if norm == 'batch_norm':
+        assert len(nt) == 32 and names[68] == 'front_conv.0.BN_1x3.moving_mean' and names[99] == 'front_conv.7.BN_3x1.moving_variance'
+        assert bool((nt[0] == 0).all()) and bool((nt[1] == 1).all()) and tuple(nt[31].shape) == (1024,)
+    else:
+        assert nt == []
+    assert set(m.state_dict()) == set(names)
+    # any string other than the two layer norms is batch normalisation (the `else` of nnfp.py:69-71)
+    assert nafp.model.fp.nnfp.norm_kind('whatever') == 2 and nafp.model.fp.nnfp.norm_kind('layer_norm2d') == 0
+
+
+@pytest.mark.parametrize('B', [1, 9, 130])
+@pytest.mark.parametrize('norm', NORMS)
+def test_forward_matches_oracle(nafp, norm, B, observe):
+    """B = 130: the launch plans of the bench sizes (256-row tiles, split-K with both finishes); 1 / 9: ragged tiles."""
+    w = _weights(norm)
+    m = _model(nafp, norm, w)
+    rng = np.random.default_rng(B)
+    feat = (-rng.uniform(0, 1.2, size=(B, 256, 32, 1))).astype(np.float32)
+    ft = torch.from_numpy(feat).cuda()
+    emb = m(ft).cpu().numpy()
+    nb = min(B, 9)
+    sel = np.linspace(0, B - 1, nb).astype(int)
+    want = o_nnfp.fingerprinter(feat[sel], w, norm=norm)
+    observe(f'{norm} fingerprint component', np.abs(emb[sel] - want).max(), 2e-5)
+    flat = m.front_conv(ft).cpu().numpy()
+    want_flat = o_nnfp.front_conv(feat[sel], w, norm=norm)
+    observe(f'{norm} flatten output, rel. to its max', np.abs(flat[sel] - want_flat).max() / np.abs(want_flat).max(), 2e-5)
+    # the training forward is the same map, and a second launch the same bits
+    assert float((m.forward_train(ft).cpu() - torch.from_numpy(emb)).abs().max()) < 2e-6
+    assert np.array_equal(m(ft).cpu().numpy(), emb)
+
+
+@pytest.mark.parametrize('norm', NORMS)
+def test_the_deferred_front_end_path(nafp, cfg, norm):
+    """m_fp(m_pre(x, defer=True)): conv0 finishes the log-mel tail as it loads -- same result as the two-call form."""
+    w = _weights(norm)
+    m = _model(nafp, norm, w)
+    m_pre = nafp.get_melspec_layer(cfg)
+    x = torch.from_numpy(_inputs.audio(6, seed=2)).cuda()
+    a = m(m_pre(x, defer=True))
+    b = m(m_pre(x))
+    assert float((a - b).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize('B', [2, 5])
+@pytest.mark.parametrize('norm', NORMS)
+def test_backward_matches_autograd(nafp, norm, B, observe):
+    w = _weights(norm, seed=12)
+    rng = np.random.default_rng(40 + B)
+    feat = (-rng.uniform(0, 1.2, size=(B, 256, 32, 1))).astype(np.float32)
+    d_emb = rng.normal(size=(B, 128)).astype(np.float32)
+    m = _model(nafp, norm, w)
+    emb = m.forward_train(torch.from_numpy(feat).cuda())
+    grads = [g.cpu().numpy() for g in m.backward(torch.from_numpy(d_emb).cuda())]
+    tf = torch_ref.TorchFingerprinter(w, dtype=torch.float64, requires_grad=True, norm=norm)
+    want_emb = tf(torch.tensor(feat, dtype=torch.float64))
+    (want_emb * torch.tensor(d_emb, dtype=torch.float64)).sum().backward()
+    want = [p.grad.numpy() for p in tf.params]
+    assert np.abs(emb.cpu().numpy() - want_emb.detach().numpy()).max() < 2e-5
+    assert len(grads) == len(want) == 68
+    names = nafp.model.fp.nnfp.tensor_names(norm)
+    worst, worst_name = 0.0, ''
+    for i, (g, wg) in enumerate(zip(grads, want)):
+        assert g.shape == wg.shape, names[i]
+        err = np.abs(g - wg).max() / (np.abs(wg).max() + 1e-12)
+        if err > worst:
+            worst, worst_name = err, names[i]
+    observe(f'{norm} gradient, rel. to the tensor max ({worst_name})', worst, 1e-4)
+    # run to run: the same forward bits; a second backward agrees to rounding (float atomics in the parameter sums)
+    g2 = [g.cpu().numpy() for g in m.backward(torch.from_numpy(d_emb).cuda())]
+    assert all(np.abs(a - b).max() <= 1e-5 * (np.abs(a).max() + 1e-12) for a, b in zip(grads, g2))
+
+
+@pytest.mark.parametrize('norm', NORMS)
+def test_backward_at_a_bench_size_is_additive_over_the_batch(nafp, norm):
+    """B = 640 (the launch plans of the bench sizes: side stream, slabs, 256-row tiles): the parameter gradient for a given
+    dL/d(emb) is a sum over samples -- also with batch_norm, whose statistics are the moving ones, not the batch's."""
+    B, Q = 640, 4
+    g = torch.Generator(device='cuda').manual_seed(3)
+    feat = -1.2 * torch.rand((B, 256, 32, 1), generator=g, device='cuda')
+    d_emb = torch.randn((B, 128), generator=g, device='cuda')
+    m = _model(nafp, norm, _weights(norm, seed=5))
+    emb = m.forward_train(feat)
+    full = [t.clone() for t in m.backward(d_emb)]
+    parts, n = None, B // Q
+    for k in range(Q):
+        e = m.forward_train(feat[k * n:(k + 1) * n])
+        assert float((e - emb[k * n:(k + 1) * n]).abs().max()) < 2e-5
+        gk = m.backward(d_emb[k * n:(k + 1) * n])
+        parts = [t.clone() for t in gk] if parts is None else [a + b for a, b in zip(parts, gk)]
+    for i, (a, b) in enumerate(zip(full, parts)):
+        assert float((a - b).abs().max()) / (float(b.abs().max()) + 1e-20) < 2e-4, i
+
+
+@pytest.mark.parametrize('norm', NORMS)
+def test_train_step_descends(nafp, cfg, norm):
+    """trainer.train_step with MODEL.BN set: the loss of a fixed batch goes down, the moving statistics never move."""
+    import copy
+    from neural_audio_fp_amd.model import trainer as T
+    c = copy.deepcopy(cfg)
+    c['MODEL']['BN'] = norm
+    c['BSZ']['TR_BATCH_SZ'] = 16
+    from neural_audio_fp_amd.model.fp.specaug_chain.specaug_chain import get_specaug_chain_layer
+    m_pre, m_aug, m_fp = nafp.get_melspec_layer(c), get_specaug_chain_layer(c), nafp.get_fingerprinter(c, trainable=True)
+    assert m_fp.norm == norm
+    m_aug.bypass = True
+    opt = T.make_optimizer(c, 100)
+    loss_obj = nafp.NTxentLoss(8, 8, 0.05)
+    x = _inputs.audio(16, seed=9)
+    Xa, Xp = torch.from_numpy(x[:8]).cuda(), torch.from_numpy(x[8:] * 0.8 + 0.05 * x[:8]).cuda()
+    before = [v.clone() for v in m_fp.non_trainable_variables]
+    losses = [float(T.train_step((Xa, Xp), m_pre, m_aug, m_fp, loss_obj, opt)[0]) for _ in range(12)]
+    assert losses[-1] < losses[0], losses
+    assert all(torch.equal(a, b) for a, b in zip(before, m_fp.non_trainable_variables))

@@ -1,6 +1,7 @@
 """CPU: the encoder oracle against known answers and independent formulations
 (model/fp/nnfp.py:20-231)."""
 import numpy as np
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -121,3 +122,26 @@ def test_non_finite_element_poisons_exactly_its_own_sample():
             got = o_nnfp.fingerprinter(dirty, w)
         assert np.isnan(got[1]).all()
         assert np.array_equal(got[[0, 2]], clean[[0, 2]])
+
+
+@pytest.mark.parametrize('norm', ['layer_norm1d', 'batch_norm'])
+def test_norm_alternates_numpy_vs_torch(norm):
+    """MODEL.BN alternates (nnfp.py:63-71): the numpy restatement against torch's own layer_norm / the affine map, float64."""
+    import torch
+    from oracle import torch_ref
+    w = o_nnfp.convert_norm(o_nnfp.init_weights(seed=2, randomize_affine=True), norm, seed=5)
+    rng = np.random.default_rng(0)
+    feat = -rng.uniform(0, 1.2, size=(2, 256, 32, 1))
+    a = o_nnfp.fingerprinter(feat, w, norm=norm)
+    b = torch_ref.TorchFingerprinter(w, dtype=torch.float64, norm=norm)(torch.tensor(feat)).numpy()
+    assert np.abs(a - b).max() < 1e-10
+    assert np.abs(a - o_nnfp.fingerprinter(feat, o_nnfp.init_weights(seed=2, randomize_affine=True))).max() > 1e-3   # (a different model)
+    if norm == 'batch_norm':
+        # as keras initialises it (moving mean 0, variance 1, gamma 1, beta 0) the layer is a division by sqrt(1.001)
+        w0 = o_nnfp.convert_norm(o_nnfp.init_weights(seed=2), norm, randomize=False)
+        x = rng.normal(size=(1, 4, 2, 128))
+        assert np.allclose(o_nnfp.apply_norm(x, w0, 0, norm, np.float64), x / np.sqrt(1.001), rtol=0, atol=1e-15)
+    else:
+        x = rng.normal(size=(3, 4, 2, 128))
+        y = o_nnfp.layer_norm1d(x, np.ones(128), np.zeros(128))
+        assert np.abs(y.mean(-1)).max() < 1e-12 and np.abs((y ** 2).mean(-1) - x.var(-1) / (x.var(-1) + 1e-3)).max() < 1e-12

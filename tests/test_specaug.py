@@ -52,3 +52,94 @@ def test_kernel_matches_oracle_with_injected_rects(nafp, cfg):
     m.bypass = True
     xt = torch.from_numpy(x).cuda()
     assert m(xt) is xt
+
+
+def test_per_sample_hole_draws_follow_reference_ranges():
+    """uniform_mask=False: `generate_mixed_mask(bsz, ...)` draws sizes and centres per (sample, hole) (ncutout_tarray.py:131-170)."""
+    from neural_audio_fp_amd.model.fp.specaug_chain.specaug_chain import draw_holes_per_sample
+    rng = np.random.default_rng(3)
+    H, W = 256, 32
+    r = draw_holes_per_sample('cutout', H, W, 3, rng, 4000)
+    assert r.shape == (4000, 3, 4) and r.dtype == np.int32
+    f0, f1, t0, t1 = r[..., 0], r[..., 1], r[..., 2], r[..., 3]
+    assert (0 <= f0).all() and (f0 < f1).all() and (f1 <= H - 1).all() and (0 <= t0).all() and (t0 < t1).all() and (t1 <= W - 1).all()
+    assert (t1 - t0).max() <= 10 and (f1 - f0).max() <= 2 * (101 // 2)
+    assert len({tuple(q) for q in r[:, 0]}) > 3000                       # the samples really differ
+    r = draw_holes_per_sample('horizontal', H, W, 3, rng, 500)            # one full-width band per sample, whatever n_holes says
+    assert r.shape == (500, 1, 4) and (r[..., 2] == 0).all() and (r[..., 3] == W - 1).all()
+    r = draw_holes_per_sample('vertical', H, W, 1, rng, 500)
+    assert (r[..., 0] == 0).all() and (r[..., 1] == H - 1).all() and ((r[..., 3] - r[..., 2]) <= 14).all()
+
+
+def test_oracle_general_form():
+    x = np.arange(2 * 4 * 4, dtype=np.float32).reshape(2, 4, 4, 1)
+    rects = np.array([[[0, 1, 0, 1], [3, 3, 3, 3]], [[2, 3, 0, 0], [0, 0, 0, 0]]])
+    act = np.array([[1, 0], [1, 1]])
+    hf = np.full((1, 4, 4), 2.0, np.float32)
+    y = o_sa.apply_holes_general(x, rects, act, hf, scale=3.0, offset=1.0)
+    assert (y[0, 0:2, 0:2, 0] == 7.0).all() and y[0, 3, 3, 0] == x[0, 3, 3, 0]           # hole 1 of sample 0 is inactive
+    assert (y[1, 2:4, 0, 0] == 7.0).all() and y[1, 0, 0, 0] == 7.0 and y[1, 1, 1, 0] == x[1, 1, 1, 0]
+    # the uniform branch is the special case of one shared set and a per-sample flag
+    y2 = o_sa.apply_holes_general(x, rects[0], np.array([1, 0]), None, scale=0.0)
+    assert np.array_equal(y2, o_sa.apply_holes(x, rects[0], [True, False], 0.0).astype(np.float32))
+
+
+@pytest.mark.gpu
+def test_general_kernel_matches_oracle(nafp):
+    """Per-sample rectangle sets, per-hole activation, a filler tensor scaled on the device: bit for bit the oracle."""
+    from neural_audio_fp_amd.model.fp.specaug_chain.specaug_chain import SpecAugChainer, draw_holes_per_sample
+    m = SpecAugChainer(chain_config=['cutout'], uniform_mask=False, n_holes=3, hole_fill='random', seed=5)
+    rng = np.random.default_rng(2)
+    B = 37
+    x = rng.normal(size=(B, 256, 32, 1)).astype(np.float32)
+    rects = draw_holes_per_sample('cutout', 256, 32, 3, rng, B)
+    act = rng.random((B, 3)) < 0.6
+    hf = rng.random((B, 256, 32)).astype(np.float32)
+    so = np.array([x.max() - x.min(), x.min()], np.float32)
+    got = m.apply_rects_ex(torch.from_numpy(x.copy()).cuda(), rects, act, torch.from_numpy(hf).cuda(), torch.from_numpy(so).cuda())
+    assert np.array_equal(got.cpu().numpy(), o_sa.apply_holes_general(x, rects, act, hf, so[0], so[1]))
+    # one shared set, per-sample flag, no filler tensor, a filler of fewer rows than the batch
+    got = m.apply_rects_ex(torch.from_numpy(x.copy()).cuda(), rects[0], act[:, 0], None, torch.tensor([0.25, -1.0]).cuda())
+    assert np.array_equal(got.cpu().numpy(), o_sa.apply_holes_general(x, rects[0], act[:, 0], None, 0.25, -1.0))
+    got = m.apply_rects_ex(torch.from_numpy(x.copy()).cuda(), rects, None, torch.from_numpy(hf[:5].copy()).cuda(), torch.tensor([1.0, 0.0]).cuda())
+    assert np.array_equal(got.cpu().numpy(), o_sa.apply_holes_general(x, rects, None, hf[:5], 1.0, 0.0))
+    # the device-side range of the 'random' filler
+    filler, so_dev = m._scale_offset(torch.from_numpy(x).cuda(), 0)
+    assert np.array_equal(so_dev.cpu().numpy(), so) and filler.shape == (B, 256, 32)
+    assert m._scale_offset(torch.from_numpy(x).cuda(), 0)[0] is filler                  # drawn once per stage (keras build)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('hole_fill', ['zeros', 'min', 'random', [-3.0, -2.5]])
+@pytest.mark.parametrize('uniform', [True, False])
+def test_layer_modes(nafp, hole_fill, uniform):
+    """SPECAUG_HOLE_FILL in {'min', 'zeros', 'random', [min_mag, max_mag]} (default.yaml:104) x uniform_mask: what a hole holds,
+    who gets holes, and that everything outside them is untouched."""
+    from neural_audio_fp_amd.model.fp.specaug_chain.specaug_chain import SpecAugChainer
+    m = SpecAugChainer(chain_config=['cutout', 'horizontal'], probs=[1.0, 0.5], uniform_mask=uniform, n_holes=2, hole_fill=hole_fill, seed=11)
+    rng = np.random.default_rng(4)
+    x = (rng.random((64, 256, 32, 1)) + 1.0).astype(np.float32)           # values in [1, 2): a hole is recognisable for every filler
+    y = m(torch.from_numpy(x).cuda()).cpu().numpy()
+    holes = y != x
+    assert holes.any() and np.array_equal(y[~holes], x[~holes])
+    per_sample = holes.reshape(64, -1).sum(1)
+    assert (per_sample > 0).all()                                         # stage 1 (prob 1) masks every sample
+    band = holes.reshape(64, 256, 32).all(axis=2).any(axis=1)            # a full-width band = the 'horizontal' stage hit the sample
+    assert 8 < band.sum() < 56                                           # ... with probability 0.5
+    if uniform:
+        nb = np.flatnonzero(~band)
+        assert all(np.array_equal(holes[nb[0]], holes[b]) for b in nb)   # samples without the band share one rectangle set
+    else:
+        assert len({holes[b].tobytes() for b in range(64)}) > 32         # own rectangles per sample
+    v = y[holes]
+    if hole_fill == 'zeros':
+        assert (v == 0).all()
+    elif hole_fill == 'min':
+        assert np.ptp(v) < 0.05 and 1.0 < v.mean() < 2.0                 # reduce_mean of the stage's input (two stages: two values)
+    elif hole_fill == 'random':
+        assert v.min() >= 0.0 and v.max() <= 2.0 and np.ptp(v) > 0.5    # noise scaled to the value range of the stage's input
+    else:
+        assert v.min() >= -3.0 and v.max() < -2.5 and np.ptp(v) > 0.4
+    # the layer is reproducible from its seed, and the noise tensor is fixed after the first call
+    m2 = SpecAugChainer(chain_config=['cutout', 'horizontal'], probs=[1.0, 0.5], uniform_mask=uniform, n_holes=2, hole_fill=hole_fill, seed=11)
+    assert np.array_equal(m2(torch.from_numpy(x).cuda()).cpu().numpy(), y)
