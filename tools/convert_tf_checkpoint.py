@@ -50,6 +50,7 @@ def main():
     ckpt.restore(path).expect_partial()
     index = int(path.split('-')[-1])
     out = {}
+    n_moving = 0
     blocks = [l for l in m_fp.front_conv.layers if hasattr(l, 'conv2d_1x3')]
     assert len(blocks) == 8, len(blocks)
     for b, blk in enumerate(blocks):
@@ -59,13 +60,17 @@ def main():
             out[f'front_conv.{b}.{conv}.bias'] = c.bias.numpy()
             out[f'front_conv.{b}.{bn}.gamma'] = n.gamma.numpy()
             out[f'front_conv.{b}.{bn}.beta'] = n.beta.numpy()
+            if hasattr(n, 'moving_mean'):              # MODEL.BN = batch normalisation: the non-trainable moving statistics
+                n_moving += n.moving_mean.numpy().size + n.moving_variance.numpy().size
+                out[f'front_conv.{b}.{bn}.moving_mean'] = n.moving_mean.numpy()
+                out[f'front_conv.{b}.{bn}.moving_variance'] = n.moving_variance.numpy()
     w1, b1, w2, b2 = [], [], [], []
     for seq in m_fp.div_enc.split_fc_layers:
         d1, d2 = seq.layers
         w1.append(d1.kernel.numpy()); b1.append(d1.bias.numpy()); w2.append(d2.kernel.numpy()); b2.append(d2.bias.numpy())
     out['div_enc.fc1.kernel'], out['div_enc.fc1.bias'] = np.stack(w1), np.stack(b1)
     out['div_enc.fc2.kernel'], out['div_enc.fc2.bias'] = np.stack(w2), np.stack(b2)
-    n_par = sum(v.size for v in out.values())
+    n_par = sum(v.size for v in out.values()) - n_moving
     assert n_par == sum(int(np.prod(v.shape)) for v in m_fp.trainable_variables), 'a variable was missed'
     dst = (args.out or cfg['DIR']['LOG_ROOT_DIR'] + 'checkpoint/').rstrip('/') + f'/{args.checkpoint_name}/'
     os.makedirs(dst, exist_ok=True)
