@@ -421,6 +421,11 @@ __device__ __forceinline__ float half_wave_sum_dpp(float x) {
     return __builtin_bit_cast(float, v);
 }
 
+// EXPERIMENT (-DNAFP_EXP_SKIP_TAP2=1, WRONG RESULTS): tap 2's activation rows are not fetched (zero rows instead): the L2 / HBM traffic
+// an input-row-staged stride-2 tile would save, for an upper bound of what that tile could gain (profiles/r05_experiments.md)
+#ifndef NAFP_EXP_SKIP_TAP2
+#define NAFP_EXP_SKIP_TAP2 0
+#endif
 // EPI selects the epilogue the instantiation carries (one per kernel: the others' code and registers are not in it):
 //   0 FULL for inference (tile = 4 or 8 samples per position: statistics in registers), 1 the same + the pre-activation
 //   kept for the backward pass, 2 FULL for any tile shape (statistics through LDS; v_out by a runtime test),
@@ -798,7 +803,7 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p, const 
 #define NAFP_DMA_TAP()                                                                         \
         {                                                                                      \
             d_tap = (int)((tap_pack >> (2 * d_tsel)) & 3u); d_tapb = (unsigned)(d_tap * p.tap_stride) * 4u; \
-            _Pragma("unroll") for (int q = 0; q < NI; ++q) cur_va[q] = ((vmaskA[q] >> d_tap) & 1u) ? voffA[q] + d_tapb : OOB; \
+            _Pragma("unroll") for (int q = 0; q < NI; ++q) cur_va[q] = (((vmaskA[q] >> d_tap) & 1u) && !(NAFP_EXP_SKIP_TAP2 && d_tap == 2)) ? voffA[q] + d_tapb : OOB; \
         }
         NAFP_DMA_TAP()
 #define NAFP_DMA_PIECE(q_, slot_)                                                              \
