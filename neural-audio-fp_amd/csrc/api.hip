@@ -92,6 +92,7 @@ struct nafp_encoder {
     int norm = NAFP_NORM_LAYER2D;
     int n_trainable = 68;
     std::vector<float*> d_gc, d_bc, d_mm, d_mv;
+    bool ln1d_images_set = false;
     std::vector<ConvGeom> geom;           // 16
     int64_t flat_dim; int S;
     // tensor table (keras shapes)
@@ -434,7 +435,8 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
     NAFP_LAUNCH_CHECK();
     // the alternates' positional images (norm.hip): 1 / 0 for layer_norm1d (the row pass applies gamma_c / beta_c), the broadcast
     // affine map of the moving statistics for batch_norm -- in front of `sw_copied`: conv0 reads gamma_pos of layer 0
-    if (e->norm == NAFP_NORM_LAYER1D) {
+    if (e->norm == NAFP_NORM_LAYER1D && !e->ln1d_images_set) {      // constants: written by the first call only
+        e->ln1d_images_set = true;
         for (int j = 0; j < 16; ++j) {
             const int64_t nln = (int64_t)e->geom[j].Fout * e->geom[j].Tout * e->geom[j].Cout;
             NAFP_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)e->d_gamma[j], 0x3f800000, nln, st));
