@@ -150,3 +150,29 @@ def test_train_step_descends(nafp, cfg, norm):
     losses = [float(T.train_step((Xa, Xp), m_pre, m_aug, m_fp, loss_obj, opt)[0]) for _ in range(12)]
     assert losses[-1] < losses[0], losses
     assert all(torch.equal(a, b) for a, b in zip(before, m_fp.non_trainable_variables))
+
+
+@pytest.mark.parametrize('norm', NORMS)
+def test_checkpoint_round_trip(nafp, cfg, norm, tmp_path):
+    """save_checkpoint / load_checkpoint (generate.py:26-52) carry every tensor of the alternates -- for batch_norm the moving
+    statistics too -- and a model restored from the file gives the same fingerprints, bit for bit."""
+    import copy
+    from neural_audio_fp_amd.model import generate as g
+    c = copy.deepcopy(cfg)
+    c['MODEL']['BN'] = norm
+    w = _weights(norm, seed=21)
+    m = nafp.get_fingerprinter(c)
+    m.set_weights(_inputs.weight_list(w))
+    feat = -1.2 * torch.rand((7, 256, 32, 1), generator=torch.Generator(device='cuda').manual_seed(1), device='cuda')
+    emb = m(feat).clone()
+    root = str(tmp_path) + '/checkpoint/'
+    g.save_checkpoint(root, 'exp', 5, m)
+    m2 = nafp.get_fingerprinter(c)
+    assert float((m2(feat) - emb).abs().max()) > 1e-3                     # (freshly initialised: another model)
+    assert g.load_checkpoint(root, 'exp', None, m2) == 5
+    assert torch.equal(m2(feat), emb)
+    # a checkpoint of another normalisation is refused by name / shape, not silently half-loaded
+    other = copy.deepcopy(cfg)
+    m3 = nafp.get_fingerprinter(other)                                     # layer_norm2d
+    with pytest.raises((KeyError, ValueError)):
+        g.load_checkpoint(root, 'exp', 5, m3)
