@@ -571,8 +571,7 @@ extern "C" int64_t nafp_encoder_workspace_bytes(const nafp_encoder* e, int64_t n
     int64_t smallz = 0;
     if (e->use_smallnet(n_seg))
         for (int j = e->smallnet_j0; j < 16; ++j) smallz += align_up((int64_t)sizeof(float) * e->geom[j].Fout * e->geom[j].Tout * e->geom[j].Cout * n_seg, 256);
-    const int64_t ident = e->norm != NAFP_NORM_LAYER2D ? align_up((int64_t)sizeof(stat_t) * 2 * 16 * n_seg, 256) : 0;      // identity statistics of the alternates (norm.hip)
-    return stats + a + b + align_up(forward_slab_floats(e, n_seg) * (int64_t)sizeof(float), 256) + smallz + ident + 256;
+    return stats + a + b + align_up(forward_slab_floats(e, n_seg) * (int64_t)sizeof(float), 256) + smallz + 256;
 }
 
 static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float* gstat, int group_size, int segment_norm,
@@ -624,15 +623,11 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
     // conv0 is either materialised (z0 written to bufA) or -- default -- only its statistics are
     // computed here and conv1 re-generates z0 tiles in-kernel from the log-mel features
     // (NAFP_FUSE0=0 selects the materialised path).
-    const bool alt = e->norm != NAFP_NORM_LAYER2D;             // layer_norm1d / batch_norm: identity statistics for every consumer (norm.hip)
-    stat_t* ident = nullptr;
-    if (alt) {
-        ident = (stat_t*)((char*)slab + align_up(slab_floats * (int64_t)sizeof(float), 256));
-        int rci = launch_identity_stats(ident, e->d_inv_n, n_seg, 16, st);
-        if (rci != NAFP_OK) return rci;
-    }
-    auto stats_of = [&](int j) { return (alt ? ident : stats) + 2 * n_seg * j; };      // what the consumers of layer j's output read
-    auto row_pass = [&](float* z, int j) -> int {               // layer_norm1d: normalise the rows of layer j's output in place
+    const bool alt = e->norm != NAFP_NORM_LAYER2D;             // layer_norm1d / batch_norm (norm.hip)
+    // The alternates: every consumer derives identity scalars (r = 1, c = 0; NaN for a poisoned sample) from the producer's
+    // statistics (`ident_stats`); layer_norm1d normalises the rows of every layer's output in place.
+    auto stats_of = [&](int j) { return stats + 2 * n_seg * j; };
+    auto row_pass = [&](float* z, int j) -> int {
         if (e->norm != NAFP_NORM_LAYER1D) return NAFP_OK;
         return launch_ln1d_fwd(z, n_seg * e->geom[j].Fout * e->geom[j].Tout, e->geom[j].Cout, e->d_gc[j], e->d_bc[j], st);
     };
@@ -669,7 +664,7 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
             break;
         }
         ConvGemmArgs a{};
-        a.x = cur; a.stats_in = stats_of(j - 1);
+        a.x = cur; a.stats_in = stats_of(j - 1); a.ident_stats = alt;
         a.wp = e->d_w[j]; a.G = e->d_G[j]; a.Hb = e->d_Hb[j]; a.gamma_out = e->d_gamma[j];
         a.y = nxt; a.stats_out = stats + 2 * n_seg * j; a.plain = false;
         a.slab = slab_floats ? slab : nullptr; a.slab_floats = slab_floats; a.tickets = tickets; a.bf16x3 = e->opt_bf16x3;
@@ -692,7 +687,7 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
         cur = nxt;
     }
     TailArgs t;
-    t.x = cur; t.stats = stats_of(15); t.gamma = e->d_gamma[15]; t.beta = e->d_beta[15];
+    t.x = cur; t.stats = stats_of(15); t.ident_stats = alt; t.gamma = e->d_gamma[15]; t.beta = e->d_beta[15];
     t.w1p = e->d_w1p; t.b1p = e->d_b1p; t.w2p = e->d_w2p; t.b2 = e->d_b2;
     t.out_flat = out_flat; t.out_emb = out_emb;
     t.D = (int)e->flat_dim; t.Q = e->emb_sz; t.S = e->S; t.l2norm = l2norm; t.nonfinite_weights = e->d_wflag; t.launch_error = nullptr;
@@ -763,7 +758,7 @@ extern "C" int nafp_encoder_div_enc(nafp_encoder* e, const float* flat, int64_t 
     if (!e || !flat || !out_emb || n_seg < 0) return NAFP_ERR_INVALID_ARG;
     if (!e->has_weights) return NAFP_ERR_NO_WEIGHTS;
     TailArgs t;
-    t.x = flat; t.stats = nullptr; t.gamma = nullptr; t.beta = nullptr;
+    t.x = flat; t.stats = nullptr; t.ident_stats = false; t.gamma = nullptr; t.beta = nullptr;
     t.w1p = e->d_w1p; t.b1p = e->d_b1p; t.w2p = e->d_w2p; t.b2 = e->d_b2;
     t.out_flat = nullptr; t.out_emb = out_emb;
     t.D = (int)e->flat_dim; t.Q = e->emb_sz; t.S = e->S; t.l2norm = l2norm; t.nonfinite_weights = e->d_wflag; t.launch_error = nullptr;
@@ -788,8 +783,7 @@ struct TrainLayout {
     float* slab2; int64_t slab2_floats; unsigned* tickets2;     // the weight-gradient stream's own slab and arrival counters (opt_bwd_overlap 2)
     float* dA; float* dB; float* dy;
     float* dts[16];                      // the small layers' gradients in buffers of their own (opt_bwd_overlap 2), else nullptr
-    stat_t* ident;                       // the alternates (norm.hip): identity statistics (16, B, 2) ...
-    float* dgp; float* dbp;              // ... and the positional (dgamma | dbeta) sums of the shared LayerNorm backward (max_n floats each)
+    float* dgp; float* dbp;              // the alternates (norm.hip): the positional (dgamma | dbeta) sums of the shared LayerNorm backward (max_n floats each)
     int64_t bytes;
 };
 
@@ -841,9 +835,8 @@ TrainLayout train_layout(const nafp_encoder* e, int64_t B, void* ws) {
         const int64_t n = (int64_t)e->geom[j].Fout * e->geom[j].Tout * e->geom[j].Cout;
         L.dts[j] = (j >= 1 && e->geom[j].Fout * e->geom[j].Tout < 16) ? (float*)take((int64_t)sizeof(float) * n * B) : nullptr;
     }
-    L.ident = nullptr; L.dgp = nullptr; L.dbp = nullptr;
+    L.dgp = nullptr; L.dbp = nullptr;
     if (e->norm != NAFP_NORM_LAYER2D) {
-        L.ident = (stat_t*)take((int64_t)sizeof(stat_t) * 2 * 16 * B);
         L.dgp = (float*)take((int64_t)sizeof(float) * 2 * max_n);
         L.dbp = L.dgp + max_n;
     }
@@ -870,8 +863,7 @@ extern "C" int nafp_encoder_forward_train(nafp_encoder* e, const float* feat, in
     { int wrc = wait_weights(e, st, split_wait ? 0 : 2); if (wrc != NAFP_OK) return wrc; }
     // (layer 0 keeps no pre-activation: the backward pass regenerates it from `feat`, 3 FMAs per element)
     const bool alt = e->norm != NAFP_NORM_LAYER2D;             // layer_norm1d / batch_norm (norm.hip), as in encoder_forward_impl
-    if (alt) { int rci = launch_identity_stats(L.ident, e->d_inv_n, n_seg, 16, st); if (rci != NAFP_OK) return rci; }
-    auto stats_of = [&](int j) { return (alt ? L.ident : L.stats) + 2 * n_seg * j; };
+    auto stats_of = [&](int j) { return L.stats + 2 * n_seg * j; };
     auto row_pass = [&](float* z, int j) -> int {
         if (e->norm != NAFP_NORM_LAYER1D) return NAFP_OK;
         return launch_ln1d_fwd(z, n_seg * e->geom[j].Fout * e->geom[j].Tout, e->geom[j].Cout, e->d_gc[j], e->d_bc[j], st);
@@ -896,7 +888,7 @@ extern "C" int nafp_encoder_forward_train(nafp_encoder* e, const float* feat, in
             break;
         }
         ConvGemmArgs a{};
-        a.x = L.z[j - 1]; a.stats_in = stats_of(j - 1);
+        a.x = L.z[j - 1]; a.stats_in = stats_of(j - 1); a.ident_stats = alt;
         a.wp = e->d_w[j]; a.G = e->d_G[j]; a.Hb = e->d_Hb[j]; a.gamma_out = e->d_gamma[j];
         a.y = L.z[j]; a.v_out = L.v[j]; a.stats_out = L.stats + 2 * n_seg * j; a.plain = false;
         a.slab = L.slab_floats ? L.slab : nullptr; a.slab_floats = L.slab_floats; a.tickets = L.tickets;
@@ -906,7 +898,7 @@ extern "C" int nafp_encoder_forward_train(nafp_encoder* e, const float* feat, in
         if (rc != NAFP_OK) return rc;
     }
     TailArgs t;
-    t.x = L.z[15]; t.stats = stats_of(15); t.gamma = e->d_gamma[15]; t.beta = e->d_beta[15];
+    t.x = L.z[15]; t.stats = stats_of(15); t.ident_stats = alt; t.gamma = e->d_gamma[15]; t.beta = e->d_beta[15];
     t.w1p = e->d_w1p; t.b1p = e->d_b1p; t.w2p = e->d_w2p; t.b2 = e->d_b2;
     t.out_flat = nullptr; t.out_emb = out_emb;
     t.D = (int)e->flat_dim; t.Q = e->emb_sz; t.S = e->S; t.l2norm = l2norm; t.nonfinite_weights = e->d_wflag; t.launch_error = sn_j0 <= 15 ? L.ctrl + 1 : nullptr;
@@ -928,7 +920,7 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
         if (!grads[i]) return NAFP_ERR_INVALID_ARG;
     { int wrc = wait_weights(e, st); if (wrc != NAFP_OK) return wrc; }
     const bool alt = e->norm != NAFP_NORM_LAYER2D;             // layer_norm1d / batch_norm (norm.hip)
-    const stat_t* const stats_r = alt ? L.ident : L.stats;     // the statistics the forward pass's consumers read
+    const stat_t* const stats_r = L.stats;
     // every gradient accumulates through atomics: zero them (adjacent tensors -- e.g. views into one flat
     // all-reduce bucket -- in one memset) together with the LN sums and S1/S2
     for (size_t i = 0; i < n_tr;) {
@@ -957,11 +949,11 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
         for (auto& ev : e->ev_main) NAFP_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         for (auto& ev : e->ev_side) NAFP_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
-    int rc = launch_stats_to_mr(stats_r, L.mr, e->d_inv_n, B, 16, st);
+    int rc = launch_stats_to_mr(stats_r, L.mr, e->d_inv_n, B, 16, st, alt);      // (the alternates: identity scalars, as the forward pass's consumers derived)
     if (rc != NAFP_OK) return rc;
     // tail: d_emb -> r * dxhat of the last conv + divide-and-encode gradients
     TailBwdArgs tb;
-    tb.z = L.z[15]; tb.stats = stats_r + 2 * B * 15; tb.gamma = e->d_gamma[15]; tb.beta = e->d_beta[15];
+    tb.z = L.z[15]; tb.stats = stats_r + 2 * B * 15; tb.ident_stats = alt; tb.gamma = e->d_gamma[15]; tb.beta = e->d_beta[15];
     tb.w1 = e->d_w1k; tb.b1 = e->d_b1k; tb.w2 = e->d_w2k; tb.b2 = e->d_b2;
     tb.w1p = e->d_w1p; tb.b1p = e->d_b1p; tb.w2p = e->d_w2p;
     // gradient buffers: layer j's incoming gradient (then dts_j, in place) lives in its own buffer when its weight gradient runs on

@@ -32,9 +32,14 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 // (mean, rstd) per sample and layer from the double (sum, sumsq) statistics.
 __global__ void stats_to_mr_kernel(const stat_t* __restrict__ stats, float* __restrict__ mr, int64_t n_pairs,
-                                   const double* __restrict__ inv_n_per_layer, int64_t B) {
+                                   const double* __restrict__ inv_n_per_layer, int64_t B, int identity) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n_pairs) return;
+    if (identity) {                       // the normalisation alternates (stat_ln_scalars): mean 0, rstd 1; NaN for a poisoned sample
+        const double z = stat_get(stats + 2 * i + 1) * 0.0;
+        mr[2 * i] = (float)z; mr[2 * i + 1] = (float)(1.0 + z);
+        return;
+    }
     const double inv_n = inv_n_per_layer[i / B];
     const double mean = stat_get(stats + 2 * i) * inv_n;
     double var = stat_get(stats + 2 * i + 1) * inv_n - mean * mean;
@@ -1233,11 +1238,8 @@ template <int S>
 __global__ __launch_bounds__(256) void tail_bwd_a_kernel(const TailBwdArgs a) {
     const int q = threadIdx.x, Q = a.Q;
     const int64_t b = blockIdx.x;
-    const double mean = stat_get(a.stats + 2 * b) / (double)a.D;
-    double var = stat_get(a.stats + 2 * b + 1) / (double)a.D - mean * mean;
-    var = var < 0.0 ? 0.0 : var;
-    const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
-    const float lnA = (float)rstd, lnC = (float)(-mean * rstd);
+    float lnA, lnC;
+    stat_ln_scalars(a.stats + 2 * b, a.ident_stats ? -1.0 : 1.0 / (double)a.D, &lnA, &lnC);
     if (q == 0) { a.ln[2 * b] = lnA; a.ln[2 * b + 1] = lnC; }     // kernel B reads them instead of redoing the double arithmetic per thread
     float x[S];
 #pragma unroll
@@ -1384,9 +1386,9 @@ __global__ void pack_dgrad_weight_kernel(const float* __restrict__ k3, float* __
 }
 
 // ---- host launch helpers used by api.hip -------------------------------------------------
-int launch_stats_to_mr(const stat_t* stats, float* mr, const double* inv_n_dev, int64_t B, int n_layers, hipStream_t st) {
+int launch_stats_to_mr(const stat_t* stats, float* mr, const double* inv_n_dev, int64_t B, int n_layers, hipStream_t st, bool identity) {
     const int64_t n = (int64_t)n_layers * B;
-    stats_to_mr_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(stats, mr, n, inv_n_dev, B);
+    stats_to_mr_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(stats, mr, n, inv_n_dev, B, identity ? 1 : 0);
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }

@@ -722,11 +722,16 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p, const 
     if (stat_thread) {
         float r = 0.f, c = 0.f;
         if (p.mode != 1 && b0 + tid - 64 < p.B) {
-            const double mean = st_sum * p.inv_n_in;
-            double var = st_sq * p.inv_n_in - mean * mean;
-            var = var < 0.0 ? 0.0 : var;                          // (keeps a NaN)
-            const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
-            r = (float)rstd; c = (float)(-mean * rstd);
+            if (p.inv_n_in < 0.0) {                               // identity statistics (stat_ln_scalars): r = 1, c = 0, NaN if poisoned
+                const double z = st_sq * 0.0;
+                r = (float)(1.0 + z); c = (float)z;
+            } else {
+                const double mean = st_sum * p.inv_n_in;
+                double var = st_sq * p.inv_n_in - mean * mean;
+                var = var < 0.0 ? 0.0 : var;                      // (keeps a NaN)
+                const double rstd = 1.0 / sqrt(var + (double)LN_EPS);
+                r = (float)rstd; c = (float)(-mean * rstd);
+            }
         }
         sRB[tid - 64] = r; sCB[tid - 64] = c;
     }
@@ -1674,7 +1679,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     p.n_sg = (int)((B + p.ST - 1) / p.ST);
     p.sample_in = (int64_t)g.Fin * g.Tin * g.Cin;
     p.tap_stride = g.axis == 0 ? g.Cin : g.Tin * g.Cin;
-    p.inv_n_in = 1.0 / (double)p.sample_in;
+    p.inv_n_in = a.ident_stats ? -1.0 : 1.0 / (double)p.sample_in;
     p.mode = a.plain ? 1 : 0;
     p.n_split = 1;
     p.dgrad = 0; p.perm_on = fwd_perm; p.perm_n0 = 0; p.perm_c0 = 0;

@@ -95,7 +95,10 @@ __device__ __forceinline__ double stat_get(const stat_t* slot) {
     return (double)x * (1.0 / (double)(1 << STAT_FRAC_BITS));
 }
 // (r_b, c_b) = (rstd, -mean * rstd) of one sample from its statistics; NaN for a poisoned sample (the variance clamp keeps a NaN)
+// inv_n < 0: IDENTITY statistics (the normalisation alternates, norm.hip): r = 1, c = 0 exactly -- NaN for a poisoned sample all the
+// same (NaN * 0), so that its row still comes out NaN
 __device__ __forceinline__ void stat_ln_scalars(const stat_t* sample_slots, double inv_n, float* r, float* c) {
+    if (inv_n < 0.0) { const double z = stat_get(sample_slots + 1) * 0.0; *r = (float)(1.0 + z); *c = (float)z; return; }
     const double mean = stat_get(sample_slots) * inv_n;
     double var = stat_get(sample_slots + 1) * inv_n - mean * mean;
     var = var < 0.0 ? 0.0 : var;
@@ -164,6 +167,7 @@ struct ConvGemmArgs {
     const float* gamma_out;  // (P,Cout) LN scale of THIS conv     FULL
     const float* bias;       // (Cout) or nullptr                  PLAIN
     const stat_t* stats_in;  // (B,2): sum, sumsq of the previous conv's ELU output (fixed point, stat_get())   FULL
+    bool ident_stats;        // FULL: derive r_b = 1, c_b = 0 from stats_in whatever it holds (a poisoned sample: NaN) -- the alternates of norm.hip
     stat_t* stats_out;       // (B,2), must be zero on entry                          FULL
     float* y;                // (B,Fout,Tout,Cout): z = gamma_out . v (FULL) or acc + bias (PLAIN)
     float* v_out;            // optional (FULL): the pre-activation t (v = ELU(t)), kept for the backward pass
@@ -231,6 +235,7 @@ struct TailArgs {
     float* out_flat;         // (B,D) or nullptr
     float* out_emb;          // (B,Q) or nullptr
     int D, Q, S, l2norm;
+    bool ident_stats;        // r_b = 1, c_b = 0 whatever `stats` holds (a poisoned sample: NaN): the alternates of norm.hip
     const int* nonfinite_weights;   // (or null) != 0: the parameter set holds a NaN / Inf -> every output row is NaN
     const unsigned* launch_error;   // (or null) != 0: the persistent small-layer launch of this pass gave up a wait (smallnet_kernel) -> NaN rows
 };
@@ -239,6 +244,7 @@ int launch_tail(const TailArgs& a, int64_t B, hipStream_t st);
 // ---- backward pass (backward.hip) ----------------------------------------------------------
 struct TailBwdArgs {
     const float* z; const stat_t* stats; const float* gamma; const float* beta;     // last conv (z = gamma . v)
+    bool ident_stats;                                                               // identity statistics (the alternates of norm.hip)
     const float* w1; const float* b1; const float* w2; const float* b2;             // keras layouts
     const float* w1p; const float* b1p; const float* w2p;                           // the forward tail's layouts (S,32,Q) / (32,Q): kernel A, thread <-> q, reads them coalesced
     const float* d_emb;                                                             // (B,Q)
@@ -249,7 +255,8 @@ struct TailBwdArgs {
     int D, Q, S, l2norm;
 };
 int launch_tail_bwd(const TailBwdArgs& a, int64_t B, hipStream_t st);
-int launch_stats_to_mr(const stat_t* stats, float* mr, const double* inv_n_dev, int64_t B, int n_layers, hipStream_t st);
+// identity: mean 0, rstd 1 for every sample (NaN for a poisoned one), see stat_ln_scalars
+int launch_stats_to_mr(const stat_t* stats, float* mr, const double* inv_n_dev, int64_t B, int n_layers, hipStream_t st, bool identity = false);
 // LayerNorm + ELU backward of one layer (backward.hip): d = r_j * dL/dxhat_j -> dts = r_{j-1} * dL/dt_j in place;
 // dgamma/dbeta/dbias/S1/S2 accumulate (zeroed by the caller, like lnsum); sc = (B, 8) scratch.
 // tpre = the layer's stored PRE-activation t (v = ELU(t) is recomputed).  reduce_here: compute this layer's (s1, s2)
@@ -278,8 +285,6 @@ int launch_conv0_bwd(const float* feat, const float* dt, float* dW0, float* dbia
 int launch_pack_dgrad_weight(const float* k3, float* wd, int Cin, int Cout, hipStream_t st);
 
 // ---- normalisation alternates (norm.hip): MODEL.BN = 'layer_norm1d' | 'batch_norm' (nnfp.py:63-71) -----------------------------
-// (layers, B, 2) statistics from which every consumer derives r_b = 1, c_b = 0 (inv_n_dev: 1 / n per layer)
-int launch_identity_stats(stat_t* ident, const double* inv_n_dev, int64_t B, int layers, hipStream_t st);
 // batch_norm: the positional scale / offset images (gamma_pos | beta_pos adjacent, n = P * C floats each) from the per-channel
 // parameters and moving statistics
 struct BnExpandTable { const float* gamma_c[16]; const float* beta_c[16]; const float* mmean[16]; const float* mvar[16];

@@ -3,8 +3,9 @@
 // GEMM epilogues (conv.hip) and needs nothing from this file.
 //
 // Both alternates run on the SAME conv / tail / backward kernels, which are given
-//   * IDENTITY statistics (identity_stats_kernel: sum = 0, sum of squares = n (1 - eps), so that every consumer derives
-//     r_b = 1, c_b = -mu_b r_b = 0 from them), and
+//   * told to derive IDENTITY scalars r_b = 1, c_b = -mu_b r_b = 0 from whatever the producer's statistics hold (`ident_stats` of
+//     the launch arguments -> stat_ln_scalars with a negative 1/n, nafp_common.h) -- except for a POISONED sample, whose scalars
+//     stay NaN: with identity scalars nothing else would carry a NaN / Inf sample through the packed ELU of the next epilogue --, and
 //   * internal positional scale / offset images (the library's gamma / beta slots of shape (F, T, C)):
 //
 // 'batch_norm' -- keras BatchNormalization(axis=-1) as the reference CALLS it: `m_fp(feat)` without a `training` argument, in the
@@ -24,20 +25,6 @@
 #include <algorithm>
 
 namespace nafp {
-
-__global__ void identity_stats_kernel(stat_t* __restrict__ ident, int64_t B, const double* __restrict__ inv_n, int layers) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= B * layers) return;
-    const double n = 1.0 / inv_n[i / B];
-    ident[2 * i] = 0;
-    ident[2 * i + 1] = __double2ll_rn(n * (1.0 - (double)LN_EPS) * (double)(1 << STAT_FRAC_BITS));
-}
-
-int launch_identity_stats(stat_t* ident, const double* inv_n_dev, int64_t B, int layers, hipStream_t st) {
-    identity_stats_kernel<<<(unsigned)((B * layers + 255) / 256), 256, 0, st>>>(ident, B, inv_n_dev, layers);
-    NAFP_LAUNCH_CHECK();
-    return NAFP_OK;
-}
 
 // ---- batch_norm (inference-mode affine) -------------------------------------------------------------------------------------
 __device__ __forceinline__ float nz_scale_n(float g) { return fabsf(g) < 1e-30f ? copysignf(1e-30f, g) : g; }     // as multi_copy_kernel (api.hip)

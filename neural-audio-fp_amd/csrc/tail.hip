@@ -52,7 +52,7 @@ __global__ __launch_bounds__(512) void tail_kernel(const TailArgs a, int64_t B) 
     const bool bad_weights = (a.nonfinite_weights && *a.nonfinite_weights != 0) || (a.launch_error && *a.launch_error != 0);
     for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
         float lnA = 1.f, lnC = 0.f;
-        if (a.stats) stat_ln_scalars(a.stats + 2 * b, 1.0 / (double)a.D, &lnA, &lnC);     // NaN for a poisoned sample: its row comes out NaN
+        if (a.stats) stat_ln_scalars(a.stats + 2 * b, a.ident_stats ? -1.0 : 1.0 / (double)a.D, &lnA, &lnC);     // NaN for a poisoned sample: its row comes out NaN
         if (bad_weights) lnA = __builtin_nanf("");
         float x[S];
 #pragma unroll

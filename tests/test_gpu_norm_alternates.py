@@ -176,3 +176,29 @@ def test_checkpoint_round_trip(nafp, cfg, norm, tmp_path):
     m3 = nafp.get_fingerprinter(other)                                     # layer_norm2d
     with pytest.raises((KeyError, ValueError)):
         g.load_checkpoint(root, 'exp', 5, m3)
+
+
+@pytest.mark.parametrize('B', [9, 130])
+@pytest.mark.parametrize('norm', NORMS)
+def test_a_non_finite_sample_gives_a_nan_row_and_nothing_else(nafp, norm, B):
+    """As with the default normalisation (tests/test_gpu_nonfinite.py): the identity statistics the alternates hand to every
+    consumer keep the sample's poison flag, so a NaN / Inf sample is a NaN fingerprint -- not finite garbage behind the packed ELU
+    of the next epilogue -- and the other rows of the launch are bit-equal to the clean launch."""
+    m = _model(nafp, norm, _weights(norm))
+    g = torch.Generator(device='cuda').manual_seed(B)
+    feat = -1.2 * torch.rand((B, 256, 32, 1), generator=g, device='cuda')
+    clean = m(feat).clone()
+    assert bool(torch.isfinite(clean).all())
+    bad = sorted({1, B // 2, B - 1})
+    dirty = feat.clone()
+    dirty[bad[0], 37, 5, 0] = float('nan')
+    dirty[bad[1], 200, 31, 0] = float('inf')
+    dirty[bad[2]] = float('nan')
+    ok = torch.ones(B, dtype=torch.bool, device='cuda')
+    ok[bad] = False
+    emb = m(dirty)
+    assert bool(torch.isnan(emb[~ok]).all()), emb[~ok]
+    assert torch.equal(emb[ok], clean[ok])
+    emb_t = m.forward_train(dirty)
+    assert bool(torch.isnan(emb_t[~ok]).all()) and bool(torch.isfinite(emb_t[ok]).all())
+    assert torch.equal(m(feat), clean)
