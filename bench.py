@@ -601,7 +601,7 @@ def main():
     # EXPERIMENTAL, reported separately and never as `value`: the unsplit GEMM convs with split-bf16 products (f32 operands
     # split into hi + lo bf16 in registers, hi*hi + hi*lo + lo*hi on the bf16 matrix pipe, f32 accumulation:
     # NAFP_OPT_BF16X3).  Narrower arithmetic than the reference's f32, so its error against the f32 path is measured here.
-    bf16x3 = None
+    bf16x3, bf16x6 = None, None
     if n_str == 1 and not args.no_pipelined:
         with torch.cuda.stream(streams[0]):
             ref_emb = m_fp(m_pre(pool[0], group_size=BSZ, defer=True)).clone()
@@ -616,7 +616,26 @@ def main():
                 m_fp(m_pre(pool[i % n_pool], group_size=BSZ, defer=True))
         torch.cuda.synchronize()
         bel = time.perf_counter() - tb0
+        # ... and the exact 3-way split with six products (option value 2): float32-equivalent arithmetic on the bf16 pipe
+        with torch.cuda.stream(streams[0]):
+            m_fp.set_option(3, 2)
+            got6_emb = m_fp(m_pre(pool[0], group_size=BSZ, defer=True)).clone()
+            for i in range(3):
+                m_fp(m_pre(pool[i % n_pool], group_size=BSZ, defer=True))
+        torch.cuda.synchronize()
+        tb0 = time.perf_counter()
+        with torch.cuda.stream(streams[0]):
+            for i in range(args.steps):
+                m_fp(m_pre(pool[i % n_pool], group_size=BSZ, defer=True))
+        torch.cuda.synchronize()
+        bel6 = time.perf_counter() - tb0
         m_fp.set_option(3, 0)
+        bf16x6 = {'value': round(world * BSZ * args.steps / bel6, 1), 'unit': 'segments/s', 'ms_per_step': round(bel6 / args.steps * 1e3, 4),
+                  'dtype': 'exact 3-way bf16 split x = h + m + l, 6 products (relative weight >= 2^-16), f32 accumulation, f32 storage',
+                  'max_abs_diff_vs_f32_path': float((got6_emb - ref_emb).abs().max()),
+                  'min_cosine_vs_f32_path': float((got6_emb * ref_emb).sum(1).min()),
+                  'note': 'experimental option NAFP_OPT_BF16X3 = 2 on the unsplit GEMM convs; float32-equivalent (error vs the float64 '
+                          'oracle = the f32 path\'s own: tests/test_gpu_parity_forward.py); a separate object, not part of `value`'}
         bf16x3 = {'value': round(world * BSZ * args.steps / bel, 1), 'unit': 'segments/s', 'ms_per_step': round(bel / args.steps * 1e3, 4),
                   'dtype': 'bf16 x 3 products (hi*hi + hi*lo + lo*hi), f32 accumulation, f32 storage',
                   'max_abs_diff_vs_f32_path': float((got_emb - ref_emb).abs().max()),
@@ -724,6 +743,8 @@ def main():
             out['pipelined'] = pipelined
         if bf16x3:
             out['bf16x3_experimental'] = bf16x3
+        if bf16x6:
+            out['bf16x6_f32_equivalent_experimental'] = bf16x6
         if train:
             out['train'] = train
         if train_1280:

@@ -260,7 +260,10 @@ int nafp_encoder_grad_group_wait(nafp_encoder* enc, int group, void* stream);
 /* EXPERIMENTAL, changes the arithmetic (the only option that does): the unsplit GEMM convs of nafp_encoder_forward form their
  * products on the bf16 matrix pipe from f32 operands split into hi + lo bf16 halves (hi*hi + hi*lo + lo*hi, f32
  * accumulation).  Fingerprints move at the 1e-6 level against the f32 path.  Off by default; bench.py reports it as a
- * separate object with its measured error, never as the headline value. */
+ * separate object with its measured error, never as the headline value.
+ * value 2: the EXACT 3-way split x = h + m + l (three bf16 terms hold a float32's 24 significant bits) with the six products of
+ * relative weight >= 2^-16 (hh, hm, mh, hl, mm, lh; the dropped ml + lm + ll < 2^-25 of |a||b|): float32-equivalent arithmetic on
+ * the bf16 matrix pipe -- its error against the float64 oracle equals the f32 path's own (tests/test_gpu_parity_forward.py). */
 #define NAFP_OPT_BF16X3 3
 int nafp_encoder_set_option(nafp_encoder* enc, int option, int value);
 

@@ -143,7 +143,10 @@ struct nafp_encoder {
     // optional per-kernel event timing (nafp_encoder_profile_*)
     std::vector<hipEvent_t> prof_events;  // (max_forwards, NAFP_PROF_EV): [conv0 a, b | conv j start, stop (j = 1..15) | tail a, b]
     int prof_max = 0, prof_count = 0;
-    bool opt_bf16x3 = false;              // NAFP_OPT_BF16X3 (experimental)
+    int opt_bf16x3 = 0;                   // NAFP_OPT_BF16X3 (experimental): 0 off, 1 hi / lo split with 3 products, 2 exact 3-way split with 6 products
+    // value 2: the packed conv kernels split into three bf16 terms (conv.hip, split_weights_bf16_kernel), refreshed by the first forward after a
+    // set_weights; one allocation of its own, made when the option is first switched on
+    float* d_x6_blob = nullptr; std::vector<float*> d_whm; std::vector<void*> d_wl; bool x6_dirty = true;
     int prof_coarse = 0;                  // 1: stamp only around conv0, the 15 GEMM convs as a group, and the tail; 2: only around the GEMM convs
     // nafp_encoder_backward records one event per gradient group (layers complete last to first), so that a
     // communication stream can start reducing a group while the rest of the backward pass still runs
@@ -352,6 +355,7 @@ extern "C" int nafp_encoder_create_ex(nafp_encoder** out, int in_f, int in_t, in
 extern "C" int nafp_encoder_destroy(nafp_encoder* e) {
     if (!e) return NAFP_OK;
     if (e->d_blob) (void)hipFree(e->d_blob);
+    if (e->d_x6_blob) (void)hipFree(e->d_x6_blob);
     profile_free(e);
     for (auto& ev : e->grad_events) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : e->ev_main) if (ev) (void)hipEventDestroy(ev);
@@ -371,7 +375,22 @@ extern "C" int nafp_encoder_set_option(nafp_encoder* e, int option, int value) {
     if (!e) return NAFP_ERR_INVALID_ARG;
     switch (option) {
         case NAFP_OPT_FUSE_CONV0: e->opt_fuse_conv0 = value != 0; return NAFP_OK;
-        case NAFP_OPT_BF16X3: e->opt_bf16x3 = value != 0; return NAFP_OK;
+        case NAFP_OPT_BF16X3:
+            if (value < 0 || value > 2) return NAFP_ERR_INVALID_ARG;
+            if (value == 2 && !e->d_x6_blob) {
+                int64_t tot = 0;
+                for (int j = 1; j < 16; ++j) tot += ((int64_t)e->geom[j].Cout * 3 * e->geom[j].Cin * 3 / 2 + 63) / 64 * 64;
+                hipError_t er = hipMalloc(&e->d_x6_blob, sizeof(float) * tot);
+                if (er != hipSuccess) { g_last_hip_error = (int)er; e->d_x6_blob = nullptr; return NAFP_ERR_HIP; }
+                float* q = e->d_x6_blob;
+                e->d_whm.assign(16, nullptr); e->d_wl.assign(16, nullptr);
+                for (int j = 1; j < 16; ++j) {
+                    const int64_t n = (int64_t)e->geom[j].Cout * 3 * e->geom[j].Cin;
+                    e->d_whm[j] = q; e->d_wl[j] = q + n; q += (n * 3 / 2 + 63) / 64 * 64;
+                }
+                e->x6_dirty = true;
+            }
+            e->opt_bf16x3 = value; return NAFP_OK;
         case NAFP_OPT_FUSED_LN_BWD:
             if (value < 0 || value > 2) return NAFP_ERR_INVALID_ARG;
             e->opt_fused_ln_bwd = value; return NAFP_OK;
@@ -539,7 +558,7 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
     if (!l1_done) NAFP_HIP_CHECK(hipEventRecord(e->sw_l1, st));
     NAFP_HIP_CHECK(hipEventRecord(e->sw_done, st));
     e->sw_stream = st; e->sw_recorded = true;
-    e->has_weights = true;
+    e->has_weights = true; e->x6_dirty = true;
     return NAFP_OK;
 }
 
@@ -615,6 +634,13 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
     const int sn_j0 = e->use_smallnet(n_seg) ? e->smallnet_j0 : 16;
     e->prof_smallnet_j0 = 16;
     { int wrc = wait_weights(e, st); if (wrc != NAFP_OK) return wrc; }
+    if (e->opt_bf16x3 == 2 && e->x6_dirty) {                          // (experimental) the weights' three bf16 terms, once per parameter set
+        for (int j = 1; j < 16; ++j) {
+            int rcs = launch_split_weights_bf16(e->d_w[j], e->d_whm[j], e->d_wl[j], e->geom[j].Cout, 3 * e->geom[j].Cin, st);
+            if (rcs != NAFP_OK) return rcs;
+        }
+        e->x6_dirty = false;
+    }
     NAFP_HIP_CHECK(hipMemsetAsync(stats, 0, stats_bytes, st));        // statistics + counters, one fill
     hipEvent_t* ev = nullptr;
     if (e->prof_max > 0 && e->prof_count < e->prof_max) ev = e->prof_events.data() + (size_t)NAFP_PROF_EV * e->prof_count++;
@@ -668,6 +694,7 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
         a.wp = e->d_w[j]; a.G = e->d_G[j]; a.Hb = e->d_Hb[j]; a.gamma_out = e->d_gamma[j];
         a.y = nxt; a.stats_out = stats + 2 * n_seg * j; a.plain = false;
         a.slab = slab_floats ? slab : nullptr; a.slab_floats = slab_floats; a.tickets = tickets; a.bf16x3 = e->opt_bf16x3;
+        if (e->opt_bf16x3 == 2) { a.wp_hm = e->d_whm[j]; a.wp_l = e->d_wl[j]; }
         a.plan_b = fwd_plan_b();              // tile shape and split-K factor as at the reference launch size: results do not depend on n_seg
         if (j == 1 && fuse0) {
             a.x = nullptr; a.f0_feat = feat; a.f0_w = e->d_w[0]; a.f0_bias = e->d_bias[0];

@@ -271,6 +271,8 @@ constexpr int BN = 128;          // BM (tile rows) is a template parameter: 128 
 struct ConvKernelParams {
     const float* x;           // (B, Fin, Tin, Cin)
     const float* wp;          // (Cout, 3*Cin)
+    const float* wp_hm;       // PREC = 2: the same shape, every group of 16 k replaced by [h(16) | m(16)] bf16 (split_weights_bf16_kernel)
+    const unsigned short* wp_l;   // PREC = 2: (Cout, 3*Cin) bf16, the third term of the split
     const float* G;           // (P, Cout)      FULL
     const float* Hb;          // (P, Cout)      FULL
     const float* gamma_out;   // (P, Cout)      FULL
@@ -434,6 +436,9 @@ __device__ __forceinline__ float half_wave_sum_dpp(float x) {
 // split in registers into hi + lo bf16 halves, hi*hi + hi*lo + lo*hi with f32 accumulation (lo*lo, ~2^-16 of a product,
 // is dropped).  Not the arithmetic of the reference: results differ from the f32 path at the 1e-6 level of a fingerprint
 // component; bench.py reports it as a separate object with its measured error and never as `value`.
+// PREC = 2 (experimental, inference only, NAFP_OPT_BF16X3 = 2): the EXACT 3-way split x = h + m + l (three bf16 terms hold the 24
+// significant bits of a float32) and the six products of relative weight >= 2^-16 -- hh, hm, mh, hl, mm, lh; ml + lm + ll < 2^-25 of
+// |a||b|, below half an ulp of the float32 product -- with f32 accumulation: float32-equivalent arithmetic on the bf16 matrix pipe.
 // PERSIST = 1: one work item of the persistent small-layer kernel (smallnet_kernel below): the tile ids come from the caller
 // instead of blockIdx, the z stores are write-through (the consumer is another workgroup of the SAME launch), and the function
 // tells its caller whether this workgroup ran the full epilogue (true) or left after handing in a split-K part (false).
@@ -454,7 +459,10 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p, const 
     static_assert(NIB >= 1, "B rows per wave");
     constexpr int TILE = BM * BK;                  // floats of the A tile
     constexpr int TILEB = BNT * BK;                 // floats of the B tile
-    constexpr int STAGE = TILE + TILEB;            // A | B
+    constexpr int LROWS = BNT / NW;                // PREC = 2: rows of the weights' third bf16 plane staged per wave (16 k x 2 B = 32 B per row and step)
+    constexpr int TILEL = PREC == 2 ? BNT * 8 : 0;
+    constexpr int STAGE = TILE + TILEB + TILEL;    // A | B (| L)
+    constexpr int NDMA = NI + NIB + (PREC == 2 ? 1 : 0);   // DMA instructions per wave and K-step
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // [stage 0: A | B] ... [stage NSTAGE-1] [sRB[BM]] [sCB[BM]] [sPos[32]] [sInner[32]] [sMask[32]] [FUSE0: conv0 w (3,Cin) | bias (Cin)]
     float* sRB = smem + NSTAGE * STAGE;
@@ -649,9 +657,16 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p, const 
 
     const u32x4 rsA = make_rsrc(p.x + (int64_t)b0 * p.sample_in,
                                 NAFP_ABL(p, 512) ? 0u : (unsigned)nb * (unsigned)p.sample_in * 4u);   // ablation 512: every A lane out of range (zero fill, no memory traffic)
-    const u32x4 rsB = make_rsrc(p.wp, p.wp_bytes);
+    const u32x4 rsB = make_rsrc(PREC == 2 ? p.wp_hm : p.wp, p.wp_bytes);
     const unsigned lds0 = (unsigned)(unsigned long long)(lds_ptr_t)smem + (unsigned)(wave * 32 * BK * 4);
     const unsigned ldsB0 = (unsigned)(unsigned long long)(lds_ptr_t)smem + (unsigned)((TILE + wave * BROWS * BK) * 4);
+    // PREC = 2: the third plane of the pre-split weights, 32 B per row and K-step: lanes 0 .. 2 LROWS - 1 of every wave stage rows
+    // wave * LROWS + lane / 2 (half lane & 1) behind the B tile, row-major
+    const u32x4 rsL = make_rsrc((const float*)p.wp_l, p.wp_bytes / 2);
+    const unsigned ldsL0 = (unsigned)(unsigned long long)(lds_ptr_t)smem + (unsigned)((TILE + TILEB) * 4 + wave * LROWS * 32);
+    const unsigned voffL = (unsigned)((tile_n0 + wave * LROWS + (lane >> 1)) * K) * 2u + (unsigned)(lane & 1) * 16u;
+#define NAFP_DMA_L(slot_, k0_)                                                                 \
+    if (PREC == 2 && lane < 2 * LROWS) lds_dma16(ldsL0 + (unsigned)((slot_) * STAGE * 4), voffL, rsL, (unsigned)((k0_) * 2));
 
     // Issue the DMA of K-step s_ into ring slot slot_ (wave-uniform LDS bases).
 #define NAFP_DMA_STEP(s_, slot_)                                                              \
@@ -667,6 +682,7 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p, const 
             if (q < NIB) lds_dma16(lb_l + q * RPI * BK * 4, voffB[q], rsB,                      \
                                    (unsigned)((tap_l * p.Cin + c0_l) * 4));                    \
         }                                                                                      \
+        NAFP_DMA_L(slot_, tap_l * p.Cin + c0_l)                                                \
     }
     // FUSE0: gamma0 of my 8 channels of K-step s_ (issued early), then build + store the A rows.
     float4 gg0 = make_float4(0.f, 0.f, 0.f, 0.f), gg1 = gg0;
@@ -787,7 +803,7 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p, const 
         }
 #define NAFP_WAIT_STEP(s_)                                                                     \
     if (NSTAGE == 2 || (s_) + NSTAGE - 2 >= n_steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
-    else asm volatile("s_waitcnt vmcnt(%0)" :: "i"((NSTAGE - 2) * (NI + NIB)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "i"((NSTAGE - 2) * NDMA) : "memory");
     // Skewed K-loop (BK = 16 = two fragment sets per step): the second half of step s is multiplied AFTER the barrier of
     // step s + 1, so that every LDS read has a block of MFMAs whose operands are already in registers in front of it --
     //   wait, barrier | read R0 = first half of s | DMA of s + 2 | MFMA R1 (second half of s - 1) | read R1 = second
@@ -826,7 +842,7 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p, const 
             acc[mi_][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[mi_].w, b_[ni].w, acc[mi_][ni], 0, 0, 0); \
         }
         static_assert(NI == 2, "the DMA of a step is issued as two pieces");
-        if (PREC == 1) {
+        if (PREC >= 1) {
             // one K-step = 16 k = one v_mfma_f32_32x32x16_bf16 per product term: lane (row rl, half hh) holds k = 8 hh .. 8 hh + 7
             // of its A rows and B rows (logical chunks 2 hh and 2 hh + 1 of the stage)
             typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -837,37 +853,68 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p, const 
                 const bool has_next = s + NSTAGE - 1 < n_steps;
                 int nslot = slot + NSTAGE - 1; if (nslot >= NSTAGE) nslot -= NSTAGE;
                 const float* St = smem + slot * STAGE;
-                float4 af[2][2], bf[NIW][2];
+                float4 af[2][2], bf[PREC == 2 ? 1 : NIW][2];
+                bf16x8 ah[2], al[2], bh[NIW], bl[NIW];
+                bf16x8 am[PREC == 2 ? 2 : 1], bm[PREC == 2 ? NIW : 1];      // PREC = 2: the middle term of the exact 3-way split x = h + m + l
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const int pc4 = ((2 * hh + c) ^ rswz) * 4;
 #pragma unroll
                     for (int mi = 0; mi < 2; ++mi) af[mi][c] = *(const float4*)(St + aoff + mi * 32 * BK + pc4);
+                    if (PREC != 2) {
 #pragma unroll
-                    for (int ni = 0; ni < NIW; ++ni) bf[ni][c] = *(const float4*)(St + boff + ni * 32 * BK + pc4);
+                        for (int ni = 0; ni < NIW; ++ni) bf[ni][c] = *(const float4*)(St + boff + ni * 32 * BK + pc4);
+                    }
                 }
-                if (has_next) { NAFP_DMA_PIECE(0, nslot) NAFP_DMA_PIECE(1, nslot) }
-                bf16x8 ah[2], al[2], bh[NIW], bl[NIW];
-#define NAFP_SPLIT8(f_, hi_, lo_)                                                              \
+                if (PREC == 2) {
+                    // the weights arrive split (split_weights_bf16_kernel): logical chunks 0, 1 of a row = h[0..7], h[8..15], chunks 2, 3 = m
+#pragma unroll
+                    for (int ni = 0; ni < NIW; ++ni) {
+                        bh[ni] = *(const bf16x8*)(St + boff + ni * 32 * BK + ((hh ^ rswz) * 4));
+                        bm[ni] = *(const bf16x8*)(St + boff + ni * 32 * BK + (((2 + hh) ^ rswz) * 4));
+                        bl[ni] = *(const bf16x8*)(St + TILE + TILEB + (wn * (BNT / 2) + ni * 32 + rl) * 8 + hh * 4);
+                    }
+                }
+                if (has_next) { NAFP_DMA_PIECE(0, nslot) NAFP_DMA_L(nslot, d_tap * p.Cin + d_c0) NAFP_DMA_PIECE(1, nslot) }
+#define NAFP_SPLIT8(f_, hi_, mid_, lo_)                                                        \
                 {                                                                                  \
                     const float x_l[8] = {f_[0].x, f_[0].y, f_[0].z, f_[0].w, f_[1].x, f_[1].y, f_[1].z, f_[1].w}; \
                     _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                \
                         const __bf16 h_l = (__bf16)x_l[e];                                         \
-                        hi_[e] = h_l; lo_[e] = (__bf16)(x_l[e] - (float)h_l);                      \
+                        const float r1_l = x_l[e] - (float)h_l;                                    \
+                        hi_[e] = h_l;                                                              \
+                        if (PREC == 2) {                                                           \
+                            const __bf16 m_l = (__bf16)r1_l;                                       \
+                            mid_[e] = m_l; lo_[e] = (__bf16)(r1_l - (float)m_l);                   \
+                        } else {                                                                   \
+                            lo_[e] = (__bf16)r1_l;                                                 \
+                        }                                                                          \
                     }                                                                              \
                 }
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) NAFP_SPLIT8(af[mi], ah[mi], al[mi])
+                for (int mi = 0; mi < 2; ++mi) NAFP_SPLIT8(af[mi], ah[mi], am[PREC == 2 ? mi : 0], al[mi])
+                if (PREC != 2) {
 #pragma unroll
-                for (int ni = 0; ni < NIW; ++ni) NAFP_SPLIT8(bf[ni], bh[ni], bl[ni])
+                    for (int ni = 0; ni < NIW; ++ni) NAFP_SPLIT8(bf[PREC == 2 ? 0 : ni], bh[ni], bm[0], bl[ni])
+                }
 #undef NAFP_SPLIT8
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NIW; ++ni) {
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                        if (PREC == 2) {
+                            // every product of relative weight >= 2^-16 (the three dropped ones sum to < 2^-25 of |a||b|), small terms first
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[PREC == 2 ? mi : 0], bm[PREC == 2 ? ni : 0], acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[PREC == 2 ? mi : 0], bh[ni], acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bm[PREC == 2 ? ni : 0], acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                        } else {
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                        }
                     }
                 if (++slot == NSTAGE) slot = 0;
             }
@@ -1265,6 +1312,10 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p, const 
     __global__ __launch_bounds__(2 * BM_, MINW_) void name_(const ConvKernelParams p) {       \
         conv_gemm_body<BM_, BN_, 16, NSTAGE_, false, 0, 1>(p);                                \
     }
+#define NAFP_GEMM_KERNEL_BF16X6(name_, BM_, BN_, NSTAGE_, MINW_)                                \
+    __global__ __launch_bounds__(2 * BM_, MINW_) void name_(const ConvKernelParams p) {       \
+        conv_gemm_body<BM_, BN_, 16, NSTAGE_, false, 0, 2>(p);                                \
+    }
 #define NAFP_GEMM_KERNELS(name_, BM_, BN_, MINW_)                                             \
     NAFP_GEMM_KERNEL(name_##_infer, BM_, BN_, 16, 3, MINW_, false, 0)                         \
     NAFP_GEMM_KERNEL(name_##_train, BM_, BN_, 16, 3, MINW_, false, 1)                         \
@@ -1307,15 +1358,49 @@ static void (*const conv_gemm_m256k16s3_tab[4])(const ConvKernelParams) = {conv_
 NAFP_GEMM_KERNEL_BF16X3(conv_gemm_k16s3_infer_bf16x3, 128, 128, 3, 3)
 NAFP_GEMM_KERNEL_BF16X3(conv_gemm_m256k16s3_infer_bf16x3, 256, 128, 3, 4)
 NAFP_GEMM_KERNEL_BF16X3(conv_gemm_n64k16s2_infer_bf16x3, 128, 64, 2, 5)
+// ... and the exact 3-way split with six products (PREC = 2); the 256-row tile at 2 waves per SIMD (the third plane does not fit 128 VGPRs)
+NAFP_GEMM_KERNEL_BF16X6(conv_gemm_k16s3_infer_bf16x6, 128, 128, 3, 3)
+NAFP_GEMM_KERNEL_BF16X6(conv_gemm_m256k16s3_infer_bf16x6, 256, 128, 3, 2)
+NAFP_GEMM_KERNEL_BF16X6(conv_gemm_n64k16s2_infer_bf16x6, 128, 64, 2, 4)
 
 // Optional timing events of the launch in flight (ConvGemmArgs::ev_start / ev_stop): they ride on a kernel's own dispatch
 // packet (hipExtLaunchKernel: time stamps of its completion signal), so -- unlike hipEventRecord between two kernels -- they
 // put nothing into the queue and cost the GPU no idle time.
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 
+// The exact 3-way bf16 split of a packed weight tensor (Cout, K), K = 3 Cin a multiple of 16, for the PREC = 2 kernels: x = h + m + l
+// with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (each difference is exact in float32; three 8-bit significands hold the 24 bits).
+// hm: the f32 tensor's shape, every group of 16 k replaced by [h(16) | m(16)] -- the B staging of the f32 kernels moves it unchanged;
+// l: plain (Cout, K) bf16.
+__global__ __launch_bounds__(256) void split_weights_bf16_kernel(const float* __restrict__ wp, unsigned short* __restrict__ hm,
+                                                                 unsigned short* __restrict__ wl, int64_t n, int K) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float x = wp[i];
+        const __bf16 h = (__bf16)x;
+        const float r1 = x - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const __bf16 l = (__bf16)(r1 - (float)m);
+        const int64_t row = i / K;
+        const int k = (int)(i - row * K);
+        const int64_t base = row * 2 * K + (int64_t)(k >> 4) * 32;
+        hm[base + (k & 15)] = __builtin_bit_cast(unsigned short, h);
+        hm[base + 16 + (k & 15)] = __builtin_bit_cast(unsigned short, m);
+        wl[i] = __builtin_bit_cast(unsigned short, l);
+    }
+}
+
+int launch_split_weights_bf16(const float* wp, float* hm, void* wl, int Cout, int K, hipStream_t st) {
+    if (K % 16 != 0) return NAFP_ERR_UNSUPPORTED;
+    const int64_t n = (int64_t)Cout * K;
+    split_weights_bf16_kernel<<<(unsigned)std::min<int64_t>((n + 255) / 256, 4096), 256, 0, st>>>(wp, (unsigned short*)hm, (unsigned short*)wl, n, K);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}
+
 template <typename KernelT>
-static int launch_variant(KernelT kernel, int BM, int BNt, int BK, int NSTAGE, const ConvKernelParams& p, dim3 grid, hipStream_t st) {
-    const int lds = (NSTAGE * (BM + BNt) * BK + 2 * BM + 96 + (p.f0_feat ? 4 * p.Cin : 0)) * (int)sizeof(float);
+static int launch_variant(KernelT kernel, int BM, int BNt, int BK, int NSTAGE, const ConvKernelParams& p, dim3 grid, hipStream_t st,
+                          int extra_stage_floats = 0) {
+    const int lds = (NSTAGE * ((BM + BNt) * BK + extra_stage_floats) + 2 * BM + 96 + (p.f0_feat ? 4 * p.Cin : 0)) * (int)sizeof(float);
     NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     if (g_ev_start || g_ev_stop) {
         ConvKernelParams pc = p;
@@ -1805,6 +1890,12 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
                         : launch_variant(conv_gemm_k16s3_plainfin, 128, 128, 16, 3, p, grid, st);
     const int epi = in_kernel_finish ? 4 : p.mode != 0 ? 3 : (!fast_st ? 2 : (p.v_out ? 1 : 0));
     const bool two_stage = n64_two_stage() && bn == 64 && (epi == 0 || epi == 1 || epi == 4);
+    if (a.bf16x3 == 2 && epi == 0 && (bn == 128 || two_stage) && a.wp_hm && a.wp_l) {
+        p.wp_hm = a.wp_hm; p.wp_l = (const unsigned short*)a.wp_l;
+        return BM == 256 ? launch_variant(conv_gemm_m256k16s3_infer_bf16x6, 256, 128, 16, 3, p, grid, st, 128 * 8)
+             : bn == 64 ? launch_variant(conv_gemm_n64k16s2_infer_bf16x6, 128, 64, 16, 2, p, grid, st, 64 * 8)
+                        : launch_variant(conv_gemm_k16s3_infer_bf16x6, 128, 128, 16, 3, p, grid, st, 128 * 8);
+    }
     if (a.bf16x3 && epi == 0 && (bn == 128 || two_stage))
         return BM == 256 ? launch_variant(conv_gemm_m256k16s3_infer_bf16x3, 256, 128, 16, 3, p, grid, st)
              : bn == 64 ? launch_variant(conv_gemm_n64k16s2_infer_bf16x3, 128, 64, 16, 2, p, grid, st)

@@ -176,7 +176,8 @@ struct ConvGemmArgs {
     float* slab;             // split-K partial sums workspace (or nullptr: never split)
     int64_t slab_floats;
     hipEvent_t ev_start, ev_stop;   // optional: time stamps attached to this conv's first / last kernel dispatch (no queue entry)
-    bool bf16x3;             // experimental: split-bf16 products for the unsplit FULL launches (NAFP_OPT_BF16X3)
+    const float* wp_hm; const void* wp_l;   // bf16x3 == 2: the weights pre-split into three bf16 terms (launch_split_weights_bf16)
+    int bf16x3;              // experimental: split-bf16 products for the unsplit FULL launches (NAFP_OPT_BF16X3): 1 = hi / lo, 3 products; 2 = exact 3-way split, 6 products
     unsigned* tickets;       // NAFP_TICKET_SLOTS arrival counters, zero on entry and on exit (or nullptr: split launches use slab + finish kernel)
     // optional: generate the A operand from the log-mel features (conv0 fused into conv1);
     // `x` is then unused.  f0_geom = geometry of conv0.
@@ -300,6 +301,8 @@ int launch_ln1d_bwd(float* d, const float* tpre, int64_t rows, int C, const floa
 struct PackTable { const float* k3[16]; float* wp[16]; float* wd[16]; int cin[16], cout[16]; int unit0[17]; int count;
                    int* nonfinite; };      // nonfinite (or null): set to 1 when a conv kernel holds a NaN / Inf (see nafp_encoder::d_wflag)
 int launch_multi_pack(const PackTable& t, hipStream_t st);
+// exact 3-way bf16 split of a packed (Cout, K) weight tensor for the bf16x3 == 2 launches: hm (Cout * K floats), wl (Cout * K bf16)
+int launch_split_weights_bf16(const float* wp, float* hm, void* wl, int Cout, int K, hipStream_t st);
 int launch_pack_conv_weight(const float* k3, float* wp, int Cin, int Cout, hipStream_t st);
 // Positional epilogue tensors G_j = conv_j(gamma_{j-1}), Hb_j = conv_j(beta_{j-1}) (bias added later) of the SMALL layers
 // (P <= 8 output positions: 2 P <= 16 GEMM rows against a 2 - 12 MB weight tensor) in ONE weight-streaming launch.

@@ -165,3 +165,36 @@ def test_experimental_bf16x3_option_stays_within_the_contract(nafp):
     assert float((got - ref).abs().max()) < 1e-4
     assert float((1 - (got * ref).sum(1)).max()) < 1e-6
     assert float((back - ref).abs().max()) < 1e-6
+
+
+def test_exact_split_option_is_float32_equivalent(nafp, observe):
+    """NAFP_OPT_BF16X3 = 2 (experimental, off by default): the EXACT 3-way bf16 split x = h + m + l with the six products of weight
+    >= 2^-16 and f32 accumulation -- float32-equivalent arithmetic on the bf16 matrix pipe.  Its error against the
+    float64 oracle is recorded next to the f32 path's own on the same inputs; the two must be of the same size, and the two paths
+    agree with each other far inside the f32 path's own error."""
+    from oracle import nnfp as o_nnfp
+    import _inputs
+    rng = np.random.default_rng(13)
+    B = 640
+    feat = (-rng.uniform(0, 1.2, size=(B, 256, 32, 1))).astype(np.float32)
+    w = _inputs.weights(seed=9)
+    m_fp = nafp.FingerPrinter(seed=0)
+    m_fp.set_weights(_inputs.weight_list(w))
+    ft = torch.from_numpy(feat).cuda()
+    ref = m_fp(ft).clone()
+    m_fp.set_option(3, 2)
+    got = m_fp(ft).clone()
+    m_fp.set_option(3, 1)
+    two_term = m_fp(ft).clone()
+    m_fp.set_option(3, 0)
+    assert torch.equal(m_fp(ft), ref)
+    sel = np.linspace(0, B - 1, 6).astype(int)
+    want = o_nnfp.fingerprinter(feat[sel], w)
+    e_f32 = np.abs(ref.cpu().numpy()[sel] - want).max()
+    e_x6 = np.abs(got.cpu().numpy()[sel] - want).max()
+    e_x3 = np.abs(two_term.cpu().numpy()[sel] - want).max()
+    observe('f32 MFMA path vs float64 oracle, fingerprint component', e_f32, 5e-6)
+    observe('exact 3-way bf16 split (6 products) vs float64 oracle', e_x6, 5e-6)
+    observe('hi / lo bf16 split (3 products) vs float64 oracle', e_x3, 1e-4)
+    observe('exact split vs f32 path, all 640 rows', float((got - ref).abs().max()), 5e-6)
+    assert e_x6 < 2.0 * e_f32 + 2e-7
