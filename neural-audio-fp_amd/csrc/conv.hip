@@ -425,6 +425,9 @@ __device__ __forceinline__ float half_wave_sum_dpp(float x) {
 
 // EXPERIMENT (-DNAFP_EXP_SKIP_TAP2=1, WRONG RESULTS): tap 2's activation rows are not fetched (zero rows instead): the L2 / HBM traffic
 // an input-row-staged stride-2 tile would save, for an upper bound of what that tile could gain (profiles/r05_experiments.md)
+#ifndef NAFP_EXP_X6_NOSPLIT
+#define NAFP_EXP_X6_NOSPLIT 0      // EXPERIMENT (wrong results): the exact-split kernels without the m / l terms of the activation split
+#endif
 #ifndef NAFP_EXP_SKIP_TAP2
 #define NAFP_EXP_SKIP_TAP2 0
 #endif
@@ -883,7 +886,9 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p, const 
                         const __bf16 h_l = (__bf16)x_l[e];                                         \
                         const float r1_l = x_l[e] - (float)h_l;                                    \
                         hi_[e] = h_l;                                                              \
-                        if (PREC == 2) {                                                           \
+                        if (PREC == 2 && NAFP_EXP_X6_NOSPLIT) {                                    \
+                            mid_[e] = h_l; lo_[e] = h_l;      /* experiment: what the split costs */ \
+                        } else if (PREC == 2) {                                                    \
                             const __bf16 m_l = (__bf16)r1_l;                                       \
                             mid_[e] = m_l; lo_[e] = (__bf16)(r1_l - (float)m_l);                   \
                         } else {                                                                   \
@@ -959,7 +964,7 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p, const 
             __builtin_amdgcn_sched_barrier(0);                                                 \
             ++s;                                                                               \
         }
-        static_assert(NSTAGE == 3 || BNT == 64, "the K-loop body is written out once per ring slot (128-column tiles)");
+        static_assert(PREC != 0 || NSTAGE == 3 || BNT == 64, "the K-loop body is written out once per ring slot (128-column tiles)");
         if (s_begin + 1 < n_steps) {
             if (BNT == 128) {
                 for (int s = s_begin + 1;;) {
@@ -1312,9 +1317,9 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p, const 
     __global__ __launch_bounds__(2 * BM_, MINW_) void name_(const ConvKernelParams p) {       \
         conv_gemm_body<BM_, BN_, 16, NSTAGE_, false, 0, 1>(p);                                \
     }
-#define NAFP_GEMM_KERNEL_BF16X6(name_, BM_, BN_, NSTAGE_, MINW_)                                \
+#define NAFP_GEMM_KERNEL_BF16X6(name_, BM_, BN_, NSTAGE_, MINW_, EPI_)                          \
     __global__ __launch_bounds__(2 * BM_, MINW_) void name_(const ConvKernelParams p) {       \
-        conv_gemm_body<BM_, BN_, 16, NSTAGE_, false, 0, 2>(p);                                \
+        conv_gemm_body<BM_, BN_, 16, NSTAGE_, false, EPI_, 2>(p);                             \
     }
 #define NAFP_GEMM_KERNELS(name_, BM_, BN_, MINW_)                                             \
     NAFP_GEMM_KERNEL(name_##_infer, BM_, BN_, 16, 3, MINW_, false, 0)                         \
@@ -1359,9 +1364,23 @@ NAFP_GEMM_KERNEL_BF16X3(conv_gemm_k16s3_infer_bf16x3, 128, 128, 3, 3)
 NAFP_GEMM_KERNEL_BF16X3(conv_gemm_m256k16s3_infer_bf16x3, 256, 128, 3, 4)
 NAFP_GEMM_KERNEL_BF16X3(conv_gemm_n64k16s2_infer_bf16x3, 128, 64, 2, 5)
 // ... and the exact 3-way split with six products (PREC = 2); the 256-row tile at 2 waves per SIMD (the third plane does not fit 128 VGPRs)
-NAFP_GEMM_KERNEL_BF16X6(conv_gemm_k16s3_infer_bf16x6, 128, 128, 3, 3)
-NAFP_GEMM_KERNEL_BF16X6(conv_gemm_m256k16s3_infer_bf16x6, 256, 128, 3, 2)
-NAFP_GEMM_KERNEL_BF16X6(conv_gemm_n64k16s2_infer_bf16x6, 128, 64, 2, 4)
+// (ring depth and occupancy bound of the two large shapes are build-time knobs: tools/build_variant.sh ... -DNAFP_X6_...)
+#ifndef NAFP_X6_K16_NSTAGE
+#define NAFP_X6_K16_NSTAGE 2                // 2 stages at 138 VGPRs = three workgroups per CU: conv1 0.795 ms against 0.839 with 3 stages (two per CU)
+#endif
+#ifndef NAFP_X6_K16_MINW
+#define NAFP_X6_K16_MINW 3
+#endif
+#ifndef NAFP_X6_M256_NSTAGE
+#define NAFP_X6_M256_NSTAGE 3
+#endif
+#ifndef NAFP_X6_M256_MINW
+#define NAFP_X6_M256_MINW 2
+#endif
+NAFP_GEMM_KERNEL_BF16X6(conv_gemm_k16s3_infer_bf16x6, 128, 128, NAFP_X6_K16_NSTAGE, NAFP_X6_K16_MINW, 0)
+NAFP_GEMM_KERNEL_BF16X6(conv_gemm_m256k16s3_infer_bf16x6, 256, 128, NAFP_X6_M256_NSTAGE, NAFP_X6_M256_MINW, 0)
+NAFP_GEMM_KERNEL_BF16X6(conv_gemm_n64k16s2_infer_bf16x6, 128, 64, 2, 4, 0)
+NAFP_GEMM_KERNEL_BF16X6(conv_gemm_k16s3_plain_bf16x6, 128, 128, NAFP_X6_K16_NSTAGE, NAFP_X6_K16_MINW, 3)      // the split-K parts of the late convs
 
 // Optional timing events of the launch in flight (ConvGemmArgs::ev_start / ev_stop): they ride on a kernel's own dispatch
 // packet (hipExtLaunchKernel: time stamps of its completion signal), so -- unlike hipEventRecord between two kernels -- they
@@ -1686,9 +1705,9 @@ static int pick_bn(int64_t n_tiles128, int Cout, int k_steps = 0) {
 // Tile plan of a FORWARD launch (rows x position slots x class order): ONE decision, shared by the launcher and by the
 // workspace sizing below -- the slab is sized for the tile count and split factor of the plan that actually runs.
 struct FwdPlan { int BM, pt, perm; };
-static FwdPlan fwd_plan(int64_t B, const ConvGeom& g, bool full_epilogue, bool fuse0) {
+static FwdPlan fwd_plan(int64_t B, const ConvGeom& g, bool full_epilogue, bool fuse0, bool force128 = false) {
     const int P = g.Fout * g.Tout;
-    FwdPlan r{fuse0 ? 128 : pick_bm(B, P, g.Cout), tile_pt(P), 0};
+    FwdPlan r{(fuse0 || force128) ? 128 : pick_bm(B, P, g.Cout), tile_pt(P), 0};
     if (r.BM == 256 && full_epilogue && 256 / r.pt != 8) r.BM = 128;      // FULL mode on 256 rows keeps its statistics in registers: 8 samples per position
     if (full_epilogue && !fuse0) {
         FwdTile ft = fwd_tile(g, r.BM);
@@ -1754,7 +1773,9 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     // forward launches: fwd_plan() (shared with conv_gemm_slab_floats); the transposed conv picks its rows from ITS output
     // (plan_b: the inference forward plans as if the launch held plan_b segments -- see fwd_plan_b())
     const int64_t Bp = (a.plan_b > 0 && !a.plain && !a.dgrad && !a.f0_feat) ? a.plan_b : B;
-    const FwdPlan fp = fwd_plan(Bp, g, !a.plain && !a.dgrad, a.f0_feat != nullptr);
+    // (the exact-split kernels, bf16x3 == 2, run best on 128-row tiles at three workgroups per CU: measured in profiles/r05_experiments.md)
+    const bool x6 = a.bf16x3 == 2 && !a.plain && !a.dgrad && a.wp_hm && a.wp_l;
+    const FwdPlan fp = fwd_plan(Bp, g, !a.plain && !a.dgrad, a.f0_feat != nullptr, x6);
     int BM = a.dgrad ? pick_bm(B, g.Fin * g.Tin, g.Cin) : fp.BM;
     int pt = fp.pt;
     const int fwd_perm = a.dgrad ? 0 : fp.perm;
@@ -1822,6 +1843,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
         if (plan_forced && plan_override().S > 0) { S = plan_override().S; while (S > 1 && k_steps / S < 4) --S; }
         if (dplan_forced && dgrad_plan_override().S > 0) { S = dgrad_plan_override().S; while (S > 1 && k_steps / S < 4) --S; }
         if ((int64_t)S * out_floats > a.slab_floats) S = 1;
+        if (x6 && bn == 64 && S == 2) S = 1;          // convs 7, 9 at B = 640: unsplit on the bf16 pipe beats the two f32 parts + finish
     }
     if (S > 1) { p.mode = a.plain ? 1 : 2; p.n_split = S; p.y = a.slab; p.bias = nullptr; }
     // FULL split launches on 64-column tiles finish in-kernel (last-arriver) when the caller provides arrival counters
@@ -1892,14 +1914,18 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     const bool two_stage = n64_two_stage() && bn == 64 && (epi == 0 || epi == 1 || epi == 4);
     if (a.bf16x3 == 2 && epi == 0 && (bn == 128 || two_stage) && a.wp_hm && a.wp_l) {
         p.wp_hm = a.wp_hm; p.wp_l = (const unsigned short*)a.wp_l;
-        return BM == 256 ? launch_variant(conv_gemm_m256k16s3_infer_bf16x6, 256, 128, 16, 3, p, grid, st, 128 * 8)
+        return BM == 256 ? launch_variant(conv_gemm_m256k16s3_infer_bf16x6, 256, 128, 16, NAFP_X6_M256_NSTAGE, p, grid, st, 128 * 8)
              : bn == 64 ? launch_variant(conv_gemm_n64k16s2_infer_bf16x6, 128, 64, 16, 2, p, grid, st, 64 * 8)
-                        : launch_variant(conv_gemm_k16s3_infer_bf16x6, 128, 128, 16, 3, p, grid, st, 128 * 8);
+                        : launch_variant(conv_gemm_k16s3_infer_bf16x6, 128, 128, 16, NAFP_X6_K16_NSTAGE, p, grid, st, 128 * 8);
     }
     if (a.bf16x3 && epi == 0 && (bn == 128 || two_stage))
         return BM == 256 ? launch_variant(conv_gemm_m256k16s3_infer_bf16x3, 256, 128, 16, 3, p, grid, st)
              : bn == 64 ? launch_variant(conv_gemm_n64k16s2_infer_bf16x3, 128, 64, 16, 2, p, grid, st)
                         : launch_variant(conv_gemm_k16s3_infer_bf16x3, 128, 128, 16, 3, p, grid, st);
+    if (x6 && epi == 3 && bn == 128 && BM == 128 && p.mode == 2) {
+        p.wp_hm = a.wp_hm; p.wp_l = (const unsigned short*)a.wp_l;
+        rc = launch_variant(conv_gemm_k16s3_plain_bf16x6, 128, 128, 16, NAFP_X6_K16_NSTAGE, p, grid, st, 128 * 8);
+    } else
     rc = BM == 256 ? launch_variant(conv_gemm_m256k16s3_tab[epi], 256, 128, 16, 3, p, grid, st)
          : (bn == 64 && two_stage) ? launch_variant(conv_gemm_n64k16s2_tab[epi], 128, 64, 16, 2, p, grid, st)
          : bn == 64 ? launch_variant(conv_gemm_n64k16s3_tab[epi], 128, 64, 16, 3, p, grid, st)
