@@ -556,9 +556,17 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
     int rc = launch_pack_div(t[64], t[65], t[66], e->d_w1p, e->d_b1p, e->d_w2p, e->emb_sz, e->S, st);
     if (rc != NAFP_OK) return rc;
     if (!l1_done) NAFP_HIP_CHECK(hipEventRecord(e->sw_l1, st));
+    e->x6_dirty = true;
+    if (e->opt_bf16x3 == 2) {                 // (experimental) the exact-split kernels' three bf16 terms of every packed conv kernel: part of this call,
+        for (int j = 1; j < 16; ++j) {        //  so that `sw_done` covers them for passes on other streams
+            int rcs = launch_split_weights_bf16(e->d_w[j], e->d_whm[j], e->d_wl[j], e->geom[j].Cout, 3 * e->geom[j].Cin, st);
+            if (rcs != NAFP_OK) return rcs;
+        }
+        e->x6_dirty = false;
+    }
     NAFP_HIP_CHECK(hipEventRecord(e->sw_done, st));
     e->sw_stream = st; e->sw_recorded = true;
-    e->has_weights = true; e->x6_dirty = true;
+    e->has_weights = true;
     return NAFP_OK;
 }
 
@@ -640,6 +648,10 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
             if (rcs != NAFP_OK) return rcs;
         }
         e->x6_dirty = false;
+        // (the option was switched on after the last set_weights: later passes on OTHER streams wait for this split like for a re-pack)
+        if (!e->sw_done) NAFP_HIP_CHECK(hipEventCreateWithFlags(&e->sw_done, hipEventDisableTiming));
+        NAFP_HIP_CHECK(hipEventRecord(e->sw_done, st));
+        e->sw_stream = st; e->sw_recorded = true;
     }
     NAFP_HIP_CHECK(hipMemsetAsync(stats, 0, stats_bytes, st));        // statistics + counters, one fill
     hipEvent_t* ev = nullptr;

@@ -198,3 +198,34 @@ def test_exact_split_option_is_float32_equivalent(nafp, observe):
     observe('hi / lo bf16 split (3 products) vs float64 oracle', e_x3, 1e-4)
     observe('exact split vs f32 path, all 640 rows', float((got - ref).abs().max()), 5e-6)
     assert e_x6 < 2.0 * e_f32 + 2e-7
+
+
+def test_exact_split_option_across_streams_and_weight_updates(nafp):
+    """The pre-split weights of NAFP_OPT_BF16X3 = 2 follow set_weights and are ordered for passes on other streams: switching the
+    option on, then launching on four streams at once, then replacing the weights -- every result equals the single-stream one."""
+    import _inputs
+    rng = np.random.default_rng(3)
+    feat = torch.from_numpy((-rng.uniform(0, 1.2, size=(130, 256, 32, 1))).astype(np.float32)).cuda()
+    m_fp = nafp.FingerPrinter(seed=0)
+    m_fp.set_weights(_inputs.weight_list(_inputs.weights(seed=5)))
+    m_fp.set_option(3, 2)
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    outs = []
+    torch.cuda.synchronize()
+    for s in streams:                       # the first launch after the switch splits the weights; the others must wait for it
+        with torch.cuda.stream(s):
+            outs.append(m_fp(feat))
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    ref = m_fp(feat).clone()
+    assert torch.equal(ref, outs[0])
+    m_fp.set_weights(_inputs.weight_list(_inputs.weights(seed=6)))      # new parameters: new split, on whatever stream comes first
+    with torch.cuda.stream(streams[2]):
+        a = m_fp(feat)
+    with torch.cuda.stream(streams[1]):
+        b = m_fp(feat)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and float((a - ref).abs().max()) > 1e-3
+    m_fp.set_option(3, 0)
+    f32 = m_fp(feat)
+    assert float((a - f32).abs().max()) < 5e-6
