@@ -229,3 +229,30 @@ def test_exact_split_option_across_streams_and_weight_updates(nafp):
     m_fp.set_option(3, 0)
     f32 = m_fp(feat)
     assert float((a - f32).abs().max()) < 5e-6
+
+
+@pytest.mark.parametrize('seed', [21, 22])
+def test_exact_split_error_statistics(nafp, observe, seed):
+    """More of the same evidence: 10 rows per weight set, keras-default initialisation (seed 21) and perturbed affine terms (22): the
+    exact split's maximum AND root-mean-square error against the float64 oracle are no larger than the fp32 MFMA path's (x 1.25)."""
+    from oracle import nnfp as o_nnfp
+    rng = np.random.default_rng(seed)
+    B = 130
+    feat = (-rng.uniform(0, 1.2, size=(B, 256, 32, 1))).astype(np.float32)
+    w = o_nnfp.init_weights(seed=seed, randomize_affine=(seed % 2 == 0))
+    m_fp = nafp.FingerPrinter(seed=0)
+    m_fp.set_weights(__import__('_inputs').weight_list(w))
+    ft = torch.from_numpy(feat).cuda()
+    ref = m_fp(ft).cpu().numpy()
+    m_fp.set_option(3, 2)
+    got = m_fp(ft).cpu().numpy()
+    m_fp.set_option(3, 0)
+    sel = np.linspace(0, B - 1, 10).astype(int)
+    want = o_nnfp.fingerprinter(feat[sel], w)
+    e32, e6 = ref[sel] - want, got[sel] - want
+    observe(f'seed {seed}: f32 path max |err|', np.abs(e32).max(), 5e-6)
+    observe(f'seed {seed}: exact split max |err|', np.abs(e6).max(), 5e-6)
+    observe(f'seed {seed}: f32 path rms err', float(np.sqrt((e32 ** 2).mean())), 1e-6)
+    observe(f'seed {seed}: exact split rms err', float(np.sqrt((e6 ** 2).mean())), 1e-6)
+    assert np.abs(e6).max() <= 1.25 * np.abs(e32).max() + 1e-7
+    assert np.sqrt((e6 ** 2).mean()) <= 1.25 * np.sqrt((e32 ** 2).mean()) + 2e-8
