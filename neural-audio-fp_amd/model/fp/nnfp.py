@@ -88,6 +88,10 @@ class FingerPrinter:
         self._weights_event, self._weights_stream, self._use_events = None, None, {}
         self._fuse0 = os.environ.get('NAFP_FUSE0', '') == '1'          # NAFP_OPT_FUSE_CONV0 (the library reads the same variable)
         self._ws = {}          # one workspace per HIP stream: batches may be pipelined across streams
+        # NAFP_BF16X3=1 | 2 (environment): the experimental split-bf16 products of the inference forward (include/nafp.h NAFP_OPT_BF16X3;
+        # 2 = the exact 3-way split: float32-equivalent, ~20 % faster than the fp32 MFMAs) for `run.py generate` without a code change
+        if os.environ.get('NAFP_BF16X3', '') in ('1', '2'):
+            self.set_option(3, int(os.environ['NAFP_BF16X3']))
 
     # ---- parameters -------------------------------------------------------
     def _init_variables(self, seed):
