@@ -226,6 +226,8 @@ def test_exact_split_option_across_streams_and_weight_updates(nafp):
         b = m_fp(feat)
     torch.cuda.synchronize()
     assert torch.equal(a, b) and float((a - ref).abs().max()) > 1e-3
+    # like the f32 path, the exact-split path gives a segment the same bytes whatever shares its launch
+    assert torch.equal(m_fp(feat[:37]), a[:37]) and torch.equal(m_fp(feat[60:61]), a[60:61])
     m_fp.set_option(3, 0)
     f32 = m_fp(feat)
     assert float((a - f32).abs().max()) < 5e-6
