@@ -265,6 +265,8 @@ int nafp_encoder_grad_group_wait(nafp_encoder* enc, int group, void* stream);
  * relative weight >= 2^-16 (hh, hm, mh, hl, mm, lh; the dropped ml + lm + ll < 2^-25 of |a||b|): float32-equivalent arithmetic on
  * the bf16 matrix pipe -- its error against the float64 oracle equals the f32 path's own (tests/test_gpu_parity_forward.py). */
 #define NAFP_OPT_BF16X3 3
+/* Options are host-side state of the handle: set them while no pass of the handle is being enqueued from another thread; passes already
+ * enqueued keep what they were launched with.  (NAFP_OPT_BF16X3 = 2 allocates its split weights, 1.5 x the packed conv kernels, on first use.) */
 int nafp_encoder_set_option(nafp_encoder* enc, int option, int value);
 
 /* m_fp.div_enc(x) alone (nnfp.py:141-156; called separately at trainer.py:73-76). */
