@@ -202,3 +202,28 @@ def test_a_non_finite_sample_gives_a_nan_row_and_nothing_else(nafp, norm, B):
     emb_t = m.forward_train(dirty)
     assert bool(torch.isnan(emb_t[~ok]).all()) and bool(torch.isfinite(emb_t[ok]).all())
     assert torch.equal(m(feat), clean)
+
+
+@pytest.mark.parametrize('emb_sz', [64, 256])
+@pytest.mark.parametrize('norm', NORMS)
+def test_other_geometries(nafp, norm, emb_sz, observe):
+    """The (256, 63, 1) input of nnfp.py:266-268 (odd frame counts: symmetric SAME padding, ragged position tiles, other row counts for
+    the row pass) and MODEL.EMB_SZ 64 / 256, forward and backward, with the alternates."""
+    rng = np.random.default_rng(emb_sz)
+    B = 3
+    feat = (-rng.uniform(0, 1.2, size=(B, 256, 63, 1))).astype(np.float32)
+    w = o_nnfp.convert_norm(o_nnfp.init_weights(seed=6, input_shape=(256, 63, 1), emb_sz=emb_sz, randomize_affine=True), norm, seed=3)
+    m = nafp.FingerPrinter(input_shape=(256, 63, 1), emb_sz=emb_sz, norm=norm)
+    m.set_weights(_inputs.weight_list(w))
+    ft = torch.from_numpy(feat).cuda()
+    emb = m(ft).cpu().numpy()
+    want = o_nnfp.fingerprinter(feat, w, norm=norm)
+    assert emb.shape == (B, emb_sz)
+    observe(f'{norm}, 63 frames, EMB_SZ {emb_sz}: fingerprint component', np.abs(emb - want).max(), 2e-5)
+    d_emb = rng.normal(size=(B, emb_sz)).astype(np.float32)
+    m.forward_train(ft)
+    grads = [g.cpu().numpy() for g in m.backward(torch.from_numpy(d_emb).cuda())]
+    tf = torch_ref.TorchFingerprinter(w, input_shape=(256, 63, 1), dtype=torch.float64, requires_grad=True, norm=norm)
+    (tf(torch.tensor(feat, dtype=torch.float64)) * torch.tensor(d_emb, dtype=torch.float64)).sum().backward()
+    worst = max(np.abs(g - p.grad.numpy()).max() / (np.abs(p.grad.numpy()).max() + 1e-12) for g, p in zip(grads, tf.params))
+    observe(f'{norm}, 63 frames, EMB_SZ {emb_sz}: gradient, rel. to the tensor max', worst, 1e-4)
