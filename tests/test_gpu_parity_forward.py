@@ -258,3 +258,28 @@ def test_exact_split_error_statistics(nafp, observe, seed):
     observe(f'seed {seed}: exact split rms err', float(np.sqrt((e6 ** 2).mean())), 1e-6)
     assert np.abs(e6).max() <= 1.25 * np.abs(e32).max() + 1e-7
     assert np.sqrt((e6 ** 2).mean()) <= 1.25 * np.sqrt((e32 ** 2).mean()) + 2e-8
+
+
+@pytest.mark.parametrize('norm', ['layer_norm2d', 'layer_norm1d', 'batch_norm'])
+@pytest.mark.parametrize('shape', [(256, 32, 1), (256, 63, 1)])
+def test_exact_split_on_ragged_launches_geometries_and_norms(nafp, shape, norm, observe):
+    """NAFP_OPT_BF16X3 = 2 away from the bench shape: B = 1 / 9 / 257 (ragged sample groups and position tiles), the 63-frame input, every
+    MODEL.BN -- always within the fp32 path's own error of the fp32 path."""
+    from oracle import nnfp as o_nnfp
+    import _inputs
+    rng = np.random.default_rng(7)
+    w = o_nnfp.init_weights(seed=8, input_shape=shape, randomize_affine=True)
+    if norm != 'layer_norm2d':
+        w = o_nnfp.convert_norm(w, norm, seed=4)
+    m_fp = nafp.FingerPrinter(input_shape=shape, norm=norm)
+    m_fp.set_weights(_inputs.weight_list(w))
+    worst = 0.0
+    for B in (1, 9, 257):
+        feat = torch.from_numpy((-rng.uniform(0, 1.2, size=(B,) + shape)).astype(np.float32)).cuda()
+        ref = m_fp(feat).clone()
+        m_fp.set_option(3, 2)
+        got = m_fp(feat).clone()
+        m_fp.set_option(3, 0)
+        assert bool(torch.isfinite(got).all())
+        worst = max(worst, float((got - ref).abs().max()))
+    observe(f'exact split vs f32 path, {shape[1]} frames, {norm}', worst, 5e-6)
