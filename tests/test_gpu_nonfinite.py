@@ -118,3 +118,21 @@ def test_a_nan_parameter_gives_nan_fingerprints(nafp, tensor):
     assert bool(torch.isnan(m.div_enc(torch.zeros((6, m.flat_dim), device='cuda'))).all())
     m.set_weights(w)
     assert bool(torch.isfinite(m(feat)).all())
+
+
+def test_non_finite_samples_with_the_exact_split_option(nafp):
+    """NAFP_OPT_BF16X3 = 2 changes the K-loop only; the statistics, the poison flag and the epilogues are the f32 path's: a NaN / Inf
+    sample is a NaN row there too, the others are bit-equal to the clean launch of the same option."""
+    m = _model(nafp)
+    m.set_option(3, 2)
+    B = 130
+    feat = _feat(B, 77)
+    clean = m(feat).clone()
+    dirty = feat.clone()
+    dirty[3, 10, 10, 0] = float('nan')
+    dirty[64, 255, 31, 0] = float('-inf')
+    emb = m(dirty)
+    ok = torch.ones(B, dtype=torch.bool, device='cuda')
+    ok[[3, 64]] = False
+    assert bool(torch.isnan(emb[~ok]).all()) and torch.equal(emb[ok], clean[ok])
+    m.set_option(3, 0)
