@@ -660,12 +660,12 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p, const 
 
     const u32x4 rsA = make_rsrc(p.x + (int64_t)b0 * p.sample_in,
                                 NAFP_ABL(p, 512) ? 0u : (unsigned)nb * (unsigned)p.sample_in * 4u);   // ablation 512: every A lane out of range (zero fill, no memory traffic)
-    const u32x4 rsB = make_rsrc(PREC == 2 ? p.wp_hm : p.wp, p.wp_bytes);
+    const u32x4 rsB = make_rsrc(PREC == 2 ? p.wp_hm : p.wp, NAFP_ABL(p, 4096) ? 0u : p.wp_bytes);      // ablation 4096: every B lane out of range
     const unsigned lds0 = (unsigned)(unsigned long long)(lds_ptr_t)smem + (unsigned)(wave * 32 * BK * 4);
     const unsigned ldsB0 = (unsigned)(unsigned long long)(lds_ptr_t)smem + (unsigned)((TILE + wave * BROWS * BK) * 4);
     // PREC = 2: the third plane of the pre-split weights, 32 B per row and K-step: lanes 0 .. 2 LROWS - 1 of every wave stage rows
     // wave * LROWS + lane / 2 (half lane & 1) behind the B tile, row-major
-    const u32x4 rsL = make_rsrc((const float*)p.wp_l, p.wp_bytes / 2);
+    const u32x4 rsL = make_rsrc((const float*)p.wp_l, NAFP_ABL(p, 4096) ? 0u : p.wp_bytes / 2);
     const unsigned ldsL0 = (unsigned)(unsigned long long)(lds_ptr_t)smem + (unsigned)((TILE + TILEB) * 4 + wave * LROWS * 32);
     const unsigned voffL = (unsigned)((tile_n0 + wave * LROWS + (lane >> 1)) * K) * 2u + (unsigned)(lane & 1) * 16u;
 #define NAFP_DMA_L(slot_, k0_)                                                                 \
@@ -853,7 +853,7 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p, const 
                 NAFP_WAIT_STEP(s)
                 __builtin_amdgcn_s_barrier();
                 if (s == s_begin) { NAFP_TL(3) }
-                const bool has_next = s + NSTAGE - 1 < n_steps;
+                const bool has_next = s + NSTAGE - 1 < n_steps && !NAFP_ABL(p, 1);
                 int nslot = slot + NSTAGE - 1; if (nslot >= NSTAGE) nslot -= NSTAGE;
                 const float* St = smem + slot * STAGE;
                 float4 af[2][2], bf[PREC == 2 ? 1 : NIW][2];
