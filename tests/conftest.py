@@ -40,6 +40,20 @@ def cfg():
         return yaml.safe_load(f)
 
 
+@pytest.fixture(params=['f32', 'x6'])
+def arith(request, monkeypatch):
+    """The arithmetic of the inference forward: 'f32' = the fp32 MFMA path (the default and the headline), 'x6' = the exact 3-way
+    bf16 split with six products (NAFP_OPT_BF16X3 = 2: float32-equivalent products on the bf16 matrix pipe).  Selected through the
+    environment (NAFP_BF16X3, read by FingerPrinter.__init__) so that every model the test -- or a child process it starts --
+    creates runs on it.  Every forward test that compares with the oracle takes this fixture: SAME tolerances for both
+    (the promotion gate of DESIGN.md section 9)."""
+    if request.param == 'x6':
+        monkeypatch.setenv('NAFP_BF16X3', '2')
+    else:
+        monkeypatch.delenv('NAFP_BF16X3', raising=False)
+    return request.param
+
+
 @pytest.fixture(scope='session')
 def golden():
     """Vectors written by tests/gen_golden.py from the float64 oracle (not from the

@@ -14,7 +14,7 @@ import _inputs
 pytestmark = pytest.mark.gpu
 
 
-def test_golden_fixtures_on_gpu(nafp, cfg, golden, observe):
+def test_golden_fixtures_on_gpu(nafp, cfg, golden, observe, arith):
     x = _inputs.audio(4, seed=11)
     m_pre, m_fp = nafp.get_melspec_layer(cfg), nafp.get_fingerprinter(cfg)
     m_fp.set_weights(_inputs.weight_list(_inputs.weights(seed=3)))

@@ -64,7 +64,7 @@ def _load_oracle_weights(m_fp, w):
 
 
 @pytest.mark.parametrize('B', [1, 5])
-def test_encoder_matches_oracle(nafp, cfg, B, observe):
+def test_encoder_matches_oracle(nafp, cfg, B, observe, arith):
     rng = np.random.default_rng(10 + B)
     feat = (-rng.uniform(0, 1.2, size=(B, 256, 32, 1))).astype(np.float32)
     w = o_nnfp.init_weights(seed=3, randomize_affine=True)
@@ -86,7 +86,7 @@ def test_encoder_matches_oracle(nafp, cfg, B, observe):
     assert np.abs(de - o_nnfp.div_enc(want_flat, w)).max() < 1e-5
 
 
-def test_end_to_end_audio_to_fingerprint(nafp, cfg):
+def test_end_to_end_audio_to_fingerprint(nafp, cfg, arith):
     x = _audio(6, seed=5)
     w = o_nnfp.init_weights(seed=4, randomize_affine=True)
     m_pre, m_fp = nafp.get_melspec_layer(cfg), nafp.get_fingerprinter(cfg)
@@ -98,7 +98,7 @@ def test_end_to_end_audio_to_fingerprint(nafp, cfg):
     assert np.abs(np.linalg.norm(emb, axis=1) - 1).max() < 1e-5
 
 
-def test_two_second_input_geometry(nafp):
+def test_two_second_input_geometry(nafp, arith):
     """nnfp.py:266-268 builds FingerPrinter on (256,63,1) as well (19,224,576 params, nnfp.py:271):
     odd frame counts exercise symmetric SAME padding (1/1) and the ragged position tiles."""
     rng = np.random.default_rng(42)

@@ -116,7 +116,7 @@ def test_sequence_evaluation_matches_oracle_and_writes_reference_files(nafp, tmp
     assert np.array_equal(preds, want[4])
 
 
-def test_identical_top1_hits_for_gpu_and_oracle_fingerprints(nafp, cfg):
+def test_identical_top1_hits_for_gpu_and_oracle_fingerprints(nafp, cfg, arith):
     """north star parity gate: the fingerprints of the HIP path and of the oracle give identical top-1
     segment hits in the same search."""
     import _inputs
@@ -141,7 +141,7 @@ def test_identical_top1_hits_for_gpu_and_oracle_fingerprints(nafp, cfg):
     assert (hits['gpu'] == np.arange(60)).mean() > 0.9
 
 
-def test_identical_top1_hits_on_a_mini_set_of_overlapping_segments(nafp, cfg):
+def test_identical_top1_hits_on_a_mini_set_of_overlapping_segments(nafp, cfg, arith):
     """The same gate on a stand-in for the reference's mini test set (no dataset exists in this image): 12 synthetic
     30-s clips cut like `get_fns_seg_list` does (1-s segments, hop 0.5 s: 59 per clip, neighbours share half their
     samples, so the nearest wrong answers are close) = 708 database segments in max-normalisation groups of 125; the
