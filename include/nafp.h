@@ -132,7 +132,7 @@ int nafp_encoder_destroy(nafp_encoder* enc);
  * With the alternates the tensors 4j+2 / 4j+3 are gamma / beta of shape (C); NAFP_NORM_BATCH appends, behind tensor 67, the
  * NON-trainable moving statistics: 68+2j moving_mean (C), 69+2j moving_variance (C), j = 0..15.  The gradient list of
  * nafp_encoder_backward covers the trainable tensors 0..67 only (nafp_encoder_n_trainable).  NAFP_OPT_FUSE_CONV0,
- * NAFP_OPT_FUSED_LN_BWD and NAFP_OPT_SMALLNET are ignored by the alternates. */
+ * and NAFP_OPT_FUSED_LN_BWD are ignored by the alternates. */
 #define NAFP_NORM_LAYER2D 0
 #define NAFP_NORM_LAYER1D 1
 #define NAFP_NORM_BATCH 2
@@ -246,17 +246,14 @@ int nafp_encoder_grad_group_wait(nafp_encoder* enc, int group, void* stream);
  *                        2 (default): those of the SMALL layers (fewer than 16 output positions), next to the LayerNorm backward
  *                        and transposed conv of the layer below; 1: every layer's (measured slower); 0: everything on
  *                        `stream`.
- *   NAFP_OPT_SMALLNET    forward passes: the layers with <= 8 output positions (b5 ... b7 of the 1-s model) as ONE persistent launch
- *                        whose workgroups claim (layer, sample group, tile, split-K part) items in order from a counter and wait only
- *                        for finished tiles of the layer below for the SAME 128 samples (deadlock-free under any residency; bounded
- *                        spins; a give-up shows as NaN rows).  0 (default): per-layer launches -- measured faster;
- *                        1: the persistent launch at batches up to NAFP_SMALLNET_MAXB (env, default 1536).  Results agree to float32
- *                        rounding (another split-K summation order), run-to-run bit-identical either way. */
+ *   (5, NAFP_OPT_SMALLNET: retired in round 6 -- the small layers as one persistent launch measured slower than the per-layer launches
+ *                        at every setting, docs/DESIGN_HISTORY.md; the number stays reserved, setting it is accepted and ignored.) */
 #define NAFP_OPT_FUSE_CONV0 1
 #define NAFP_OPT_FUSED_LN_BWD 2
 #define NAFP_OPT_BWD_OVERLAP 4
-#define NAFP_OPT_SMALLNET 5
-#define NAFP_OPT_DEBUG_SIDE_DELAY 6   /* TEST HOOK: value = microseconds the handle's weight-gradient stream idles in front of its first launch of a backward pass */
+#define NAFP_OPT_SMALLNET 5           /* retired, ignored */
+/* (6 is a test hook of tests/test_gpu_train_dp.py -- it delays the handle's weight-gradient stream -- and is refused unless the process
+ * runs with NAFP_TEST_HOOKS=1 in its environment; not part of the interface.) */
 /* EXPERIMENTAL, changes the arithmetic (the only option that does): the unsplit GEMM convs of nafp_encoder_forward form their
  * products on the bf16 matrix pipe from f32 operands split into hi + lo bf16 halves (hi*hi + hi*lo + lo*hi, f32
  * accumulation).  Fingerprints move at the 1e-6 level against the f32 path.  Off by default; bench.py reports it as a

@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void multi_copy_kernel(const CopyTable t) {
     }
     if (bad && t.nonfinite) atomicOr(t.nonfinite, 1);
 }
+#define NAFP_OPT_DEBUG_SIDE_DELAY 6
 // TEST HOOK (NAFP_OPT_DEBUG_SIDE_DELAY): holds a stream for `us` microseconds (100 MHz real-time counter), so that a test can make the
 // weight-gradient stream lag the main stream deterministically and see whether every event is ordered behind what it stands for
 __global__ void debug_delay_kernel(long long us) {
@@ -171,19 +172,22 @@ struct nafp_encoder {
     // LayerNorm-backward path (opt_fused_ln_bwd) reads t and therefore implies keeping it.
     bool keep_t_env = []() { const char* v = getenv("NAFP_KEEP_T"); return v && v[0] == '1'; }();
     bool keep_t() const { return keep_t_env || (opt_fused_ln_bwd != 0 && norm == NAFP_NORM_LAYER2D) || norm == NAFP_NORM_LAYER1D; }   // (layer_norm1d overwrites z with the normalised rows: v = z / gamma is gone)
-    // what the last forward_train laid the training workspace out with: the backward pass re-derives the layout from (B, keep_t())
-    // and must find the same one (an option changed in between would make it read activations at other offsets)
-    int64_t train_B = -1; bool train_keep_t = false, train_smallnet = false;
-    // [r5] NAFP_OPT_SMALLNET (default: NAFP_SMALLNET env, else OFF): the small layers (P <= 8 output positions: convs 10-15 of the 1-s
-    // model) as ONE persistent launch (conv.hip, smallnet_kernel) at batches up to NAFP_SMALLNET_MAXB.  Built for VERDICT r4 item 1 and
-    // MEASURED SLOWER than the per-layer launches it replaces (B = 640, same box, the six layers incl. finishes: 0.343 ms by launches,
-    // 0.358-0.374 ms persistent with one workgroup per CU, 0.48-0.54 ms with any co-residency; DESIGN.md section 4.2 [r5] says why):
-    // kept as an option with its parity and multi-stream tests, not used by default.
-    int smallnet_j0 = 16;                 // first layer of the persistent launch (16: none): all layers j0 .. 15 qualify
-    int64_t smallnet_max_b = []() { const char* v = getenv("NAFP_SMALLNET_MAXB"); return v ? atoll(v) : (int64_t)1536; }();
-    bool smallnet_on = []() { const char* v = getenv("NAFP_SMALLNET"); return v && v[0] == '1'; }();
-    bool use_smallnet(int64_t B) const { return smallnet_on && smallnet_j0 <= 15 && B <= smallnet_max_b; }
-    int prof_smallnet_j0 = 16;            // per-conv stamps: the layers from here on were stamped as ONE span (slot of this layer)
+    // what forward_train laid a training workspace out with, PER WORKSPACE (the last 16 distinct ones): the backward pass re-derives the
+    // layout from (B, keep_t()) and must find the one that forward pass wrote -- an option changed in between would make it read
+    // activations at other offsets.  Keyed by the workspace pointer, so two forward passes into two workspaces (micro-batches in
+    // flight) can both be followed by their backward passes, and a backward pass on a workspace no forward pass of this handle
+    // wrote is refused (round-5 ADVICE: the record used to be one per handle)
+    struct TrainRec { const void* ws; int64_t B; bool keep_t; };
+    std::vector<TrainRec> train_recs;
+    void train_rec_put(const void* ws, int64_t B, bool kt) {
+        for (auto& r : train_recs) if (r.ws == ws) { r.B = B; r.keep_t = kt; return; }
+        if (train_recs.size() >= 16) train_recs.erase(train_recs.begin());
+        train_recs.push_back({ws, B, kt});
+    }
+    bool train_rec_ok(const void* ws, int64_t B, bool kt) const {
+        for (const auto& r : train_recs) if (r.ws == ws) return r.B == B && r.keep_t == kt;
+        return false;
+    }
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_main[16] = {}, ev_side[16] = {};
     int debug_side_delay_us = 0;          // NAFP_OPT_DEBUG_SIDE_DELAY (tests only): the weight-gradient stream idles this long in front of its first launch of a pass
@@ -334,8 +338,6 @@ extern "C" int nafp_encoder_create_ex(nafp_encoder** out, int in_f, int in_t, in
         err = hipMemcpy(e->d_inv_n, inv_n, sizeof(inv_n), hipMemcpyHostToDevice);
         if (err != hipSuccess) { g_last_hip_error = (int)err; (void)hipFree(e->d_blob); delete e; return NAFP_ERR_HIP; }
     }
-    e->smallnet_j0 = 16;
-    for (int j = 15; j >= 10 && smallnet_layer_ok(e->geom[j]); --j) e->smallnet_j0 = j;       // (at most 6 layers per persistent launch)
     for (int j = 0; j < 16; ++j) {
         const ConvGeom& g = e->geom[j];
         const int64_t n = (int64_t)g.Fout * g.Tout * g.Cout;
@@ -346,7 +348,6 @@ extern "C" int nafp_encoder_create_ex(nafp_encoder** out, int in_f, int in_t, in
         for (int j = 0; j < 16; ++j) { e->shapes[4 * j + 2] = {e->geom[j].Cout}; e->shapes[4 * j + 3] = {e->geom[j].Cout}; }
         if (norm == NAFP_NORM_BATCH)
             for (int j = 0; j < 16; ++j) { e->shapes.push_back({e->geom[j].Cout}); e->shapes.push_back({e->geom[j].Cout}); }
-        e->smallnet_j0 = 16;                 // (the persistent small-layer launch has no place for the row pass between its layers)
     }
     *out = e;
     return NAFP_OK;
@@ -395,8 +396,12 @@ extern "C" int nafp_encoder_set_option(nafp_encoder* e, int option, int value) {
             if (value < 0 || value > 2) return NAFP_ERR_INVALID_ARG;
             e->opt_fused_ln_bwd = value; return NAFP_OK;
         case NAFP_OPT_BWD_OVERLAP: e->opt_bwd_overlap = value < 0 ? 0 : (value > 2 ? 1 : value); return NAFP_OK;
-        case NAFP_OPT_SMALLNET: e->smallnet_on = value != 0; return NAFP_OK;
-        case NAFP_OPT_DEBUG_SIDE_DELAY: e->debug_side_delay_us = value < 0 ? 0 : value; return NAFP_OK;
+        case NAFP_OPT_SMALLNET: return NAFP_OK;          // retired in round 6 (the persistent small-layer launch lost to the per-layer launches at every setting): accepted, ignored
+        case NAFP_OPT_DEBUG_SIDE_DELAY: {     // test hook, not in include/nafp.h: refused outside a test process (round-5 ADVICE)
+            static const bool hooks = []() { const char* v = getenv("NAFP_TEST_HOOKS"); return v && v[0] == '1'; }();
+            if (!hooks) return NAFP_ERR_UNSUPPORTED;
+            e->debug_side_delay_us = value < 0 ? 0 : value; return NAFP_OK;
+        }
         default: return NAFP_ERR_INVALID_ARG;
     }
 }
@@ -579,26 +584,19 @@ static int wait_weights(nafp_encoder* e, hipStream_t st, int stage = 2) {       
 
 static int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
-// split-K slab of a forward pass: the largest per-layer need, or -- when the small layers run as one persistent launch -- the sum of
-// their regions (groups of different layers are in flight at the same time)
+// split-K slab of a forward pass: the largest per-layer need
 static int64_t forward_slab_floats(const nafp_encoder* e, int64_t n_seg) {
     int64_t slab = 0;
     for (int j = 1; j < 16; ++j) slab = std::max(slab, conv_gemm_slab_floats(n_seg, e->geom[j], false, fwd_plan_b()));
-    if (e->use_smallnet(n_seg)) slab = std::max(slab, smallnet_slab_floats(n_seg, e->geom.data(), e->smallnet_j0, 15));
     return slab;
 }
 
 extern "C" int64_t nafp_encoder_workspace_bytes(const nafp_encoder* e, int64_t n_seg) {
     if (!e || n_seg < 0) return -1;
-    const int64_t stats = align_up((int64_t)sizeof(double) * 2 * 16 * n_seg, 256) + (NAFP_TICKET_SLOTS + NAFP_SMALLNET_CTRL_WORDS) * (int64_t)sizeof(unsigned);
+    const int64_t stats = align_up((int64_t)sizeof(double) * 2 * 16 * n_seg, 256) + NAFP_TICKET_SLOTS * (int64_t)sizeof(unsigned);
     const int64_t a = align_up((int64_t)sizeof(float) * e->bufA_per_seg * n_seg, 256);
     const int64_t b = align_up((int64_t)sizeof(float) * e->bufB_per_seg * n_seg, 256);
-    // the persistent small-layer launch keeps every layer's z in a buffer of its own (61 KB per segment together): groups of different
-    // layers are in flight at once, a ping-pong pair would be overwritten under a reader of another group
-    int64_t smallz = 0;
-    if (e->use_smallnet(n_seg))
-        for (int j = e->smallnet_j0; j < 16; ++j) smallz += align_up((int64_t)sizeof(float) * e->geom[j].Fout * e->geom[j].Tout * e->geom[j].Cout * n_seg, 256);
-    return stats + a + b + align_up(forward_slab_floats(e, n_seg) * (int64_t)sizeof(float), 256) + smallz + 256;
+    return stats + a + b + align_up(forward_slab_floats(e, n_seg) * (int64_t)sizeof(float), 256) + 256;
 }
 
 static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float* gstat, int group_size, int segment_norm,
@@ -631,16 +629,13 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)align_up((int64_t)(uintptr_t)workspace, 256);
     const int64_t stats_only = align_up((int64_t)sizeof(double) * 2 * 16 * n_seg, 256);
-    const int64_t stats_bytes = stats_only + (NAFP_TICKET_SLOTS + NAFP_SMALLNET_CTRL_WORDS) * (int64_t)sizeof(unsigned);
+    const int64_t stats_bytes = stats_only + NAFP_TICKET_SLOTS * (int64_t)sizeof(unsigned);
     stat_t* stats = (stat_t*)ws;
     unsigned* tickets = (unsigned*)(ws + stats_only);       // arrival counters of the split-K launches (zero between launches)
-    unsigned* ctrl = tickets + NAFP_TICKET_SLOTS;           // control block of the persistent small-layer launch (zeroed with the statistics)
     float* bufA = (float*)(ws + stats_bytes);
     float* bufB = (float*)(ws + stats_bytes + align_up((int64_t)sizeof(float) * e->bufA_per_seg * n_seg, 256));
     float* slab = (float*)((char*)bufB + align_up((int64_t)sizeof(float) * e->bufB_per_seg * n_seg, 256));
     const int64_t slab_floats = forward_slab_floats(e, n_seg);
-    const int sn_j0 = e->use_smallnet(n_seg) ? e->smallnet_j0 : 16;
-    e->prof_smallnet_j0 = 16;
     { int wrc = wait_weights(e, st); if (wrc != NAFP_OK) return wrc; }
     if (e->opt_bf16x3 == 2 && e->x6_dirty) {                          // (experimental) the weights' three bf16 terms, once per parameter set
         for (int j = 1; j < 16; ++j) {
@@ -673,34 +668,13 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
     if (fuse0 && gstat) return NAFP_ERR_UNSUPPORTED;          // the in-kernel conv0 generator reads finished features
     int rc = fuse0 ? launch_conv0_stats(feat, e->d_w[0], e->d_bias[0], stats, n_seg, e->geom[0], st)
                    : launch_conv0(feat, e->d_w[0], e->d_bias[0], e->d_gamma[0], bufA, nullptr, stats, n_seg, e->geom[0], st,
-                                  gstat, group_size, segment_norm);
+                                  gstat, group_size, segment_norm, alt);
     if (rc != NAFP_OK) return rc;
     if (!fuse0) { rc = row_pass(bufA, 0); if (rc != NAFP_OK) return rc; }
     if (ev && e->prof_coarse < 2) NAFP_HIP_CHECK(hipEventRecord(ev[1], st));
     float* cur = bufA;
     for (int j = 1; j < 16; ++j) {
         float* nxt = (j % 2 == 0) ? bufA : bufB;
-        if (j == sn_j0) {
-            // layers j .. 15 in one persistent launch
-            SmallNetArgs sa{};
-            sa.j0 = j; sa.j1 = 15;
-            float* c2 = cur;
-            char* zp = (char*)slab + align_up(slab_floats * (int64_t)sizeof(float), 256);      // own z buffers (see nafp_encoder_workspace_bytes)
-            for (int k = j; k < 16; ++k) {
-                float* n2 = (float*)zp;
-                zp += align_up((int64_t)sizeof(float) * e->geom[k].Fout * e->geom[k].Tout * e->geom[k].Cout * n_seg, 256);
-                sa.x[k - j] = c2; sa.wp[k - j] = e->d_w[k]; sa.G[k - j] = e->d_G[k]; sa.Hb[k - j] = e->d_Hb[k]; sa.gamma_out[k - j] = e->d_gamma[k];
-                sa.stats_in[k - j] = stats + 2 * n_seg * (k - 1); sa.stats_out[k - j] = stats + 2 * n_seg * k; sa.y[k - j] = n2;
-                c2 = n2;
-            }
-            sa.slab = slab; sa.slab_floats = slab_floats; sa.tickets = tickets; sa.ctrl = ctrl;
-            if (ev && e->prof_coarse == 0) { sa.ev_start = ev[2 * j]; sa.ev_stop = ev[2 * j + 1]; e->prof_smallnet_j0 = j; }
-            if (ev && e->prof_coarse == 2) sa.ev_stop = ev[31];
-            rc = launch_smallnet(sa, n_seg, e->geom.data(), st);
-            if (rc != NAFP_OK) return rc;
-            cur = c2;
-            break;
-        }
         ConvGemmArgs a{};
         a.x = cur; a.stats_in = stats_of(j - 1); a.ident_stats = alt;
         a.wp = e->d_w[j]; a.G = e->d_G[j]; a.Hb = e->d_Hb[j]; a.gamma_out = e->d_gamma[j];
@@ -730,7 +704,6 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
     t.w1p = e->d_w1p; t.b1p = e->d_b1p; t.w2p = e->d_w2p; t.b2 = e->d_b2;
     t.out_flat = out_flat; t.out_emb = out_emb;
     t.D = (int)e->flat_dim; t.Q = e->emb_sz; t.S = e->S; t.l2norm = l2norm; t.nonfinite_weights = e->d_wflag; t.launch_error = nullptr;
-    if (sn_j0 <= 15) t.launch_error = ctrl + 1;
     if (ev && e->prof_coarse < 2) NAFP_HIP_CHECK(hipEventRecord(ev[32], st));
     rc = launch_tail(t, n_seg, st);
     if (rc != NAFP_OK) return rc;
@@ -779,7 +752,7 @@ extern "C" int nafp_encoder_profile_read(nafp_encoder* e, int slot, float* ms_ou
         return NAFP_OK;
     }
     // every conv: start of its first kernel -> end of its last (a split-K finish kernel included)
-    for (int j = 1; j < 16 && j <= e->prof_smallnet_j0; ++j) NAFP_HIP_CHECK(hipEventElapsedTime(ms_out_host + j, ev[2 * j], ev[2 * j + 1]));     // (the persistent launch of the small layers: one span, in its first layer's slot)
+    for (int j = 1; j < 16; ++j) NAFP_HIP_CHECK(hipEventElapsedTime(ms_out_host + j, ev[2 * j], ev[2 * j + 1]));
     return NAFP_OK;
 }
 
@@ -818,7 +791,6 @@ struct TrainLayout {
     double* lnsum[16]; float* S1[16]; float* S2[16];
     float* z[16]; float* v[16];          // z = gamma . ELU(t) (operand of the next conv), v = the pre-activation t
     float* slab; int64_t slab_floats;
-    unsigned* ctrl;
     float* slab2; int64_t slab2_floats; unsigned* tickets2;     // the weight-gradient stream's own slab and arrival counters (opt_bwd_overlap 2)
     float* dA; float* dB; float* dy;
     float* dts[16];                      // the small layers' gradients in buffers of their own (opt_bwd_overlap 2), else nullptr
@@ -832,9 +804,8 @@ TrainLayout train_layout(const nafp_encoder* e, int64_t B, void* ws) {
     char* p0 = p;
     auto take = [&](int64_t bytes) { char* r = p; p += (bytes + 255) / 256 * 256; return r; };
     L.stats = (stat_t*)take((int64_t)sizeof(stat_t) * 2 * 16 * B);
-    L.tickets = (unsigned*)take((2 * NAFP_TICKET_SLOTS + NAFP_SMALLNET_CTRL_WORDS) * (int64_t)sizeof(unsigned));  // directly behind the statistics: one fill covers all
+    L.tickets = (unsigned*)take(2 * NAFP_TICKET_SLOTS * (int64_t)sizeof(unsigned));  // directly behind the statistics: one fill covers all
     L.tickets2 = L.tickets + NAFP_TICKET_SLOTS;                                       // (second half: the weight-gradient stream's counters)
-    L.ctrl = L.tickets + 2 * NAFP_TICKET_SLOTS;                                       // control block of the persistent small-layer launch
     L.mr = (float*)take((int64_t)sizeof(float) * 2 * 16 * B);
     L.sc = (float*)take((int64_t)sizeof(float) * 8 * B);
     L.zero_begin = p;
@@ -857,7 +828,6 @@ TrainLayout train_layout(const nafp_encoder* e, int64_t B, void* ws) {
     L.slab_floats = 0;
     for (int j = 1; j < 16; ++j)
         L.slab_floats = std::max(L.slab_floats, std::max(conv_gemm_slab_floats(B, e->geom[j], true), wgrad_slab_floats(B, e->geom[j])));
-    if (e->use_smallnet(B)) L.slab_floats = std::max(L.slab_floats, smallnet_slab_floats(B, e->geom.data(), e->smallnet_j0, 15));
     L.slab = (float*)take((int64_t)sizeof(float) * L.slab_floats);
     L.slab2_floats = 0;
     for (int j = 1; j < 16; ++j)
@@ -896,8 +866,8 @@ extern "C" int nafp_encoder_forward_train(nafp_encoder* e, const float* feat, in
     if (workspace_bytes < nafp_encoder_train_workspace_bytes(e, n_seg)) return NAFP_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     TrainLayout L = train_layout(e, n_seg, workspace);
-    e->train_B = n_seg; e->train_keep_t = e->keep_t(); e->train_smallnet = e->use_smallnet(n_seg);
-    NAFP_HIP_CHECK(hipMemsetAsync(L.stats, 0, (char*)(L.ctrl + NAFP_SMALLNET_CTRL_WORDS) - (char*)L.stats, st));
+    e->train_rec_put(workspace, n_seg, e->keep_t());
+    NAFP_HIP_CHECK(hipMemsetAsync(L.stats, 0, (char*)(L.tickets + 2 * NAFP_TICKET_SLOTS) - (char*)L.stats, st));
     static const bool split_wait = []() { const char* v = getenv("NAFP_SW_SPLIT_WAIT"); return !v || v[0] != '0'; }();
     { int wrc = wait_weights(e, st, split_wait ? 0 : 2); if (wrc != NAFP_OK) return wrc; }
     // (layer 0 keeps no pre-activation: the backward pass regenerates it from `feat`, 3 FMAs per element)
@@ -907,25 +877,12 @@ extern "C" int nafp_encoder_forward_train(nafp_encoder* e, const float* feat, in
         if (e->norm != NAFP_NORM_LAYER1D) return NAFP_OK;
         return launch_ln1d_fwd(z, n_seg * e->geom[j].Fout * e->geom[j].Tout, e->geom[j].Cout, e->d_gc[j], e->d_bc[j], st);
     };
-    int rc = launch_conv0(feat, e->d_w[0], e->d_bias[0], e->d_gamma[0], L.z[0], L.v[0], L.stats, n_seg, e->geom[0], st);
+    int rc = launch_conv0(feat, e->d_w[0], e->d_bias[0], e->d_gamma[0], L.z[0], L.v[0], L.stats, n_seg, e->geom[0], st, nullptr, 0, 0, alt);
     if (rc != NAFP_OK) return rc;
     rc = row_pass(L.z[0], 0);
     if (rc != NAFP_OK) return rc;
-    const int sn_j0 = (e->use_smallnet(n_seg) && !e->keep_t()) ? e->smallnet_j0 : 16;      // (the persistent launch keeps z only)
     for (int j = 1; j < 16; ++j) {
         if (split_wait && j <= 2) { int wrc = wait_weights(e, st, j); if (wrc != NAFP_OK) return wrc; }
-        if (j == sn_j0) {
-            SmallNetArgs sa{};
-            sa.j0 = j; sa.j1 = 15;
-            for (int k = j; k < 16; ++k) {
-                sa.x[k - j] = L.z[k - 1]; sa.wp[k - j] = e->d_w[k]; sa.G[k - j] = e->d_G[k]; sa.Hb[k - j] = e->d_Hb[k]; sa.gamma_out[k - j] = e->d_gamma[k];
-                sa.stats_in[k - j] = L.stats + 2 * n_seg * (k - 1); sa.stats_out[k - j] = L.stats + 2 * n_seg * k; sa.y[k - j] = L.z[k];
-            }
-            sa.slab = L.slab; sa.slab_floats = L.slab_floats; sa.tickets = L.tickets; sa.ctrl = L.ctrl;
-            rc = launch_smallnet(sa, n_seg, e->geom.data(), st);
-            if (rc != NAFP_OK) return rc;
-            break;
-        }
         ConvGemmArgs a{};
         a.x = L.z[j - 1]; a.stats_in = stats_of(j - 1); a.ident_stats = alt;
         a.wp = e->d_w[j]; a.G = e->d_G[j]; a.Hb = e->d_Hb[j]; a.gamma_out = e->d_gamma[j];
@@ -940,7 +897,7 @@ extern "C" int nafp_encoder_forward_train(nafp_encoder* e, const float* feat, in
     t.x = L.z[15]; t.stats = stats_of(15); t.ident_stats = alt; t.gamma = e->d_gamma[15]; t.beta = e->d_beta[15];
     t.w1p = e->d_w1p; t.b1p = e->d_b1p; t.w2p = e->d_w2p; t.b2 = e->d_b2;
     t.out_flat = nullptr; t.out_emb = out_emb;
-    t.D = (int)e->flat_dim; t.Q = e->emb_sz; t.S = e->S; t.l2norm = l2norm; t.nonfinite_weights = e->d_wflag; t.launch_error = sn_j0 <= 15 ? L.ctrl + 1 : nullptr;
+    t.D = (int)e->flat_dim; t.Q = e->emb_sz; t.S = e->S; t.l2norm = l2norm; t.nonfinite_weights = e->d_wflag; t.launch_error = nullptr;
     return launch_tail(t, n_seg, st);
 }
 
@@ -950,7 +907,7 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
     if (!e || !feat || !d_emb || !workspace || !grads || n_seg <= 0) return NAFP_ERR_INVALID_ARG;
     if (!e->has_weights) return NAFP_ERR_NO_WEIGHTS;
     if (workspace_bytes < nafp_encoder_train_workspace_bytes(e, n_seg)) return NAFP_ERR_WORKSPACE;
-    if (e->train_B != n_seg || e->train_keep_t != e->keep_t() || e->train_smallnet != e->use_smallnet(n_seg)) return NAFP_ERR_INVALID_ARG;     // not the layout forward_train wrote
+    if (!e->train_rec_ok(workspace, n_seg, e->keep_t())) return NAFP_ERR_INVALID_ARG;     // not a layout forward_train wrote into THIS workspace
     hipStream_t st = (hipStream_t)stream;
     const int64_t B = n_seg;
     TrainLayout L = train_layout(e, B, workspace);

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(
         const float* __restrict__ feat, const float* __restrict__ w3, const float* __restrict__ bias,
         const float* __restrict__ gamma, float* __restrict__ y, float* __restrict__ v_out,
         stat_t* __restrict__ stats, int F, int Tin, int Tout, int Cout, int stride, int pad,
-        const float* __restrict__ gstat, int group_size, int segment_norm) {
+        const float* __restrict__ gstat, int group_size, int segment_norm, int ident_stats) {
     constexpr int NP = 4;                           // positions per thread and batch
     __shared__ float s_x[ROWS0 * 64 + 8];           // rows of the input, Tin <= 64, with one zero in front (index -1)
     __shared__ double red[8];
@@ -172,14 +172,14 @@ __global__ __launch_bounds__(256) void conv0_kernel(
     if (lane == 0) { red[wave] = ds; red[4 + wave] = dq; }
     __syncthreads();
     if (tid == 0) {
-        stat_add(stats + 2 * b, red[0] + red[1] + red[2] + red[3]);
-        stat_add(stats + 2 * b + 1, red[4] + red[5] + red[6] + red[7]);
+        stat_add(stats + 2 * b, red[0] + red[1] + red[2] + red[3], ident_stats != 0);
+        stat_add(stats + 2 * b + 1, red[4] + red[5] + red[6] + red[7], ident_stats != 0);
     }
 }
 
 int launch_conv0(const float* feat, const float* w3, const float* bias, const float* gamma, float* y,
                  float* v_out, stat_t* stats, int64_t B, const ConvGeom& g, hipStream_t st, const float* gstat,
-                 int group_size, int segment_norm) {
+                 int group_size, int segment_norm, bool ident_stats) {
     if (g.Cin != 1 || g.axis != 0 || (g.Cout % 4) != 0 || 256 % (g.Cout / 4) != 0 || g.Tin > 64) return NAFP_ERR_UNSUPPORTED;
     // rows per workgroup, measured at B = 640 on one box (ms): 4 -> 0.339, 8 -> 0.291, 16 -> 0.272 (the plain per-position
     // loop of round 1 ran 0.344; a store-only kernel of this shape 0.230: tools/probes/store_probe.hip)
@@ -187,19 +187,19 @@ int launch_conv0(const float* feat, const float* w3, const float* bias, const fl
     if (rows == 4) {
         const int64_t blocks = B * ((g.Fin + 3) / 4);
         conv0_kernel<true, 4><<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, gamma, y, v_out, stats, g.Fin, g.Tin, g.Tout,
-                                                                    g.Cout, g.stride, g.pad, gstat, group_size, segment_norm);
+                                                                    g.Cout, g.stride, g.pad, gstat, group_size, segment_norm, ident_stats ? 1 : 0);
     } else if (rows == 16) {
         const int64_t blocks = B * ((g.Fin + 15) / 16);
         conv0_kernel<true, 16><<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, gamma, y, v_out, stats, g.Fin, g.Tin, g.Tout,
-                                                                     g.Cout, g.stride, g.pad, gstat, group_size, segment_norm);
+                                                                     g.Cout, g.stride, g.pad, gstat, group_size, segment_norm, ident_stats ? 1 : 0);
     } else if (rows == 32) {
         const int64_t blocks = B * ((g.Fin + 31) / 32);
         conv0_kernel<true, 32><<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, gamma, y, v_out, stats, g.Fin, g.Tin, g.Tout,
-                                                                     g.Cout, g.stride, g.pad, gstat, group_size, segment_norm);
+                                                                     g.Cout, g.stride, g.pad, gstat, group_size, segment_norm, ident_stats ? 1 : 0);
     } else {
         const int64_t blocks = B * ((g.Fin + 7) / 8);
         conv0_kernel<true, 8><<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, gamma, y, v_out, stats, g.Fin, g.Tin, g.Tout,
-                                                                    g.Cout, g.stride, g.pad, gstat, group_size, segment_norm);
+                                                                    g.Cout, g.stride, g.pad, gstat, group_size, segment_norm, ident_stats ? 1 : 0);
     }
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
@@ -211,7 +211,7 @@ int launch_conv0_stats(const float* feat, const float* w3, const float* bias, st
     constexpr int R = 32;
     const int64_t blocks = B * ((g.Fin + R - 1) / R);
     conv0_kernel<false, R><<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, nullptr, nullptr, nullptr, stats,
-                                                                   g.Fin, g.Tin, g.Tout, g.Cout, g.stride, g.pad, nullptr, 0, 0);
+                                                                   g.Fin, g.Tin, g.Tout, g.Cout, g.stride, g.pad, nullptr, 0, 0, 0);
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }
@@ -442,12 +442,9 @@ __device__ __forceinline__ float half_wave_sum_dpp(float x) {
 // PREC = 2 (experimental, inference only, NAFP_OPT_BF16X3 = 2): the EXACT 3-way split x = h + m + l (three bf16 terms hold the 24
 // significant bits of a float32) and the six products of relative weight >= 2^-16 -- hh, hm, mh, hl, mm, lh; ml + lm + ll < 2^-25 of
 // |a||b|, below half an ulp of the float32 product -- with f32 accumulation: float32-equivalent arithmetic on the bf16 matrix pipe.
-// PERSIST = 1: one work item of the persistent small-layer kernel (smallnet_kernel below): the tile ids come from the caller
-// instead of blockIdx, the z stores are write-through (the consumer is another workgroup of the SAME launch), and the function
-// tells its caller whether this workgroup ran the full epilogue (true) or left after handing in a split-K part (false).
-template <int BM, int BNT, int BK, int NSTAGE, bool FUSE0, int EPI, int PREC = 0, int PERSIST = 0>
-__device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p, const int it_sg = 0, const int it_pb = 0, const int it_col = 0,
-                                               const int it_z = 0) {
+// Returns whether this workgroup ran the full epilogue (true) or left after handing in a split-K part (false).
+template <int BM, int BNT, int BK, int NSTAGE, bool FUSE0, int EPI, int PREC = 0>
+__device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p) {
     static_assert(!FUSE0 || (BK == 16 && BM == 128), "the in-kernel conv0 generator is written for BK = 16, BM = 128");
     static_assert(BM == 128 || BM == 256, "tile rows");
     static_assert(BNT == 128 || (BNT == 64 && BM == 128 && !FUSE0), "tile columns");
@@ -480,7 +477,6 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p, const 
     // grid = (sample groups, position blocks, column tiles): no division to take a block id apart
     // (split-K launches keep (sample groups x position blocks, column tiles, parts): their dispatch order matters more)
     int sg = blockIdx.x, pb = blockIdx.y, colz = blockIdx.z, zsp = 0;      // ..., column tile, split-K part
-    if (PERSIST) { sg = it_sg; pb = it_pb; colz = it_col; zsp = it_z; } else
     if (p.opt & 8) {
         // XCD-aware order on a 1-D grid: workgroup b runs on XCD b % 8 and every XCD has its own L2.  The
         // work items v are laid out so that the G items which share an operand are consecutive (G = p.xcd_group), and
@@ -533,10 +529,10 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p, const 
     const int K = 3 * p.Cin;
     // diagnostic timeline: lane 0 of every wave stamps the shader clock at the phase boundaries of its tile
 #define NAFP_TL(k_)                                                                            \
-    if (!PERSIST && p.tl && lane == 0)                                                                     \
+    if (p.tl && lane == 0)                                                                                 \
         p.tl[(((size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z)) * 8 + wave) * 8 + (k_)] = \
             __builtin_readcyclecounter();
-    if (!PERSIST && p.tl && lane == 0)
+    if (p.tl && lane == 0)
         p.tl[(((size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z)) * 8 + wave) * 8] =
             (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) |                    // HW_REG_HW_ID: wave/simd/cu/sh/se
             ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32);             // HW_REG_XCC_ID
@@ -1225,8 +1221,8 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p, const 
                     const f32x2 v2 = NAFP_ABL(p, 128) ? t2 : elu2(t2);    /* ablation 128: no exp */ \
                     const f32x2 z2 = v2 * gv[ms][rg][ni];                                      \
                     if (!NAFP_ABL(p, 64)) {                                /* ablation 64: no stores */ \
-                        __builtin_amdgcn_raw_buffer_store_b32(f2i(z2.x), rsY, voff, (2 * qp) * ystep_b + ni * 128, PERSIST ? 16 : NAFP_Z_AUX); \
-                        __builtin_amdgcn_raw_buffer_store_b32(f2i(z2.y), rsY, voff, (2 * qp + 1) * ystep_b + ni * 128, PERSIST ? 16 : NAFP_Z_AUX); \
+                        __builtin_amdgcn_raw_buffer_store_b32(f2i(z2.x), rsY, voff, (2 * qp) * ystep_b + ni * 128, NAFP_Z_AUX); \
+                        __builtin_amdgcn_raw_buffer_store_b32(f2i(z2.y), rsY, voff, (2 * qp + 1) * ystep_b + ni * 128, NAFP_Z_AUX); \
                     }                                                                          \
                     if (KEEP_) {                                           /* training keeps the pre-activation */ \
                         __builtin_amdgcn_raw_buffer_store_b32(f2i(t2.x), rsV, voff, (2 * qp) * ystep_b + ni * 128, NAFP_T_AUX); \
@@ -1288,7 +1284,7 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p, const 
 #pragma unroll
                     for (int w = 0; w < NW; ++w) t += red[w * 16 + which * 4 + sl] + red[w * 16 + 8 + which * 4 + sl];
                 }
-                stat_add(p.stats_out + 2 * (int64_t)b + which, t);
+                stat_add(p.stats_out + 2 * (int64_t)b + which, t, p.inv_n_in < 0.0);
             }
         }
     } else {
@@ -1298,8 +1294,8 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p, const 
             if (b < p.B) {
                 double ds = 0.0, dq = 0.0;
                 for (int pl = 0; pl < p.PT; ++pl) { ds += (double)rowS[pl * p.ST + tid]; dq += (double)rowQ[pl * p.ST + tid]; }
-                stat_add(p.stats_out + 2 * (int64_t)b, ds);
-                stat_add(p.stats_out + 2 * (int64_t)b + 1, dq);
+                stat_add(p.stats_out + 2 * (int64_t)b, ds, p.inv_n_in < 0.0);
+                stat_add(p.stats_out + 2 * (int64_t)b + 1, dq, p.inv_n_in < 0.0);
             }
         }
     }
@@ -1511,8 +1507,8 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(
             for (int e = 0; e < FIN_F4 / 256; ++e)
                 for (int h = 0; h < 2; ++h)
                     if (sPartB[w][e][h] == b) { ds += (double)sPart[w][e][h][0]; dq += (double)sPart[w][e][h][1]; }
-        stat_add(stats_out + 2 * (int64_t)b, ds);
-        stat_add(stats_out + 2 * (int64_t)b + 1, dq);
+        stat_add(stats_out + 2 * (int64_t)b, ds, inv_n_in < 0.0);
+        stat_add(stats_out + 2 * (int64_t)b + 1, dq, inv_n_in < 0.0);
     }
 }
 
@@ -1952,194 +1948,6 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     else if (f4_plan >= 1024 * 512) { NAFP_FIN(512); }
     else { NAFP_FIN(256); }
 #undef NAFP_FIN
-    NAFP_LAUNCH_CHECK();
-    return NAFP_OK;
-}
-
-// ============================================================================
-// [r5] The SMALL layers (b5 ... b7: convs 10-15 of the 1-s model; P <= 8 output positions) in ONE persistent launch.
-//
-// At the batch sizes the metric runs (640 per step / per rank) these six GEMMs have 40-160 output tiles each: every one of them
-// was a launch of <= 480 short workgroups (one round, split-K 3-6) plus a finish launch -- twelve launches that spend more time
-// filling, draining and waiting for their longest tile than multiplying (62-83 TFLOP/s; 316 us of a 3,345 us step for 7 % of its
-// FLOPs).  Here the work of all six layers is ONE ordered list of items (layer, 128-sample group, tile, split-K part), and a fixed
-// grid of workgroups claims items IN ORDER from a counter:
-//   * an item is the body of conv_gemm_body<128, 128, 16, 3, ., EPI 4>: its K-range of one output tile into the layer's slab,
-//     arrival ticket, and -- for the last arriver of the tile -- the parts summed in part order and the FULL epilogue;
-//   * the only dependency is per SAMPLE GROUP: a tile of layer j reads z_{j-1} and the statistics of ITS 128 samples only, so an
-//     item of (layer j, group g) waits until all tiles of (layer j-1, group g) are finished (one counter per (layer, group)),
-//     while other groups are layers ahead or behind: no per-layer barrier, the fill and drain of one layer overlaps the K-loops of
-//     its neighbours, and the live-tap classes / tile counts of different layers average out over the 256 CUs;
-//   * DEADLOCK-FREE under any residency (four generate streams share the chip): a waiter only ever waits for items with a
-//     SMALLER index, all of which were claimed before its own by workgroups that are running (a claim is made by a resident
-//     workgroup) and that in turn wait only for smaller indices; the smallest unfinished item never waits.  Every spin is bounded:
-//     on a time-out the workgroup raises the launch's error word and goes on (the tail then writes NaN rows: loud, never a hang);
-//   * visibility between workgroups of one launch (MI355X_MICROARCH.md): z and slab stores are write-through (sc1), every storing
-//     wave drains vmcnt before the finisher's counter increment; a consumer polls the counter relaxed, then ONE agent-scope
-//     acquire, then plain loads / LDS-DMA.  The statistics travel by agent-scope atomics as before.
-// ============================================================================
-constexpr int SMALLNET_MAX_LAYERS = 6;
-struct SmallNetLayer {
-    ConvKernelParams p;
-    int item0, n_items;            // this layer's items are [item0, item0 + n_items) of the launch
-    int sg_per_group;              // sample groups (tile rows of ST samples) per 128-sample dependency group
-    int items_per_group;           // of a FULL group: sg_per_group * n_pb * n_col * n_split
-    int n_groups, n_col;
-};
-struct SmallNetParams {
-    SmallNetLayer L[SMALLNET_MAX_LAYERS];
-    int n_layers, n_items, n_groups, prio_mode;
-    unsigned* ctrl;                // [0] next item, [1] error word, [16 + l * n_groups + g] finished tiles of (layer l, group g); zero at launch
-};
-constexpr int SMALLNET_CTRL_WORDS = 1024;
-constexpr unsigned SMALLNET_SPIN_LIMIT = 1u << 22;      // polls of ~0.25 us each: ~1 s
-
-__global__ __launch_bounds__(256, 2) void smallnet_kernel(const SmallNetParams P) {
-    __shared__ int s_item[4];
-    const int tid = threadIdx.x;
-    for (;;) {
-        if (tid == 0) s_item[0] = (int)__hip_atomic_fetch_add(P.ctrl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const int item = __builtin_amdgcn_readfirstlane(s_item[0]);
-        if (item >= P.n_items) return;
-        int l = 0;
-#pragma unroll
-        for (int k = 1; k < SMALLNET_MAX_LAYERS; ++k)
-            if (k < P.n_layers && item >= P.L[k].item0) l = k;
-        const SmallNetLayer& Ly = P.L[l];
-        const ConvKernelParams& p = Ly.p;
-        const int il = item - Ly.item0;
-        const int g = min(il / Ly.items_per_group, Ly.n_groups - 1);      // (only the last group can be short)
-        int rem = il - g * Ly.items_per_group;
-        const int zsp = rem % p.n_split; rem /= p.n_split;
-        const int colz = rem % Ly.n_col; rem /= Ly.n_col;
-        const int pb = rem % p.n_pb;
-        const int sg = g * Ly.sg_per_group + rem / p.n_pb;
-        // ---- dependency: every tile of (layer l - 1, group g) is finished ----
-        if (l > 0) {
-            if (tid == 0) {
-                const SmallNetLayer& Lp = P.L[l - 1];
-                const int sgs = min(Lp.sg_per_group, Lp.p.n_sg - g * Lp.sg_per_group);
-                const unsigned target = (unsigned)(sgs * Lp.p.n_pb * Lp.n_col);
-                const unsigned* cnt = P.ctrl + 16 + (l - 1) * P.n_groups + g;
-                unsigned spins = 0;
-                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > SMALLNET_SPIN_LIMIT) { __hip_atomic_store(P.ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-            __syncthreads();
-        }
-        // two workgroups of a CU share its matrix pipes: the one with the EARLIER layer goes first (its tiles are what later items wait for)
-        if (P.prio_mode == 1) {
-            if (l == 0) __builtin_amdgcn_s_setprio(3); else if (l == 1) __builtin_amdgcn_s_setprio(2);
-            else if (l == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-        } else if (P.prio_mode == 2) {
-            if (l & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
-        }
-        const bool finished = conv_gemm_body<128, 128, 16, 3, false, 4, 0, 1>(p, sg, pb, colz, zsp);
-        // every wave's stores (z, statistics) have left before the tile is counted as finished
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                    // ... and the LDS of this item is free for the next one
-        if (finished && tid == 0)
-            __hip_atomic_fetch_add(P.ctrl + 16 + l * P.n_groups + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// Split-K parts per tile of a small layer: parts of ~NAFP_SMALLNET_STEPS K-steps (the longest live-tap class decides)
-static int smallnet_split(const ConvGeom& g) {
-    static const int target = []() { const char* e = getenv("NAFP_SMALLNET_STEPS"); return e && atoi(e) > 0 ? atoi(e) : 24; }();
-    const int k = live_k_steps(g);
-    int S = (k + target / 2) / target;
-    S = std::max(1, std::min(8, S));
-    while (S > 1 && k / S < 8) --S;
-    return S;
-}
-bool smallnet_layer_ok(const ConvGeom& g) {
-    const int P = g.Fout * g.Tout;
-    return P <= 8 && g.Cin % 32 == 0 && g.Cout % BN == 0 && (g.stride == 1 || g.stride == 2);
-}
-// floats of split-K slab the persistent launch needs for layers [j0, j1]: every layer has a region of its own (groups of
-// different layers are in flight at the same time)
-int64_t smallnet_slab_floats(int64_t B, const ConvGeom* geoms, int j0, int j1) {
-    int64_t tot = 0;
-    for (int j = j0; j <= j1; ++j) tot += (int64_t)smallnet_split(geoms[j]) * B * geoms[j].Fout * geoms[j].Tout * geoms[j].Cout;
-    return tot;
-}
-
-int launch_smallnet(const SmallNetArgs& a, int64_t B, const ConvGeom* geoms, hipStream_t st) {
-    const int nl = a.j1 - a.j0 + 1;
-    if (nl < 1 || nl > SMALLNET_MAX_LAYERS || B <= 0 || B > (1 << 24)) return NAFP_ERR_UNSUPPORTED;
-    SmallNetParams P;
-    P.n_layers = nl; P.ctrl = a.ctrl;
-    static const int prio_mode = []() { const char* e = getenv("NAFP_SMALLNET_PRIO"); return e ? atoi(e) : 0; }();
-    P.prio_mode = prio_mode;
-    P.n_groups = (int)((B + 127) / 128);
-    if (16 + nl * P.n_groups > SMALLNET_CTRL_WORDS) return NAFP_ERR_UNSUPPORTED;
-    int item0 = 0; int64_t slab_off = 0; int ticket_off = 0;
-    static const int gemm_prio = []() { const char* e = getenv("NAFP_GEMM_PRIO"); return e ? atoi(e) : 0; }();
-    for (int k = 0; k < nl; ++k) {
-        const int j = a.j0 + k;
-        const ConvGeom& g = geoms[j];
-        if (!smallnet_layer_ok(g)) return NAFP_ERR_UNSUPPORTED;
-        SmallNetLayer& Ly = P.L[k];
-        ConvKernelParams& p = Ly.p;
-        p = ConvKernelParams{};
-        const FwdPlan fp = fwd_plan(B, g, true, false);
-        const int pt = fp.BM == 128 ? fp.pt : fwd_tile(g, 128).pt;
-        p.x = a.x[k]; p.wp = a.wp[k]; p.G = a.G[k]; p.Hb = a.Hb[k]; p.gamma_out = a.gamma_out[k]; p.bias = nullptr;
-        p.stats_in = a.stats_in[k]; p.stats_out = a.stats_out[k]; p.v_out = nullptr;
-        p.Fin = g.Fin; p.Tin = g.Tin; p.Cin = g.Cin; p.Tout = g.Tout; p.Cout = g.Cout;
-        p.axis = g.axis; p.stride = g.stride; p.pad = g.pad;
-        p.B = (int)B; p.P = g.Fout * g.Tout;
-        p.PT = pt; p.ST = 128 / pt;
-        p.log2ST = 0;
-        while ((1 << p.log2ST) < p.ST) ++p.log2ST;
-        if ((1 << p.log2ST) != p.ST || p.ST < 4) return NAFP_ERR_UNSUPPORTED;
-        p.n_sg = (int)((B + p.ST - 1) / p.ST);
-        p.n_pb = (p.P + p.PT - 1) / p.PT; p.log2_ncol = 0; p.xcd_group = 1; p.xcd_full = 0;
-        p.sample_in = (int64_t)g.Fin * g.Tin * g.Cin;
-        p.tap_stride = g.axis == 0 ? g.Cin : g.Tin * g.Cin;
-        p.inv_n_in = 1.0 / (double)p.sample_in;
-        p.mode = 2; p.dgrad = 0;
-        p.perm_on = (fp.BM == 128 ? fp.perm : (g.axis == 0 ? (fwd_tile(g, 128).perm) : 0)); p.perm_n0 = 0; p.perm_c0 = 0;
-        if ((int64_t)p.ST * p.sample_in * 4 >= ((int64_t)1 << 31)) return NAFP_ERR_UNSUPPORTED;
-        const int64_t wbytes = (int64_t)g.Cout * 3 * g.Cin * 4;
-        if (wbytes >= ((int64_t)1 << 31)) return NAFP_ERR_UNSUPPORTED;
-        p.wp_bytes = (unsigned)wbytes;
-        p.n_split = smallnet_split(g);
-        p.abl = 0; p.tl = nullptr; p.opt = gemm_prio & 3;
-        const int64_t out_floats = B * p.P * p.Cout;
-        if (slab_off + (int64_t)p.n_split * out_floats > a.slab_floats) return NAFP_ERR_WORKSPACE;
-        p.y = a.slab + slab_off; slab_off += (int64_t)p.n_split * out_floats;
-        p.y_final = a.y[k];
-        Ly.n_col = p.Cout / BN;
-        const int n_tiles = p.n_sg * p.n_pb * Ly.n_col;
-        if (ticket_off + n_tiles > NAFP_TICKET_SLOTS) return NAFP_ERR_UNSUPPORTED;
-        p.tickets = a.tickets + ticket_off; ticket_off += n_tiles;
-        p.f0_feat = nullptr; p.f0_w = nullptr; p.f0_bias = nullptr; p.f0_gamma = nullptr; p.f0_T = 0; p.f0_stride = 1; p.f0_pad = 0;
-        p.sj = ScalarsJob{nullptr, nullptr, nullptr, nullptr, 0, 0.0};
-        if (128 % p.ST != 0) return NAFP_ERR_UNSUPPORTED;
-        Ly.sg_per_group = 128 / p.ST;
-        Ly.n_groups = P.n_groups;
-        Ly.items_per_group = Ly.sg_per_group * p.n_pb * Ly.n_col * p.n_split;
-        Ly.item0 = item0; Ly.n_items = n_tiles * p.n_split;
-        item0 += Ly.n_items;
-    }
-    P.n_items = item0;
-    static bool attr = false;
-    const int lds = (3 * (128 + 128) * 16 + 2 * 128 + 96) * (int)sizeof(float);
-    if (!attr) { NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)smallnet_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr = true; }
-    static const int wgs = []() { const char* e = getenv("NAFP_SMALLNET_WGS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
-    const unsigned grid = (unsigned)std::min(P.n_items, wgs);
-    if (a.ev_start || a.ev_stop) {
-        SmallNetParams pc = P;
-        void* args[] = {(void*)&pc};
-        NAFP_HIP_CHECK(hipExtLaunchKernel((const void*)smallnet_kernel, dim3(grid), dim3(256), args, (size_t)lds, st, a.ev_start, a.ev_stop, 0));
-    } else {
-        smallnet_kernel<<<grid, 256, lds, st>>>(P);
-    }
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }

@@ -83,10 +83,13 @@ __device__ __forceinline__ void stat_poison(stat_t* sample_slots) {      // samp
     atomicOr((unsigned long long*)(sample_slots + 1), STAT_POISON);
 }
 // `slot` = &stats[2 b + which]; the pair of a sample is 16-byte aligned, so (slot | 8) is its sum-of-squares slot
-__device__ __forceinline__ void stat_add(stat_t* slot, double v) {
+// `range_is_benign` (the normalisation alternates, where nothing is normalised by these sums -- they only carry the poison): a FINITE
+// partial beyond the range is dropped instead of poisoning the sample.  keras gives finite rows for finite, large activations under
+// inference-mode batch_norm / layer_norm1d (a restored checkpoint with a large scale or a small moving variance); so does this.
+__device__ __forceinline__ void stat_add(stat_t* slot, double v, bool range_is_benign = false) {
     if (fabs(v) < STAT_PARTIAL_LIMIT)
         atomicAdd((unsigned long long*)slot, (unsigned long long)__double2ll_rn(v * (double)(1 << STAT_FRAC_BITS)));
-    else
+    else if (!(range_is_benign && fabs(v) < 1.0e300))          // (NaN and infinity fail the comparison: they poison either way)
         atomicOr((unsigned long long*)((uintptr_t)slot | 8), STAT_POISON);
 }
 __device__ __forceinline__ double stat_get(const stat_t* slot) {
@@ -152,7 +155,7 @@ __device__ __forceinline__ void atomic_min_float(float* addr, float v) {
 // subtraction / clamp / segment normalisation of melspectrogram.py:108-111 is applied on load.
 int launch_conv0(const float* feat, const float* w3, const float* bias, const float* gamma, float* y,
                  float* v_out, stat_t* stats, int64_t B, const ConvGeom& g, hipStream_t st,
-                 const float* gstat = nullptr, int group_size = 0, int segment_norm = 0);
+                 const float* gstat = nullptr, int group_size = 0, int segment_norm = 0, bool ident_stats = false);
 
 // implicit-GEMM conv (see conv.hip for the LayerNorm folding).
 constexpr int NAFP_TICKET_SLOTS = 4096;      // output tiles of a split-K launch that finishes in-kernel
@@ -193,20 +196,6 @@ int launch_conv0_stats(const float* feat, const float* w3, const float* bias, st
 int64_t conv_gemm_slab_floats(int64_t B, const ConvGeom& g, bool with_dgrad = false, int64_t plan_b = 0);   // workspace the split-K policy wants
 int64_t fwd_plan_b();      // the batch size the inference forward plans its tiles for (NAFP_PLAN_B, default 640; 0 = the launch's own size)
 int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStream_t st);
-// The small layers (P <= 8: convs 10-15 of the 1-s model) in one persistent launch (conv.hip, smallnet_kernel): layers j0 .. j1.
-constexpr int NAFP_SMALLNET_CTRL_WORDS = 1024;          // control block (next item, error word, per (layer, group) counters): zero at launch
-struct SmallNetArgs {
-    int j0, j1;
-    const float* x[6]; const float* wp[6]; const float* G[6]; const float* Hb[6]; const float* gamma_out[6];
-    const stat_t* stats_in[6]; stat_t* stats_out[6]; float* y[6];
-    float* slab; int64_t slab_floats;                    // >= smallnet_slab_floats()
-    unsigned* tickets;                                   // NAFP_TICKET_SLOTS arrival counters, zero on entry and exit
-    unsigned* ctrl;                                      // NAFP_SMALLNET_CTRL_WORDS words, zero on entry
-    hipEvent_t ev_start, ev_stop;
-};
-bool smallnet_layer_ok(const ConvGeom& g);
-int64_t smallnet_slab_floats(int64_t B, const ConvGeom* geoms, int j0, int j1);
-int launch_smallnet(const SmallNetArgs& a, int64_t B, const ConvGeom* geoms, hipStream_t st);
 int conv_timeline_set(unsigned long long* buf, int64_t capacity_u64, int cin, int cout, int positions);
 int conv_timeline_grid(int* out5);
 
@@ -238,7 +227,7 @@ struct TailArgs {
     int D, Q, S, l2norm;
     bool ident_stats;        // r_b = 1, c_b = 0 whatever `stats` holds (a poisoned sample: NaN): the alternates of norm.hip
     const int* nonfinite_weights;   // (or null) != 0: the parameter set holds a NaN / Inf -> every output row is NaN
-    const unsigned* launch_error;   // (or null) != 0: the persistent small-layer launch of this pass gave up a wait (smallnet_kernel) -> NaN rows
+    const unsigned* launch_error;   // (or null) != 0: a launch of this pass raised its error word -> NaN rows
 };
 int launch_tail(const TailArgs& a, int64_t B, hipStream_t st);
 

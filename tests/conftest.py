@@ -5,6 +5,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault('NAFP_TEST_HOOKS', '1')      # the library's test hook (option 6, tests/test_gpu_backward.py) is refused in any other process
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 if os.path.join(ROOT, 'tests') not in sys.path:

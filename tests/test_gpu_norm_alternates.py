@@ -227,3 +227,27 @@ def test_other_geometries(nafp, norm, emb_sz, observe):
     (tf(torch.tensor(feat, dtype=torch.float64)) * torch.tensor(d_emb, dtype=torch.float64)).sum().backward()
     worst = max(np.abs(g - p.grad.numpy()).max() / (np.abs(p.grad.numpy()).max() + 1e-12) for g, p in zip(grads, tf.params))
     observe(f'{norm}, 63 frames, EMB_SZ {emb_sz}: gradient, rel. to the tensor max', worst, 1e-4)
+
+
+def test_batch_norm_with_large_finite_activations_stays_finite(nafp, observe):
+    """Round-5 ADVICE: inference-mode batch normalisation normalises nothing per sample, so a checkpoint with a large scale (or a small
+    moving variance) drives the activations into the thousands.  keras gives finite rows for finite activations; the statistics these
+    kernels still accumulate (they only carry the NaN poison of a sample here) must not poison a sample because a partial sum left the
+    fixed-point range -- a finite partial beyond the range is dropped (nafp_common.h stat_add, range_is_benign)."""
+    w = _weights('batch_norm')
+    w['ln0.gamma'] = (w['ln0.gamma'] * 3000.0).astype(np.float32)        # (C,): the batch-norm scale of layer 0
+    m = _model(nafp, 'batch_norm', w)
+    rng = np.random.default_rng(5)
+    feat = (-rng.uniform(0, 1.2, size=(9, 256, 32, 1))).astype(np.float32)
+    flat = m.front_conv(torch.from_numpy(feat).cuda()).cpu().numpy()
+    emb = m(torch.from_numpy(feat).cuda()).cpu().numpy()
+    want_flat = o_nnfp.front_conv(feat, w, dtype=np.float64, norm='batch_norm')
+    want = o_nnfp.fingerprinter(feat, w, dtype=np.float64, norm='batch_norm')
+    assert np.abs(want_flat).max() > 100.0, 'the case must reach large activations'
+    assert np.isfinite(flat).all() and np.isfinite(emb).all()
+    observe('|d flat| / max |flat|', np.abs(flat - want_flat).max() / np.abs(want_flat).max(), 1e-5)
+    observe('|d emb|', np.abs(emb - want).max(), 1e-5)
+    # a NaN sample is still a NaN row and nothing else
+    feat[4, 10, 3, 0] = np.nan
+    emb2 = m(torch.from_numpy(feat).cuda()).cpu().numpy()
+    assert np.isnan(emb2[4]).all() and np.array_equal(np.delete(emb2, 4, 0), np.delete(emb, 4, 0))
