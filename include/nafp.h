@@ -168,7 +168,15 @@ int64_t nafp_encoder_workspace_bytes(const nafp_encoder* enc, int64_t n_seg);
 /* m_fp(feat) (nnfp.py:223-231).  feat (n_seg, in_f, in_t) float32.
  *   out_flat  optional (n_seg, flat_dim): front_conv output (nnfp.py:225), may be NULL
  *   out_emb   optional (n_seg, emb_sz): l2_normalize(div_enc(.)) if l2norm != 0,
- *             else div_enc(.) (use_L2layer, nnfp.py:228-231), may be NULL   */
+ *             else div_enc(.) (use_L2layer, nnfp.py:228-231), may be NULL
+ * LAUNCH-SIZE INDEPENDENCE AND WHAT IT COSTS SMALL LAUNCHES.  Every launch is planned -- tile shape, split-K factor, which finish runs --
+ * as if it held 640 segments (environment NAFP_PLAN_B; the generate / bench launch size), whatever n_seg is, and only the grids follow
+ * n_seg: the bytes of a segment's fingerprint do not depend on what shares its launch, at any n_seg (a launch with more split-K tiles
+ * than arrival counters, n_seg > ~4096, runs those layers as several sample ranges).  The price is paid by very small launches
+ * (n_seg = 1 .. 8, query-time latency): they no longer get the deeper split-K a plan for their own size would choose and leave most
+ * of the chip idle in the mid layers.  NAFP_PLAN_B=0 plans per launch again (fastest single-segment latency, fingerprints then differ
+ * in their last bits between launch sizes); a deployment that serves single queries next to a database built at 640 per launch
+ * should keep the default.   */
 int nafp_encoder_forward(nafp_encoder* enc, const float* feat, int64_t n_seg,
                          void* workspace, int64_t workspace_bytes,
                          float* out_flat, float* out_emb, int l2norm, void* stream);

@@ -1847,7 +1847,11 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     // conv7 0.119 -> 0.104 ms, conv9 0.193 -> 0.178 --, with 160 or fewer the finish kernel's finer split wins by 2-8 %)
     static const int fin_min = []() { const char* e = getenv("NAFP_SPLIT_INKERNEL"); return e ? atoi(e) : 320; }();
     // (decided at the planning batch like S itself: the two finishes group a sample's statistics into different partial sums)
-    const bool in_kernel_finish = fin_min > 0 && S > 1 && !a.plain && bn == 64 && a.tickets && n_tiles128_plan * (BN / bn) >= fin_min && n_tiles <= NAFP_TICKET_SLOTS;
+    // (round-5 ADVICE: the launch's own tile count used to decide as well -- above ~4096 segments convs 7 and 9 fell back to the finish
+    // kernel and a fingerprint's last bits depended on the launch size again; now a launch with more tiles than arrival counters runs as
+    // several launches over sample ranges, see below)
+    const bool in_kernel_finish = fin_min > 0 && S > 1 && !a.plain && bn == 64 && a.tickets && n_tiles128_plan * (BN / bn) >= fin_min &&
+                                  (int64_t)n_pb * (p.Cout / bn) <= NAFP_TICKET_SLOTS;
     // PLAIN split launches (the transposed convs) with arrival counters: the last arriver adds the parts and stores the result
     // (its epilogue is a sum: nothing like the FULL epilogue's serial tail) -- NAFP_PLAIN_INKERNEL=0 restores slab + plain_finish_kernel
     static const int plain_fin = []() { const char* e = getenv("NAFP_PLAIN_INKERNEL"); return e ? atoi(e) : 1; }();
@@ -1922,6 +1926,30 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
         p.wp_hm = a.wp_hm; p.wp_l = (const unsigned short*)a.wp_l;
         rc = launch_variant(conv_gemm_k16s3_plain_bf16x6, 128, 128, 16, NAFP_X6_K16_NSTAGE, p, grid, st, 128 * 8);
     } else
+    if (in_kernel_finish && n_tiles > NAFP_TICKET_SLOTS) {
+        // more output tiles than arrival counters: sample ranges of at most NAFP_TICKET_SLOTS tiles, one launch each (the last arrivers
+        // leave the counters at zero, so the ranges reuse them and the slab in stream order); every sample sees exactly the launch it
+        // would have seen in a smaller batch
+        const int64_t tiles_per_sg = (int64_t)n_pb * (p.Cout / bn);
+        const int64_t sg_per_launch = NAFP_TICKET_SLOTS / tiles_per_sg;
+        const int64_t b_step = sg_per_launch * p.ST;
+        const int64_t out_per_sample = (int64_t)p.P * p.Cout;
+        hipEvent_t ev0 = g_ev_start, ev1 = g_ev_stop;
+        rc = NAFP_OK;
+        for (int64_t b0 = 0; b0 < B && rc == NAFP_OK; b0 += b_step) {
+            ConvKernelParams q = p;
+            const int64_t bc = std::min<int64_t>(b_step, B - b0);
+            q.B = (int)bc; q.n_sg = (int)((bc + p.ST - 1) / p.ST);
+            q.x = p.x + b0 * p.sample_in; q.y_final = p.y_final + b0 * out_per_sample;
+            if (p.v_out) q.v_out = p.v_out + b0 * out_per_sample;
+            q.stats_in = p.stats_in + 2 * b0; q.stats_out = p.stats_out + 2 * b0;
+            g_ev_start = b0 == 0 ? ev0 : nullptr; g_ev_stop = b0 + b_step >= B ? ev1 : nullptr;
+            const dim3 gq((unsigned)((int64_t)q.n_sg * n_pb), (unsigned)(p.Cout / bn), (unsigned)S);
+            rc = two_stage ? launch_variant(conv_gemm_n64k16s2_tab[epi], 128, 64, 16, 2, q, gq, st)
+                           : launch_variant(conv_gemm_n64k16s3_tab[epi], 128, 64, 16, 3, q, gq, st);
+        }
+        return rc;
+    }
     rc = BM == 256 ? launch_variant(conv_gemm_m256k16s3_tab[epi], 256, 128, 16, 3, p, grid, st)
          : (bn == 64 && two_stage) ? launch_variant(conv_gemm_n64k16s2_tab[epi], 128, 64, 16, 2, p, grid, st)
          : bn == 64 ? launch_variant(conv_gemm_n64k16s3_tab[epi], 128, 64, 16, 3, p, grid, st)

@@ -58,6 +58,21 @@ def test_batch_independence_and_ragged_sizes(nafp, cfg):
     assert (1 - (full[idx].cpu().numpy() * want).sum(1)).max() < 1e-6
 
 
+def test_launch_size_independence_beyond_the_arrival_counters(nafp):
+    """Round-5 ADVICE: convs 7 and 9 finish their split-K in-kernel on one arrival counter per output tile (4096 of them); a launch of
+    more than ~4096 segments used to fall back to the finish kernel, which groups a sample's statistics into other partial sums -- the
+    last bits of a fingerprint depended on the launch size again.  Now such a launch runs those layers as sample ranges: 4,500 rows in
+    ONE launch == the same rows in launches of 640 and of 3, byte for byte."""
+    g = torch.Generator(device='cuda').manual_seed(11)
+    B = 4500
+    feat = -1.2 * torch.rand((B, 256, 32, 1), generator=g, device='cuda')
+    m_fp = nafp.FingerPrinter(seed=5)
+    whole = m_fp(feat).clone()
+    assert bool(torch.isfinite(whole).all())
+    for lo, n in ((0, 640), (640 * 6, 640), (4096, 404), (4497, 3)):
+        assert torch.equal(m_fp(feat[lo:lo + n]), whole[lo:lo + n]), (lo, n)
+
+
 def test_melspec_full_batch_properties(nafp, cfg):
     x = torch.from_numpy(_inputs.audio(640, seed=21)).cuda()
     m_pre = nafp.get_melspec_layer(cfg)
