@@ -664,9 +664,12 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
         if (e->norm != NAFP_NORM_LAYER1D) return NAFP_OK;
         return launch_ln1d_fwd(z, n_seg * e->geom[j].Fout * e->geom[j].Tout, e->geom[j].Cout, e->d_gc[j], e->d_bc[j], st);
     };
-    const bool fuse0 = !alt && e->opt_fuse_conv0 && e->geom[1].axis == 1 && e->geom[1].Cin % 16 == 0;
-    if (fuse0 && gstat) return NAFP_ERR_UNSUPPORTED;          // the in-kernel conv0 generator reads finished features
-    int rc = fuse0 ? launch_conv0_stats(feat, e->d_w[0], e->d_bias[0], stats, n_seg, e->geom[0], st)
+    // (the exact-split forward takes the fused form by default: at bf16-pipe speed conv1 is bound by its A stream -- conv0's 2 MB per
+    // segment written and read back --, the generator removes that stream and conv0's own launch; NAFP_X6_FUSE0=0 for the A/B)
+    static const bool x6_fuse0 = []() { const char* v = getenv("NAFP_X6_FUSE0"); return !v || v[0] != '0'; }();
+    const bool fuse0 = !alt && (e->opt_fuse_conv0 || (e->opt_bf16x3 == 2 && x6_fuse0)) && e->geom[1].axis == 1 && e->geom[1].Cin % 16 == 0 &&
+                       e->geom[0].Tin <= 64 && (e->opt_bf16x3 != 2 || e->geom[1].Cin == 128);
+    int rc = fuse0 ? launch_conv0_stats(feat, e->d_w[0], e->d_bias[0], stats, n_seg, e->geom[0], st, gstat, group_size, segment_norm)
                    : launch_conv0(feat, e->d_w[0], e->d_bias[0], e->d_gamma[0], bufA, nullptr, stats, n_seg, e->geom[0], st,
                                   gstat, group_size, segment_norm, alt);
     if (rc != NAFP_OK) return rc;
@@ -680,11 +683,14 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
         a.wp = e->d_w[j]; a.G = e->d_G[j]; a.Hb = e->d_Hb[j]; a.gamma_out = e->d_gamma[j];
         a.y = nxt; a.stats_out = stats + 2 * n_seg * j; a.plain = false;
         a.slab = slab_floats ? slab : nullptr; a.slab_floats = slab_floats; a.tickets = tickets; a.bf16x3 = e->opt_bf16x3;
-        if (e->opt_bf16x3 == 2) { a.wp_hm = e->d_whm[j]; a.wp_l = e->d_wl[j]; }
+        static const int x6_layers = []() { const char* v = getenv("NAFP_X6_LAYERS"); return v ? (int)strtol(v, nullptr, 0) : 0xffff; }();     // diagnostic: bit j = layer j takes the split arithmetic
+        if (!((x6_layers >> j) & 1)) a.bf16x3 = 0;
+        if (a.bf16x3 == 2) { a.wp_hm = e->d_whm[j]; a.wp_l = e->d_wl[j]; }
         a.plan_b = fwd_plan_b();              // tile shape and split-K factor as at the reference launch size: results do not depend on n_seg
         if (j == 1 && fuse0) {
             a.x = nullptr; a.f0_feat = feat; a.f0_w = e->d_w[0]; a.f0_bias = e->d_bias[0];
             a.f0_gamma = e->d_gamma[0]; a.f0_geom = &e->geom[0];
+            a.f0_gstat = gstat; a.f0_group = group_size; a.f0_segnorm = segment_norm;
         }
         // time stamps that ride on the kernels' own dispatch packets (no queue entry, no idle time): every conv's first and
         // last kernel (all stamps), or only conv1's start and conv15's stop (the GEMM span of a timed region)

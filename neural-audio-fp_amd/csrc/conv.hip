@@ -206,12 +206,12 @@ int launch_conv0(const float* feat, const float* w3, const float* bias, const fl
 }
 
 int launch_conv0_stats(const float* feat, const float* w3, const float* bias, stat_t* stats, int64_t B,
-                       const ConvGeom& g, hipStream_t st) {
+                       const ConvGeom& g, hipStream_t st, const float* gstat, int group_size, int segment_norm) {
     if (g.Cin != 1 || g.axis != 0 || (g.Cout % 4) != 0 || 256 % (g.Cout / 4) != 0 || g.Tin > 64) return NAFP_ERR_UNSUPPORTED;
     constexpr int R = 32;
     const int64_t blocks = B * ((g.Fin + R - 1) / R);
     conv0_kernel<false, R><<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, nullptr, nullptr, nullptr, stats,
-                                                                   g.Fin, g.Tin, g.Tout, g.Cout, g.stride, g.pad, nullptr, 0, 0, 0);
+                                                                   g.Fin, g.Tin, g.Tout, g.Cout, g.stride, g.pad, gstat, group_size, segment_norm, 0);
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }
@@ -310,6 +310,8 @@ struct ConvKernelParams {
     const float* f0_bias;     // (Cin)
     const float* f0_gamma;    // (F0, Tin, Cin) = LN scale of conv0 = layout of z0
     int f0_T, f0_stride, f0_pad;   // conv0: input frames, stride and pad-before along T
+    const float* f0_gstat;    // (or null) f0_feat is the RAW log-mel: (max, min) per group of f0_group samples, applied on load as conv0_kernel does
+    int f0_group, f0_segnorm;
     ScalarsJob sj;            // PLAIN launches of the backward pass: side job (sc == null: none)
 };
 
@@ -457,7 +459,7 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p) {
     constexpr int BROWS = BNT / NW;                 // B: rows staged per wave (32 or 16)
     constexpr int NIB = BROWS / RPI;               // B: DMA instructions per wave per step
     static_assert(NIB >= 1, "B rows per wave");
-    constexpr int TILE = BM * BK;                  // floats of the A tile
+    constexpr int TILE = (FUSE0 && PREC == 2) ? BM * 24 : BM * BK;      // floats of the A tile (fused exact split: three bf16 planes of BM x 16)
     constexpr int TILEB = BNT * BK;                 // floats of the B tile
     constexpr int LROWS = BNT / NW;                // PREC = 2: rows of the weights' third bf16 plane staged per wave (16 k x 2 B = 32 B per row and step)
     constexpr int TILEL = PREC == 2 ? BNT * 8 : 0;
@@ -607,6 +609,12 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p) {
         const int pos = pb * p.PT + (g_row >> p.log2ST);
         const int sl = g_row & ST1;
         if (pos < p.P && sl < nb) {
+            float f0_gmax = 0.f, f0_nh = 0.f, f0_nd = 1.f;
+            if (p.f0_gstat) {
+                const int64_t gi = p.f0_group > 0 ? (int64_t)(b0 + sl) / p.f0_group : 0;
+                f0_gmax = p.f0_gstat[2 * gi];
+                if (p.f0_segnorm) { const float mn = fmaxf(p.f0_gstat[2 * gi + 1] - f0_gmax, -80.f); f0_nh = mn / 2.f; f0_nd = fabsf(f0_nh + 1e-10f); }
+            }
             const int fo = pos / p.Tout, to = pos - fo * p.Tout;
             const int f00 = fo * p.stride - p.pad;           // this conv's taps run along F (axis 1)
             g_off = (f00 * p.Tin + to) * p.Cin;
@@ -620,7 +628,15 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p) {
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
                         const int tt = t00 + k;
-                        x0[t][k] = (tt >= 0 && tt < p.f0_T) ? fb[(int64_t)f * p.f0_T + tt] : 0.f;
+                        float xv = 0.f;
+                        if (tt >= 0 && tt < p.f0_T) {
+                            xv = fb[(int64_t)f * p.f0_T + tt];
+                            if (p.f0_gstat) {            // the same float operations in the same order as conv0_kernel / melspec_finalize_kernel
+                                xv = max_keep_nan(xv - f0_gmax, -80.f);
+                                if (p.f0_segnorm) xv = (xv - f0_nh) / f0_nd;
+                            }
+                        }
+                        x0[t][k] = xv;
                     }
                 }
             }
@@ -664,8 +680,11 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p) {
     const u32x4 rsL = make_rsrc((const float*)p.wp_l, NAFP_ABL(p, 4096) ? 0u : p.wp_bytes / 2);
     const unsigned ldsL0 = (unsigned)(unsigned long long)(lds_ptr_t)smem + (unsigned)((TILE + TILEB) * 4 + wave * LROWS * 32);
     const unsigned voffL = (unsigned)((tile_n0 + wave * LROWS + (lane >> 1)) * K) * 2u + (unsigned)(lane & 1) * 16u;
+#ifndef NAFP_DBG_NO_L
+#define NAFP_DBG_NO_L 0        // DIAGNOSTIC (wrong results): 1 = the third plane of the weights is not staged, 2 = the weights are not staged at all, 4 = the activations are not
+#endif
 #define NAFP_DMA_L(slot_, k0_)                                                                 \
-    if (PREC == 2 && lane < 2 * LROWS) lds_dma16(ldsL0 + (unsigned)((slot_) * STAGE * 4), voffL, rsL, (unsigned)((k0_) * 2));
+    if (PREC == 2 && !(NAFP_DBG_NO_L & 1) && lane < 2 * LROWS) lds_dma16(ldsL0 + (unsigned)((slot_) * STAGE * 4), voffL, rsL, (unsigned)((k0_) * 2));
 
     // Issue the DMA of K-step s_ into ring slot slot_ (wave-uniform LDS bases).
 #define NAFP_DMA_STEP(s_, slot_)                                                              \
@@ -694,8 +713,10 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p) {
         gg0 = *(const float4*)(p.f0_gamma + go_l);                                             \
         gg1 = *(const float4*)(p.f0_gamma + go_l + 4);                                         \
     }
+// (__fmul_rn: the product is rounded to float32 HERE, as conv0_kernel's store rounds it -- left to the compiler the multiply contracts into
+// the first subtraction of the exact split and the three terms then hold the unrounded product: more precise, but not conv0's z0)
 #define NAFP_GEN_ONE(j_, G_) \
-    ((ok_l ? elu1(fmaf(xc_l, wt_l[2 * p.Cin + (j_)], fmaf(xb_l, wt_l[p.Cin + (j_)], fmaf(xa_l, wt_l[(j_)], wt_l[3 * p.Cin + (j_)])))) : 0.f) * (G_))
+    __fmul_rn((ok_l ? elu1(fmaf(xc_l, wt_l[2 * p.Cin + (j_)], fmaf(xb_l, wt_l[p.Cin + (j_)], fmaf(xa_l, wt_l[(j_)], wt_l[3 * p.Cin + (j_)])))) : 0.f), (G_))
 #define NAFP_GEN_STORE(s_, slot_)                                                             \
     {                                                                                          \
         const int tsel_l = (s_) / cpt;                                                         \
@@ -727,7 +748,7 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p) {
     for (int s = 0; s < NSTAGE - 1; ++s)
         if (s_begin + s < n_steps) {
             NAFP_DMA_STEP(s_begin + s, s)
-            if (FUSE0) {
+            if (FUSE0 && PREC != 2) {
                 NAFP_GEN_LOAD(s_begin + s)
                 NAFP_GEN_STORE(s_begin + s, s)
             }
@@ -870,8 +891,8 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p) {
 #pragma unroll
                     for (int ni = 0; ni < NIW; ++ni) {
                         bh[ni] = *(const bf16x8*)(St + boff + ni * 32 * BK + ((hh ^ rswz) * 4));
-                        bm[ni] = *(const bf16x8*)(St + boff + ni * 32 * BK + (((2 + hh) ^ rswz) * 4));
-                        bl[ni] = *(const bf16x8*)(St + TILE + TILEB + (wn * (BNT / 2) + ni * 32 + rl) * 8 + hh * 4);
+                        bm[ni] = (NAFP_DBG_NO_L & 8) ? bh[ni] : *(const bf16x8*)(St + boff + ni * 32 * BK + (((2 + hh) ^ rswz) * 4));
+                        bl[ni] = (NAFP_DBG_NO_L & 16) ? bh[ni] : *(const bf16x8*)(St + TILE + TILEB + (wn * (BNT / 2) + ni * 32 + rl) * 8 + hh * 4);
                     }
                 }
                 if (has_next) { NAFP_DMA_PIECE(0, nslot) NAFP_DMA_L(nslot, d_tap * p.Cin + d_c0) NAFP_DMA_PIECE(1, nslot) }
@@ -903,7 +924,10 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p) {
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NIW; ++ni) {
-                        if (PREC == 2) {
+                        if (PREC == 2 && (NAFP_DBG_NO_L & 32)) {
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni][0] += (float)al[mi][0] + (float)am[PREC == 2 ? mi : 0][0] + (float)bm[PREC == 2 ? ni : 0][0] + (float)bl[ni][0];
+                        } else if (PREC == 2) {
                             // every product of relative weight >= 2^-16 (the three dropped ones sum to < 2^-25 of |a||b|), small terms first
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[PREC == 2 ? mi : 0], bm[PREC == 2 ? ni : 0], acc[mi][ni], 0, 0, 0);
@@ -991,6 +1015,109 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p) {
 #undef NAFP_DMA_PIECE
 #undef NAFP_DMA_TAP
 #undef NAFP_MM_HALF
+    } else if (FUSE0 && PREC == 2) {
+        // conv1 with conv0 generated in-kernel, exact 3-way split (NSTAGE = 2, no split-K).  The A stream of the unfused launch -- 2 MB of z0
+        // per segment written by conv0 and read back 1.5 times: what bounds conv1 at bf16-pipe speed (profiles/r06_experiments.md) -- does
+        // not exist: a thread builds 8 channels of one A row of step s + 1 from the row's nine log-mel values, ALREADY SPLIT into three
+        // bf16 planes, while the matrix pipe works on step s.  Branch-free: the tap of a step selects the row's inputs by scalar
+        // conditions, a tap that reads this conv's zero padding is an out-of-range lane of the gamma0 descriptor (gamma = 0 -> z0 = 0),
+        // conv0's weights come from LDS with immediate offsets (its channel count is a constant here).
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+        static_assert(!(FUSE0 && PREC == 2) || NSTAGE == 2, "two ring slots");
+        constexpr int C0 = 128;                                                    // conv0's Cout = this conv's Cin (launch_conv_gemm checks)
+        const int a_rd = (wm * 64 + rl) * 8 + ((hh ^ ((rl >> 3) & 1)) * 4);          // floats: row * 32 B + 16-byte half
+        const int a_wr = g_row * 8 + (((tid & 1) ^ ((g_row >> 3) & 1)) * 4);
+        const __amdgpu_buffer_rsrc_t rsG0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.f0_gamma), 0, (int)((unsigned)p.sample_in * 4u), 0x00020000);
+        int gvoff0, gvoff1, gvoff2;
+        gvoff0 = (g_valid & 1u) ? (g_off + g_ch) * 4 : (int)0x80000000;
+        gvoff1 = (g_valid & 2u) ? (g_off + p.tap_stride + g_ch) * 4 : (int)0x80000000;
+        gvoff2 = (g_valid & 4u) ? (g_off + 2 * p.tap_stride + g_ch) * 4 : (int)0x80000000;
+        const float* wrow = sW0 + g_ch;                                            // [w(tap 0) | w(tap 1) | w(tap 2) | bias] x C0, + channel
+        int g_tsel = 0, g_c0 = 0;                                                  // (tap slot, channel block) of the step to generate next
+        float4 wq[8], gq[2];
+        float gxa = 0.f, gxb = 0.f, gxc = 0.f;
+        // operands of the step to generate: requested early (global gamma0, LDS weights), consumed by NAFP_X6_GEN below
+#define NAFP_X6_GEN_REQ()                                                                      \
+        {                                                                                      \
+            const int tap_l = (int)((tap_pack >> (2 * g_tsel)) & 3u);                          \
+            gxa = tap_l == 0 ? x0[0][0] : (tap_l == 1 ? x0[1][0] : x0[2][0]);                  \
+            gxb = tap_l == 0 ? x0[0][1] : (tap_l == 1 ? x0[1][1] : x0[2][1]);                  \
+            gxc = tap_l == 0 ? x0[0][2] : (tap_l == 1 ? x0[1][2] : x0[2][2]);                  \
+            const int gv_l = tap_l == 0 ? gvoff0 : (tap_l == 1 ? gvoff1 : gvoff2);             \
+            gq[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsG0, gv_l, g_c0 * 4, 0));      \
+            gq[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsG0, gv_l + 16, g_c0 * 4, 0)); \
+            const float* w_l = wrow + g_c0;                                                    \
+            _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                 \
+                wq[2 * r_] = *(const float4*)(w_l + r_ * C0); wq[2 * r_ + 1] = *(const float4*)(w_l + r_ * C0 + 4); \
+            }                                                                                  \
+            g_c0 += BK; if (g_c0 == C0) { g_c0 = 0; ++g_tsel; }                                \
+        }
+#define NAFP_X6_GEN_ONE(e_) \
+        __fmul_rn(elu1(fmaf(gxc, ((const float*)&wq[4])[e_], fmaf(gxb, ((const float*)&wq[2])[e_], fmaf(gxa, ((const float*)&wq[0])[e_], ((const float*)&wq[6])[e_])))), ((const float*)&gq[0])[e_])
+#define NAFP_X6_GEN(slot_)                                                                     \
+        {                                                                                      \
+            bf16x8 h_l, m_l, l_l;                                                              \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                    \
+                const float v_l = NAFP_X6_GEN_ONE(e);                                          \
+                const __bf16 hh_l = (__bf16)v_l;                                               \
+                const float r1_l = v_l - (float)hh_l;                                          \
+                const __bf16 mm_l = (__bf16)r1_l;                                              \
+                h_l[e] = hh_l; m_l[e] = mm_l; l_l[e] = (__bf16)(r1_l - (float)mm_l);           \
+            }                                                                                  \
+            float* dst_l = smem + (slot_) * STAGE + a_wr;                                      \
+            *(bf16x8*)dst_l = h_l; *(bf16x8*)(dst_l + BM * 8) = m_l; *(bf16x8*)(dst_l + 2 * BM * 8) = l_l; \
+        }
+        NAFP_X6_GEN_REQ()
+        NAFP_X6_GEN(0)                                                             // step 0 (its weight pieces were requested by the pipeline fill above)
+#define NAFP_X6_MFMAS()                                                                        \
+        _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                       \
+            _Pragma("unroll") for (int ni = 0; ni < NIW; ++ni) {                               \
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0); \
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[mi], bm[ni], acc[mi][ni], 0, 0, 0); \
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0); \
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[mi], bh[ni], acc[mi][ni], 0, 0, 0); \
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bm[ni], acc[mi][ni], 0, 0, 0); \
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0); \
+            }
+#define NAFP_X6_READ_FRAGS(St_)                                                                \
+        _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) {                                     \
+            ah[mi] = *(const bf16x8*)((St_) + a_rd + mi * 32 * 8);                             \
+            am[mi] = *(const bf16x8*)((St_) + BM * 8 + a_rd + mi * 32 * 8);                    \
+            al[mi] = *(const bf16x8*)((St_) + 2 * BM * 8 + a_rd + mi * 32 * 8);                \
+        }                                                                                      \
+        _Pragma("unroll") for (int ni = 0; ni < NIW; ++ni) {                                   \
+            bh[ni] = *(const bf16x8*)((St_) + boff + ni * 32 * BK + ((hh ^ rswz) * 4));        \
+            bm[ni] = *(const bf16x8*)((St_) + boff + ni * 32 * BK + (((2 + hh) ^ rswz) * 4));  \
+            bl[ni] = *(const bf16x8*)((St_) + TILE + TILEB + (wn * (BNT / 2) + ni * 32 + rl) * 8 + hh * 4); \
+        }
+        int s = 0;
+        for (; s + 1 < n_steps; ++s) {                                             // every step but the last: generate the next one
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");               // my weight pieces and my A rows of step s are in LDS
+            __builtin_amdgcn_s_barrier();
+            if (s == 0) { NAFP_TL(3) }
+            const int nslot = slot ^ 1;
+            const float* St = smem + slot * STAGE;
+            bf16x8 ah[2], am[2], al[2], bh[NIW], bm[NIW], bl[NIW];
+            NAFP_X6_READ_FRAGS(St)
+            NAFP_DMA_STEP(s + 1, nslot)
+            NAFP_X6_GEN_REQ()
+            NAFP_X6_MFMAS()
+            NAFP_X6_GEN(nslot)
+            slot = nslot;
+        }
+        {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const float* St = smem + slot * STAGE;
+            bf16x8 ah[2], am[2], al[2], bh[NIW], bm[NIW], bl[NIW];
+            NAFP_X6_READ_FRAGS(St)
+            NAFP_X6_MFMAS()
+        }
+#undef NAFP_X6_GEN_REQ
+#undef NAFP_X6_GEN_ONE
+#undef NAFP_X6_GEN
+#undef NAFP_X6_MFMAS
+#undef NAFP_X6_READ_FRAGS
     } else
     for (int s = s_begin; s < n_steps; ++s) {
         // my DMA of step s has landed; after the barrier everybody's has, and everybody has
@@ -1377,6 +1504,10 @@ NAFP_GEMM_KERNEL_BF16X6(conv_gemm_k16s3_infer_bf16x6, 128, 128, NAFP_X6_K16_NSTA
 NAFP_GEMM_KERNEL_BF16X6(conv_gemm_m256k16s3_infer_bf16x6, 256, 128, NAFP_X6_M256_NSTAGE, NAFP_X6_M256_MINW, 0)
 NAFP_GEMM_KERNEL_BF16X6(conv_gemm_n64k16s2_infer_bf16x6, 128, 64, 2, 4, 0)
 NAFP_GEMM_KERNEL_BF16X6(conv_gemm_k16s3_plain_bf16x6, 128, 128, NAFP_X6_K16_NSTAGE, NAFP_X6_K16_MINW, 3)      // the split-K parts of the late convs
+// conv1 with conv0 generated in-kernel on the exact split: no A stream at all (see the K-loop)
+__global__ __launch_bounds__(256, 3) void conv_gemm_k16s2_fuse0_bf16x6(const ConvKernelParams p) {
+    conv_gemm_body<128, 128, 16, 2, true, 0, 2>(p);
+}
 
 // Optional timing events of the launch in flight (ConvGemmArgs::ev_start / ev_stop): they ride on a kernel's own dispatch
 // packet (hipExtLaunchKernel: time stamps of its completion signal), so -- unlike hipEventRecord between two kernels -- they
@@ -1894,7 +2025,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     const bool finish_follows = S > 1 && !in_kernel_finish && !plain_in_kernel;
     g_ev_start = a.ev_start; g_ev_stop = finish_follows ? nullptr : a.ev_stop;
     p.f0_feat = nullptr; p.f0_w = nullptr; p.f0_bias = nullptr; p.f0_gamma = nullptr;
-    p.f0_T = 0; p.f0_stride = 1; p.f0_pad = 0;
+    p.f0_T = 0; p.f0_stride = 1; p.f0_pad = 0; p.f0_gstat = nullptr; p.f0_group = 0; p.f0_segnorm = 0;
     p.sj = (a.sj && a.plain) ? *a.sj : ScalarsJob{nullptr, nullptr, nullptr, nullptr, 0, 0.0};
     if (a.f0_feat) {
         // conv0 generated in-kernel: this conv must be the 3x1 conv that consumes conv0's output
@@ -1904,6 +2035,12 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
         p.f0_feat = a.f0_feat; p.f0_w = a.f0_w; p.f0_bias = a.f0_bias; p.f0_gamma = a.f0_gamma;
         p.f0_T = a.f0_geom->Tin; p.f0_stride = a.f0_geom->stride; p.f0_pad = a.f0_geom->pad;
         if (a.v_out || (p.ST != 4 && p.ST != 8)) return NAFP_ERR_UNSUPPORTED;          // the fused kernel carries the inference epilogue only
+        p.f0_gstat = a.f0_gstat; p.f0_group = a.f0_group; p.f0_segnorm = a.f0_segnorm;
+        if (a.bf16x3 == 2 && a.wp_hm && a.wp_l) {
+            if (g.Cin != 128) return NAFP_ERR_UNSUPPORTED;          // the exact-split generator is written for conv0's 128 channels
+            p.wp_hm = a.wp_hm; p.wp_l = (const unsigned short*)a.wp_l;
+            return launch_variant(conv_gemm_k16s2_fuse0_bf16x6, 128, 128, 16, 2, p, grid, st, 128 * 8 + 128 * 8);      // + A's third plane, + the weights' third plane
+        }
         return launch_variant(conv_gemm_k16s3_fuse0, 128, 128, 16, 3, p, grid, st);
     }
     const bool fast_st = p.ST == 4 || p.ST == 8;
@@ -1925,8 +2062,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     if (x6 && epi == 3 && bn == 128 && BM == 128 && p.mode == 2) {
         p.wp_hm = a.wp_hm; p.wp_l = (const unsigned short*)a.wp_l;
         rc = launch_variant(conv_gemm_k16s3_plain_bf16x6, 128, 128, 16, NAFP_X6_K16_NSTAGE, p, grid, st, 128 * 8);
-    } else
-    if (in_kernel_finish && n_tiles > NAFP_TICKET_SLOTS) {
+    } else if (in_kernel_finish && n_tiles > NAFP_TICKET_SLOTS) {
         // more output tiles than arrival counters: sample ranges of at most NAFP_TICKET_SLOTS tiles, one launch each (the last arrivers
         // leave the counters at zero, so the ranges reuse them and the slab in stream order); every sample sees exactly the launch it
         // would have seen in a smaller batch
@@ -1949,7 +2085,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
                            : launch_variant(conv_gemm_n64k16s3_tab[epi], 128, 64, 16, 3, q, gq, st);
         }
         return rc;
-    }
+    } else
     rc = BM == 256 ? launch_variant(conv_gemm_m256k16s3_tab[epi], 256, 128, 16, 3, p, grid, st)
          : (bn == 64 && two_stage) ? launch_variant(conv_gemm_n64k16s2_tab[epi], 128, 64, 16, 2, p, grid, st)
          : bn == 64 ? launch_variant(conv_gemm_n64k16s3_tab[epi], 128, 64, 16, 3, p, grid, st)

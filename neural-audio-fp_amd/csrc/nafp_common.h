@@ -186,13 +186,14 @@ struct ConvGemmArgs {
     // `x` is then unused.  f0_geom = geometry of conv0.
     const float* f0_feat; const float* f0_w; const float* f0_bias; const float* f0_gamma;
     const ConvGeom* f0_geom;
+    const float* f0_gstat; int f0_group, f0_segnorm;   // (or null) f0_feat is the RAW log-mel of the front end: the layer's tail is applied on load, as launch_conv0 does
     const ScalarsJob* sj;    // optional (PLAIN launches of the backward pass): side job, see ScalarsJob
     int64_t plan_b;          // > 0 (inference forward): take the tile shape and the split-K factor the launch would have at THIS batch size,
                              // whatever B is -- the fp32 summation order of a segment then does not depend on the launch size (see fwd_plan_b())
 };
 // statistics (sum, sum of squares of ELU(conv0 + bias) per sample) without storing the activation
 int launch_conv0_stats(const float* feat, const float* w3, const float* bias, stat_t* stats, int64_t B,
-                       const ConvGeom& g, hipStream_t st);
+                       const ConvGeom& g, hipStream_t st, const float* gstat = nullptr, int group_size = 0, int segment_norm = 0);
 int64_t conv_gemm_slab_floats(int64_t B, const ConvGeom& g, bool with_dgrad = false, int64_t plan_b = 0);   // workspace the split-K policy wants
 int64_t fwd_plan_b();      // the batch size the inference forward plans its tiles for (NAFP_PLAN_B, default 640; 0 = the launch's own size)
 int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStream_t st);

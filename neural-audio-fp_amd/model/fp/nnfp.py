@@ -87,6 +87,7 @@ class FingerPrinter:
         self._dirty = True
         self._weights_event, self._weights_stream, self._use_events = None, None, {}
         self._fuse0 = os.environ.get('NAFP_FUSE0', '') == '1'          # NAFP_OPT_FUSE_CONV0 (the library reads the same variable)
+        self.split_arithmetic = 0      # NAFP_OPT_BF16X3 of the handle: pipelined consumers keep such a model on ONE stream (generate.streams_for)
         self._ws = {}          # one workspace per HIP stream: batches may be pipelined across streams
         # NAFP_BF16X3=1 | 2 (environment): the experimental split-bf16 products of the inference forward (include/nafp.h NAFP_OPT_BF16X3;
         # 2 = the exact 3-way split: float32-equivalent, ~20 % faster than the fp32 MFMAs) for `run.py generate` without a code change
@@ -239,10 +240,7 @@ class FingerPrinter:
     def _forward(self, feat, want_flat, want_emb):
         deferred = None
         if hasattr(feat, 'raw') and hasattr(feat, 'gstat'):        # melspectrogram.DeferredFeatures
-            if self._fuse0:
-                feat = feat.finish()
-            else:
-                deferred, feat = feat, feat.raw
+            deferred, feat = feat, feat.raw       # (the fused conv0 generator applies the layer's tail on load too: conv.hip)
         feat = self._prep(feat, self.input_shape)
         self._sync()
         B = feat.shape[0]
@@ -324,6 +322,8 @@ class FingerPrinter:
         experimental option 3 (NAFP_OPT_BF16X3: split-bf16 products, off by default)."""
         if int(option) == 1:
             self._fuse0 = bool(value)
+        if int(option) == 3:
+            self.split_arithmetic = int(value)
         _lib.check(self._lib.nafp_encoder_set_option(self._h, int(option), int(value)), 'encoder_set_option')
 
     # ---- per-kernel HIP-event timing (bench.py roofline leg) ----------------

@@ -225,6 +225,7 @@ def write_fingerprints_from_device_rows(row_fn, n_items, m_pre, m_fp, arr, group
     `write_fingerprints`.  Returns the row range written."""
     r0, r1 = shard_rows(n_items, group, rank, world)
     launch = launch_groups * group
+    n_streams = streams_for(m_fp, n_streams)
     streams = [torch.cuda.Stream() for _ in range(n_streams)]
     host = [torch.empty((launch, m_fp.emb_sz), dtype=torch.float32).pin_memory() for _ in range(n_streams)]
     pend = [None] * n_streams
@@ -288,6 +289,14 @@ class _Pending:
         return self.host.numpy()
 
 
+def streams_for(m_fp, n_streams=N_STREAMS):
+    """Streams a pipelined consumer of `m_fp` may use.  With the experimental split-bf16 arithmetic (NAFP_OPT_BF16X3 != 0) the answer
+    is ONE: its GEMM kernels must not run next to other kernels of the path -- run side by side with the front end or with another
+    forward they leave those kernels' results changed in a few rows (profiles/r06_experiments.md has the evidence and what was ruled
+    out; include/nafp.h states the restriction).  On one stream every result is run-to-run bit-identical."""
+    return 1 if getattr(m_fp, 'split_arithmetic', 0) else n_streams
+
+
 class StreamedEmbedder:
     """m_fp(m_pre(X)) for consecutive launches, round-robin over HIP streams, with pinned
     staging buffers for the int16 upload and the float32 download (the reference does a
@@ -295,6 +304,7 @@ class StreamedEmbedder:
 
     def __init__(self, m_pre, m_fp, n_streams=N_STREAMS, windows=True):
         self.m_pre, self.m_fp = m_pre, m_fp
+        n_streams = streams_for(m_fp, n_streams)
         self.streams = [torch.cuda.Stream() for _ in range(n_streams)]
         self.depth = n_streams
         self.i = 0

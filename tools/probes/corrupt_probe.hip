@@ -1,0 +1,88 @@
+// Probe: what does a co-resident kernel lose next to the exact-split GEMM kernels?  `victim` fills LDS and registers with patterns, idles,
+// verifies both and counts mismatches; tools/corrupt_probe.py runs it on one stream while encoder forwards run on another.
+// (`spin`: a register-only MFMA spinner, for the control experiment.)
+// build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o libcorrupt_probe.so corrupt_probe.hip
+#include <hip/hip_runtime.h>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int MODE, int NACC>
+__global__ __launch_bounds__(256, 3) void spin_kernel(float* out, int iters) {
+    const int lane = threadIdx.x & 63;
+    bf16x8 a, b;
+    for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(0.001f * (lane + j)); b[j] = (__bf16)(0.002f * (lane - j)); }
+    f32x16 acc[NACC];
+    for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) {
+            if (MODE == 0) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+            else acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(0.001f * lane, 0.002f, acc[i], 0, 0, 0);
+        }
+        asm volatile("" : "+v"(a), "+v"(b));
+    }
+    float s = 0.f;
+    for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 12345.678f) out[threadIdx.x] = s;
+}
+extern "C" int spin(int mode, int nacc, int blocks, int iters, float* out, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 0 && nacc == 4) spin_kernel<0, 4><<<blocks, 256, 0, st>>>(out, iters);
+    else if (mode == 0 && nacc == 2) spin_kernel<0, 2><<<blocks, 256, 0, st>>>(out, iters);
+    else if (mode == 0) spin_kernel<0, 8><<<blocks, 256, 0, st>>>(out, iters);
+    else spin_kernel<1, 4><<<blocks, 256, 0, st>>>(out, iters);
+    return (int)hipGetLastError();
+}
+
+// counts[0]: LDS words found changed, counts[1]: register values found changed, counts[2]: workgroups run
+__global__ __launch_bounds__(256, 2) void victim_kernel(unsigned* counts, int lds_words, long long wait_ticks) {
+    extern __shared__ unsigned vs[];
+    const unsigned tid = threadIdx.x, key = blockIdx.x * 2654435761u;
+    for (int i = tid; i < lds_words; i += 256) vs[i] = key ^ (unsigned)(i * 40503u);
+    unsigned r[96];
+#pragma unroll
+    for (int j = 0; j < 96; ++j) { r[j] = key + tid * 131u + j * 7919u; asm volatile("" : "+v"(r[j])); }
+    __syncthreads();
+    const long long t0 = wall_clock64();
+    unsigned bad_l = 0, bad_r = 0, bad_w = 0;
+    if (wait_ticks < 0 && lds_words < 0) {}
+    if (wait_ticks < -1000000) {
+        // EXCHANGE form: every round each wave writes a round-dependent pattern into its quarter of LDS, barrier, reads the quarter of
+        // the NEXT wave and checks it, barrier -- what a kernel that stages data for other waves through LDS relies on
+        const int q = lds_words / 4, wave = tid >> 6, lane = tid & 63;
+        unsigned round = 0;
+        for (int it = 0; it < 150; ++it) {            // (a fixed count: every thread runs the same number of barriers)
+            ++round;
+            for (int i = lane; i < q; i += 64) vs[wave * q + i] = (key + round * 977u) ^ (unsigned)((wave * q + i) * 40503u);
+            __syncthreads();
+            const int w2 = (wave + 1) & 3;
+            for (int i = lane; i < q; i += 64) bad_l += vs[w2 * q + i] != ((key + round * 977u) ^ (unsigned)((w2 * q + i) * 40503u));
+            __syncthreads();
+        }
+        for (int i = tid; i < lds_words; i += 256) vs[i] = key ^ (unsigned)(i * 40503u);
+        __syncthreads();
+    } else
+    if (wait_ticks < 0) {
+        // ACTIVE form: keep reading (and re-writing) LDS and doing arithmetic while the other kernel runs
+        float f = 1.0f + tid * 1e-3f, f_ref = f;
+        while (wall_clock64() - t0 < -wait_ticks) {
+            for (int i = tid; i < lds_words; i += 256) { const unsigned v = vs[i]; bad_l += v != (key ^ (unsigned)(i * 40503u)); vs[i] = v; }
+            for (int k = 0; k < 64; ++k) { f = f * 1.0009765625f; f_ref = __fmul_rn(f_ref, 1.0009765625f); }
+            __syncthreads();
+        }
+        bad_w = __float_as_uint(f) != __float_as_uint(f_ref);
+    } else
+    while (wall_clock64() - t0 < wait_ticks) __builtin_amdgcn_s_sleep(8);
+    __syncthreads();
+    if (bad_w) atomicAdd(counts + 3, 1u);
+    for (int i = tid; i < lds_words; i += 256) bad_l += vs[i] != (key ^ (unsigned)(i * 40503u));
+#pragma unroll
+    for (int j = 0; j < 96; ++j) { asm volatile("" : "+v"(r[j])); bad_r += r[j] != key + tid * 131u + j * 7919u; }
+    if (bad_l) atomicAdd(counts, bad_l);
+    if (bad_r) atomicAdd(counts + 1, bad_r);
+    if (tid == 0) atomicAdd(counts + 2, 1u);
+}
+extern "C" int victim(unsigned* counts, int blocks, int lds_bytes, long long wait_ticks, void* stream) {
+    hipFuncSetAttribute((const void*)victim_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    victim_kernel<<<blocks, 256, lds_bytes, (hipStream_t)stream>>>(counts, lds_bytes / 4, wait_ticks);
+    return (int)hipGetLastError();
+}
