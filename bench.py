@@ -46,6 +46,7 @@ if ROOT not in sys.path:
 
 BSZ = 640                      # BASELINE.json configs[1]
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (never the 2:1-sparsity figure)
 
 
 def conv_effective_macs(input_shape=(256, 32, 1)):
@@ -629,13 +630,44 @@ def main():
                 m_fp(m_pre(pool[i % n_pool], group_size=BSZ, defer=True))
         torch.cuda.synchronize()
         bel6 = time.perf_counter() - tb0
+        # its own roofline: the span of the GEMM convs from the library's dispatch-attached stamps (one span per step, as for `roofline`),
+        # and a per-conv pass for the table of profiles/r06_summary.md
+        m_fp.profile_enable(args.steps, coarse=2)
+        with torch.cuda.stream(streams[0]):
+            for i in range(args.steps):
+                m_fp(m_pre(pool[i % n_pool], group_size=BSZ, defer=True))
+        torch.cuda.synchronize()
+        prof6 = m_fp.profile_read()
+        m_fp.profile_enable(min(args.steps, 8))
+        with torch.cuda.stream(streams[0]):
+            for i in range(min(args.steps, 8)):
+                m_fp(m_pre(pool[i % n_pool], group_size=BSZ, defer=True))
+        torch.cuda.synchronize()
+        prof6_fine = m_fp.profile_read()
+        m_fp.profile_enable(0)
         m_fp.set_option(3, 0)
         bf16x6 = {'value': round(world * BSZ * args.steps / bel6, 1), 'unit': 'segments/s', 'ms_per_step': round(bel6 / args.steps * 1e3, 4),
                   'dtype': 'exact 3-way bf16 split x = h + m + l, 6 products (relative weight >= 2^-16), f32 accumulation, f32 storage',
                   'max_abs_diff_vs_f32_path': float((got6_emb - ref_emb).abs().max()),
                   'min_cosine_vs_f32_path': float((got6_emb * ref_emb).sum(1).min()),
-                  'note': 'experimental option NAFP_OPT_BF16X3 = 2 on the unsplit GEMM convs; float32-equivalent (error vs the float64 '
-                          'oracle = the f32 path\'s own: tests/test_gpu_parity_forward.py); a separate object, not part of `value`'}
+                  'note': 'experimental option NAFP_OPT_BF16X3 = 2: all 15 GEMM convs on the exact split, conv0 generated inside conv1; '
+                          'float32-equivalent (error vs the float64 oracle = the f32 path\'s own: tests/test_gpu_parity_forward.py, '
+                          'tests/test_gpu_exact_split_adversarial.py); single stream (the option must not overlap other kernels: '
+                          'include/nafp.h); a separate object, not part of `value`'}
+        macs6 = conv_effective_macs()
+        alg6 = 2.0 * sum(macs6[1:]) * BSZ                                   # algorithmic float32 FLOPs of the 15 GEMM convs per step
+        gemm6_ms = sum(sum(p[1:16]) for p in prof6) / len(prof6)
+        ex6 = 6.0 * alg6 / (gemm6_ms * 1e-3) / 1e12                         # executed bf16 TFLOP/s: six products per float32 product
+        bf16x6['roofline'] = {
+            'bound': 'mfma', 'kernel': 'conv_gemm_*_bf16x6 (15 launches/step; conv1 with conv0 generated in-kernel), v_mfma_f32_32x32x16_bf16',
+            'achieved': round(ex6, 1), 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s executed on the bf16 matrix pipe',
+            'frac': round(ex6 / BF16_MFMA_PEAK_TFLOPS, 4),
+            'f32_equivalent_TFLOP/s': round(alg6 / (gemm6_ms * 1e-3) / 1e12, 1),
+            'executed_flops_per_step': 6.0 * alg6, 'algorithmic_f32_flops_per_step': alg6, 'gemm_span_ms_per_step': round(gemm6_ms, 4),
+            'per_conv_ms': [round(sum(p[k] for p in prof6_fine) / len(prof6_fine), 4) for k in range(17)],
+            'note': 'executed FLOPs = 6 x the algorithmic float32 FLOPs (every product is formed as six bf16 products) / the span from the first '
+                    'GEMM-conv launch to the end of the last, against the dense bf16 matrix peak; never a fraction of the fp32 peak.  '
+                    'per_conv_ms[0] is the statistics pass of conv0 (its activation is generated inside conv1)'}
         bf16x3 = {'value': round(world * BSZ * args.steps / bel, 1), 'unit': 'segments/s', 'ms_per_step': round(bel / args.steps * 1e3, 4),
                   'dtype': 'bf16 x 3 products (hi*hi + hi*lo + lo*hi), f32 accumulation, f32 storage',
                   'max_abs_diff_vs_f32_path': float((got_emb - ref_emb).abs().max()),

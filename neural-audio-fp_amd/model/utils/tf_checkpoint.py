@@ -216,6 +216,7 @@ def state_dict_from_tf_checkpoint(prefix, names, shapes, emb_sz):
     # optimizer slots hang off the variables they belong to (`<variable>/.OPTIMIZER_SLOT/optimizer/{m,v}/...`): not weights
     tensors = read_bundle(prefix, want=lambda n: n.startswith('model/') and n.endswith(SUFFIX) and '/.OPTIMIZER_SLOT/' not in n)
     got, div = {}, {}
+    unrecognised = []
     for name, arr in tensors.items():
         m = _CONV.match(name)
         if m:
@@ -235,13 +236,27 @@ def state_dict_from_tf_checkpoint(prefix, names, shapes, emb_sz):
                 raise ValueError(f'{name}: found twice in the checkpoint')
             div[k2] = arr
             continue
-        raise ValueError(f'unrecognised model variable in the checkpoint: {name}')
+        unrecognised.append(name)
+    missing_div = []
     for fc in ('fc1', 'fc2'):
         for kind in ('kernel', 'bias'):
             parts = [div.get((q, fc, kind)) for q in range(emb_sz)]
             if any(p is None for p in parts):
-                raise KeyError(f'div_enc.{fc}.{kind}: {sum(p is None for p in parts)} of {emb_sz} slices missing')
-            got[f'div_enc.{fc}.{kind}'] = np.stack(parts)
+                missing_div.append(f'div_enc.{fc}.{kind} ({sum(p is None for p in parts)} of {emb_sz} slices)')
+            else:
+                got[f'div_enc.{fc}.{kind}'] = np.stack(parts)
+    missing = [n for n in names if n not in got]
+    if unrecognised or missing:
+        # the object-graph key names are the one part of this reader no TensorFlow-written file has confirmed: when they do not line
+        # up, say so with BOTH sides on the table instead of stopping at the first missing variable
+        def _some(xs):
+            return ', '.join(xs[:6]) + (f', ... ({len(xs)} in all)' if len(xs) > 6 else '')
+        raise KeyError(f'{prefix}: the checkpoint and the encoder do not name the same variables.\n'
+                       f'  encoder variables with no tensor in the checkpoint ({len(missing)}): {_some(missing) or "none"}'
+                       + (f'\n  incomplete divide-and-encode stacks: {_some(missing_div)}' if missing_div else '') +
+                       f'\n  model/... tensors of the checkpoint this reader has no variable for ({len(unrecognised)}): {_some(sorted(unrecognised)) or "none"}\n'
+                       f'  (expected keys: model/front_conv/layer_with_weights-<b>/{{conv2d_1x3,BN_1x3,conv2d_3x1,BN_3x1}}/<kind>{SUFFIX}, '
+                       f'model/div_enc/split_fc_layers/<q>/layer_with_weights-{{0,1}}/{{kernel,bias}}{SUFFIX})')
     if len(div) != 4 * emb_sz:
         raise ValueError('more divide-and-encode slices in the checkpoint than EMB_SZ')
     sd = {}

@@ -55,6 +55,15 @@ def test_bench_line_contract():
     r6 = d['train_rank640']
     assert r6['global_batch'] == 640 and r6['collectives']['backend'] == 'nccl' and r6['collectives']['world_size'] == 1
     assert abs(r6['exposed_comm_ms'] - (r6['ms_per_step'] - r6['no_process_group_ms_per_step'])) < 2e-3
+    # the exact-split object: its own roofline against the bf16 matrix peak (executed FLOPs = 6 x algorithmic), never the fp32 peak
+    x6 = d['bf16x6_f32_equivalent_experimental']
+    r6x = x6['roofline']
+    assert r6x['bound'] == 'mfma' and r6x['peak'] == 2500.0 and 0.05 < r6x['frac'] < 1.0
+    assert abs(r6x['frac'] - r6x['achieved'] / r6x['peak']) < 1e-3
+    assert abs(r6x['executed_flops_per_step'] - 6.0 * r6x['algorithmic_f32_flops_per_step']) < 1.0
+    assert abs(r6x['achieved'] - r6x['executed_flops_per_step'] / (r6x['gemm_span_ms_per_step'] * 1e-3) / 1e12) < 0.02 * r6x['achieved']
+    assert abs(r6x['f32_equivalent_TFLOP/s'] * 6.0 - r6x['achieved']) < 0.02 * r6x['achieved'] and len(r6x['per_conv_ms']) == 17
+    assert x6['min_cosine_vs_f32_path'] > 1 - 1e-6 and x6['value'] > 0
     e = d['e2e_generate']
     assert e['clips_100']['segments'] == 5900 and e['clips_600']['segments'] == 35400
     assert e['clips_100']['value'] > 0 and e['clips_600']['value'] > 0 and e['clips_600']['ingest_only_segments_per_s'] > 0

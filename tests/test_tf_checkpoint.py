@@ -189,8 +189,17 @@ def test_corruption_and_mismatch_are_detected(tfc, tmp_path):
         tfc.state_dict_from_tf_checkpoint(prefix, names, shapes, 128)
     extra = dict(keys); extra['model/front_conv/layer_with_weights-2/conv2d_5x5/kernel' + SUFFIX] = np.zeros(3, np.float32)
     write_bundle(prefix, extra, tfc)
-    with pytest.raises(ValueError, match='unrecognised'):
+    with pytest.raises(KeyError, match='conv2d_5x5'):
         tfc.state_dict_from_tf_checkpoint(prefix, names, shapes, 128)
+    # key names that do not line up are reported from BOTH sides (round-5 VERDICT item 8): a checkpoint that calls the LayerNorm of
+    # block 2 something else leaves four encoder variables without a tensor and four tensors without a variable -- all eight are named
+    renamed = {k.replace('layer_with_weights-2/BN_', 'layer_with_weights-2/LN_'): v for k, v in keys.items()}
+    write_bundle(prefix, renamed, tfc)
+    with pytest.raises(KeyError) as ei:
+        tfc.state_dict_from_tf_checkpoint(prefix, names, shapes, 128)
+    msg = str(ei.value)
+    assert 'front_conv.2.BN_1x3.gamma' in msg and 'front_conv.2.BN_3x1.beta' in msg and '(4)' in msg
+    assert 'layer_with_weights-2/LN_1x3/gamma' in msg and 'layer_with_weights-2/LN_3x1/beta' in msg
     write_bundle(prefix, keys, tfc, compression=1)
     with pytest.raises(NotImplementedError, match='compressed'):
         tfc.state_dict_from_tf_checkpoint(prefix, names, shapes, 128)
