@@ -1546,7 +1546,8 @@ int launch_split_weights_bf16(const float* wp, float* hm, void* wl, int Cout, in
 template <typename KernelT>
 static int launch_variant(KernelT kernel, int BM, int BNt, int BK, int NSTAGE, const ConvKernelParams& p, dim3 grid, hipStream_t st,
                           int extra_stage_floats = 0) {
-    const int lds = (NSTAGE * ((BM + BNt) * BK + extra_stage_floats) + 2 * BM + 96 + (p.f0_feat ? 4 * p.Cin : 0)) * (int)sizeof(float);
+    static const int lds_pad = []() { const char* e = getenv("NAFP_LDS_PAD"); return e ? atoi(e) : 0; }();      // diagnostic: extra dynamic LDS per workgroup (changes co-residency)
+    const int lds = (NSTAGE * ((BM + BNt) * BK + extra_stage_floats) + 2 * BM + 96 + (p.f0_feat ? 4 * p.Cin : 0)) * (int)sizeof(float) + lds_pad;
     NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     if (g_ev_start || g_ev_stop) {
         ConvKernelParams pc = p;

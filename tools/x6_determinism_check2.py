@@ -44,5 +44,8 @@ if __name__ == '__main__':
         n_emb = sum(0 if torch.equal(o[2], refs[i]) else 1 for i, o in enumerate(outs))
         # the encoder again, alone, on the features the concurrent pass produced
         n_again = sum(0 if torch.equal(m(o[3]), refs[i]) else 1 for i, o in enumerate(outs))
+        # ... and on the REFERENCE features once more: has the model's own state moved since the references were taken?
+        n_state = sum(0 if torch.equal(m(ref_f[i]), refs[i]) else 1 for i in range(n_l))
+        n_pair = sum(0 if torch.equal(m(o[3]), m(ref_f[i])) else 1 for i, o in enumerate(outs))
         print(f'opt {opt} rep {rep}: of {n_l} launches -- raw features differ {n_raw}, group statistics differ {n_gs}, fingerprints differ {n_emb}; '
-              f'encoder re-run alone on the same features differs {n_again}', flush=True)
+              f'encoder re-run alone on the same features differs {n_again}; alone on the REFERENCE features vs the first references {n_state}; concurrent-pass features vs reference features, both alone now {n_pair}', flush=True)
