@@ -205,9 +205,66 @@ int launch_conv0(const float* feat, const float* w3, const float* bias, const fl
     return NAFP_OK;
 }
 
+// conv0's statistics alone (the fused forms generate its activation inside conv1): one THREAD per output position, the channels in a
+// loop with conv0's weights as wave-uniform scalar operands -- 3 FMAs, the ELU and two accumulations per element and nothing else (no
+// LDS, no address arithmetic; conv0_kernel<false> spends more on its indexing than on the arithmetic: 177 us per 640 segments against
+// ~70 us of vector issue time).  A workgroup owns 256 consecutive positions of one sample; the sums leave as ONE fixed-point partial per
+// workgroup and statistic, formed in a fixed order.
+__global__ __launch_bounds__(256) void conv0_stats_kernel(const float* __restrict__ feat, const float* __restrict__ w3, const float* __restrict__ bias,
+                                                         stat_t* __restrict__ stats, int F, int Tin, int Tout, int Cout, int stride, int pad,
+                                                         const float* __restrict__ gstat, int group_size, int segment_norm) {
+    __shared__ double red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = F * Tout, blocks_per_sample = (P + 255) / 256;
+    const int64_t b = blockIdx.x / blocks_per_sample;
+    const int pos = (blockIdx.x % blocks_per_sample) * 256 + tid;
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+    const bool live = pos < P;
+    if (live) {
+        float gmax = 0.f, nh = 0.f, nd = 1.f;
+        if (gstat) {
+            const int64_t g = group_size > 0 ? b / group_size : 0;
+            gmax = gstat[2 * g];
+            if (segment_norm) { const float mn = fmaxf(gstat[2 * g + 1] - gmax, -80.f); nh = mn / 2.f; nd = fabsf(nh + 1e-10f); }
+        }
+        const int f = pos / Tout, to = pos - f * Tout;
+        const int t0 = to * stride - pad;
+        const float* xr = feat + (b * F + f) * (int64_t)Tin;
+        auto ld = [&](int t) {
+            if (t < 0 || t >= Tin) return 0.f;
+            float v = xr[t];
+            if (gstat) { v = max_keep_nan(v - gmax, -80.f); if (segment_norm) v = (v - nh) / nd; }
+            return v;
+        };
+        x0 = ld(t0); x1 = ld(t0 + 1); x2 = ld(t0 + 2);
+    }
+    float s = 0.f, q = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < Cout; ++c) {
+        const float v = elu1(fmaf(x2, w3[2 * Cout + c], fmaf(x1, w3[Cout + c], fmaf(x0, w3[c], bias[c]))));
+        s += v; q = fmaf(v, v, q);
+    }
+    if (!live) { s = 0.f; q = 0.f; }
+    const double ds = wave_sum((double)s), dq = wave_sum((double)q);
+    if (lane == 0) { red[wave] = ds; red[4 + wave] = dq; }
+    __syncthreads();
+    if (tid == 0) {
+        stat_add(stats + 2 * b, red[0] + red[1] + red[2] + red[3]);
+        stat_add(stats + 2 * b + 1, red[4] + red[5] + red[6] + red[7]);
+    }
+}
+
 int launch_conv0_stats(const float* feat, const float* w3, const float* bias, stat_t* stats, int64_t B,
                        const ConvGeom& g, hipStream_t st, const float* gstat, int group_size, int segment_norm) {
     if (g.Cin != 1 || g.axis != 0 || (g.Cout % 4) != 0 || 256 % (g.Cout / 4) != 0 || g.Tin > 64) return NAFP_ERR_UNSUPPORTED;
+    static const bool old_form = []() { const char* e = getenv("NAFP_CONV0_STATS_OLD"); return e && e[0] == '1'; }();
+    if (!old_form) {
+        const int64_t bps = ((int64_t)g.Fin * g.Tout + 255) / 256;
+        conv0_stats_kernel<<<dim3((unsigned)(B * bps)), 256, 0, st>>>(feat, w3, bias, stats, g.Fin, g.Tin, g.Tout, g.Cout, g.stride, g.pad,
+                                                                      gstat, group_size, segment_norm);
+        NAFP_LAUNCH_CHECK();
+        return NAFP_OK;
+    }
     constexpr int R = 32;
     const int64_t blocks = B * ((g.Fin + R - 1) / R);
     conv0_kernel<false, R><<<dim3((unsigned)blocks), 256, 0, st>>>(feat, w3, bias, nullptr, nullptr, nullptr, stats,
@@ -680,11 +737,8 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p) {
     const u32x4 rsL = make_rsrc((const float*)p.wp_l, NAFP_ABL(p, 4096) ? 0u : p.wp_bytes / 2);
     const unsigned ldsL0 = (unsigned)(unsigned long long)(lds_ptr_t)smem + (unsigned)((TILE + TILEB) * 4 + wave * LROWS * 32);
     const unsigned voffL = (unsigned)((tile_n0 + wave * LROWS + (lane >> 1)) * K) * 2u + (unsigned)(lane & 1) * 16u;
-#ifndef NAFP_DBG_NO_L
-#define NAFP_DBG_NO_L 0        // DIAGNOSTIC (wrong results): 1 = the third plane of the weights is not staged, 2 = the weights are not staged at all, 4 = the activations are not
-#endif
 #define NAFP_DMA_L(slot_, k0_)                                                                 \
-    if (PREC == 2 && !(NAFP_DBG_NO_L & 1) && lane < 2 * LROWS) lds_dma16(ldsL0 + (unsigned)((slot_) * STAGE * 4), voffL, rsL, (unsigned)((k0_) * 2));
+    if (PREC == 2 && lane < 2 * LROWS) lds_dma16(ldsL0 + (unsigned)((slot_) * STAGE * 4), voffL, rsL, (unsigned)((k0_) * 2));
 
     // Issue the DMA of K-step s_ into ring slot slot_ (wave-uniform LDS bases).
 #define NAFP_DMA_STEP(s_, slot_)                                                              \
@@ -891,8 +945,8 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p) {
 #pragma unroll
                     for (int ni = 0; ni < NIW; ++ni) {
                         bh[ni] = *(const bf16x8*)(St + boff + ni * 32 * BK + ((hh ^ rswz) * 4));
-                        bm[ni] = (NAFP_DBG_NO_L & 8) ? bh[ni] : *(const bf16x8*)(St + boff + ni * 32 * BK + (((2 + hh) ^ rswz) * 4));
-                        bl[ni] = (NAFP_DBG_NO_L & 16) ? bh[ni] : *(const bf16x8*)(St + TILE + TILEB + (wn * (BNT / 2) + ni * 32 + rl) * 8 + hh * 4);
+                        bm[ni] = *(const bf16x8*)(St + boff + ni * 32 * BK + (((2 + hh) ^ rswz) * 4));
+                        bl[ni] = *(const bf16x8*)(St + TILE + TILEB + (wn * (BNT / 2) + ni * 32 + rl) * 8 + hh * 4);
                     }
                 }
                 if (has_next) { NAFP_DMA_PIECE(0, nslot) NAFP_DMA_L(nslot, d_tap * p.Cin + d_c0) NAFP_DMA_PIECE(1, nslot) }
@@ -924,10 +978,7 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p) {
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NIW; ++ni) {
-                        if (PREC == 2 && (NAFP_DBG_NO_L & 32)) {
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-                            acc[mi][ni][0] += (float)al[mi][0] + (float)am[PREC == 2 ? mi : 0][0] + (float)bm[PREC == 2 ? ni : 0][0] + (float)bl[ni][0];
-                        } else if (PREC == 2) {
+                        if (PREC == 2) {
                             // every product of relative weight >= 2^-16 (the three dropped ones sum to < 2^-25 of |a||b|), small terms first
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[PREC == 2 ? mi : 0], bm[PREC == 2 ? ni : 0], acc[mi][ni], 0, 0, 0);
