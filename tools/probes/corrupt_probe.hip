@@ -86,3 +86,37 @@ extern "C" int victim(unsigned* counts, int blocks, int lds_bytes, long long wai
     victim_kernel<<<blocks, 256, lds_bytes, (hipStream_t)stream>>>(counts, lds_bytes / 4, wait_ticks);
     return (int)hipGetLastError();
 }
+
+// A victim with NO shared state at all: every thread recomputes the same chain of float operations (FMAs, packed FMAs, sqrt, exp2, log2,
+// a DPP add) from fixed inputs over and over and compares with its own first result.  counts[4 + which]: mismatching recomputations.
+__global__ __launch_bounds__(256, 2) void selfcheck_kernel(unsigned* counts, int rounds, int which) {
+    const unsigned tid = threadIdx.x;
+    float x[16], first[16];
+    unsigned bad = 0;
+    for (int rd = 0; rd < rounds; ++rd) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) x[j] = 0.37f + 0.011f * j + 0.0007f * tid + 0.05f * (blockIdx.x & 7);
+        asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+#pragma unroll 1
+        for (int it = 0; it < 24; ++it) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                float v = x[j];
+                if (which == 0) v = fmaf(v, 1.0009765625f, 0.03125f) - 0.03f * v;                                  // plain FMAs
+                else if (which == 1) v = sqrtf(v * v + 0.5f) * 0.9f;                                                 // v_sqrt_f32
+                else if (which == 2) v = __builtin_amdgcn_exp2f(v * 0.25f) - 0.4f;                                   // v_exp_f32
+                else if (which == 3) v = __builtin_amdgcn_logf(v + 1.5f) + 0.3f;                                     // v_log_f32
+                else v = v * 0.75f + __shfl_xor(v, 1 + (j & 3), 64) * 0.25f;                                         // cross-lane
+                x[j] = v;
+            }
+        }
+        if (rd == 0) { for (int j = 0; j < 16; ++j) first[j] = x[j]; }
+        else { for (int j = 0; j < 16; ++j) bad += __float_as_uint(x[j]) != __float_as_uint(first[j]); }
+    }
+    if (bad) atomicAdd(counts + 4 + which, bad);
+    if (tid == 0) atomicAdd(counts + 2, 1u);
+}
+extern "C" int selfcheck(unsigned* counts, int blocks, int rounds, int which, void* stream) {
+    selfcheck_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(counts, rounds, which);
+    return (int)hipGetLastError();
+}

@@ -379,110 +379,26 @@ __global__ __launch_bounds__(256, 2) void x6_gemm_256x128_sp(const float* __rest
             }
 }
 
-static unsigned short f2bf(float x) {      // round to nearest even
-    unsigned u; memcpy(&u, &x, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-static float bf2f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
-template <typename KT>
-static float time_kernel(KT kern, dim3 grid, int lds, const float* A, const unsigned short* Bhm, const unsigned short* Bl, float* C, int M, int K, int N, int reps) {
+// ---- library form (tools/corrupt_probe2.py): launch one of the probe's kernels on a caller's stream ----
+extern "C" int x6_probe_launch(int variant, const float* A, const unsigned short* Bhm, const unsigned short* Bl, float* C, int M, void* stream) {
+    const int K = 384, N = 128;
     const unsigned a_bytes = 640u * 256 * 16 * 128 * 4;
-    CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) kern<<<grid, 256, lds>>>(A, Bhm, Bl, C, M, K, N, a_bytes);
-    CHECK(hipDeviceSynchronize());
-    CHECK(hipEventRecord(e0));
-    for (int i = 0; i < reps; ++i) kern<<<grid, 256, lds>>>(A, Bhm, Bl, C, M, K, N, a_bytes);
-    CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
-    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-    return ms / reps;
-}
-
-int main(int argc, char** argv) {
-    const int rows_per = argc > 1 ? atoi(argv[1]) : 2048;
-    const int M = 640 * rows_per, K = 384, N = 128;
-    std::vector<float> hA((size_t)640 * 256 * 16 * 128), hB((size_t)N * K);
-    unsigned s = 12345u;
-    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
-    for (auto& v : hA) v = rnd() * 2.0f;
-    for (auto& v : hB) v = rnd() * 0.2f;
-    std::vector<unsigned short> hHm((size_t)N * K * 2), hL((size_t)N * K);
-    for (int n = 0; n < N; ++n)
-        for (int k = 0; k < K; ++k) {
-            const float x = hB[(size_t)n * K + k];
-            const unsigned short h = f2bf(x); const float r1 = x - bf2f(h);
-            const unsigned short m = f2bf(r1); const unsigned short l = f2bf(r1 - bf2f(m));
-            const size_t base = (size_t)n * 2 * K + (size_t)(k >> 4) * 32;
-            hHm[base + (k & 15)] = h; hHm[base + 16 + (k & 15)] = m; hL[(size_t)n * K + k] = l;
-        }
-    float *dA, *dC; unsigned short *dHm, *dL;
-    CHECK(hipMalloc(&dA, hA.size() * 4)); CHECK(hipMalloc(&dC, (size_t)M * N * 4));
-    CHECK(hipMalloc(&dHm, hHm.size() * 2)); CHECK(hipMalloc(&dL, hL.size() * 2));
-    CHECK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
-    CHECK(hipMemcpy(dHm, hHm.data(), hHm.size() * 2, hipMemcpyHostToDevice));
-    CHECK(hipMemcpy(dL, hL.data(), hL.size() * 2, hipMemcpyHostToDevice));
     const dim3 grid(M / 256, N / 128);
-    const unsigned a_bytes = 640u * 256 * 16 * 128 * 4;
-    const double flop = 2.0 * M * K * N;
-    auto report = [&](const char* name, float ms) {
-        printf("%-34s %.3f ms  %.1f TFLOP/s f32-equivalent  (matrix pipe %.0f %% of 2.5 PF)\n", name, ms, flop / ms * 1e-9, 6.0 * flop / ms * 1e-9 / 2500.0 * 100.0);
-    };
-    const int ldsA = 256 * 16 * 4, ldsB = (128 * 16 + 128 * 8) * 4;
-    // correctness of the default variant against a float64 host product on the first 256 rows
-    CHECK(hipMemset(dC, 0, (size_t)M * N * 4));
-    {
-        auto kern = x6_gemm_256x128<3, 2, 0>;
-        const int lds = 3 * ldsA + 2 * ldsB;
-        CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        kern<<<grid, 256, lds>>>(dA, dHm, dL, dC, M, K, N, a_bytes);
-        CHECK(hipDeviceSynchronize());
-        std::vector<float> hC((size_t)512 * N);
-        CHECK(hipMemcpy(hC.data(), dC + (size_t)(M - 512) * N, hC.size() * 4, hipMemcpyDeviceToHost));
-        double emax = 0, ref_max = 0;
-        for (int i = 0; i < 512; ++i)
-            for (int n = 0; n < N; ++n) {
-                double w = 0;
-                for (int k = 0; k < K; ++k) { const size_t o = (size_t)a_row_off((M - 512 + i) / 256, (M - 512 + i) % 256) + a_step_off(k >> 4) + (k & 15); w += (o < hA.size() ? (double)hA[o] : 0.0) * (double)hB[(size_t)n * K + b_step(k >> 4) * 16 + (k & 15)]; }
-                emax = fmax(emax, fabs(w - hC[(size_t)i * N + n])); ref_max = fmax(ref_max, fabs(w));
-            }
-        printf("check: max |C - A B^T| = %.3g  (max |C| = %.3g, relative %.3g)\n", emax, ref_max, emax / ref_max);
+    const int ldsA = 256 * 16 * 4, ldsB = (128 * 16 + 128 * 8) * 4, lds = 2 * ldsA + 2 * ldsB;
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(kern_) { auto k_ = kern_; hipFuncSetAttribute((const void*)k_, hipFuncAttributeMaxDynamicSharedMemorySize, lds); k_<<<grid, 256, lds, st>>>(A, Bhm, Bl, C, M, K, N, a_bytes); }
+    switch (variant) {
+        case 0: LAUNCH((x6_gemm_256x128<2, 2, 0>)) break;            // the whole K-loop
+        case 1: LAUNCH((x6_gemm_256x128<2, 2, 1>)) break;            // no DMA inside the loop
+        case 2: LAUNCH((x6_gemm_256x128<2, 2, 4>)) break;            // DMA only
+        case 3: LAUNCH((x6_gemm_256x128<2, 2, 1 | 64>)) break;       // register-only MFMAs (+ barrier)
+        case 4: LAUNCH((x6_gemm_256x128<2, 2, 2>)) break;            // no split (one cvt per element)
+        case 5: LAUNCH((x6_gemm_256x128<2, 2, 1 | 256>)) break;      // LDS reads + split, NO MFMAs
+        case 6: LAUNCH((x6_gemm_256x128<2, 2, 1 | 512 | 1024>)) break;   // split + MFMAs on computed operands, NO LDS reads
+        case 7: LAUNCH((x6_gemm_256x128<2, 2, 1 | 512>)) break;      // no A reads (B from LDS)
+        case 8: LAUNCH((x6_gemm_256x128<2, 2, 1 | 1024>)) break;     // no B reads (A from LDS)
+        default: return -1;
     }
-    auto check = [&](const char* name) {
-        std::vector<float> hC((size_t)512 * N);
-        CHECK(hipMemcpy(hC.data(), dC + (size_t)(M - 512) * N, hC.size() * 4, hipMemcpyDeviceToHost));
-        double emax = 0, ref_max = 0;
-        for (int i = 0; i < 512; ++i)
-            for (int n = 0; n < N; ++n) {
-                double w = 0;
-                for (int k = 0; k < K; ++k) { const size_t o = (size_t)a_row_off((M - 512 + i) / 256, (M - 512 + i) % 256) + a_step_off(k >> 4) + (k & 15); w += (o < hA.size() ? (double)hA[o] : 0.0) * (double)hB[(size_t)n * K + b_step(k >> 4) * 16 + (k & 15)]; }
-                emax = fmax(emax, fabs(w - hC[(size_t)i * N + n])); ref_max = fmax(ref_max, fabs(w));
-            }
-        printf("check %s: max |C - A B^T| = %.3g  (relative %.3g)\n", name, emax, emax / ref_max);
-    };
-    {
-        CHECK(hipMemset(dC, 0, (size_t)M * N * 4));
-        time_kernel(x6_gemm_256x128_sp<2, 2, 1>, grid, 2 * ldsA + 2 * ldsB, dA, dHm, dL, dC, M, K, N, 1); check("sp<2,2,1>");
-        CHECK(hipMemset(dC, 0, (size_t)M * N * 4));
-        time_kernel(x6_gemm_256x128_sp<3, 2, 0>, grid, 3 * ldsA + 2 * ldsB, dA, dHm, dL, dC, M, K, N, 1); check("sp<3,2,0>");
-    }
-    for (int rep = 0; rep < 2; ++rep) {
-        report("sp 256x128 NA=2 NB=2 sched", time_kernel(x6_gemm_256x128_sp<2, 2, 1>, grid, 2 * ldsA + 2 * ldsB, dA, dHm, dL, dC, M, K, N, 20));
-        report("sp 256x128 NA=3 NB=2 sched", time_kernel(x6_gemm_256x128_sp<3, 2, 1>, grid, 3 * ldsA + 2 * ldsB, dA, dHm, dL, dC, M, K, N, 20));
-        report("256x128 NA=2 NB=2", time_kernel(x6_gemm_256x128<2, 2, 0>, grid, 2 * ldsA + 2 * ldsB, dA, dHm, dL, dC, M, K, N, 20));
-        report("256x128 NA=2 NB=2 no DMA in loop", time_kernel(x6_gemm_256x128<2, 2, 1>, grid, 2 * ldsA + 2 * ldsB, dA, dHm, dL, dC, M, K, N, 20));
-        report("256x128 MFMA only (registers), barrier", time_kernel(x6_gemm_256x128<2, 2, 1 | 64>, grid, 2 * ldsA + 2 * ldsB, dA, dHm, dL, dC, M, K, N, 20));
-        report("256x128 MFMA only (registers), no barrier", time_kernel(x6_gemm_256x128<2, 2, 1 | 64 | 128>, grid, 2 * ldsA + 2 * ldsB, dA, dHm, dL, dC, M, K, N, 20));
-        report("256x128 NA=2 NB=2 DMA only", time_kernel(x6_gemm_256x128<2, 2, 4>, grid, 2 * ldsA + 2 * ldsB, dA, dHm, dL, dC, M, K, N, 20));
-        report("256x128 NA=2 NB=2 DMA only, A only", time_kernel(x6_gemm_256x128<2, 2, 4 | 32>, grid, 2 * ldsA + 2 * ldsB, dA, dHm, dL, dC, M, K, N, 20));
-        report("256x128 NA=2 NB=2 DMA only, B only", time_kernel(x6_gemm_256x128<2, 2, 4 | 16>, grid, 2 * ldsA + 2 * ldsB, dA, dHm, dL, dC, M, K, N, 20));
-        report("256x128 NA=2 NB=2 DMA only, B only, B contiguous", time_kernel(x6_gemm_256x128<2, 2, 4 | 16 | 8>, grid, 2 * ldsA + 2 * ldsB, dA, dHm, dL, dC, M, K, N, 20));
-        report("256x128 NA=2 NB=2 DMA only, B contiguous", time_kernel(x6_gemm_256x128<2, 2, 4 | 8>, grid, 2 * ldsA + 2 * ldsB, dA, dHm, dL, dC, M, K, N, 20));
-        report("256x128 NA=2 NB=2 B contiguous (wrong B)", time_kernel(x6_gemm_256x128<2, 2, 8>, grid, 2 * ldsA + 2 * ldsB, dA, dHm, dL, dC, M, K, N, 20));
-        report("256x128 NA=2 NB=2 no B DMA", time_kernel(x6_gemm_256x128<2, 2, 32>, grid, 2 * ldsA + 2 * ldsB, dA, dHm, dL, dC, M, K, N, 20));
-        report("256x128 NA=2 NB=2 no A DMA", time_kernel(x6_gemm_256x128<2, 2, 16>, grid, 2 * ldsA + 2 * ldsB, dA, dHm, dL, dC, M, K, N, 20));
-    }
-    return 0;
+    return (int)hipGetLastError();
 }

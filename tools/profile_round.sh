@@ -15,6 +15,10 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_sq2 -o p -- python bench.py --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-pipelined --no-train --no-e2e > /dev/null 2> $O/pmc_sq2.err
 find $O -name "*.csv" | head -20
 tail -c 600 $O/bench.json
+# [r6] the exact-split forward (NAFP_OPT_BF16X3 = 2) alone: kernel trace and one SQ pass (matrix-pipe busy share, clock)
+X6_ONLY=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/x6_trace -o t -- python tools/x6_per_conv.py > $O/x6_per_conv.txt 2> $O/x6_trace.err
+X6_ONLY=1 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $O/x6_pmc_sq -o p -- python tools/x6_per_conv.py > /dev/null 2> $O/x6_pmc_sq.err
+python tools/x6_per_conv.py > $O/x6_per_conv_plain.txt 2>&1
 # train step (BSZ 1280, Adam: SURVEY 8d config 3) kernel trace
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_trace -o t -- python tools/train_probe.py 1280 adam 5 > $O/train_probe.txt 2> $O/train_trace.err
 # train step at the headline batch (BASELINE configs[3] on one GPU: BSZ 5120, LAMB)

@@ -334,6 +334,37 @@ for name, title in (('search', 'Exact search (eval side): `python tools/search_b
         for r in read_csv(st)[:5]:
             f.write(f'| `{r["Name"][:70]}` | {r["Calls"]} | {float(r["AverageNs"]) / 1e3:.1f} | {float(r["TotalDurationNs"]) / 1e6:.2f} |\n')
         f.write('\n```\n' + '\n'.join(txt) + '\n```\n')
+# ---- [r6] the exact-split forward: per-kernel durations and matrix-pipe busy share ----
+x6s = os.path.join(src, 'x6_trace', 't_kernel_stats.csv')
+if os.path.exists(x6s):
+    shutil.copy(x6s, os.path.join(dst, f'{tag}_x6_kernel_stats.csv'))
+    with open(os.path.join(dst, f'{tag}_summary.md'), 'a') as f:
+        f.write('\n## The exact 3-way bf16 split (NAFP_OPT_BF16X3 = 2; `tools/x6_per_conv.py`, B = 640, one stream)\n\n')
+        for nm in ('x6_per_conv_plain.txt', 'x6_per_conv.txt'):
+            pth = os.path.join(src, nm)
+            if os.path.exists(pth):
+                lines = [l for l in open(pth).read().splitlines() if l.startswith('opt')]
+                if lines:
+                    f.write(('un-profiled' if 'plain' in nm else 'under rocprofv3') + ' (per-conv ms from the dispatch-attached stamps):\n\n```\n' + '\n'.join(lines) + '\n```\n\n')
+        f.write(f'Kernels under `rocprofv3 --kernel-trace --stats` (full CSV: `{tag}_x6_kernel_stats.csv`):\n\n| kernel | calls | avg us | total ms |\n|---|---|---|---|\n')
+        for r in read_csv(x6s)[:12]:
+            f.write(f'| `{r["Name"][:80]}` | {r["Calls"]} | {float(r["AverageNs"]) / 1e3:.1f} | {float(r["TotalDurationNs"]) / 1e6:.2f} |\n')
+        pq = os.path.join(src, 'x6_pmc_sq', 'p_counter_collection.csv')
+        if os.path.exists(pq):
+            acc = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(int)
+            for r in read_csv(pq):
+                k = r['Kernel_Name'].split('(')[0].replace('nafp::', '').replace('void ', '')[:60]
+                acc[k][r['Counter_Name']] += float(r['Counter_Value'])
+                if r['Counter_Name'] == 'GRBM_GUI_ACTIVE':
+                    acc[k]['_dur'] += int(r['End_Timestamp']) - int(r['Start_Timestamp']); cnt[k] += 1
+            f.write('\nSQ counters (one `--pmc` pass; sums over the launches of the run; busy % = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x shader cycles), '
+                    'GHz = GRBM_GUI_ACTIVE / 8 XCDs / duration):\n\n| kernel | launches | mean us | clock GHz | matrix pipe busy % | WAIT_ANY % | WAIT_INST % |\n|---|---|---|---|---|---|---|\n')
+            for k, a in sorted(acc.items(), key=lambda kv: -kv[1].get('_dur', 0)):
+                if 'conv_gemm' not in k or not a.get('GRBM_GUI_ACTIVE') or not cnt[k]:
+                    continue
+                cyc = a['GRBM_GUI_ACTIVE'] / 8.0
+                f.write(f'| `{k}` | {cnt[k]} | {a["_dur"] / cnt[k] / 1e3:.1f} | {cyc / a["_dur"]:.2f} | {a["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc) * 100:.1f} | '
+                        f'{a["SQ_WAIT_ANY"] / a["SQ_WAVE_CYCLES"] * 100:.1f} | {a["SQ_WAIT_INST_ANY"] / a["SQ_WAVE_CYCLES"] * 100:.1f} |\n')
 for b_, title_ in ((5120, 'Global batch 5120, LAMB'), (640, 'Per-rank batch 640, LAMB')):
     sqp = os.path.join(dst, f'{tag}_train{b_}_sq.txt')
     if os.path.exists(sqp):
