@@ -136,6 +136,13 @@ __global__ __launch_bounds__(256, 2) void x6_gemm_256x128(const float* __restric
         }
         for (int s = 0; s < S; ++s) {
             if (!(MODE & 128)) __builtin_amdgcn_s_barrier();
+            if (MODE & 2048) {
+                // product-major: consecutive MFMAs go to DIFFERENT accumulators (8 independent ones between two uses of the same)
+#define PROD(A_, B_) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) \
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[mi], B_[ni], acc[mi][ni], 0, 0, 0);
+                PROD(al, bh) PROD(am, bm) PROD(ah, bl) PROD(am, bh) PROD(ah, bm) PROD(ah, bh)
+#undef PROD
+            } else
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -474,6 +481,7 @@ int main(int argc, char** argv) {
         report("256x128 NA=2 NB=2", time_kernel(x6_gemm_256x128<2, 2, 0>, grid, 2 * ldsA + 2 * ldsB, dA, dHm, dL, dC, M, K, N, 20));
         report("256x128 NA=2 NB=2 no DMA in loop", time_kernel(x6_gemm_256x128<2, 2, 1>, grid, 2 * ldsA + 2 * ldsB, dA, dHm, dL, dC, M, K, N, 20));
         report("256x128 MFMA only (registers), barrier", time_kernel(x6_gemm_256x128<2, 2, 1 | 64>, grid, 2 * ldsA + 2 * ldsB, dA, dHm, dL, dC, M, K, N, 20));
+        report("256x128 MFMA only (registers), product-major order", time_kernel(x6_gemm_256x128<2, 2, 1 | 64 | 2048>, grid, 2 * ldsA + 2 * ldsB, dA, dHm, dL, dC, M, K, N, 20));
         report("256x128 MFMA only (registers), no barrier", time_kernel(x6_gemm_256x128<2, 2, 1 | 64 | 128>, grid, 2 * ldsA + 2 * ldsB, dA, dHm, dL, dC, M, K, N, 20));
         report("256x128 NA=2 NB=2 DMA only", time_kernel(x6_gemm_256x128<2, 2, 4>, grid, 2 * ldsA + 2 * ldsB, dA, dHm, dL, dC, M, K, N, 20));
         report("256x128 NA=2 NB=2 DMA only, A only", time_kernel(x6_gemm_256x128<2, 2, 4 | 32>, grid, 2 * ldsA + 2 * ldsB, dA, dHm, dL, dC, M, K, N, 20));
