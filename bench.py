@@ -645,6 +645,27 @@ def main():
         torch.cuda.synchronize()
         prof6_fine = m_fp.profile_read()
         m_fp.profile_enable(0)
+        # the same steps pipelined over 4 streams, as `pipelined` does for the f32 path (front end and forwards of other batches next
+        # to the split kernels: allowed since the library holds no packed-f32 instruction, include/nafp.h) -- with a bit-equality
+        # check of every pipelined result against the single-stream result of the same batch
+        solo6 = []
+        with torch.cuda.stream(streams[0]):
+            for i in range(n_pool):
+                solo6.append(m_fp(m_pre(pool[i], group_size=BSZ, defer=True)).clone())
+        ps6 = [torch.cuda.Stream(device=dev) for _ in range(4)]
+
+        def pstep6(i):
+            with torch.cuda.stream(ps6[i % 4]):
+                return m_fp(m_pre(pool[i % n_pool], group_size=BSZ, defer=True))
+        torch.cuda.synchronize()
+        keep6 = [pstep6(i).clone() for i in range(8)]
+        torch.cuda.synchronize()
+        pipe6_equal = all(torch.equal(keep6[i], solo6[i % n_pool]) for i in range(8))
+        tb0 = time.perf_counter()
+        for i in range(args.steps):
+            pstep6(i)
+        torch.cuda.synchronize()
+        pel6 = time.perf_counter() - tb0
         m_fp.set_option(3, 0)
         bf16x6 = {'value': round(world * BSZ * args.steps / bel6, 1), 'unit': 'segments/s', 'ms_per_step': round(bel6 / args.steps * 1e3, 4),
                   'dtype': 'exact 3-way bf16 split x = h + m + l, 6 products (relative weight >= 2^-16), f32 accumulation, f32 storage',
@@ -652,8 +673,9 @@ def main():
                   'min_cosine_vs_f32_path': float((got6_emb * ref_emb).sum(1).min()),
                   'note': 'experimental option NAFP_OPT_BF16X3 = 2: all 15 GEMM convs on the exact split, conv0 generated inside conv1; '
                           'float32-equivalent (error vs the float64 oracle = the f32 path\'s own: tests/test_gpu_parity_forward.py, '
-                          'tests/test_gpu_exact_split_adversarial.py); single stream (the option must not overlap other kernels: '
-                          'include/nafp.h); a separate object, not part of `value`'}
+                          'tests/test_gpu_exact_split_adversarial.py); `value` on a single stream like the headline; a separate object, not part of `value`',
+                  'pipelined': {'streams': 4, 'value': round(world * BSZ * args.steps / pel6, 1), 'unit': 'segments/s',
+                                'ms_per_step': round(pel6 / args.steps * 1e3, 4), 'bit_identical_to_single_stream': bool(pipe6_equal)}}
         macs6 = conv_effective_macs()
         alg6 = 2.0 * sum(macs6[1:]) * BSZ                                   # algorithmic float32 FLOPs of the 15 GEMM convs per step
         gemm6_ms = sum(sum(p[1:16]) for p in prof6) / len(prof6)

@@ -269,12 +269,15 @@ int nafp_encoder_grad_group_wait(nafp_encoder* enc, int group, void* stream);
  * value 2: the EXACT 3-way split x = h + m + l (three bf16 terms hold a float32's 24 significant bits) with the six products of
  * relative weight >= 2^-16 (hh, hm, mh, hl, mm, lh; the dropped ml + lm + ll < 2^-25 of |a||b|): float32-equivalent arithmetic on
  * the bf16 matrix pipe -- its error against the float64 oracle equals the f32 path's own (tests/test_gpu_parity_forward.py).
- * RESTRICTION (values 1 and 2): a forward with this option must not OVERLAP other kernels of this library on the device -- another
- * forward of any handle or the front end on a second stream.  Side by side with the split-arithmetic GEMM kernels those kernels
- * (and the forward itself) come out changed in a few rows, run to run (found in round 6; tools/x6_determinism_check2.py shows it,
- * profiles/r06_experiments.md lists what was ruled out: the kernels' LDS and register footprints, their LDS-DMA, the matrix pipe
- * alone).  Keep such a handle on ONE stream with nothing else in flight: results are then run-to-run bit-identical.  The Python
- * host side does that by itself (model/generate.py streams_for).  The fp32 path has no such restriction. */
+ * CAUTION for kernels of OTHER libraries (values 1 and 2): on gfx950 a packed-f32 vector instruction that carries an op_sel modifier
+ * (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 ... op_sel:[..]; compilers emit them for complex arithmetic -- rocFFT's kernels hold
+ * them) returns wrong values in a wave that shares a compute unit with waves issuing the 128-bit-operand matrix instructions
+ * (v_mfma_f32_32x32x16_bf16, what this option runs on) next to vector work.  Found in round 6; tools/probes/pk_opsel_hazard_probe.hip
+ * reproduces it without this library, profiles/r06_experiments.md section 5 has the matrix of instructions.  EVERY kernel of this
+ * library is compiled without packed-f32 instructions (build.py NO_PACKED_F32; tests/test_abi.py disassembles the library and holds
+ * it), so the library's own kernels -- front end, other forwards, training -- overlap such a forward freely and stay run-to-run
+ * bit-identical (tests/test_gpu_generate.py, tools/x6_determinism_check*.py).  A foreign kernel holding such instructions must not
+ * run on the device while a forward with this option is in flight.  The fp32 path (f32 matrix instructions) does not disturb anything. */
 #define NAFP_OPT_BF16X3 3
 /* Options are host-side state of the handle: set them while no pass of the handle is being enqueued from another thread; passes already
  * enqueued keep what they were launched with.  (NAFP_OPT_BF16X3 = 2 allocates its split weights, 1.5 x the packed conv kernels, on first use.) */

@@ -87,7 +87,7 @@ class FingerPrinter:
         self._dirty = True
         self._weights_event, self._weights_stream, self._use_events = None, None, {}
         self._fuse0 = os.environ.get('NAFP_FUSE0', '') == '1'          # NAFP_OPT_FUSE_CONV0 (the library reads the same variable)
-        self.split_arithmetic = 0      # NAFP_OPT_BF16X3 of the handle: pipelined consumers keep such a model on ONE stream (generate.streams_for)
+        self.split_arithmetic = 0      # NAFP_OPT_BF16X3 of the handle (what bench.py / the tests report it as)
         self._ws = {}          # one workspace per HIP stream: batches may be pipelined across streams
         # NAFP_BF16X3=1 | 2 (environment): the experimental split-bf16 products of the inference forward (include/nafp.h NAFP_OPT_BF16X3;
         # 2 = the exact 3-way split: float32-equivalent, ~20 % faster than the fp32 MFMAs) for `run.py generate` without a code change

@@ -290,11 +290,11 @@ class _Pending:
 
 
 def streams_for(m_fp, n_streams=N_STREAMS):
-    """Streams a pipelined consumer of `m_fp` may use.  With the experimental split-bf16 arithmetic (NAFP_OPT_BF16X3 != 0) the answer
-    is ONE: its GEMM kernels must not run next to other kernels of the path -- run side by side with the front end or with another
-    forward they leave those kernels' results changed in a few rows (profiles/r06_experiments.md has the evidence and what was ruled
-    out; include/nafp.h states the restriction).  On one stream every result is run-to-run bit-identical."""
-    return 1 if getattr(m_fp, 'split_arithmetic', 0) else n_streams
+    """Streams a pipelined consumer of `m_fp` may use: all of them, whatever the arithmetic.  (For most of round 6 a model on the
+    split-bf16 arithmetic, NAFP_OPT_BF16X3 != 0, was kept on ONE stream here: its GEMM kernels left the front end and the 64-column
+    f32 GEMM kernels of other streams changed in a few rows.  Cause found since -- packed-f32 instructions with op_sel next to the
+    128-bit-operand matrix instructions, include/nafp.h -- and removed at the root: the library holds no packed-f32 instruction.)"""
+    return n_streams
 
 
 class StreamedEmbedder:

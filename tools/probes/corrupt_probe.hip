@@ -120,3 +120,47 @@ extern "C" int selfcheck(unsigned* counts, int blocks, int rounds, int which, vo
     selfcheck_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(counts, rounds, which);
     return (int)hipGetLastError();
 }
+
+// Packed-f32 victims (the front end, rocFFT and the GEMM epilogues are full of v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32; the victims above
+// hardly hold any): chains of exactly one kind of instruction, written in assembly so that the compiler cannot choose another, recomputed and
+// compared with the thread's own first result.  counts[10 + which]: mismatching recomputations.
+typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256, 2) void pkcheck_kernel(unsigned* counts, int rounds, int which) {
+    const unsigned tid = threadIdx.x;
+    pk_f32x2 x[8], first[8];
+    pk_f32x2 ca = {1.0009765625f, 0.99951171875f}, cb = {0.03125f, -0.015625f};
+    asm volatile("" : "+v"(ca), "+v"(cb));
+    unsigned bad = 0;
+    for (int rd = 0; rd < rounds; ++rd) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { x[j][0] = 0.37f + 0.011f * j + 0.0007f * tid + 0.05f * (blockIdx.x & 7); x[j][1] = 0.41f + 0.013f * j + 0.0005f * tid; }
+#pragma unroll 1
+        for (int it = 0; it < 48; ++it) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (which == 0) asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(x[j]) : "v"(x[j]), "v"(ca), "v"(cb));
+                else if (which == 1) { asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(x[j]) : "v"(x[j]), "v"(ca)); asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(x[j]) : "v"(x[j]), "v"(cb)); }
+                else if (which == 2) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1] neg_lo:[0,0,1]" : "=v"(x[j]) : "v"(x[j]), "v"(ca), "v"(cb));
+                else if (which == 3) { asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(x[j][0]) : "v"(x[j][0]), "v"(ca[0]), "v"(cb[0])); asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(x[j][1]) : "v"(x[j][1]), "v"(ca[1]), "v"(cb[1])); }
+                else { asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(x[j]) : "v"(x[j]), "v"(ca)); asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(x[j]) : "v"(x[j]), "v"(cb)); }
+            }
+        }
+        if (rd == 0) { for (int j = 0; j < 8; ++j) first[j] = x[j]; }
+        else {
+            for (int j = 0; j < 8; ++j)
+                for (int h = 0; h < 2; ++h)
+                    if (__float_as_uint(x[j][h]) != __float_as_uint(first[j][h])) {
+                        ++bad;
+                        const unsigned slot = atomicAdd(counts + 15, 1u);          // the first 64 mismatches are recorded: expected bits, found bits, (round, j, half, lane)
+                        if (slot < 64) { counts[16 + slot * 4] = __float_as_uint(first[j][h]); counts[17 + slot * 4] = __float_as_uint(x[j][h]); counts[18 + slot * 4] = (rd << 16) | (j << 8) | (h << 7) | (tid & 63);
+                                         counts[19 + slot * 4] = blockIdx.x; }
+                    }
+        }
+    }
+    if (bad) atomicAdd(counts + 10 + which, bad);
+    if (tid == 0) atomicAdd(counts + 2, 1u);
+}
+extern "C" int pkcheck(unsigned* counts, int blocks, int rounds, int which, void* stream) {
+    pkcheck_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(counts, rounds, which);
+    return (int)hipGetLastError();
+}
