@@ -1,9 +1,13 @@
-// Stand-alone reproducer (no library, no torch): packed-f32 vector instructions that carry op_sel / neg modifiers return wrong values in a wave
-// that shares a compute unit with waves issuing matrix instructions whose operands were just written by vector instructions.
+// Stand-alone reproducer (no library, no torch), gfx950 / MI355X, ROCm 7.2: a packed-f32 vector instruction that carries an op_sel modifier
+// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 ... op_sel:[..]) returns wrong values in a wave that shares a compute unit with waves issuing the
+// 128-bit-operand matrix instructions (v_mfma_f32_32x32x16_bf16 / _f16, 16x16x32, i32_32x32x32_i8, f8f6f4), worst with vector work between them.
 //
 //   victim  : every thread runs fixed chains of ONE kind of instruction (written in assembly) and compares each recomputation with its own
 //             first result -- no memory, no LDS, no cross-lane traffic, nothing shared with anybody;
-//   culprit : a loop of matrix instructions on another stream, in several forms (KIND below): which ingredient is needed?
+//   culprit : a loop of matrix instructions on another stream.  First table: which ingredient of the loop is needed (KIND below);
+//             second table: which matrix instruction, on static registers / with independent vector work in the loop.
+// Measured (profiles/r06_experiments.md section 5c): zero mismatches without a culprit, with f32 matrix instructions, with the 64-bit-operand
+// bf16_1k instruction, and for victims without op_sel (plain packed, neg only, scalar); 10^6 - 10^8 mismatches otherwise.
 //
 // build: hipcc --offload-arch=gfx950 -O3 -o pk_opsel_hazard_probe pk_opsel_hazard_probe.hip ;  run: ./pk_opsel_hazard_probe
 #include <hip/hip_runtime.h>
