@@ -150,7 +150,7 @@ def cpu_baseline(target_s=10.0, max_batches=40):
                       f"for {best['seconds']} s; the host was timed half-filled and filled ({cores} logical cores), the faster is reported"}
 
 
-def train_region(cfg, world, rank, dist, global_bsz, steps, torch, warmup=2, optimizer='LAMB', repeats=3):
+def train_region(cfg, world, rank, dist, global_bsz, steps, torch, warmup=2, optimizer='LAMB', repeats=3, arith=None):
     """Second half of BASELINE.json's metric: contrastive-train steps/s at a GLOBAL batch of 5120
     (configs[3]: config/640_lamb.yaml scaled, LAMB, tau 0.05), strong scaling: every rank takes
     5120/N segments (anchors + replicas), all-gathers the embeddings, all-reduces the gradients.
@@ -165,7 +165,19 @@ def train_region(cfg, world, rank, dist, global_bsz, steps, torch, warmup=2, opt
     c['TRAIN']['OPTIMIZER'], c['TRAIN']['LR'] = optimizer, 1e-4
     if (global_bsz // 2) % world:
         return {'skipped': f'global batch {global_bsz} does not split over {world} ranks'}
-    m_pre, m_specaug, m_fp, opt, loss_obj, bucket = T.setup(c, 1000)
+    # arith = 'x6': forward_train and the transposed convs on the exact 3-way bf16 split (NAFP_OPT_BF16X3 = 2; weight gradients stay f32)
+    prev_env = os.environ.get('NAFP_BF16X3')
+    if arith == 'x6':
+        os.environ['NAFP_BF16X3'] = '2'
+    try:
+        m_pre, m_specaug, m_fp, opt, loss_obj, bucket = T.setup(c, 1000)
+    finally:
+        if arith == 'x6':
+            if prev_env is None:
+                os.environ.pop('NAFP_BF16X3', None)
+            else:
+                os.environ['NAFP_BF16X3'] = prev_env
+    assert getattr(m_fp, 'split_arithmetic', 0) == (2 if arith == 'x6' else (int(prev_env) if prev_env in ('1', '2') else 0))
     batches = list(T.synthetic_batches(c, 2)(1))
     for i in range(warmup):
         T.train_step(batches[i % 2], m_pre, m_specaug, m_fp, loss_obj, opt, bucket)
@@ -213,7 +225,7 @@ def train_region(cfg, world, rank, dist, global_bsz, steps, torch, warmup=2, opt
         # the rank's n x N share), timed the same way in this run: step - that = what the collectives leave exposed
         T.NO_DIST = True
         try:
-            plain = train_region(cfg, 1, 0, None, global_bsz // world, steps, torch, warmup=warmup, optimizer=optimizer, repeats=repeats)
+            plain = train_region(cfg, 1, 0, None, global_bsz // world, steps, torch, warmup=warmup, optimizer=optimizer, repeats=repeats, arith=arith)
         finally:
             T.NO_DIST = False
         dist.barrier()
@@ -658,7 +670,7 @@ def main():
             with torch.cuda.stream(ps6[i % 4]):
                 return m_fp(m_pre(pool[i % n_pool], group_size=BSZ, defer=True))
         torch.cuda.synchronize()
-        keep6 = [pstep6(i).clone() for i in range(8)]
+        keep6 = [pstep6(i) for i in range(8)]             # (fresh output tensors; compared after the synchronize below)
         torch.cuda.synchronize()
         pipe6_equal = all(torch.equal(keep6[i], solo6[i % n_pool]) for i in range(8))
         tb0 = time.perf_counter()
@@ -696,9 +708,19 @@ def main():
                   'min_cosine_vs_f32_path': float((got_emb * ref_emb).sum(1).min()),
                   'note': 'experimental option NAFP_OPT_BF16X3 on the unsplit GEMM convs (convs 1-6, 8 at BSZ 640); NOT the '
                           "reference's arithmetic, not part of `value`"}
-    train, train_1280, train_r640 = None, None, None
+    train, train_1280, train_r640, train_x6 = None, None, None, None
     if not args.no_train:
         train = train_region(cfg, world, rank, dist, args.train_bsz, args.train_steps, torch, repeats=args.train_repeats)
+        if world == 1:
+            # EXPERIMENTAL, a separate object, never `train`: the same step with the GEMM products of forward_train and of the transposed
+            # convs on the exact 3-way bf16 split (gradient parity: tests/test_gpu_backward.py, tests/test_gpu_configs.py)
+            try:
+                train_x6 = train_region(cfg, world, rank, dist, args.train_bsz, args.train_steps, torch, repeats=args.train_repeats, arith='x6')
+                train_x6['dtype'] = ('forward_train and transposed convs: exact 3-way bf16 split, 6 products, f32 accumulation (float32-equivalent); '
+                                     'weight gradients, LayerNorm backward, loss, optimizer: f32')
+                train_x6['vs_f32_step'] = round(train['ms_per_step'] / train_x6['ms_per_step'], 4)
+            except Exception as ex:      # a secondary object must not take the headline line down
+                train_x6 = {'error': f'{type(ex).__name__}: {ex}'}
         if world == 1:                                  # BSZ 1280, Adam, one GPU
             train_1280 = train_region(cfg, world, rank, dist, min(1280, args.train_bsz), max(args.train_steps, 12), torch,
                                       warmup=3, optimizer='Adam', repeats=args.train_repeats)
@@ -799,6 +821,8 @@ def main():
             out['bf16x3_experimental'] = bf16x3
         if bf16x6:
             out['bf16x6_f32_equivalent_experimental'] = bf16x6
+        if train_x6:
+            out['train_x6_experimental'] = train_x6
         if train:
             out['train'] = train
         if train_1280:

@@ -148,6 +148,7 @@ struct nafp_encoder {
     // value 2: the packed conv kernels split into three bf16 terms (conv.hip, split_weights_bf16_kernel), refreshed by the first forward after a
     // set_weights; one allocation of its own, made when the option is first switched on
     float* d_x6_blob = nullptr; std::vector<float*> d_whm; std::vector<void*> d_wl; bool x6_dirty = true;
+    std::vector<float*> d_wdhm; std::vector<void*> d_wdl;      // ... and of the flipped kernels (Cin, 3 Cout) of the transposed convs (the train step under the option)
     int prof_coarse = 0;                  // 1: stamp only around conv0, the 15 GEMM convs as a group, and the tail; 2: only around the GEMM convs
     // nafp_encoder_backward records one event per gradient group (layers complete last to first), so that a
     // communication stream can start reducing a group while the rest of the backward pass still runs
@@ -372,6 +373,20 @@ extern "C" int nafp_encoder_destroy(nafp_encoder* e) {
     return NAFP_OK;
 }
 
+// NAFP_OPT_BF16X3 = 2: the three bf16 terms of every packed conv kernel and of its flipped form (conv.hip split_weights_bf16_kernel)
+static int split_all_weights(nafp_encoder* e, hipStream_t st) {
+    for (int j = 1; j < 16; ++j) {
+        int rcs = launch_split_weights_bf16(e->d_w[j], e->d_whm[j], e->d_wl[j], e->geom[j].Cout, 3 * e->geom[j].Cin, st);
+        if (rcs != NAFP_OK) return rcs;
+        if (e->geom[j].Cout % 16 == 0 && e->d_wd[j]) {          // (Cin, 3 Cout): K = 3 Cout must be whole 16-k groups
+            rcs = launch_split_weights_bf16(e->d_wd[j], e->d_wdhm[j], e->d_wdl[j], e->geom[j].Cin, 3 * e->geom[j].Cout, st);
+            if (rcs != NAFP_OK) return rcs;
+        }
+    }
+    e->x6_dirty = false;
+    return NAFP_OK;
+}
+
 extern "C" int nafp_encoder_set_option(nafp_encoder* e, int option, int value) {
     if (!e) return NAFP_ERR_INVALID_ARG;
     switch (option) {
@@ -380,14 +395,15 @@ extern "C" int nafp_encoder_set_option(nafp_encoder* e, int option, int value) {
             if (value < 0 || value > 2) return NAFP_ERR_INVALID_ARG;
             if (value == 2 && !e->d_x6_blob) {
                 int64_t tot = 0;
-                for (int j = 1; j < 16; ++j) tot += ((int64_t)e->geom[j].Cout * 3 * e->geom[j].Cin * 3 / 2 + 63) / 64 * 64;
+                for (int j = 1; j < 16; ++j) tot += 2 * (((int64_t)e->geom[j].Cout * 3 * e->geom[j].Cin * 3 / 2 + 63) / 64 * 64);
                 hipError_t er = hipMalloc(&e->d_x6_blob, sizeof(float) * tot);
                 if (er != hipSuccess) { g_last_hip_error = (int)er; e->d_x6_blob = nullptr; return NAFP_ERR_HIP; }
                 float* q = e->d_x6_blob;
-                e->d_whm.assign(16, nullptr); e->d_wl.assign(16, nullptr);
+                e->d_whm.assign(16, nullptr); e->d_wl.assign(16, nullptr); e->d_wdhm.assign(16, nullptr); e->d_wdl.assign(16, nullptr);
                 for (int j = 1; j < 16; ++j) {
                     const int64_t n = (int64_t)e->geom[j].Cout * 3 * e->geom[j].Cin;
                     e->d_whm[j] = q; e->d_wl[j] = q + n; q += (n * 3 / 2 + 63) / 64 * 64;
+                    e->d_wdhm[j] = q; e->d_wdl[j] = q + n; q += (n * 3 / 2 + 63) / 64 * 64;
                 }
                 e->x6_dirty = true;
             }
@@ -563,11 +579,8 @@ extern "C" int nafp_encoder_set_weights(nafp_encoder* e, const float* const* t, 
     if (!l1_done) NAFP_HIP_CHECK(hipEventRecord(e->sw_l1, st));
     e->x6_dirty = true;
     if (e->opt_bf16x3 == 2) {                 // (experimental) the exact-split kernels' three bf16 terms of every packed conv kernel: part of this call,
-        for (int j = 1; j < 16; ++j) {        //  so that `sw_done` covers them for passes on other streams
-            int rcs = launch_split_weights_bf16(e->d_w[j], e->d_whm[j], e->d_wl[j], e->geom[j].Cout, 3 * e->geom[j].Cin, st);
-            if (rcs != NAFP_OK) return rcs;
-        }
-        e->x6_dirty = false;
+        int rcs = split_all_weights(e, st);   //  so that `sw_done` covers them for passes on other streams
+        if (rcs != NAFP_OK) return rcs;
     }
     NAFP_HIP_CHECK(hipEventRecord(e->sw_done, st));
     e->sw_stream = st; e->sw_recorded = true;
@@ -638,11 +651,7 @@ static int encoder_forward_impl(nafp_encoder* e, const float* feat, const float*
     const int64_t slab_floats = forward_slab_floats(e, n_seg);
     { int wrc = wait_weights(e, st); if (wrc != NAFP_OK) return wrc; }
     if (e->opt_bf16x3 == 2 && e->x6_dirty) {                          // (experimental) the weights' three bf16 terms, once per parameter set
-        for (int j = 1; j < 16; ++j) {
-            int rcs = launch_split_weights_bf16(e->d_w[j], e->d_whm[j], e->d_wl[j], e->geom[j].Cout, 3 * e->geom[j].Cin, st);
-            if (rcs != NAFP_OK) return rcs;
-        }
-        e->x6_dirty = false;
+        { int rcs = split_all_weights(e, st); if (rcs != NAFP_OK) return rcs; }
         // (the option was switched on after the last set_weights: later passes on OTHER streams wait for this split like for a re-pack)
         if (!e->sw_done) NAFP_HIP_CHECK(hipEventCreateWithFlags(&e->sw_done, hipEventDisableTiming));
         NAFP_HIP_CHECK(hipEventRecord(e->sw_done, st));
@@ -876,6 +885,14 @@ extern "C" int nafp_encoder_forward_train(nafp_encoder* e, const float* feat, in
     NAFP_HIP_CHECK(hipMemsetAsync(L.stats, 0, (char*)(L.tickets + 2 * NAFP_TICKET_SLOTS) - (char*)L.stats, st));
     static const bool split_wait = []() { const char* v = getenv("NAFP_SW_SPLIT_WAIT"); return !v || v[0] != '0'; }();
     { int wrc = wait_weights(e, st, split_wait ? 0 : 2); if (wrc != NAFP_OK) return wrc; }
+    if (e->opt_bf16x3 == 2 && e->x6_dirty) {      // the option was switched on after the last set_weights (which splits by itself otherwise)
+        int wrc = wait_weights(e, st);
+        if (wrc != NAFP_OK) return wrc;
+        { int rcs = split_all_weights(e, st); if (rcs != NAFP_OK) return rcs; }
+        if (!e->sw_done) NAFP_HIP_CHECK(hipEventCreateWithFlags(&e->sw_done, hipEventDisableTiming));
+        NAFP_HIP_CHECK(hipEventRecord(e->sw_done, st));
+        e->sw_stream = st; e->sw_recorded = true;
+    }
     // (layer 0 keeps no pre-activation: the backward pass regenerates it from `feat`, 3 FMAs per element)
     const bool alt = e->norm != NAFP_NORM_LAYER2D;             // layer_norm1d / batch_norm (norm.hip), as in encoder_forward_impl
     auto stats_of = [&](int j) { return L.stats + 2 * n_seg * j; };
@@ -894,6 +911,8 @@ extern "C" int nafp_encoder_forward_train(nafp_encoder* e, const float* feat, in
         a.wp = e->d_w[j]; a.G = e->d_G[j]; a.Hb = e->d_Hb[j]; a.gamma_out = e->d_gamma[j];
         a.y = L.z[j]; a.v_out = L.v[j]; a.stats_out = L.stats + 2 * n_seg * j; a.plain = false;
         a.slab = L.slab_floats ? L.slab : nullptr; a.slab_floats = L.slab_floats; a.tickets = L.tickets;
+        // NAFP_OPT_BF16X3 = 2: the GEMM products of the training forward on the exact 3-way bf16 split too (same kernels, training epilogue)
+        if (e->opt_bf16x3 == 2 && !alt) { a.bf16x3 = 2; a.wp_hm = e->d_whm[j]; a.wp_l = e->d_wl[j]; }
         rc = launch_conv_gemm(a, n_seg, e->geom[j], st);
         if (rc != NAFP_OK) return rc;
         rc = row_pass(L.z[j], j);
@@ -1031,6 +1050,8 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
             // r_{j-1} * dxhat_{j-1} = transposed conv of dts_j
             ConvGemmArgs a{};
             a.x = cur; a.wp = e->d_wd[j]; a.y = other; a.plain = true; a.dgrad = true;
+            // NAFP_OPT_BF16X3 = 2: the transposed conv on the exact 3-way bf16 split as well (dts split in registers like the forward's activations)
+            if (e->opt_bf16x3 == 2 && !alt && !e->x6_dirty && g.Cout % 16 == 0) { a.bf16x3 = 2; a.wp_hm = e->d_wdhm[j]; a.wp_l = e->d_wdl[j]; }
             a.slab = L.slab_floats ? L.slab : nullptr; a.slab_floats = L.slab_floats;
             a.tickets = overlap ? nullptr : L.tickets;      // split-K finished in-kernel (mode 1: the side stream's wgrad shares the counters)
             a.sj = &sj;                                     // side job: the scalar records of layer j - 1

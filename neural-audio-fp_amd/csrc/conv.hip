@@ -1555,6 +1555,11 @@ NAFP_GEMM_KERNEL_BF16X6(conv_gemm_k16s3_infer_bf16x6, 128, 128, NAFP_X6_K16_NSTA
 NAFP_GEMM_KERNEL_BF16X6(conv_gemm_m256k16s3_infer_bf16x6, 256, 128, NAFP_X6_M256_NSTAGE, NAFP_X6_M256_MINW, 0)
 NAFP_GEMM_KERNEL_BF16X6(conv_gemm_n64k16s2_infer_bf16x6, 128, 64, 2, 4, 0)
 NAFP_GEMM_KERNEL_BF16X6(conv_gemm_k16s3_plain_bf16x6, 128, 128, NAFP_X6_K16_NSTAGE, NAFP_X6_K16_MINW, 3)      // the split-K parts of the late convs
+// ... with the TRAINING epilogue (forward_train under NAFP_OPT_BF16X3 = 2: the pre-activation is kept for the backward pass)
+NAFP_GEMM_KERNEL_BF16X6(conv_gemm_k16s3_train_bf16x6, 128, 128, NAFP_X6_K16_NSTAGE, NAFP_X6_K16_MINW, 1)
+NAFP_GEMM_KERNEL_BF16X6(conv_gemm_n64k16s2_train_bf16x6, 128, 64, 2, 4, 1)
+// ... and the PLAIN epilogue on 64-column tiles (the transposed convs of the train step; their 128-column form is conv_gemm_k16s3_plain_bf16x6)
+NAFP_GEMM_KERNEL_BF16X6(conv_gemm_n64k16s2_plain_bf16x6, 128, 64, 2, 4, 3)
 // conv1 with conv0 generated in-kernel on the exact split: no A stream at all (see the K-loop)
 __global__ __launch_bounds__(256, 3) void conv_gemm_k16s2_fuse0_bf16x6(const ConvKernelParams p) {
     conv_gemm_body<128, 128, 16, 2, true, 0, 2>(p);
@@ -1954,8 +1959,9 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     const int64_t Bp = (a.plan_b > 0 && !a.plain && !a.dgrad && !a.f0_feat) ? a.plan_b : B;
     // (the exact-split kernels, bf16x3 == 2, run best on 128-row tiles at three workgroups per CU: measured in profiles/r05_experiments.md)
     const bool x6 = a.bf16x3 == 2 && !a.plain && !a.dgrad && a.wp_hm && a.wp_l;
+    const bool x6d = a.bf16x3 == 2 && a.plain && a.dgrad && a.wp_hm && a.wp_l;        // a transposed conv on the exact split: 128-row tiles as well
     const FwdPlan fp = fwd_plan(Bp, g, !a.plain && !a.dgrad, a.f0_feat != nullptr, x6);
-    int BM = a.dgrad ? pick_bm(B, g.Fin * g.Tin, g.Cin) : fp.BM;
+    int BM = a.dgrad ? (x6d ? 128 : pick_bm(B, g.Fin * g.Tin, g.Cin)) : fp.BM;
     int pt = fp.pt;
     const int fwd_perm = a.dgrad ? 0 : fp.perm;
     p.PT = pt; p.ST = BM / pt;
@@ -2038,7 +2044,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     // PLAIN split launches (the transposed convs) with arrival counters: the last arriver adds the parts and stores the result
     // (its epilogue is a sum: nothing like the FULL epilogue's serial tail) -- NAFP_PLAIN_INKERNEL=0 restores slab + plain_finish_kernel
     static const int plain_fin = []() { const char* e = getenv("NAFP_PLAIN_INKERNEL"); return e ? atoi(e) : 1; }();
-    const bool plain_in_kernel = plain_fin > 0 && S > 1 && a.plain && a.tickets && n_tiles <= NAFP_TICKET_SLOTS;
+    const bool plain_in_kernel = plain_fin > 0 && S > 1 && a.plain && a.tickets && n_tiles <= NAFP_TICKET_SLOTS && !x6d;      // (the exact-split parts finish through plain_finish_kernel)
     p.tickets = (in_kernel_finish || plain_in_kernel) ? a.tickets : nullptr; p.y_final = a.y;
     if (plain_in_kernel) p.bias = a.bias;
     static const int grid3d = []() { const char* e = getenv("NAFP_GRID3D"); return e ? atoi(e) : 1; }();
@@ -2107,6 +2113,13 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
              : bn == 64 ? launch_variant(conv_gemm_n64k16s2_infer_bf16x6, 128, 64, 16, 2, p, grid, st, 64 * 8)
                         : launch_variant(conv_gemm_k16s3_infer_bf16x6, 128, 128, 16, NAFP_X6_K16_NSTAGE, p, grid, st, 128 * 8);
     }
+    // the training epilogue on the exact split (x6 forces 128-row tiles; launches that need the generic-statistics or the in-kernel-finish
+    // epilogue -- the small late layers -- stay on the f32 kernels)
+    if (x6 && epi == 1 && BM == 128 && (bn == 128 || two_stage)) {
+        p.wp_hm = a.wp_hm; p.wp_l = (const unsigned short*)a.wp_l;
+        return bn == 64 ? launch_variant(conv_gemm_n64k16s2_train_bf16x6, 128, 64, 16, 2, p, grid, st, 64 * 8)
+                        : launch_variant(conv_gemm_k16s3_train_bf16x6, 128, 128, 16, NAFP_X6_K16_NSTAGE, p, grid, st, 128 * 8);
+    }
     if (a.bf16x3 && epi == 0 && (bn == 128 || two_stage))
         return BM == 256 ? launch_variant(conv_gemm_m256k16s3_infer_bf16x3, 256, 128, 16, 3, p, grid, st)
              : bn == 64 ? launch_variant(conv_gemm_n64k16s2_infer_bf16x3, 128, 64, 16, 2, p, grid, st)
@@ -2114,6 +2127,10 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     if (x6 && epi == 3 && bn == 128 && BM == 128 && p.mode == 2) {
         p.wp_hm = a.wp_hm; p.wp_l = (const unsigned short*)a.wp_l;
         rc = launch_variant(conv_gemm_k16s3_plain_bf16x6, 128, 128, 16, NAFP_X6_K16_NSTAGE, p, grid, st, 128 * 8);
+    } else if (x6d && epi == 3 && BM == 128) {
+        p.wp_hm = a.wp_hm; p.wp_l = (const unsigned short*)a.wp_l;
+        rc = bn == 64 ? launch_variant(conv_gemm_n64k16s2_plain_bf16x6, 128, 64, 16, 2, p, grid, st, 64 * 8)
+                      : launch_variant(conv_gemm_k16s3_plain_bf16x6, 128, 128, 16, NAFP_X6_K16_NSTAGE, p, grid, st, 128 * 8);
     } else if (in_kernel_finish && n_tiles > NAFP_TICKET_SLOTS) {
         // more output tiles than arrival counters: sample ranges of at most NAFP_TICKET_SLOTS tiles, one launch each (the last arrivers
         // leave the counters at zero, so the ranges reuse them and the slab in stream order); every sample sees exactly the launch it

@@ -165,13 +165,14 @@ def _oracle_update(which, w0, g, lr, var_len):
 
 
 @pytest.mark.parametrize('bsz,which', [(1280, 'adam'), (5120, 'lamb')])
-def test_whole_train_step_at_baseline_batch(nafp, cfg, bsz, which, observe):
+def test_whole_train_step_at_baseline_batch(nafp, cfg, bsz, which, observe, arith):
     from neural_audio_fp_amd.model import trainer as T
     from neural_audio_fp_amd.model.fp.lamb_optimizer import Adam, LAMB
     from neural_audio_fp_amd.model.fp.specaug_chain.specaug_chain import get_specaug_chain_layer
     n = bsz // 2
     xa, xp = _synthetic_pairs(n, seed=bsz)
     m_pre, m_specaug, m_fp = T.build_fp(cfg)
+    assert m_fp.split_arithmetic == (2 if arith == 'x6' else 0)      # x6: forward_train and the transposed convs on the exact split
     w = _inputs.weights(seed=40 + (bsz % 7))
     m_fp.set_weights(_inputs.weight_list(w))
     # the step's own features: spec-augment with the same seeded draws on a second chain object

@@ -88,34 +88,43 @@ GATE_RMS = {'channel_scales_extreme': 2.0}
 
 @pytest.mark.parametrize('case', sorted(CASES))
 def test_exact_split_on_adversarial_ranges(nafp, observe, case):
-    rng = np.random.default_rng(1234)
-    B = 9
-    feat = (-rng.uniform(0, 1.2, size=(B, 256, 32, 1))).astype(np.float32)
-    feat[:, ::7] *= 1e-3                                           # a few mel rows near zero as well
-    w = CASES[case](o_nnfp.init_weights(seed=31, randomize_affine=True), rng)
+    """Errors of both arithmetics against the float64 oracle, POOLED over three independent draws of the case (weights and features):
+    these weights amplify rounding by construction (errors of tens to hundreds of ulps), so a single draw's error is a sample of
+    rounding noise and the ratio of two such samples moves by +-30 % with any change of the instruction sequence (it did when the
+    library lost its packed-f32 instructions); the pooled maximum and the pooled rms are what the gate compares."""
+    B = 6
     m_fp = nafp.FingerPrinter(seed=0)
-    m_fp.set_weights(_inputs.weight_list(w))
-    ft = torch.from_numpy(feat).cuda()
-    out = {}
-    for name, opt in (('f32', 0), ('x6', 2)):
-        m_fp.set_option(3, opt)
-        out[name] = (m_fp.front_conv(ft).cpu().numpy().astype(np.float64), m_fp(ft).cpu().numpy().astype(np.float64))
-    m_fp.set_option(3, 0)
-    want_flat = o_nnfp.front_conv(feat, w, dtype=np.float64)
-    want_emb = o_nnfp.fingerprinter(feat, w, dtype=np.float64)
-    assert np.isfinite(want_flat).all() and np.abs(want_flat).max() > 1e-3, 'the case must leave the model alive'
-    for what, k, want in (('flat', 0, want_flat), ('emb', 1, want_emb)):
-        assert np.isfinite(out['f32'][k]).all() and np.isfinite(out['x6'][k]).all(), (case, what)
-        e32, e6 = out['f32'][k] - want, out['x6'][k] - want
-        scale = np.abs(want).max()
-        ulp = scale * 2.0 ** -23
+    pool = {'flat': {'e32': [], 'e6': [], 'scale': 0.0}, 'emb': {'e32': [], 'e6': [], 'scale': 0.0}}
+    for draw in range(3):
+        rng = np.random.default_rng(1234 + 101 * draw)
+        feat = (-rng.uniform(0, 1.2, size=(B, 256, 32, 1))).astype(np.float32)
+        feat[:, ::7] *= 1e-3                                           # a few mel rows near zero as well
+        w = CASES[case](o_nnfp.init_weights(seed=31 + draw, randomize_affine=True), rng)
+        m_fp.set_weights(_inputs.weight_list(w))
+        ft = torch.from_numpy(feat).cuda()
+        out = {}
+        for name, opt in (('f32', 0), ('x6', 2)):
+            m_fp.set_option(3, opt)
+            out[name] = (m_fp.front_conv(ft).cpu().numpy().astype(np.float64), m_fp(ft).cpu().numpy().astype(np.float64))
+        m_fp.set_option(3, 0)
+        want_flat = o_nnfp.front_conv(feat, w, dtype=np.float64)
+        want_emb = o_nnfp.fingerprinter(feat, w, dtype=np.float64)
+        assert np.isfinite(want_flat).all() and np.abs(want_flat).max() > 1e-3, 'the case must leave the model alive'
+        for what, k, want in (('flat', 0, want_flat), ('emb', 1, want_emb)):
+            assert np.isfinite(out['f32'][k]).all() and np.isfinite(out['x6'][k]).all(), (case, what, draw)
+            sc = np.abs(want).max()                                    # (every draw's errors in units of its own output scale)
+            pool[what]['e32'].append((out['f32'][k] - want).ravel() / sc)
+            pool[what]['e6'].append((out['x6'][k] - want).ravel() / sc)
+    for what in ('flat', 'emb'):
+        e32, e6 = np.concatenate(pool[what]['e32']), np.concatenate(pool[what]['e6'])
+        ulp = 2.0 ** -23
         m32, m6 = np.abs(e32).max(), np.abs(e6).max()
         r32, r6 = np.sqrt((e32 ** 2).mean()), np.sqrt((e6 ** 2).mean())
-        # recorded with a loose absolute bound (1e-3 of the outputs' scale: these weights amplify rounding by construction) ...
-        observe(f'{case} {what}: f32 path max |err| / scale', m32 / scale, 1e-3)
-        observe(f'{case} {what}: exact split max |err| / scale', m6 / scale, 1e-3)
-        observe(f'{case} {what}: f32 path rms err / scale', r32 / scale, 1e-3)
-        observe(f'{case} {what}: exact split rms err / scale', r6 / scale, 1e-3)
+        # recorded with a loose absolute bound (1e-3 of the outputs' scale) ...
+        observe(f'{case} {what}: f32 path max |err| / scale', m32, 1e-3)
+        observe(f'{case} {what}: exact split max |err| / scale', m6, 1e-3)
+        observe(f'{case} {what}: f32 path rms err / scale', r32, 1e-3)
+        observe(f'{case} {what}: exact split rms err / scale', r6, 1e-3)
         # ... the gate is relative to the fp32 MFMA path (the ratios are recorded too)
         observe(f'{case} {what}: exact split / f32 path, max', m6 / (m32 + ulp), GATE_MAX.get(case, 1.25))
         observe(f'{case} {what}: exact split / f32 path, rms', r6 / (r32 + 0.25 * ulp), GATE_RMS.get(case, 1.25))
