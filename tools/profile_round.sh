@@ -25,6 +25,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_trace -o t -- p
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train5120_trace -o t -- python tools/train_probe.py 5120 lamb 3 > $O/train5120_probe.txt 2> $O/train5120_trace.err
 # the 8-GPU operating point of the train metric on one GPU: per-rank batch 640, LAMB
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train640_trace -o t -- python tools/train_probe.py 640 lamb 5 > $O/train640_probe.txt 2> $O/train640_trace.err
+# [r6] the same two steps with forward_train and the transposed convs on the exact 3-way bf16 split (NAFP_BF16X3=2 in the environment of the probe)
+export NAFP_BF16X3=2
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/train5120x6_trace -o t -- python tools/train_probe.py 5120 lamb 3 > $O/train5120x6_probe.txt 2> $O/train5120x6_trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/train640x6_trace -o t -- python tools/train_probe.py 640 lamb 5 > $O/train640x6_probe.txt 2> $O/train640x6_trace.err
+unset NAFP_BF16X3
 for b in 640 1280 5120; do d=train_trace; [ $b = 640 ] && d=train640_trace; [ $b = 5120 ] && d=train5120_trace; python tools/train_layer_table.py $(find $O/$d -name "*kernel_trace.csv" | head -1) $b > $O/layers_$b.txt 2>&1; done
 # eval side: exact search of 38,000 query segments over 10 M resident fingerprints; training loader
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/search_trace -o t -- python tools/search_bench.py 10000000 38000 2 > $O/search_bench.txt 2> $O/search_trace.err
