@@ -719,6 +719,10 @@ def main():
                 train_x6['dtype'] = ('forward_train and transposed convs: exact 3-way bf16 split, 6 products, f32 accumulation (float32-equivalent); '
                                      'weight gradients, LayerNorm backward, loss, optimizer: f32')
                 train_x6['vs_f32_step'] = round(train['ms_per_step'] / train_x6['ms_per_step'], 4)
+                # ... and at the 8-GPU operating point (per-rank batch 640, no process group: compare `train_rank640.no_process_group_ms_per_step`)
+                r6 = train_region(cfg, 1, 0, None, 640, 20, torch, warmup=4, optimizer='LAMB', repeats=args.train_repeats, arith='x6')
+                train_x6['rank640'] = {k: r6[k] for k in ('value', 'unit', 'ms_per_step', 'spread', 'global_batch', 'optimizer')}
+                train_x6['rank640']['what'] = 'one rank\'s share (640 of 5120 segments) on ONE GPU, no process group: a one-GPU compute bound of the 8-rank step'
             except Exception as ex:      # a secondary object must not take the headline line down
                 train_x6 = {'error': f'{type(ex).__name__}: {ex}'}
         if world == 1:                                  # BSZ 1280, Adam, one GPU

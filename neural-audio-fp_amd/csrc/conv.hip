@@ -498,7 +498,7 @@ __device__ __forceinline__ float half_wave_sum_dpp(float x) {
 // split in registers into hi + lo bf16 halves, hi*hi + hi*lo + lo*hi with f32 accumulation (lo*lo, ~2^-16 of a product,
 // is dropped).  Not the arithmetic of the reference: results differ from the f32 path at the 1e-6 level of a fingerprint
 // component; bench.py reports it as a separate object with its measured error and never as `value`.
-// PREC = 2 (experimental, inference only, NAFP_OPT_BF16X3 = 2): the EXACT 3-way split x = h + m + l (three bf16 terms hold the 24
+// PREC = 2 (experimental, NAFP_OPT_BF16X3 = 2; inference, training-forward and plain / transposed-conv epilogues): the EXACT 3-way split x = h + m + l (three bf16 terms hold the 24
 // significant bits of a float32) and the six products of relative weight >= 2^-16 -- hh, hm, mh, hl, mm, lh; ml + lm + ll < 2^-25 of
 // |a||b|, below half an ulp of the float32 product -- with f32 accumulation: float32-equivalent arithmetic on the bf16 matrix pipe.
 // Returns whether this workgroup ran the full epilogue (true) or left after handing in a split-K part (false).

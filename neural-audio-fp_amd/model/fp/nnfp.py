@@ -89,7 +89,7 @@ class FingerPrinter:
         self._fuse0 = os.environ.get('NAFP_FUSE0', '') == '1'          # NAFP_OPT_FUSE_CONV0 (the library reads the same variable)
         self.split_arithmetic = 0      # NAFP_OPT_BF16X3 of the handle (what bench.py / the tests report it as)
         self._ws = {}          # one workspace per HIP stream: batches may be pipelined across streams
-        # NAFP_BF16X3=1 | 2 (environment): the experimental split-bf16 products of the inference forward (include/nafp.h NAFP_OPT_BF16X3;
+        # NAFP_BF16X3=1 | 2 (environment): the experimental split-bf16 products of the forward -- with 2 also of forward_train and the transposed convs (include/nafp.h NAFP_OPT_BF16X3;
         # 2 = the exact 3-way split: float32-equivalent, ~20 % faster than the fp32 MFMAs) for `run.py generate` without a code change
         if os.environ.get('NAFP_BF16X3', '') in ('1', '2'):
             self.set_option(3, int(os.environ['NAFP_BF16X3']))

@@ -64,6 +64,9 @@ def test_bench_line_contract():
     assert abs(r6x['achieved'] - r6x['executed_flops_per_step'] / (r6x['gemm_span_ms_per_step'] * 1e-3) / 1e12) < 0.02 * r6x['achieved']
     assert abs(r6x['f32_equivalent_TFLOP/s'] * 6.0 - r6x['achieved']) < 0.02 * r6x['achieved'] and len(r6x['per_conv_ms']) == 17
     assert x6['min_cosine_vs_f32_path'] > 1 - 1e-6 and x6['value'] > 0
+    tx = d['train_x6_experimental']
+    assert 'error' not in tx, tx
+    assert tx['global_batch'] == 256 and tx['value'] > 0 and tx['vs_f32_step'] > 0 and tx['rank640']['ms_per_step'] > 0 and 'exact 3-way bf16 split' in tx['dtype']
     assert x6['pipelined']['streams'] == 4 and x6['pipelined']['value'] > 0 and x6['pipelined']['bit_identical_to_single_stream'] is True
     e = d['e2e_generate']
     assert e['clips_100']['segments'] == 5900 and e['clips_600']['segments'] == 35400
