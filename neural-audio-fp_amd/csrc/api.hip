@@ -375,14 +375,15 @@ extern "C" int nafp_encoder_destroy(nafp_encoder* e) {
 
 // NAFP_OPT_BF16X3 = 2: the three bf16 terms of every packed conv kernel and of its flipped form (conv.hip split_weights_bf16_kernel)
 static int split_all_weights(nafp_encoder* e, hipStream_t st) {
+    SplitTable t; t.count = 0;
     for (int j = 1; j < 16; ++j) {
-        int rcs = launch_split_weights_bf16(e->d_w[j], e->d_whm[j], e->d_wl[j], e->geom[j].Cout, 3 * e->geom[j].Cin, st);
-        if (rcs != NAFP_OK) return rcs;
-        if (e->geom[j].Cout % 16 == 0 && e->d_wd[j]) {          // (Cin, 3 Cout): K = 3 Cout must be whole 16-k groups
-            rcs = launch_split_weights_bf16(e->d_wd[j], e->d_wdhm[j], e->d_wdl[j], e->geom[j].Cin, 3 * e->geom[j].Cout, st);
-            if (rcs != NAFP_OK) return rcs;
+        const int64_t n = (int64_t)e->geom[j].Cout * 3 * e->geom[j].Cin;
+        t.wp[t.count] = e->d_w[j]; t.hm[t.count] = e->d_whm[j]; t.wl[t.count] = e->d_wl[j]; t.n8[t.count] = n / 8; t.K[t.count] = 3 * e->geom[j].Cin; ++t.count;
+        if (e->geom[j].Cout % 16 == 0 && e->d_wd[j]) {          // the flipped kernel (Cin, 3 Cout): K = 3 Cout must be whole 16-k groups
+            t.wp[t.count] = e->d_wd[j]; t.hm[t.count] = e->d_wdhm[j]; t.wl[t.count] = e->d_wdl[j]; t.n8[t.count] = n / 8; t.K[t.count] = 3 * e->geom[j].Cout; ++t.count;
         }
     }
+    { int rcs = launch_split_weights_multi(t, st); if (rcs != NAFP_OK) return rcs; }
     e->x6_dirty = false;
     return NAFP_OK;
 }

@@ -1591,6 +1591,51 @@ __global__ __launch_bounds__(256) void split_weights_bf16_kernel(const float* __
     }
 }
 
+// All tensors of a parameter set in ONE launch (blockIdx.y = tensor), 8 consecutive k per thread: two 16-B loads, three 16-B stores.
+// (Round 6, the train step under the option: 30 tensors per step -- 15 packed kernels and their 15 flipped forms -- were 30 launches of
+// 24 us each with 2-byte stores.)
+__global__ __launch_bounds__(256) void split_weights_multi_kernel(const SplitTable t) {
+    const float* __restrict__ wp = t.wp[blockIdx.y];
+    unsigned short* __restrict__ hm = (unsigned short*)t.hm[blockIdx.y];
+    unsigned short* __restrict__ wl = (unsigned short*)t.wl[blockIdx.y];
+    const int64_t n8 = t.n8[blockIdx.y];
+    const int K = t.K[blockIdx.y];
+    typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+    for (int64_t i8 = blockIdx.x * 256ll + threadIdx.x; i8 < n8; i8 += (int64_t)gridDim.x * 256) {
+        const int64_t i = i8 * 8;
+        const float4 a = *(const float4*)(wp + i), b = *(const float4*)(wp + i + 4);
+        const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        u16x8 vh, vm, vl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const __bf16 h = (__bf16)x[e];
+            const float r1 = x[e] - (float)h;
+            const __bf16 m = (__bf16)r1;
+            vh[e] = __builtin_bit_cast(unsigned short, h);
+            vm[e] = __builtin_bit_cast(unsigned short, m);
+            vl[e] = __builtin_bit_cast(unsigned short, (__bf16)(r1 - (float)m));
+        }
+        const int64_t row = i / K;
+        const int k = (int)(i - row * K);
+        const int64_t base = row * 2 * K + (int64_t)(k >> 4) * 32 + (k & 8);
+        *(u16x8*)(hm + base) = vh;
+        *(u16x8*)(hm + base + 16) = vm;
+        *(u16x8*)(wl + i) = vl;
+    }
+}
+
+int launch_split_weights_multi(const SplitTable& t, hipStream_t st) {
+    if (t.count <= 0) return NAFP_OK;
+    int64_t n8_max = 0;
+    for (int j = 0; j < t.count; ++j) {
+        if (t.K[j] % 16 != 0) return NAFP_ERR_UNSUPPORTED;
+        n8_max = std::max(n8_max, t.n8[j]);
+    }
+    split_weights_multi_kernel<<<dim3((unsigned)std::min<int64_t>((n8_max + 255) / 256, 1024), (unsigned)t.count), 256, 0, st>>>(t);
+    NAFP_LAUNCH_CHECK();
+    return NAFP_OK;
+}
+
 int launch_split_weights_bf16(const float* wp, float* hm, void* wl, int Cout, int K, hipStream_t st) {
     if (K % 16 != 0) return NAFP_ERR_UNSUPPORTED;
     const int64_t n = (int64_t)Cout * K;

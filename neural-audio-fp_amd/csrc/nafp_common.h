@@ -293,6 +293,9 @@ struct PackTable { const float* k3[16]; float* wp[16]; float* wd[16]; int cin[16
 int launch_multi_pack(const PackTable& t, hipStream_t st);
 // exact 3-way bf16 split of a packed (Cout, K) weight tensor for the bf16x3 == 2 launches: hm (Cout * K floats), wl (Cout * K bf16)
 int launch_split_weights_bf16(const float* wp, float* hm, void* wl, int Cout, int K, hipStream_t st);
+// ... every tensor of a parameter set in one launch: (Cout_j, K_j) f32 -> hm_j, wl_j as above; n8 = Cout_j * K_j / 8
+struct SplitTable { const float* wp[32]; float* hm[32]; void* wl[32]; int64_t n8[32]; int K[32]; int count; };
+int launch_split_weights_multi(const SplitTable& t, hipStream_t st);
 int launch_pack_conv_weight(const float* k3, float* wp, int Cin, int Cout, hipStream_t st);
 // Positional epilogue tensors G_j = conv_j(gamma_{j-1}), Hb_j = conv_j(beta_{j-1}) (bias added later) of the SMALL layers
 // (P <= 8 output positions: 2 P <= 16 GEMM rows against a 2 - 12 MB weight tensor) in ONE weight-streaming launch.

@@ -77,7 +77,8 @@ def test_f32_forward_next_to_split_forward(nafp, cfg):
 
 def test_train_step_next_to_split_forward(nafp, cfg):
     """A whole f32 train pass (forward_train + backward: LayerNorm backward, weight gradients, transposed convs) on one stream while a
-    split forward of another handle runs on a second one: gradients bit-identical to the pass alone."""
+    split forward of another handle runs on a second one: the embeddings bit-identical to the pass alone, the gradients within the
+    noise of their float atomics (2e-6 of each tensor's largest entry)."""
     m_pre, m6, m32 = _models(nafp, cfg)
     g = torch.Generator(device='cuda').manual_seed(6)
     feat = m_pre(0.1 * torch.randn((128, 1, 8000), generator=g, device='cuda'), group_size=128)
@@ -90,10 +91,6 @@ def test_train_step_next_to_split_forward(nafp, cfg):
         return emb.clone(), [t.clone() for t in grads]
     emb0, g0 = train_pass()
     torch.cuda.synchronize()
-    _, g0b = train_pass()
-    torch.cuda.synchronize()
-    # (tensors whose solo passes already differ in the last bits -- float atomics in a reduction -- are compared within that noise)
-    noise = [float((g0b[k] - g0[k]).abs().max()) for k in range(len(g0))]
     s_t, s_f = torch.cuda.Stream(), torch.cuda.Stream()
     for rep in range(4):
         with torch.cuda.stream(s_f):
@@ -103,8 +100,8 @@ def test_train_step_next_to_split_forward(nafp, cfg):
             emb1, g1 = train_pass()
         torch.cuda.synchronize()
         assert torch.equal(emb1, emb0), f'rep {rep}: forward_train moved'
-        moved = [k for k in range(len(g0)) if (not torch.equal(g1[k], g0[k])) if noise[k] == 0.0]
-        assert not moved, f'rep {rep}: gradient tensors {moved[:8]} moved'
+        # the gradients meet in float atomics (dgamma / dbeta / dbias, the weight-gradient chunks): their order follows the timing, so
+        # the last bits may move with ANY neighbour; the effect this file guards against moved single values by 1e-3 .. 1e-2 relative
         for k in range(len(g0)):
-            if noise[k] > 0.0:
-                assert float((g1[k] - g0[k]).abs().max()) <= 8 * noise[k] + 1e-7 * float(g0[k].abs().max()), (rep, k)
+            scale = float(g0[k].abs().max()) + 1e-30
+            assert float((g1[k] - g0[k]).abs().max()) <= 2e-6 * scale, (rep, k, float((g1[k] - g0[k]).abs().max()) / scale)
