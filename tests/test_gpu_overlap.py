@@ -78,7 +78,7 @@ def test_f32_forward_next_to_split_forward(nafp, cfg):
 def test_train_step_next_to_split_forward(nafp, cfg):
     """A whole f32 train pass (forward_train + backward: LayerNorm backward, weight gradients, transposed convs) on one stream while a
     split forward of another handle runs on a second one: the embeddings bit-identical to the pass alone, the gradients within the
-    noise of their float atomics (2e-6 of each tensor's largest entry)."""
+    noise of their float atomics (1e-5 of each tensor's largest entry)."""
     m_pre, m6, m32 = _models(nafp, cfg)
     g = torch.Generator(device='cuda').manual_seed(6)
     feat = m_pre(0.1 * torch.randn((128, 1, 8000), generator=g, device='cuda'), group_size=128)
@@ -104,4 +104,4 @@ def test_train_step_next_to_split_forward(nafp, cfg):
         # the last bits may move with ANY neighbour; the effect this file guards against moved single values by 1e-3 .. 1e-2 relative
         for k in range(len(g0)):
             scale = float(g0[k].abs().max()) + 1e-30
-            assert float((g1[k] - g0[k]).abs().max()) <= 2e-6 * scale, (rep, k, float((g1[k] - g0[k]).abs().max()) / scale)
+            assert float((g1[k] - g0[k]).abs().max()) <= 1e-5 * scale, (rep, k, float((g1[k] - g0[k]).abs().max()) / scale)
