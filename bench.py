@@ -719,6 +719,9 @@ def main():
                 train_x6['dtype'] = ('forward_train and transposed convs: exact 3-way bf16 split, 6 products, f32 accumulation (float32-equivalent); '
                                      'weight gradients, LayerNorm backward, loss, optimizer: f32')
                 train_x6['vs_f32_step'] = round(train['ms_per_step'] / train_x6['ms_per_step'], 4)
+                # (its work rate is float32-EQUIVALENT work per time on two pipes: never a fraction of the fp32 matrix peak)
+                train_x6['f32_equivalent_TFLOP/s'] = train_x6.pop('achieved_TFLOP/s')
+                train_x6.pop('mfma_frac_of_peak', None)
                 # ... and at the 8-GPU operating point (per-rank batch 640, no process group: compare `train_rank640.no_process_group_ms_per_step`)
                 r6 = train_region(cfg, 1, 0, None, 640, 20, torch, warmup=4, optimizer='LAMB', repeats=args.train_repeats, arith='x6')
                 train_x6['rank640'] = {k: r6[k] for k in ('value', 'unit', 'ms_per_step', 'spread', 'global_batch', 'optimizer')}
