@@ -145,7 +145,7 @@ struct nafp_encoder {
     std::vector<hipEvent_t> prof_events;  // (max_forwards, NAFP_PROF_EV): [conv0 a, b | conv j start, stop (j = 1..15) | tail a, b]
     int prof_max = 0, prof_count = 0;
     int opt_bf16x3 = 0;                   // NAFP_OPT_BF16X3 (experimental): 0 off, 1 hi / lo split with 3 products, 2 exact 3-way split with 6 products
-    // value 2: the packed conv kernels split into three bf16 terms (conv.hip, split_weights_bf16_kernel), refreshed by the first forward after a
+    // value 2: the packed conv kernels split into three bf16 terms (conv.hip, split_weights_multi_kernel), refreshed by the first forward after a
     // set_weights; one allocation of its own, made when the option is first switched on
     float* d_x6_blob = nullptr; std::vector<float*> d_whm; std::vector<void*> d_wl; bool x6_dirty = true;
     std::vector<float*> d_wdhm; std::vector<void*> d_wdl;      // ... and of the flipped kernels (Cin, 3 Cout) of the transposed convs (the train step under the option)
@@ -373,7 +373,7 @@ extern "C" int nafp_encoder_destroy(nafp_encoder* e) {
     return NAFP_OK;
 }
 
-// NAFP_OPT_BF16X3 = 2: the three bf16 terms of every packed conv kernel and of its flipped form (conv.hip split_weights_bf16_kernel)
+// NAFP_OPT_BF16X3 = 2: the three bf16 terms of every packed conv kernel and of its flipped form (conv.hip split_weights_multi_kernel)
 static int split_all_weights(nafp_encoder* e, hipStream_t st) {
     SplitTable t; t.count = 0;
     for (int j = 1; j < 16; ++j) {

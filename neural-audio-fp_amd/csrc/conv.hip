@@ -328,7 +328,7 @@ constexpr int BN = 128;          // BM (tile rows) is a template parameter: 128 
 struct ConvKernelParams {
     const float* x;           // (B, Fin, Tin, Cin)
     const float* wp;          // (Cout, 3*Cin)
-    const float* wp_hm;       // PREC = 2: the same shape, every group of 16 k replaced by [h(16) | m(16)] bf16 (split_weights_bf16_kernel)
+    const float* wp_hm;       // PREC = 2: the same shape, every group of 16 k replaced by [h(16) | m(16)] bf16 (split_weights_multi_kernel)
     const unsigned short* wp_l;   // PREC = 2: (Cout, 3*Cin) bf16, the third term of the split
     const float* G;           // (P, Cout)      FULL
     const float* Hb;          // (P, Cout)      FULL
@@ -941,7 +941,7 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p) {
                     }
                 }
                 if (PREC == 2) {
-                    // the weights arrive split (split_weights_bf16_kernel): logical chunks 0, 1 of a row = h[0..7], h[8..15], chunks 2, 3 = m
+                    // the weights arrive split (split_weights_multi_kernel): logical chunks 0, 1 of a row = h[0..7], h[8..15], chunks 2, 3 = m
 #pragma unroll
                     for (int ni = 0; ni < NIW; ++ni) {
                         bh[ni] = *(const bf16x8*)(St + boff + ni * 32 * BK + ((hh ^ rswz) * 4));
@@ -1574,23 +1574,6 @@ static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 // with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (each difference is exact in float32; three 8-bit significands hold the 24 bits).
 // hm: the f32 tensor's shape, every group of 16 k replaced by [h(16) | m(16)] -- the B staging of the f32 kernels moves it unchanged;
 // l: plain (Cout, K) bf16.
-__global__ __launch_bounds__(256) void split_weights_bf16_kernel(const float* __restrict__ wp, unsigned short* __restrict__ hm,
-                                                                 unsigned short* __restrict__ wl, int64_t n, int K) {
-    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float x = wp[i];
-        const __bf16 h = (__bf16)x;
-        const float r1 = x - (float)h;
-        const __bf16 m = (__bf16)r1;
-        const __bf16 l = (__bf16)(r1 - (float)m);
-        const int64_t row = i / K;
-        const int k = (int)(i - row * K);
-        const int64_t base = row * 2 * K + (int64_t)(k >> 4) * 32;
-        hm[base + (k & 15)] = __builtin_bit_cast(unsigned short, h);
-        hm[base + 16 + (k & 15)] = __builtin_bit_cast(unsigned short, m);
-        wl[i] = __builtin_bit_cast(unsigned short, l);
-    }
-}
-
 // All tensors of a parameter set in ONE launch (blockIdx.y = tensor), 8 consecutive k per thread: two 16-B loads, three 16-B stores.
 // (Round 6, the train step under the option: 30 tensors per step -- 15 packed kernels and their 15 flipped forms -- were 30 launches of
 // 24 us each with 2-byte stores.)
@@ -1632,14 +1615,6 @@ int launch_split_weights_multi(const SplitTable& t, hipStream_t st) {
         n8_max = std::max(n8_max, t.n8[j]);
     }
     split_weights_multi_kernel<<<dim3((unsigned)std::min<int64_t>((n8_max + 255) / 256, 1024), (unsigned)t.count), 256, 0, st>>>(t);
-    NAFP_LAUNCH_CHECK();
-    return NAFP_OK;
-}
-
-int launch_split_weights_bf16(const float* wp, float* hm, void* wl, int Cout, int K, hipStream_t st) {
-    if (K % 16 != 0) return NAFP_ERR_UNSUPPORTED;
-    const int64_t n = (int64_t)Cout * K;
-    split_weights_bf16_kernel<<<(unsigned)std::min<int64_t>((n + 255) / 256, 4096), 256, 0, st>>>(wp, (unsigned short*)hm, (unsigned short*)wl, n, K);
     NAFP_LAUNCH_CHECK();
     return NAFP_OK;
 }

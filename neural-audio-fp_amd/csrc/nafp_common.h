@@ -179,7 +179,7 @@ struct ConvGemmArgs {
     float* slab;             // split-K partial sums workspace (or nullptr: never split)
     int64_t slab_floats;
     hipEvent_t ev_start, ev_stop;   // optional: time stamps attached to this conv's first / last kernel dispatch (no queue entry)
-    const float* wp_hm; const void* wp_l;   // bf16x3 == 2: the weights pre-split into three bf16 terms (launch_split_weights_bf16)
+    const float* wp_hm; const void* wp_l;   // bf16x3 == 2: the weights pre-split into three bf16 terms (launch_split_weights_multi)
     int bf16x3;              // experimental: split-bf16 products for the unsplit FULL launches (NAFP_OPT_BF16X3): 1 = hi / lo, 3 products; 2 = exact 3-way split, 6 products
     unsigned* tickets;       // NAFP_TICKET_SLOTS arrival counters, zero on entry and on exit (or nullptr: split launches use slab + finish kernel)
     // optional: generate the A operand from the log-mel features (conv0 fused into conv1);
@@ -292,8 +292,7 @@ struct PackTable { const float* k3[16]; float* wp[16]; float* wd[16]; int cin[16
                    int* nonfinite; };      // nonfinite (or null): set to 1 when a conv kernel holds a NaN / Inf (see nafp_encoder::d_wflag)
 int launch_multi_pack(const PackTable& t, hipStream_t st);
 // exact 3-way bf16 split of a packed (Cout, K) weight tensor for the bf16x3 == 2 launches: hm (Cout * K floats), wl (Cout * K bf16)
-int launch_split_weights_bf16(const float* wp, float* hm, void* wl, int Cout, int K, hipStream_t st);
-// ... every tensor of a parameter set in one launch: (Cout_j, K_j) f32 -> hm_j, wl_j as above; n8 = Cout_j * K_j / 8
+// every tensor of a parameter set in one launch: (Cout_j, K_j) f32 -> hm_j ([h(16) | m(16)] bf16 per group of 16 k, the f32 tensor's shape), wl_j ((Cout_j, K_j) bf16); n8 = Cout_j * K_j / 8
 struct SplitTable { const float* wp[32]; float* hm[32]; void* wl[32]; int64_t n8[32]; int K[32]; int count; };
 int launch_split_weights_multi(const SplitTable& t, hipStream_t st);
 int launch_pack_conv_weight(const float* k3, float* wp, int Cin, int Cout, hipStream_t st);
