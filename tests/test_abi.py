@@ -98,8 +98,8 @@ def test_kernels_do_not_spill_beyond_what_is_known(nafp):
     """The build keeps the compiler's per-kernel resource remarks (build.py: `-Rpass-analysis=kernel-resource-usage`).  A kernel
     that starts spilling to scratch still passes every parity test -- 5-10x slower (round 4: the tail's backward kernel went
     38 -> 182 us that way).  Every kernel of the library is listed in the remarks; only the ones below may use scratch, and no
-    more than they do today (none of it inside a K-loop: the in-kernel split-K finish, the generic-statistics epilogue, two 8-byte
-    prologue values of the 256-row tile, the by-value tables of the set_weights launch, the emb_sz = 64 tail)."""
+    more than they do today (none of it inside a K-loop: the in-kernel split-K finish, the generic-statistics epilogue, the by-value
+    tables of the set_weights launch, the emb_sz = 64 tail)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location('nafp_build', os.path.join(ROOT, 'neural-audio-fp_amd', 'build.py'))
     build = importlib.util.module_from_spec(spec)
@@ -109,8 +109,9 @@ def test_kernels_do_not_spill_beyond_what_is_known(nafp):
         build.build(force=True, verbose=False)
         res = build.kernel_resources()
     assert len(res) >= 90, 'kernel resource remarks missing'
-    known = {'conv_gemm_k16s3_any': 232, 'conv_gemm_n64k16s2_splitfin': 148, 'conv_gemm_m256k16s3_infer': 12,
-             'conv_gemm_m256k16s3_train': 20, 'gh_gemv_kernel': 272, 'tail_kernelILi16E': 416}
+    # (round 6: the build without packed-f32 instructions left the 256-row tile's two kernels without scratch -- 12 / 20 B before -- and cut the
+    # generic-statistics epilogue from 232 to 48 B, the in-kernel finish from 148 to 56 B)
+    known = {'conv_gemm_k16s3_any': 48, 'conv_gemm_n64k16s2_splitfin': 56, 'gh_gemv_kernel': 272, 'tail_kernelILi16E': 396}
     spilling = {n: r['ScratchSize [bytes/lane]'] for n, r in res.items() if r.get('ScratchSize [bytes/lane]', 0) > 0}
     for name, scratch in spilling.items():
         bound = max([v for k, v in known.items() if k in name] or [0])
