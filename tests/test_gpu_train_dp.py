@@ -16,16 +16,22 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('world,n', [(2, 4), (4, 2), (8, 2)])
-def test_multi_rank_step_equals_single_process_step(nafp, tmp_path, world, n):
+@pytest.mark.parametrize('world,n,arithmetic', [(2, 4, 'f32'), (2, 4, 'x6'), (4, 2, 'f32'), (8, 2, 'f32')])
+def test_multi_rank_step_equals_single_process_step(nafp, tmp_path, monkeypatch, world, n, arithmetic):
     """`world` ranks x n anchors each: all-gather of the embeddings, reduce-scatter of d(emb), the flat gradient
     buffer all-reduced in NAFP_GRAD_GROUPS pieces on the communication stream behind the library's gradient-group
     events (trainer.GradientBucket.all_reduce).  (8, 2): the rank-offset labels and the reduce-scatter layout at the
     world size of BASELINE.json configs[3] (NTxent_loss_tpu.py:42-54, 57-87) -- eight processes share the one GPU over gloo."""
     from neural_audio_fp_amd.model import trainer as T
     from neural_audio_fp_amd.model.fp.lamb_optimizer import LAMB
+    # (2, 4, 'x6'): the same step with forward_train and the transposed convs on the exact 3-way bf16 split (NAFP_BF16X3=2 in the environment of the
+    # ranks and of this process): the distributed path under the option -- replicas bit-identical, equal to the single-process step
+    if arithmetic == 'x6':
+        monkeypatch.setenv('NAFP_BF16X3', '2')
+    else:
+        monkeypatch.delenv('NAFP_BF16X3', raising=False)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
-    port = 29600 + (os.getpid() % 300) + world
+    port = 29600 + (os.getpid() % 300) + world + (7 if arithmetic == 'x6' else 0)
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
                         '--master-addr', '127.0.0.1', '--master-port', str(port),
                         os.path.join(ROOT, 'tests', '_dp_train_worker.py'), str(tmp_path), str(n)],
@@ -43,6 +49,7 @@ def test_multi_rank_step_equals_single_process_step(nafp, tmp_path, world, n):
     X = (torch.from_numpy(np.concatenate([f[0] for f in feats])).cuda(),
          torch.from_numpy(np.concatenate([f[1] for f in feats])).cuda())
     m_fp = nafp.FingerPrinter(seed=0)
+    assert m_fp.split_arithmetic == (2 if arithmetic == 'x6' else 0)
     m_fp.set_weights(_inputs.weight_list(_inputs.weights(seed=31)))
     bucket = T.GradientBucket(m_fp)
     opt = LAMB(learning_rate=1e-3)
