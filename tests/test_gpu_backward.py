@@ -65,7 +65,7 @@ def test_encoder_backward_matches_autograd(nafp, B, fused_ln, observe, arith):
         observe('gradient error vs float64 autograd (worst entry), exact split / f32 path', worst / worst32, 2.0)
 
 
-def test_backward_is_additive_over_the_batch_at_bsz_5120(nafp):
+def test_backward_is_additive_over_the_batch_at_bsz_5120(nafp, arith):
     """Size-independent property at BASELINE's full train batch (5120 per GPU when N = 1): the encoder's
     parameter gradient for a given dL/d(emb) is a sum over samples, so one backward over 5120 samples
     equals the sum of four backwards over its 1280-sample quarters (also guards the >2^31-element
@@ -114,7 +114,7 @@ def test_other_fingerprint_dimensions_forward_and_backward(nafp, emb_sz, observe
     assert m_fp.variable_lengths()[64] == w['div.w1'].size // emb_sz
 
 
-def test_two_second_segments_forward_and_backward(nafp, observe):
+def test_two_second_segments_forward_and_backward(nafp, observe, arith):
     """input (256, 63, 1) (2-s segments: the shape behind the reference's `Total params: 19,224,576`,
     nnfp.py:262-271): odd extents exercise the asymmetric SAME padding and the parity classes of the
     transposed conv with an odd number of positions."""
@@ -162,7 +162,7 @@ def test_fused_ln_backward_equals_the_separate_pass(nafp, B):
 
 @pytest.mark.parametrize('side_mode', [1, 2])
 @pytest.mark.parametrize('B', [5, 130, 160])
-def test_weight_gradients_on_the_side_stream_equal_the_single_stream_pass(nafp, B, side_mode, observe):
+def test_weight_gradients_on_the_side_stream_equal_the_single_stream_pass(nafp, B, side_mode, observe, arith):
     """NAFP_OPT_BWD_OVERLAP (option 4; 2 = the small layers' weight gradients, the default; 1 = every layer's, measured slower;
     0 = single stream): the weight gradients run on a second stream of the handle behind per-layer events, over the same
     dA / dB ping-pong buffers the main chain keeps rewriting (B = 160: B * P is a multiple of 16 for every layer, so the small
@@ -240,7 +240,7 @@ def test_each_gradient_group_event_covers_exactly_its_own_tensors(nafp, B, side_
                 assert torch.equal(t, grads[i]), (rep, k, i)
 
 
-def test_backward_with_aux_rows_and_small_layer_kernel(nafp, observe):
+def test_backward_with_aux_rows_and_small_layer_kernel(nafp, observe, arith):
     """B = 32: B * P is a multiple of 16 for every layer, so the weight gradients take the round-4 paths -- the two rank-one
     terms (gamma | beta against S1 | S2) as aux rows of the main launch, the small-layer kernel (P < 16: plain stores or
     slab + last-arriver, no atomics) and the scalar records of the next layer as a side job of the wgrad launch -- where
