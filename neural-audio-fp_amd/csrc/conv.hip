@@ -2048,7 +2048,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
         if (plan_forced && plan_override().S > 0) { S = plan_override().S; while (S > 1 && k_steps / S < 4) --S; }
         if (dplan_forced && dgrad_plan_override().S > 0) { S = dgrad_plan_override().S; while (S > 1 && k_steps / S < 4) --S; }
         if ((int64_t)S * out_floats > a.slab_floats) S = 1;
-        if (x6 && bn == 64 && S == 2) S = 1;          // convs 7, 9 at B = 640: unsplit on the bf16 pipe beats the two f32 parts + finish
+        if (x6 && bn == 64 && S == 2 && (p.ST == 4 || p.ST == 8)) S = 1;      // convs 7, 9 at B = 640: unsplit on the bf16 pipe beats the two f32 parts + finish (only where the unsplit launch IS a split-arithmetic one: register-resident statistics)
     }
     if (S > 1) { p.mode = a.plain ? 1 : 2; p.n_split = S; p.y = a.slab; p.bias = nullptr; }
     // FULL split launches on 64-column tiles finish in-kernel (last-arriver) when the caller provides arrival counters
