@@ -31,7 +31,9 @@ from .fp.melspec.melspectrogram import get_melspec_layer
 from .fp.nnfp import get_fingerprinter
 
 LAUNCH_SEGMENTS = 640       # target segments per launch (whole groups)
-N_STREAMS = 4               # consecutive launches are pipelined round-robin over this many HIP streams
+# consecutive launches are pipelined round-robin over this many HIP streams (NAFP_GEN_STREAMS overrides; round 6, same box: the device-only loop
+# gains 2 - 3 % from 6 streams, the disk -> .mm and full-scale drivers nothing: 4 / 6 / 8 -> 183 / 180 / 183 k and 179 / 177 / 181 k segments/s)
+N_STREAMS = int(os.environ.get('NAFP_GEN_STREAMS', '4'))
 
 
 def build_fp(cfg):
