@@ -1082,7 +1082,11 @@ extern "C" int nafp_encoder_backward(nafp_encoder* e, const float* feat, const f
         // (its sums are final since ln_bwd of layer j; the fused dgrad path and the side stream keep the separate launch)
         const bool pairs = L.S2[j] == L.S1[j] + (int64_t)P * g.Cout;
         if (pairs) {
-            rc = launch_wgrad(L.z[j - 1], cur, grads[4 * j], B, g, sw, e->d_gamma[j - 1], L.S1[j], w_slab, w_slab_floats, w_tickets, nullptr);
+            // NAFP_OPT_BF16X3 = 2: the weight gradients of the regular shapes (wgrad_fast_kernel's) on the split arithmetic as well -- both operands are
+            // activations, split in registers (NAFP_X6_WGRAD=0 keeps them on the f32 pipe for an A/B: 76.8 -> 72.9 ms per step at BSZ 5120)
+            static const bool x6_wgrad = []() { const char* v = getenv("NAFP_X6_WGRAD"); return !v || v[0] != '0'; }();
+            rc = launch_wgrad(L.z[j - 1], cur, grads[4 * j], B, g, sw, e->d_gamma[j - 1], L.S1[j], w_slab, w_slab_floats, w_tickets, nullptr,
+                              (x6_wgrad && e->opt_bf16x3 == 2 && !alt) ? 2 : 0);
             if (rc != NAFP_OK) return rc;
         } else {
             rc = launch_wgrad(L.z[j - 1], cur, grads[4 * j], B, g, sw, nullptr, nullptr, nullptr, 0, nullptr, nullptr);

@@ -623,7 +623,11 @@ __global__ __launch_bounds__(256, 3) void wgrad_kernel(const WgradParams p) {
 // The f32 MFMAs share the SIMD's issue time with every VALU instruction (see conv.hip): the generic kernel above spends
 // ~160 VALU instructions per 32 MFMAs on row bookkeeping, this one at most 12.  The loop body exists once per ring slot
 // so that LDS addresses are immediates.
-__global__ __launch_bounds__(256, 3) void wgrad_fast_kernel(const WgradParams p, const int lt, const int lfo) {
+// PREC = 2 (the train step under NAFP_OPT_BF16X3 = 2, experimental): the products on the bf16 matrix pipe from the exact 3-way split of BOTH operands
+// (each is an activation: nothing to pre-split), six v_mfma_f32_32x32x16_bf16 per 16 rows and 32 x 32 block instead of eight f32 MFMAs;
+// lane (rl, hh) then supplies k = 8 hh + j = rows 8 hh .. 8 hh + 7 of the K-step for its column pair.
+template <int PREC>
+__device__ __forceinline__ void wgrad_fast_body(const WgradParams& p, const int lt, const int lfo) {
     constexpr int NST = 3, KR = 16;
     constexpr int TILE = KR * 128, STAGE = 2 * TILE;           // X rows | D rows
     constexpr unsigned OOB = 0x80000000u;
@@ -741,8 +745,8 @@ __global__ __launch_bounds__(256, 3) void wgrad_fast_kernel(const WgradParams p,
     // the even / odd columns), so that the two values of a k-row are one 8-byte LDS read at base + immediate.
     const int rl = lane & 31;
     typedef float f32x2w __attribute__((ext_vector_type(2)));
-    const float* Xl = smem + hh * 128 + wc * 64 + 2 * rl;
-    const float* Dl = smem + TILE + hh * 128 + wn * 64 + 2 * rl;
+    const float* Xl = smem + (PREC == 2 ? 8 : 1) * hh * 128 + wc * 64 + 2 * rl;
+    const float* Dl = smem + TILE + (PREC == 2 ? 8 : 1) * hh * 128 + wn * 64 + 2 * rl;
     int slot = 0;
     for (int s = 0; s < n_steps; ++s) {
         if (s + NST - 2 >= n_steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -750,6 +754,45 @@ __global__ __launch_bounds__(256, 3) void wgrad_fast_kernel(const WgradParams p,
         __builtin_amdgcn_s_barrier();
         const float* Xs = Xl + slot * STAGE;
         const float* Ds = Dl + slot * STAGE;
+        if (PREC == 2) {
+            typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+            f32x2w a[8], bq[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                a[j] = *(const f32x2w*)(Xs + j * 128);
+                bq[j] = *(const f32x2w*)(Ds + j * 128);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            int nslot6 = slot + NST - 1; if (nslot6 >= NST) nslot6 -= NST;
+            if (s + NST - 1 < n_steps) { NAFP_WGF_DMA(s + NST - 1, nslot6) }
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8w ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xa = a[j][q], xb = bq[j][q];
+                    const __bf16 ha = (__bf16)xa, hb = (__bf16)xb;
+                    const float ra = xa - (float)ha, rb = xb - (float)hb;
+                    const __bf16 ma = (__bf16)ra, mb = (__bf16)rb;
+                    ah[q][j] = ha; am[q][j] = ma; al[q][j] = (__bf16)(ra - (float)ma);
+                    bh[q][j] = hb; bm[q][j] = mb; bl[q][j] = (__bf16)(rb - (float)mb);
+                }
+            }
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    acc[ci][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ci], bh[ni], acc[ci][ni], 0, 0, 0);
+                    acc[ci][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[ci], bm[ni], acc[ci][ni], 0, 0, 0);
+                    acc[ci][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ci], bl[ni], acc[ci][ni], 0, 0, 0);
+                    acc[ci][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[ci], bh[ni], acc[ci][ni], 0, 0, 0);
+                    acc[ci][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ci], bm[ni], acc[ci][ni], 0, 0, 0);
+                    acc[ci][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ci], bh[ni], acc[ci][ni], 0, 0, 0);
+                }
+            if (++slot == NST) slot = 0;
+            continue;
+        }
         f32x2w a[KR / 2], bq[KR / 2];
 #pragma unroll
         for (int kp = 0; kp < KR / 2; ++kp) {
@@ -802,6 +845,9 @@ __global__ __launch_bounds__(256, 3) void wgrad_fast_kernel(const WgradParams p,
                 atomicAdd(p.dW + ((long long)tap * p.Cin + c) * p.Cout + n, acc[ci][ni][r]);
             }
 }
+
+__global__ __launch_bounds__(256, 3) void wgrad_fast_kernel(const WgradParams p, const int lt, const int lfo) { wgrad_fast_body<0>(p, lt, lfo); }
+__global__ __launch_bounds__(256, 3) void wgrad_fast_bf16x6_kernel(const WgradParams p, const int lt, const int lfo) { wgrad_fast_body<2>(p, lt, lfo); }
 
 // dW tile = sum over the row chunks of its partial tiles, in a fixed order (deterministic), stored once.
 // grid = (128 slices of 128 elements, n-tiles, live taps x c-tiles) -- the wgrad grid's y / z.  A lane owns 2 elements of the slice
@@ -1095,7 +1141,7 @@ int64_t wgrad_slab_floats(int64_t B, const ConvGeom& g) {
 // each pair adjacent in memory, folded into the main launch where the shape allows (else two more launches, as before).
 // slab / tickets (or null): workspace of the small-P kernel (null: it is not used).  sj: optional side job (see ScalarsJob).
 int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const ConvGeom& g, hipStream_t st,
-                 const float* X2, const float* D2, float* slab, int64_t slab_floats, unsigned* tickets, const ScalarsJob* sj) {
+                 const float* X2, const float* D2, float* slab, int64_t slab_floats, unsigned* tickets, const ScalarsJob* sj, int prec) {
     if (g.Cin % 128 != 0 || g.Cout % 128 != 0) return NAFP_ERR_UNSUPPORTED;
     WgradParams p;
     p.X = X; p.D = D; p.dW = dW; p.B = (int)B; p.P = g.Fout * g.Tout; p.Tout = g.Tout;
@@ -1117,6 +1163,7 @@ int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const Con
     if (!attr) {
         NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_fast_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_smallp_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_smallp_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr = true;
@@ -1167,7 +1214,8 @@ int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const Con
         static const bool slab_on = []() { const char* e = getenv("NAFP_WGRAD_SLAB"); return !e || e[0] != '0'; }();
         const bool use_slab = slab_on && fast && is_main && slab && (int64_t)col_tiles * gx * 128 * 128 <= slab_floats;
         q.slab = use_slab ? slab : nullptr; q.n_chunks = (int)gx;
-        if (fast) wgrad_fast_kernel<<<dim3(gx, g.Cout / 128, q.n_live * g.Cin / 128), 256, lds, st>>>(q, lt, lfo);
+        if (fast && prec == 2) wgrad_fast_bf16x6_kernel<<<dim3(gx, g.Cout / 128, q.n_live * g.Cin / 128), 256, lds, st>>>(q, lt, lfo);
+        else if (fast) wgrad_fast_kernel<<<dim3(gx, g.Cout / 128, q.n_live * g.Cin / 128), 256, lds, st>>>(q, lt, lfo);
         else wgrad_kernel<<<dim3(gx, g.Cout / 128, q.n_live * g.Cin / 128), 256, lds, st>>>(q);
         NAFP_LAUNCH_CHECK();
         if (use_slab) {

@@ -269,7 +269,7 @@ int launch_ln_bwd(float* d, const float* tpre, const float* gamma, const float* 
 // rank-one terms of dW_j; slab / tickets: workspace of the small-layer kernel (or null); sj: optional side job.
 int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const ConvGeom& g, hipStream_t st,
                  const float* X2 = nullptr, const float* D2 = nullptr, float* slab = nullptr, int64_t slab_floats = 0,
-                 unsigned* tickets = nullptr, const ScalarsJob* sj = nullptr);
+                 unsigned* tickets = nullptr, const ScalarsJob* sj = nullptr, int prec = 0);      // prec 2: the regular-shape kernel on the exact 3-way bf16 split (the train step under NAFP_OPT_BF16X3 = 2)
 int64_t wgrad_slab_floats(int64_t B, const ConvGeom& g);
 int launch_conv0_bwd(const float* feat, const float* dt, float* dW0, float* dbias0, int64_t B, const ConvGeom& g,
                      hipStream_t st);
