@@ -766,18 +766,34 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradParams& p, const int 
             int nslot6 = slot + NST - 1; if (nslot6 >= NST) nslot6 -= NST;
             if (s + NST - 1 < n_steps) { NAFP_WGF_DMA(s + NST - 1, nslot6) }
             __builtin_amdgcn_sched_barrier(0);
+            // the split, two k at a time: one packed conversion per term and pair, the bf16 -> f32 back-conversions as a shift and a mask of the
+            // packed word (11 vector instructions per pair; written per element the compiler spent 19 incl. the moves that assemble the operands)
+            typedef __bf16 bf16x2w __attribute__((ext_vector_type(2)));
+            typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+            u32x4w uh[4], um[4], ul[4];            // [0, 1]: A columns ci = 0, 1; [2, 3]: B columns ni = 0, 1
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) {
+                    f32x2w x;
+                    x.x = q < 2 ? a[2 * jp][q] : bq[2 * jp][q - 2];
+                    x.y = q < 2 ? a[2 * jp + 1][q] : bq[2 * jp + 1][q - 2];
+                    const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2w));
+                    f32x2w r;
+                    r.x = x.x - __uint_as_float(h2 << 16);
+                    r.y = x.y - __uint_as_float(h2 & 0xffff0000u);
+                    const unsigned m2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2w));
+                    f32x2w t;
+                    t.x = r.x - __uint_as_float(m2 << 16);
+                    t.y = r.y - __uint_as_float(m2 & 0xffff0000u);
+                    uh[q][jp] = h2; um[q][jp] = m2; ul[q][jp] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2w));
+                }
+            }
             bf16x8w ah[2], am[2], al[2], bh[2], bm[2], bl[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float xa = a[j][q], xb = bq[j][q];
-                    const __bf16 ha = (__bf16)xa, hb = (__bf16)xb;
-                    const float ra = xa - (float)ha, rb = xb - (float)hb;
-                    const __bf16 ma = (__bf16)ra, mb = (__bf16)rb;
-                    ah[q][j] = ha; am[q][j] = ma; al[q][j] = (__bf16)(ra - (float)ma);
-                    bh[q][j] = hb; bm[q][j] = mb; bl[q][j] = (__bf16)(rb - (float)mb);
-                }
+                ah[q] = __builtin_bit_cast(bf16x8w, uh[q]); am[q] = __builtin_bit_cast(bf16x8w, um[q]); al[q] = __builtin_bit_cast(bf16x8w, ul[q]);
+                bh[q] = __builtin_bit_cast(bf16x8w, uh[2 + q]); bm[q] = __builtin_bit_cast(bf16x8w, um[2 + q]); bl[q] = __builtin_bit_cast(bf16x8w, ul[2 + q]);
             }
 #pragma unroll
             for (int ci = 0; ci < 2; ++ci)
