@@ -967,8 +967,33 @@ __device__ __forceinline__ bool conv_gemm_body(const ConvKernelParams& p) {
                         }                                                                          \
                     }                                                                              \
                 }
+                // PREC = 2: the same split written two k at a time -- one packed conversion per term and pair, the bf16 -> f32 back-conversions as a
+                // shift and a mask of the packed word: 11 vector instructions per pair where the per-element form compiles to 12 - 13
+#define NAFP_SPLIT8_PAIRS(f_, hi_, mid_, lo_)                                                  \
+                {                                                                                  \
+                    typedef __bf16 bf16x2_l __attribute__((ext_vector_type(2)));                   \
+                    typedef float f32x2_l __attribute__((ext_vector_type(2)));                     \
+                    typedef unsigned u32x4_l __attribute__((ext_vector_type(4)));                  \
+                    const float x_l[8] = {f_[0].x, f_[0].y, f_[0].z, f_[0].w, f_[1].x, f_[1].y, f_[1].z, f_[1].w}; \
+                    u32x4_l uh_l, um_l, ul_l;                                                      \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                \
+                        f32x2_l x2; x2.x = x_l[2 * e]; x2.y = x_l[2 * e + 1];                      \
+                        const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_convertvector(x2, bf16x2_l)); \
+                        f32x2_l r2; r2.x = x2.x - __uint_as_float(h2 << 16); r2.y = x2.y - __uint_as_float(h2 & 0xffff0000u); \
+                        const unsigned m2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_l)); \
+                        f32x2_l t2; t2.x = r2.x - __uint_as_float(m2 << 16); t2.y = r2.y - __uint_as_float(m2 & 0xffff0000u); \
+                        uh_l[e] = h2; um_l[e] = m2; ul_l[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(t2, bf16x2_l)); \
+                    }                                                                              \
+                    hi_ = __builtin_bit_cast(bf16x8, uh_l); mid_ = __builtin_bit_cast(bf16x8, um_l); lo_ = __builtin_bit_cast(bf16x8, ul_l); \
+                }
+                if (PREC == 2 && !NAFP_EXP_X6_NOSPLIT) {
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) NAFP_SPLIT8_PAIRS(af[mi], ah[mi], am[PREC == 2 ? mi : 0], al[mi])
+                } else {
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) NAFP_SPLIT8(af[mi], ah[mi], am[PREC == 2 ? mi : 0], al[mi])
+                }
+#undef NAFP_SPLIT8_PAIRS
                 if (PREC != 2) {
 #pragma unroll
                     for (int ni = 0; ni < NIW; ++ni) NAFP_SPLIT8(bf[PREC == 2 ? 0 : ni], bh[ni], bm[0], bl[ni])
