@@ -322,8 +322,8 @@ train_section('train640_trace', 'train640_probe.txt', f'{tag}_train640_kernel_st
               'the bench object `train_rank640` runs the same step through a 1-rank RCCL group)',
               'python tools/train_probe.py 640 lamb 5', 640)
 train_section('train5120x6_trace', 'train5120x6_probe.txt', f'{tag}_train5120_x6_kernel_stats.csv',
-              'Train step at the headline batch with forward_train and the transposed convs on the exact 3-way bf16 split (NAFP_BF16X3=2; global BSZ 5120, LAMB; '
-              'weight gradients stay f32): the bench object `train_x6_experimental`',
+              'Train step at the headline batch with forward_train, the transposed convs and the weight gradients of layers 1 - 9 on the exact 3-way bf16 split '
+              '(NAFP_BF16X3=2; global BSZ 5120, LAMB): the bench object `train_x6_experimental`',
               'NAFP_BF16X3=2 python tools/train_probe.py 5120 lamb 3')
 train_section('train640x6_trace', 'train640x6_probe.txt', f'{tag}_train640_x6_kernel_stats.csv',
               'Train step at the 8-GPU operating point (per-rank batch 640) on the exact split',
