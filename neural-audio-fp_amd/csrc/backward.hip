@@ -913,7 +913,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //     the caches, draws an arrival ticket for the tile, and the LAST arriver adds the parts in chunk order and stores dW
 //     once (n_chunks == 1: straight from the accumulators).  No atomics: the gradient is bit-reproducible;
 //   * the aux samples (gamma | beta against S1 | S2) are rows B*P ... of the same loop.
-template <int BNT>
+// PREC = 2: as wgrad_fast_body<2> -- the exact 3-way bf16 split of both operands in registers, six bf16 MFMAs per 16 rows and 32 x 32 block.
+template <int BNT, int PREC = 0>
 __global__ __launch_bounds__(256, 3) void wgrad_smallp_kernel(const WgradParams p, const int lp) {
     constexpr int NST = 3, KR = 16;
     constexpr int TX = KR * 128, TD = KR * BNT, STAGE = TX + TD;   // X rows | D rows
@@ -997,8 +998,8 @@ __global__ __launch_bounds__(256, 3) void wgrad_smallp_kernel(const WgradParams 
     // odd channels) and -- BNT = 128 -- the column pair 2 rl, 2 rl + 1 of its wave's 64 columns, or -- BNT = 64 -- column rl of 32
     const int rl = lane & 31;
     typedef float f32x2w __attribute__((ext_vector_type(2)));
-    const float* Xl = smem + hh * 128 + wc * 64 + 2 * rl;
-    const float* Dl = smem + TX + hh * BNT + wn * (BNT / 2) + (BNT == 128 ? 2 * rl : rl);
+    const float* Xl = smem + (PREC == 2 ? 8 : 1) * hh * 128 + wc * 64 + 2 * rl;
+    const float* Dl = smem + TX + (PREC == 2 ? 8 : 1) * hh * BNT + wn * (BNT / 2) + (BNT == 128 ? 2 * rl : rl);
     int slot = 0;
     for (int s = 0; s < n_steps; ++s) {
         if (s + NST - 2 >= n_steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1006,6 +1007,57 @@ __global__ __launch_bounds__(256, 3) void wgrad_smallp_kernel(const WgradParams 
         __builtin_amdgcn_s_barrier();
         const float* Xs = Xl + slot * STAGE;
         const float* Ds = Dl + slot * STAGE;
+        if (PREC == 2) {
+            // lane (rl, hh) supplies k = 8 hh + j = rows 8 hh .. 8 hh + 7 of the K-step; the split two k at a time (wgrad_fast_body)
+            typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+            typedef __bf16 bf16x2w __attribute__((ext_vector_type(2)));
+            typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+            f32x2w a[8], bq[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                a[j] = *(const f32x2w*)(Xs + j * 128);
+                if (BNT == 128) bq[j] = *(const f32x2w*)(Ds + j * BNT);
+                else { bq[j].x = Ds[j * BNT]; bq[j].y = 0.f; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            int nslot6 = slot + NST - 1; if (nslot6 >= NST) nslot6 -= NST;
+            if (s + NST - 1 < n_steps) { NAFP_WSP_DMA(s + NST - 1, nslot6) }
+            __builtin_amdgcn_sched_barrier(0);
+            u32x4w uh[2 + NIW], um[2 + NIW], ul[2 + NIW];          // [0, 1]: X channels ci = 0, 1; [2 ..]: D columns
+#pragma unroll
+            for (int q = 0; q < 2 + NIW; ++q) {
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) {
+                    f32x2w x;
+                    x.x = q < 2 ? a[2 * jp][q] : bq[2 * jp][q - 2];
+                    x.y = q < 2 ? a[2 * jp + 1][q] : bq[2 * jp + 1][q - 2];
+                    const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2w));
+                    f32x2w r;
+                    r.x = x.x - __uint_as_float(h2 << 16);
+                    r.y = x.y - __uint_as_float(h2 & 0xffff0000u);
+                    const unsigned m2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2w));
+                    f32x2w t;
+                    t.x = r.x - __uint_as_float(m2 << 16);
+                    t.y = r.y - __uint_as_float(m2 & 0xffff0000u);
+                    uh[q][jp] = h2; um[q][jp] = m2; ul[q][jp] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2w));
+                }
+            }
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                for (int ni = 0; ni < NIW; ++ni) {
+                    const bf16x8w xh = __builtin_bit_cast(bf16x8w, uh[ci]), xm = __builtin_bit_cast(bf16x8w, um[ci]), xl = __builtin_bit_cast(bf16x8w, ul[ci]);
+                    const bf16x8w dh = __builtin_bit_cast(bf16x8w, uh[2 + ni]), dm = __builtin_bit_cast(bf16x8w, um[2 + ni]), dl = __builtin_bit_cast(bf16x8w, ul[2 + ni]);
+                    acc[ci][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, dh, acc[ci][ni], 0, 0, 0);
+                    acc[ci][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, dm, acc[ci][ni], 0, 0, 0);
+                    acc[ci][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, dl, acc[ci][ni], 0, 0, 0);
+                    acc[ci][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, dh, acc[ci][ni], 0, 0, 0);
+                    acc[ci][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, dm, acc[ci][ni], 0, 0, 0);
+                    acc[ci][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, dh, acc[ci][ni], 0, 0, 0);
+                }
+            if (++slot == NST) slot = 0;
+            continue;
+        }
         f32x2w a[KR / 2], bq[KR / 2];
 #pragma unroll
         for (int kp = 0; kp < KR / 2; ++kp) {
@@ -1182,6 +1234,8 @@ int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const Con
         NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_fast_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_smallp_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_smallp_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_smallp_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        NAFP_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_smallp_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr = true;
     }
     const bool have_aux = X2 && D2;
@@ -1191,7 +1245,11 @@ int launch_wgrad(const float* X, const float* D, float* dW, int64_t B, const Con
         p.X2 = X2; p.D2 = D2; p.n_aux = 2;
         p.rows_per_wg = sp.rows_per_wg; p.n_chunks = sp.chunks; p.slab = slab; p.tickets = tickets;
         const dim3 grid((unsigned)sp.chunks, (unsigned)(g.Cout / sp.bnt), (unsigned)(p.n_live * g.Cin / 128));
-        if (sp.bnt == 64) wgrad_smallp_kernel<64><<<grid, 256, 3 * (16 * 128 + 16 * 64) * sizeof(float), st>>>(p, sp.lp);
+        static const bool x6_small = []() { const char* e = getenv("NAFP_X6_WGRAD_SMALL"); return !e || e[0] != '0'; }();      // (A/B knob of the split arithmetic on the small layers)
+        if (prec == 2 && x6_small) {
+            if (sp.bnt == 64) wgrad_smallp_kernel<64, 2><<<grid, 256, 3 * (16 * 128 + 16 * 64) * sizeof(float), st>>>(p, sp.lp);
+            else wgrad_smallp_kernel<128, 2><<<grid, 256, lds, st>>>(p, sp.lp);
+        } else if (sp.bnt == 64) wgrad_smallp_kernel<64><<<grid, 256, 3 * (16 * 128 + 16 * 64) * sizeof(float), st>>>(p, sp.lp);
         else wgrad_smallp_kernel<128><<<grid, 256, lds, st>>>(p, sp.lp);
         NAFP_LAUNCH_CHECK();
         return NAFP_OK;
