@@ -269,10 +269,10 @@ int nafp_encoder_grad_group_wait(nafp_encoder* enc, int group, void* stream);
  * value 2: the EXACT 3-way split x = h + m + l (three bf16 terms hold a float32's 24 significant bits) with the six products of
  * relative weight >= 2^-16 (hh, hm, mh, hl, mm, lh; the dropped ml + lm + ll < 2^-25 of |a||b|): float32-equivalent arithmetic on
  * the bf16 matrix pipe -- its error against the float64 oracle equals the f32 path's own (tests/test_gpu_parity_forward.py).
- * Value 2 also covers the TRAIN step: nafp_encoder_forward_train, the transposed convs and the weight gradients (layers 1 - 9) of
+ * Value 2 also covers the TRAIN step: nafp_encoder_forward_train, the transposed convs and the weight gradients of
  * nafp_encoder_backward run on the same arithmetic (the flipped kernels are split alongside in nafp_encoder_set_weights; LayerNorm
- * backward, the small layers' weight gradients, loss and optimizer stay f32): gradients within the f32 path's tolerances
- * (tests/test_gpu_backward.py, tests/test_gpu_configs.py), the step 84 -> 71 ms at BSZ 5120, 11.9 -> 10.05 ms at 640 (bench.py
+ * backward, loss and optimizer stay f32): gradients within the f32 path's tolerances
+ * (tests/test_gpu_backward.py, tests/test_gpu_configs.py), the step 84 -> 69 ms at BSZ 5120, 11.9 -> 9.7 ms at 640 (bench.py
  * `train_x6_experimental`).
  * CAUTION for kernels of OTHER libraries (values 1 and 2): on gfx950 a packed-f32 vector instruction that carries an op_sel modifier
  * (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 ... op_sel:[..]; compilers emit them for complex arithmetic -- rocFFT's kernels hold
