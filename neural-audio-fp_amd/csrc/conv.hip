@@ -1583,6 +1583,9 @@ NAFP_GEMM_KERNEL_BF16X6(conv_gemm_k16s3_plain_bf16x6, 128, 128, NAFP_X6_K16_NSTA
 // ... with the TRAINING epilogue (forward_train under NAFP_OPT_BF16X3 = 2: the pre-activation is kept for the backward pass)
 NAFP_GEMM_KERNEL_BF16X6(conv_gemm_k16s3_train_bf16x6, 128, 128, NAFP_X6_K16_NSTAGE, NAFP_X6_K16_MINW, 1)
 NAFP_GEMM_KERNEL_BF16X6(conv_gemm_n64k16s2_train_bf16x6, 128, 64, 2, 4, 1)
+// ... with the generic-statistics epilogue (samples per position other than 4 / 8: the small late layers of a large training batch)
+NAFP_GEMM_KERNEL_BF16X6(conv_gemm_k16s3_any_bf16x6, 128, 128, NAFP_X6_K16_NSTAGE, NAFP_X6_K16_MINW, 2)
+NAFP_GEMM_KERNEL_BF16X6(conv_gemm_n64k16s2_any_bf16x6, 128, 64, 2, 4, 2)
 // ... and the PLAIN epilogue on 64-column tiles (the transposed convs of the train step; their 128-column form is conv_gemm_k16s3_plain_bf16x6)
 NAFP_GEMM_KERNEL_BF16X6(conv_gemm_n64k16s2_plain_bf16x6, 128, 64, 2, 4, 3)
 // conv1 with conv0 generated in-kernel on the exact split: no A stream at all (see the K-loop)
@@ -2160,6 +2163,12 @@ int launch_conv_gemm(const ConvGemmArgs& a, int64_t B, const ConvGeom& g, hipStr
     }
     // the training epilogue on the exact split (x6 forces 128-row tiles; launches that need the generic-statistics or the in-kernel-finish
     // epilogue -- the small late layers -- stay on the f32 kernels)
+    static const bool x6_any = []() { const char* e = getenv("NAFP_X6_ANY"); return !e || e[0] != '0'; }();      // (A/B knob)
+    if (x6 && epi == 2 && BM == 128 && x6_any) {
+        p.wp_hm = a.wp_hm; p.wp_l = (const unsigned short*)a.wp_l;
+        return bn == 64 ? launch_variant(conv_gemm_n64k16s2_any_bf16x6, 128, 64, 16, 2, p, grid, st, 64 * 8)
+                        : launch_variant(conv_gemm_k16s3_any_bf16x6, 128, 128, 16, NAFP_X6_K16_NSTAGE, p, grid, st, 128 * 8);
+    }
     if (x6 && epi == 1 && BM == 128 && (bn == 128 || two_stage)) {
         p.wp_hm = a.wp_hm; p.wp_l = (const unsigned short*)a.wp_l;
         return bn == 64 ? launch_variant(conv_gemm_n64k16s2_train_bf16x6, 128, 64, 16, 2, p, grid, st, 64 * 8)
